@@ -1,0 +1,84 @@
+"""Weights of the pose network: layer table, Chainer-NPZ reader/writer, seeded synthetic weights.
+
+Layer names, shapes and order follow the reference `models/CocoPoseNet.py:26-129`; the on-disk format is
+the one `chainer.serializers.save_npz` writes for that Chain (`models/convert_model.py:281`) and
+`serializers.load_npz` reads at `pose_detector.py:26`: one array `<layer>/W` (float32, OIHW) and one
+`<layer>/b` (float32) per layer.
+
+No trained weights can be fetched offline (they are `wget`-ed in the reference README), so tests and
+bench use `synthetic_weights(seed)`: He-scaled Gaussian weights, which keep activations O(1) through
+all 92 layers, with the last heat-map layer shifted so that a realistic (tens, not thousands) number
+of peaks survives the 0.05 threshold.
+"""
+import numpy as np
+
+N_LAYERS = 92
+
+
+def layer_table():
+    """[(name, cin, cout, ksize)] -- 92 convolutions, reference declaration order."""
+    t = [
+        ('conv1_1', 3, 64, 3), ('conv1_2', 64, 64, 3),
+        ('conv2_1', 64, 128, 3), ('conv2_2', 128, 128, 3),
+        ('conv3_1', 128, 256, 3), ('conv3_2', 256, 256, 3), ('conv3_3', 256, 256, 3),
+        ('conv3_4', 256, 256, 3),
+        ('conv4_1', 256, 512, 3), ('conv4_2', 512, 512, 3), ('conv4_3_CPM', 512, 256, 3),
+        ('conv4_4_CPM', 256, 128, 3),
+    ]
+    for br, co in (('L1', 38), ('L2', 19)):
+        for i in (1, 2, 3):
+            t.append(('conv5_%d_CPM_%s' % (i, br), 128, 128, 3))
+        t.append(('conv5_4_CPM_' + br, 128, 512, 1))
+        t.append(('conv5_5_CPM_' + br, 512, co, 1))
+    for s in range(2, 7):
+        for br, co in (('L1', 38), ('L2', 19)):
+            t.append(('Mconv1_stage%d_%s' % (s, br), 185, 128, 7))
+            for i in range(2, 6):
+                t.append(('Mconv%d_stage%d_%s' % (i, s, br), 128, 128, 7))
+            t.append(('Mconv6_stage%d_%s' % (s, br), 128, 128, 1))
+            t.append(('Mconv7_stage%d_%s' % (s, br), 128, co, 1))
+    assert len(t) == N_LAYERS
+    return t
+
+
+def n_params():
+    return sum(co * ci * k * k + co for _, ci, co, k in layer_table())
+
+
+def synthetic_weights(seed=0, heat_scale=0.25, heat_bias=-0.55, paf_scale=1.0):
+    """{name: (W OIHW float32, b float32)} -- deterministic for a given seed (numpy PCG64)."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, ci, co, k in layer_table():
+        std = np.sqrt(2.0 / (ci * k * k))
+        W = (rng.standard_normal((co, ci, k, k), dtype=np.float32) * np.float32(std))
+        b = (rng.standard_normal(co, dtype=np.float32) * np.float32(0.01))
+        if name == 'Mconv7_stage6_L2':
+            W *= np.float32(heat_scale)
+            b = b + np.float32(heat_bias)
+        if name == 'Mconv7_stage6_L1':
+            W *= np.float32(paf_scale)
+        out[name] = (np.ascontiguousarray(W, dtype=np.float32), np.ascontiguousarray(b, dtype=np.float32))
+    return out
+
+
+def load_npz(path):
+    """Chainer NPZ (`<layer>/W`, `<layer>/b`) -> {name: (W, b)}; every one of the 92 layers must be present."""
+    out = {}
+    with np.load(path) as z:
+        for name, ci, co, k in layer_table():
+            W = np.ascontiguousarray(z[name + '/W'], dtype=np.float32)
+            b = np.ascontiguousarray(z[name + '/b'], dtype=np.float32)
+            if W.shape != (co, ci, k, k) or b.shape != (co,):
+                raise ValueError('%s: expected W %s b %s, file has %s %s'
+                                 % (name, (co, ci, k, k), (co,), W.shape, b.shape))
+            out[name] = (W, b)
+    return out
+
+
+def save_npz(path, weights):
+    flat = {}
+    for name, (W, b) in weights.items():
+        flat[name + '/W'] = W
+        flat[name + '/b'] = b
+    np.savez(path, **flat)
