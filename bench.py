@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""bench.py -- frames/s of the MI355X-native OpenPose hot path on synthetic 368x368 batches.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, 1 rank/GPU)
+
+A "step" is one pass of the hot path -- PoseDetector.__call__ semantics for every image of one batch:
+uint8 BGR NHWC images already resident in HBM -> fused preprocess -> 92-layer CocoPoseNet (47 fp32-MFMA conv
+launches) -> upsample + Gaussian + NMS peaks -> PAF scoring + greedy matching -> grouping -> result records
+copied to the host (+ for N > 1 the RCCL all_gather of the records).  Weak scaling: every rank processes its
+own batch of `--batch` images (BASELINE.json config "Batch 256 sharded 8 x 32"); value = all images / max-rank time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      the dominant kernel (7x7 128->128 conv, two branch groups per launch): algorithmic FLOP per launch
+                / its average launch duration, measured live with HIP events on the stream the kernels run on
+                (per-launch event pairs inside the timed region), against the dense fp32-MFMA peak (157.3 TFLOP/s,
+                MI355X_MICROARCH.md).  `traffic` (HBM bytes/launch from PMC counters) is filled from
+                profiles/ when a counter pass exists, else null.
+  cpu_baseline  the oracle (torch-CPU fp32 restatement of the network + NumPy restatement of the reference
+                post-process, one image per call as the reference does) timed on this box's host cores, rank 0, N=1
+                only, on a bounded sample of the same workload.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = 'chainer_realtime_multi-person_pose_estimation_amd'
+FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+FLOP_PER_FRAME = 271868013568          # 2 x MACs of the 92 convs at 368 x 368
+DOMINANT_KERNEL = 'conv7x7_t8x16_n128'
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU per step')
+    ap.add_argument('--size', type=int, default=368)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-frames', type=int, default=8)
+    ap.add_argument('--no-profile', action='store_true', help='skip the per-launch HIP events (roofline object null)')
+    ap.add_argument('--dump-profile', default=None, help='write the per-layer table to this JSON file')
+    return ap.parse_args()
+
+
+def cpu_baseline(weights, img, map_hw, frames):
+    """Oracle timed on the host: one image per call, as the reference does (pose_detector.py:430,501)."""
+    import torch
+    from oracle import network_ref, postprocess_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+
+    def one():
+        x = postprocess_ref.preprocess(img)
+        paf, heat = network_ref.forward(weights, x)
+        return postprocess_ref.postprocess_from_net_output(paf[0], heat[0], map_hw[0], map_hw[1])
+    one()                      # warm-up (thread pool, oneDNN primitives)
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        one()
+    dt = time.perf_counter() - t0
+    return {'value': frames / dt, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d frames of the same 368x368 synthetic workload, batch 1 per call, torch-CPU fp32 (oneDNN) '
+                      'network restatement + NumPy restatement of the reference post-process; %.1f s' % (frames, dt)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    import torch
+    import torch.distributed as dist
+    native = importlib.import_module(PKG + '.native')
+    weights_mod = importlib.import_module(PKG + '.weights')
+    dist_mod = importlib.import_module(PKG + '.dist')
+    if native.needs_build():
+        if local_rank == 0:
+            native.build()
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        dist.barrier()
+    dev = torch.device('cuda', local_rank)
+    B, S = a.batch, a.size
+    map_s = 320 if S == 368 else (S * 320) // 368 // 8 * 8
+
+    eng = native.Engine(local_rank, max_batch=B, max_h=S, max_w=S)
+    weights = weights_mod.synthetic_weights(0)
+    eng.set_weights(weights)
+    # calibrate the synthetic head on one fixed image (same on every rank) so the post-process has a COCO-like load
+    cal = np.random.default_rng(1234).integers(0, 256, (1, S, S, 3), dtype=np.uint8)
+    eng.forward_u8(cal)
+    paf, heat = eng.get_maps()
+    weights = weights_mod.calibrate_head(weights, paf[0], heat[0])
+    eng.set_weights({k: weights[k] for k in ('Mconv7_stage6_L1', 'Mconv7_stage6_L2')})
+
+    imgs = np.random.default_rng(1 + rank).integers(0, 256, (B, S, S, 3), dtype=np.uint8)
+    d_imgs = torch.from_numpy(imgs).to(dev)          # inputs resident in HBM before the timed region
+    torch.cuda.synchronize()
+
+    def step():
+        eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(B, S, S), map_h=map_s, map_w=map_s)
+        rec = eng.results()                           # stream sync + D2H of the fixed-size records
+        if world > 1:
+            rec = dist_mod.gather_records(rec, device=dev)     # RCCL all_gather (the only collective)
+        return rec
+
+    for _ in range(a.warmup):
+        rec = step()
+    profile = not a.no_profile
+    if profile:
+        eng.profile_reset()
+        eng.profile_enable(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        rec = step()
+    eng.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    prof = eng.profile() if profile else []
+    if profile:
+        eng.profile_enable(False)
+    if rank == 0:
+        frames = B * world * a.steps
+        ms_per_step = dt / a.steps * 1e3
+        status_bits = int(np.bitwise_or.reduce(rec['status'])) if len(rec) else 0
+        out = {
+            'metric': 'frames/sec at 368x368 batch (1/2/4/8 GPU) + keypoint-match vs reference',
+            'value': frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'batch%d_%dx%d_synthetic_uint8_per_gpu' % (B, S, S), 'per_gpu_batch': B,
+                       'global_batch': B * world, 'map': '%dx%d' % (map_s, map_s), 'weights': 'seeded He + calibrated head',
+                       'parallelism': 'dp%d (independent images, RCCL gather of result records)' % world,
+                       'people_per_frame_mean': float(np.mean(rec['n_people'])) if len(rec) else 0.0,
+                       'peaks_per_frame_mean': float(np.mean(rec['n_peaks'])) if len(rec) else 0.0,
+                       'status_bits': status_bits},
+            'achieved_tflops_whole_net': FLOP_PER_FRAME * (S * S / (368.0 * 368.0)) * frames / dt / 1e12,
+        }
+        roof = None
+        if prof:
+            dom = [p for p in prof if p['kernel'] == DOMINANT_KERNEL and p['layer'].startswith('Mconv')
+                   and not p['layer'].startswith('Mconv1_')]
+            if dom:
+                launches = sum(p['launches'] for p in dom)
+                total_ms = sum(p['total_ms'] for p in dom)
+                flop = dom[0]['flop_per_launch']
+                avg_ms = total_ms / launches
+                ach = flop / (avg_ms * 1e-3) / 1e12
+                roof = {'kernel': DOMINANT_KERNEL, 'bound': 'mfma', 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS,
+                        'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                        'flop_per_launch': flop, 'avg_launch_ms': avg_ms, 'launches_timed': launches,
+                        'note': '7x7 128->128 conv at 46x46, both branch groups per launch, B=%d; HIP events on the launch stream' % B}
+            conv_ms = sum(p['total_ms'] for p in prof if p['kernel'].startswith('conv'))
+            pp_ms = sum(p['total_ms'] for p in prof if p['kernel'].startswith('pp_'))
+            out['kernel_time_ms_per_step'] = {'conv': conv_ms / a.steps, 'postprocess': pp_ms / a.steps}
+            if a.dump_profile:
+                with open(a.dump_profile, 'w') as f:
+                    json.dump({'batch': B, 'steps': a.steps, 'entries': prof}, f, indent=1)
+        out['roofline'] = roof
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(weights, imgs[0], (map_s, map_s), a.cpu_frames)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,294 @@
+// conv_mfma.hip -- im2col-free implicit-GEMM convolution on the fp32 matrix cores of gfx950.
+//
+// Replaces every `L.Convolution2D` (+ `F.relu`, + `F.max_pooling_2d(2,2)`) call of the reference network
+// (models/CocoPoseNet.py:26-129 layer table, :136-260 dataflow): stride 1, zero pad ksize/2, ksize in {1,3,7}.
+//
+//   GEMM view        M = pixels of one (TH x TW) spatial tile, N = BN output channels, K = ks*ks*Cin
+//   matrix core      v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 64 cycles / SIMD, 157.3 TFLOP/s chip peak)
+//   activations      NHWC fp32, channel stride lda/ldc (lets a layer read/write a channel slice of a wider
+//                    buffer, which is how F.concat (CocoPoseNet.py:168) is eliminated)
+//   input panel      (TH+ks-1) x (TW+ks-1) halo tile x CK channels staged once per channel chunk in LDS
+//                    (zero-filled outside the image = the conv's zero padding), re-used by all ks*ks taps
+//   weight panel     per (tap, chunk): BN x CK floats, pre-packed contiguous, double-buffered in LDS,
+//                    next tap's panel prefetched into registers under the current tap's MFMAs
+//   K ordering       one ds_read_b128 gives a lane 4 consecutive channels; lanes 0-31 hold k-half 0 (channels
+//                    c..c+3), lanes 32-63 k-half 1 (c+4..c+7); MFMA step e pairs channel c+e with c+4+e.  The
+//                    same permutation is applied to A (pixels) and B (weights), so the sum over K is unchanged.
+//   M ordering       row m of a 32-row MFMA tile = pixel (2*wy + (m>>1&1), 2*wx + (m&1)) of 2x2 window m>>2, so the
+//                    4 accumulator registers (reg&3) of a lane are one pooling window: the 2x2 max-pool is done
+//                    in registers in the epilogue.
+//   epilogue         + bias, ReLU, optional 2x2 max-pool, masked NHWC store (lanes run along output channels:
+//                    128 B contiguous per half-wave).
+//   grid             x = tiles * batch, y = cout_pad / BN, z = group (the PAF and heat-map branches of a stage
+//                    run as the two groups of one launch).
+#include "pmx_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int KS, int TH, int TW, int BN, int CK, int WM, int WN>
+struct ConvCfg {
+    static constexpr int T = KS * KS;
+    static constexpr int PADK = KS / 2;
+    static constexpr int M = TH * TW;
+    static constexpr int MTILES = M / 32;
+    static constexpr int NTILES = BN / 32;
+    static constexpr int MT = MTILES / WM;   // 32-row tiles per wave
+    static constexpr int NT = NTILES / WN;   // 32-col tiles per wave
+    static constexpr int HALO_H = TH + KS - 1;
+    static constexpr int HALO_W = TW + KS - 1;
+    static constexpr int LDP = CK + 4;       // padded LDS row (floats): breaks the power-of-two stride
+    static constexpr int IN_ELEMS = HALO_H * HALO_W * LDP;
+    static constexpr int W_ELEMS = BN * LDP;
+    static constexpr int LDS_BYTES = (IN_ELEMS + 2 * W_ELEMS) * 4;
+    static constexpr int WREGS = (BN * CK / 4 + 255) / 256;   // float4 per thread per weight panel (1 or 2)
+    static_assert(WM * WN == 4, "4 waves per block");
+    static_assert(M % 32 == 0 && BN % 32 == 0, "tile must be a multiple of the 32x32 MFMA");
+    static_assert(MTILES % WM == 0 && NTILES % WN == 0, "wave grid must divide the tile grid");
+    static_assert(TH % 2 == 0 && TW % 2 == 0, "2x2 window mapping");
+    static_assert(CK % 8 == 0, "k8 steps");
+    static_assert((BN * CK / 4) % 256 == 0 && WREGS <= 2, "weight panel must be 1 or 2 float4 per thread");
+};
+
+template <int KS, int TH, int TW, int BN, int CK, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
+{
+    using C = ConvCfg<KS, TH, TW, BN, CK, WM, WN>;
+    extern __shared__ float4 smem4[];
+    float* const s_in = reinterpret_cast<float*>(smem4);
+    float* const s_w = s_in + C::IN_ELEMS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31;      // row (A) / column (B, C/D) index inside a 32x32 MFMA tile
+    const int kh = lane >> 5;      // k-half
+
+    // select the group's arguments field by field (a dynamic index into the by-value kernarg struct would be
+    // copied to scratch)
+    const bool g1 = blockIdx.z != 0;
+    ConvGroupArgs G;
+    G.in = g1 ? a.g[1].in : a.g[0].in;
+    G.w = g1 ? a.g[1].w : a.g[0].w;
+    G.bias = g1 ? a.g[1].bias : a.g[0].bias;
+    G.out = g1 ? a.g[1].out : a.g[0].out;
+    G.cout = g1 ? a.g[1].cout : a.g[0].cout;
+    const int H = a.H, W = a.W;
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int bimg = blockIdx.x / tiles_per_img;
+    const int trem = blockIdx.x - bimg * tiles_per_img;
+    const int y0 = (trem / a.tiles_x) * TH;
+    const int x0 = (trem % a.tiles_x) * TW;
+    const int n0 = blockIdx.y * BN;
+
+    const float* in_b = G.in + (size_t)bimg * H * W * a.lda;
+
+    // per-lane LDS offsets of the A (pixel) and B (weight) fragments
+    int a_base[C::MT];
+#pragma unroll
+    for (int t = 0; t < C::MT; ++t) {
+        const int m = (wm * C::MT + t) * 32 + li;
+        const int q = m >> 2, r = m & 3;
+        const int wy = q / (TW / 2), wx = q % (TW / 2);
+        const int py = 2 * wy + (r >> 1), px = 2 * wx + (r & 1);
+        a_base[t] = (py * C::HALO_W + px) * C::LDP + kh * 4;
+    }
+    int b_base[C::NT];
+#pragma unroll
+    for (int u = 0; u < C::NT; ++u) b_base[u] = ((wn * C::NT + u) * 32 + li) * C::LDP + kh * 4;
+
+    f32x16 acc[C::MT][C::NT];
+#pragma unroll
+    for (int t = 0; t < C::MT; ++t)
+#pragma unroll
+        for (int u = 0; u < C::NT; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
+
+    // weight panel (tap, chunk) for this block's BN columns: contiguous BN*CK floats
+    const size_t w_panel_stride = (size_t)a.cout_pad * CK;     // floats between consecutive (tap, chunk) panels
+    const float* const w_blk = G.w + (size_t)n0 * CK;
+
+    for (int ch = 0; ch < a.nch; ++ch) {
+        __syncthreads();   // previous chunk's MFMAs are done with s_in / s_w
+        // ---- stage the input halo tile for this channel chunk (zero fill = conv zero padding) ----
+        for (int f = tid; f < C::HALO_H * C::HALO_W * (CK / 4); f += 256) {
+            const int hp = f / (CK / 4), c4 = f % (CK / 4);
+            const int hy = hp / C::HALO_W, hx = hp - hy * C::HALO_W;
+            const int gy = y0 + hy - C::PADK, gx = x0 + hx - C::PADK;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+                v = *reinterpret_cast<const float4*>(in_b + ((size_t)gy * W + gx) * a.lda + ch * CK + c4 * 4);
+            *reinterpret_cast<float4*>(&s_in[hp * C::LDP + c4 * 4]) = v;
+        }
+        // ---- stage tap 0's weight panel ----
+        {
+            const float* wp = w_blk + (size_t)ch * w_panel_stride;     // tap 0
+#pragma unroll
+            for (int r = 0; r < C::WREGS; ++r) {
+                const int f = tid + r * 256;
+                const int n = f / (CK / 4), c4 = f % (CK / 4);
+                const float4 v = *reinterpret_cast<const float4*>(wp + (size_t)f * 4);
+                *reinterpret_cast<float4*>(&s_w[n * C::LDP + c4 * 4]) = v;
+            }
+        }
+        __syncthreads();
+
+#pragma unroll 1
+        for (int tap = 0; tap < C::T; ++tap) {
+            // prefetch the next tap's weight panel into registers (lands under this tap's MFMAs)
+            float4 wr0, wr1;      // named registers (a small array here ends up in scratch)
+            {
+                // Unconditional loads, store and barrier (the last tap re-reads its own panel into the idle
+                // buffer): with a conditional use the compiler sinks the loads below the MFMAs and the L2 latency
+                // is exposed every tap.
+                const int tn = (tap + 1 < C::T) ? tap + 1 : tap;
+                const float* wp = w_blk + ((size_t)tn * a.nch + ch) * w_panel_stride;
+                wr0 = *reinterpret_cast<const float4*>(wp + (size_t)tid * 4);
+                if constexpr (C::WREGS > 1) wr1 = *reinterpret_cast<const float4*>(wp + (size_t)(tid + 256) * 4);
+                else wr1 = wr0;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const float* sw = s_w + (tap & 1) * C::W_ELEMS;
+            const int ky = tap / KS, kx = tap - ky * KS;
+            const int tapoff = (ky * C::HALO_W + kx) * C::LDP;
+#pragma unroll
+            for (int s = 0; s < CK / 8; ++s) {
+                float4 av[C::MT], bv[C::NT];
+#pragma unroll
+                for (int t = 0; t < C::MT; ++t)
+                    av[t] = *reinterpret_cast<const float4*>(&s_in[a_base[t] + tapoff + s * 8]);
+#pragma unroll
+                for (int u = 0; u < C::NT; ++u)
+                    bv[u] = *reinterpret_cast<const float4*>(&sw[b_base[u] + s * 8]);
+#pragma unroll
+                for (int t = 0; t < C::MT; ++t)
+#pragma unroll
+                    for (int u = 0; u < C::NT; ++u) {
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].x, bv[u].x, acc[t][u], 0, 0, 0);
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].y, bv[u].y, acc[t][u], 0, 0, 0);
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].z, bv[u].z, acc[t][u], 0, 0, 0);
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].w, bv[u].w, acc[t][u], 0, 0, 0);
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the wait for the prefetched panel behind this tap's MFMAs
+            {
+                float* swn = s_w + ((tap + 1) & 1) * C::W_ELEMS;
+                {
+                    const int n = tid / (CK / 4), c4 = tid % (CK / 4);
+                    *reinterpret_cast<float4*>(&swn[n * C::LDP + c4 * 4]) = wr0;
+                }
+                if constexpr (C::WREGS > 1) {
+                    const int f = tid + 256;
+                    const int n = f / (CK / 4), c4 = f % (CK / 4);
+                    *reinterpret_cast<float4*>(&swn[n * C::LDP + c4 * 4]) = wr1;
+                }
+                __syncthreads();   // next panel visible; everyone done reading the buffer it will replace next
+            }
+        }
+    }
+
+    // ---- epilogue: bias + ReLU (+ 2x2 max-pool) + masked NHWC store ----
+    // C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+#pragma unroll
+    for (int t = 0; t < C::MT; ++t) {
+#pragma unroll
+        for (int u = 0; u < C::NT; ++u) {
+            const int n = n0 + (wn * C::NT + u) * 32 + li;
+            const bool nok = n < G.cout;
+            const float bias = G.bias[n];      // bias is padded to cout_pad
+            if (!a.pool) {
+                float* out_b = G.out + (size_t)bimg * H * W * a.ldc;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                    const int m = (wm * C::MT + t) * 32 + row;
+                    const int q = m >> 2, r = m & 3;
+                    const int wy = q / (TW / 2), wx = q % (TW / 2);
+                    const int gy = y0 + 2 * wy + (r >> 1), gx = x0 + 2 * wx + (r & 1);
+                    float v = acc[t][u][reg] + bias;
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (nok && gy < H && gx < W) out_b[((size_t)gy * W + gx) * a.ldc + n] = v;
+                }
+            } else {
+                const int Hp = H >> 1, Wp = W >> 1;
+                float* out_b = G.out + (size_t)bimg * Hp * Wp * a.ldc;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float v = fmaxf(fmaxf(acc[t][u][4 * g4 + 0], acc[t][u][4 * g4 + 1]),
+                                    fmaxf(acc[t][u][4 * g4 + 2], acc[t][u][4 * g4 + 3]));
+                    v += bias;
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    const int q = (wm * C::MT + t) * 8 + 2 * g4 + kh;
+                    const int wy = q / (TW / 2), wx = q % (TW / 2);
+                    const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
+                    if (nok && oy < Hp && ox < Wp) out_b[((size_t)oy * Wp + ox) * a.ldc + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---- variant table ---------------------------------------------------------------------------------------
+static const ConvVariant g_variants[] = {
+    {7, 8, 16, 128, 16, "conv7x7_t8x16_n128"},    // 0: stages 2-6, the dominant kernel
+    {3, 8, 16, 128, 16, "conv3x3_t8x16_n128"},    // 1
+    {3, 8, 16, 64, 16, "conv3x3_t8x16_n64"},      // 2
+    {1, 8, 16, 128, 16, "conv1x1_t8x16_n128"},    // 3
+    {1, 8, 16, 64, 16, "conv1x1_t8x16_n64"},      // 4
+    {7, 8, 8, 64, 16, "conv7x7_t8x8_n64"},        // 5: small batches (more blocks)
+    {3, 8, 8, 64, 16, "conv3x3_t8x8_n64"},        // 6
+    {1, 8, 8, 64, 16, "conv1x1_t8x8_n64"},        // 7
+};
+
+int conv_num_variants() { return (int)(sizeof(g_variants) / sizeof(g_variants[0])); }
+const ConvVariant& conv_variant(int idx) { return g_variants[idx]; }
+
+int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced)
+{
+    if (forced >= 0 && forced < conv_num_variants() && g_variants[forced].ks == ks) return forced;
+    // enough 8x16 tiles to fill 256 CUs a few times over?  otherwise use the small tiles
+    const long tiles816 = (long)((H + 7) / 8) * ((W + 15) / 16) * B;
+    const bool small = tiles816 * ((cout + 127) / 128) < 512;
+    if (ks == 7) return small ? 5 : 0;
+    if (ks == 3) return small ? 6 : (cout <= 64 ? 2 : 1);
+    return small ? 7 : (cout <= 64 ? 4 : 3);
+}
+
+template <int KS, int TH, int TW, int BN, int CK, int WM, int WN>
+static int launch_cfg(const ConvArgs& a0, int groups, hipStream_t stream)
+{
+    using C = ConvCfg<KS, TH, TW, BN, CK, WM, WN>;
+    ConvArgs a = a0;
+    a.tiles_x = (a.W + TW - 1) / TW;
+    a.tiles_y = (a.H + TH - 1) / TH;
+    PMX_CHECK(a.cout_pad % BN == 0, PMX_ERR_INVALID, "conv: cout_pad %d not a multiple of BN %d", a.cout_pad, BN);
+    PMX_CHECK(!a.pool || (a.H % 2 == 0 && a.W % 2 == 0), PMX_ERR_INVALID, "conv: pooled layer needs even H, W");
+    auto kern = conv_mfma_kernel<KS, TH, TW, BN, CK, WM, WN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / BN), (unsigned)groups);
+    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, a);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream)
+{
+    switch (variant) {
+        case 0: return launch_cfg<7, 8, 16, 128, 16, 2, 2>(a, groups, stream);
+        case 1: return launch_cfg<3, 8, 16, 128, 16, 2, 2>(a, groups, stream);
+        case 2: return launch_cfg<3, 8, 16, 64, 16, 4, 1>(a, groups, stream);
+        case 3: return launch_cfg<1, 8, 16, 128, 16, 2, 2>(a, groups, stream);
+        case 4: return launch_cfg<1, 8, 16, 64, 16, 4, 1>(a, groups, stream);
+        case 5: return launch_cfg<7, 8, 8, 64, 16, 2, 2>(a, groups, stream);
+        case 6: return launch_cfg<3, 8, 8, 64, 16, 2, 2>(a, groups, stream);
+        case 7: return launch_cfg<1, 8, 8, 64, 16, 2, 2>(a, groups, stream);
+    }
+    pmx_set_error("conv_launch: unknown variant %d", variant);
+    return PMX_ERR_INVALID;
+}

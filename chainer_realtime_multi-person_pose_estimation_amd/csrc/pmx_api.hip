@@ -1,0 +1,907 @@
+// pmx_api.hip -- C ABI of libpose_mi355x (include/pose_mi355x.h): context, weights, forward plan, accessors.
+//
+// Forward plan = models/CocoPoseNet.py:132-262 expressed as 47 convolution launches on NHWC buffers:
+//   stem (12 launches; the three F.max_pooling_2d are fused into the epilogues of conv1_2, conv2_2, conv3_4),
+//   stage 1 (5 launches) and stages 2-6 (7 launches each); the PAF branch (L1) and the heat-map branch (L2)
+//   of a stage are the two groups (blockIdx.z) of one launch; F.concat (:168,...) is replaced by channel-slice
+//   writes into the 192-channel "cat" buffer (layout in pmx_common.h).
+#include "pmx_common.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <map>
+
+// ------------------------------------------------------------------------------------------- errors
+static thread_local char g_err[1024] = "";
+void pmx_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* pmx_last_error(void) { return g_err; }
+extern "C" const char* pmx_version(void) { return "pose_mi355x 0.1 (gfx950, fp32 MFMA)"; }
+
+extern "C" int pmx_device_count(int* n)
+{
+    PMX_CHECK(n, PMX_ERR_INVALID, "pmx_device_count: null");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { (void)hipGetLastError(); c = 0; }
+    *n = c;
+    return PMX_OK;
+}
+
+// -------------------------------------------------------------------------------------- layer table
+struct LayerDesc { std::string name; int cin, cout, ks; };
+
+static std::vector<LayerDesc> make_layer_table()   // models/CocoPoseNet.py:26-129
+{
+    std::vector<LayerDesc> t = {
+        {"conv1_1", 3, 64, 3}, {"conv1_2", 64, 64, 3}, {"conv2_1", 64, 128, 3}, {"conv2_2", 128, 128, 3},
+        {"conv3_1", 128, 256, 3}, {"conv3_2", 256, 256, 3}, {"conv3_3", 256, 256, 3}, {"conv3_4", 256, 256, 3},
+        {"conv4_1", 256, 512, 3}, {"conv4_2", 512, 512, 3}, {"conv4_3_CPM", 512, 256, 3}, {"conv4_4_CPM", 256, 128, 3}};
+    const char* br[2] = {"L1", "L2"};
+    const int bco[2] = {38, 19};
+    char buf[64];
+    for (int g = 0; g < 2; ++g) {
+        for (int i = 1; i <= 3; ++i) { snprintf(buf, sizeof buf, "conv5_%d_CPM_%s", i, br[g]); t.push_back({buf, 128, 128, 3}); }
+        snprintf(buf, sizeof buf, "conv5_4_CPM_%s", br[g]); t.push_back({buf, 128, 512, 1});
+        snprintf(buf, sizeof buf, "conv5_5_CPM_%s", br[g]); t.push_back({buf, 512, bco[g], 1});
+    }
+    for (int s = 2; s <= 6; ++s)
+        for (int g = 0; g < 2; ++g) {
+            snprintf(buf, sizeof buf, "Mconv1_stage%d_%s", s, br[g]); t.push_back({buf, 185, 128, 7});
+            for (int i = 2; i <= 5; ++i) { snprintf(buf, sizeof buf, "Mconv%d_stage%d_%s", i, s, br[g]); t.push_back({buf, 128, 128, 7}); }
+            snprintf(buf, sizeof buf, "Mconv6_stage%d_%s", s, br[g]); t.push_back({buf, 128, 128, 1});
+            snprintf(buf, sizeof buf, "Mconv7_stage%d_%s", s, br[g]); t.push_back({buf, 128, bco[g], 1});
+        }
+    return t;
+}
+
+static const int CK = 16;   // channel chunk of every kernel variant
+
+struct PackedLayer {
+    bool set = false;
+    float* d_w = nullptr;
+    float* d_b = nullptr;
+    int cin = 0, cout = 0, ks = 0, cin_pad = 0, cout_pad = 0, nch = 0;
+};
+
+static int cout_pad_of(int cout) { return cout <= 64 ? 64 : round_up(cout, 128); }
+
+// pack OIHW -> [tap][chunk][cout_pad][CK]; cin_map[k] = source input channel of packed channel k (or -1 = zero)
+static void pack_weights(const float* w, const float* bias, int cout, int cin, int ks, const std::vector<int>& cin_map,
+                         int cout_pad, std::vector<float>& wp, std::vector<float>& bp)
+{
+    const int cin_pad = (int)cin_map.size(), nch = cin_pad / CK, T = ks * ks;
+    wp.assign((size_t)T * nch * cout_pad * CK, 0.f);
+    bp.assign((size_t)cout_pad, 0.f);
+    for (int n = 0; n < cout; ++n) bp[n] = bias ? bias[n] : 0.f;
+    for (int tap = 0; tap < T; ++tap)
+        for (int k = 0; k < cin_pad; ++k) {
+            const int src = cin_map[k];
+            if (src < 0) continue;
+            const int ch = k / CK, c = k % CK;
+            for (int n = 0; n < cout; ++n)
+                wp[(((size_t)tap * nch + ch) * cout_pad + n) * CK + c] = w[((size_t)n * cin + src) * T + tap];
+        }
+}
+
+static std::vector<int> identity_map(int cin)
+{
+    std::vector<int> m(round_up(cin, CK), -1);
+    for (int i = 0; i < cin; ++i) m[i] = i;
+    return m;
+}
+
+// F.concat((h1, h2, feature_map)) channel c of the reference (0..37 PAF, 38..56 heat, 57..184 feature) lives at
+// cat-buffer channel: feature -> 0..127, PAF -> 128..165, heat -> 168..186
+static std::vector<int> concat_map()
+{
+    std::vector<int> m(PMX_CAT_C, -1);
+    for (int i = 0; i < 128; ++i) m[PMX_CAT_FEAT + i] = 57 + i;
+    for (int i = 0; i < 38; ++i) m[PMX_CAT_PAF + i] = i;
+    for (int i = 0; i < 19; ++i) m[PMX_CAT_HEAT + i] = 38 + i;
+    return m;
+}
+
+// ------------------------------------------------------------------------------------------ profiler
+struct ProfEntry {
+    std::string name;
+    double total_ms = 0;
+    int64_t launches = 0;
+    double flops = 0, bytes = 0;   // per launch
+};
+struct ProfPending { int entry; hipEvent_t e0, e1; };
+
+// ------------------------------------------------------------------------------------------- context
+struct pmx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr, own_stream = nullptr;
+    int max_batch = 0, max_h = 0, max_w = 0;
+    std::vector<LayerDesc> table;
+    std::map<std::string, int> index;
+    std::vector<PackedLayer> layers;
+    // buffers
+    float *in16 = nullptr, *act0 = nullptr, *act1 = nullptr, *cat = nullptr, *brA = nullptr, *brB = nullptr, *brT = nullptr;
+    float* nchw_tmp = nullptr;       // staging for NCHW host <-> NHWC device conversions
+    size_t nchw_tmp_bytes = 0;
+    uint8_t* u8_tmp = nullptr;
+    // state of the last forward / set_maps
+    bool maps_valid = false, maps_external = false;
+    int cur_B = 0, cur_fh = 0, cur_fw = 0;
+    float *ext_paf = nullptr, *ext_heat = nullptr;   // NCHW copies installed by pmx_set_maps
+    size_t ext_cap = 0;
+    // post-process
+    PPTables tab{};
+    int tab_cap = 0;
+    int tab_in_h = -1, tab_in_w = -1, tab_out_h = -1, tab_out_w = -1;
+    std::vector<double> gauss;
+    PPBuffers pp{};
+    double* d_scale = nullptr;
+    bool pp_valid = false;
+    int pp_B = 0, pp_h = 0, pp_w = 0;
+    size_t smoothed_cap = 0;
+    // options
+    int opt_force[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // by ksize
+    int opt_keep_smoothed = 0, opt_stop_stage = 6;
+    // timing / profiling
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool prof_on = false;
+    std::vector<ProfEntry> prof;
+    std::map<std::string, int> prof_index;
+    std::vector<ProfPending> pending;
+    int prof_open = -1;
+};
+
+static int prof_begin(pmx_ctx* c, const std::string& name, double flops, double bytes)
+{
+    if (!c->prof_on) return PMX_OK;
+    int idx;
+    auto it = c->prof_index.find(name);
+    if (it == c->prof_index.end()) {
+        idx = (int)c->prof.size();
+        ProfEntry e; e.name = name; e.flops = flops; e.bytes = bytes;
+        c->prof.push_back(e);
+        c->prof_index[name] = idx;
+    } else idx = it->second;
+    ProfPending p; p.entry = idx;
+    PMX_HIP(hipEventCreate(&p.e0));
+    PMX_HIP(hipEventCreate(&p.e1));
+    PMX_HIP(hipEventRecord(p.e0, c->stream));
+    c->pending.push_back(p);
+    c->prof_open = (int)c->pending.size() - 1;
+    return PMX_OK;
+}
+static int prof_end(pmx_ctx* c)
+{
+    if (!c->prof_on || c->prof_open < 0) return PMX_OK;
+    PMX_HIP(hipEventRecord(c->pending[c->prof_open].e1, c->stream));
+    c->prof_open = -1;
+    return PMX_OK;
+}
+static int prof_collect(pmx_ctx* c)
+{
+    if (c->pending.empty()) return PMX_OK;
+    PMX_HIP(hipStreamSynchronize(c->stream));
+    for (auto& p : c->pending) {
+        float ms = 0.f;
+        PMX_HIP(hipEventElapsedTime(&ms, p.e0, p.e1));
+        c->prof[p.entry].total_ms += ms;
+        c->prof[p.entry].launches += 1;
+        (void)hipEventDestroy(p.e0);
+        (void)hipEventDestroy(p.e1);
+    }
+    c->pending.clear();
+    return PMX_OK;
+}
+static void pp_prof_cb(void* vc, const char* name, int begin)
+{
+    pmx_ctx* c = (pmx_ctx*)vc;
+    if (begin) (void)prof_begin(c, std::string(name) + "|" + name, 0, 0);
+    else (void)prof_end(c);
+}
+
+#define PMX_DEV(c) PMX_HIP(hipSetDevice((c)->device))
+
+template <typename T>
+static int dev_alloc(T** p, size_t count)
+{
+    PMX_HIP(hipMalloc((void**)p, count * sizeof(T) ? count * sizeof(T) : 16));
+    return PMX_OK;
+}
+
+extern "C" int pmx_create(pmx_ctx** out, int device, int max_batch, int max_h, int max_w)
+{
+    PMX_CHECK(out, PMX_ERR_INVALID, "pmx_create: null out");
+    *out = nullptr;
+    PMX_CHECK(max_batch >= 1 && max_h >= 8 && max_w >= 8 && max_h % 8 == 0 && max_w % 8 == 0, PMX_ERR_INVALID,
+              "pmx_create: max_batch >= 1 and max_h/max_w positive multiples of 8 required (got %d, %d, %d)", max_batch, max_h, max_w);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        pmx_set_error("pmx_create: no HIP device visible (this library has no CPU fallback)");
+        return PMX_ERR_NO_DEVICE;
+    }
+    PMX_CHECK(device >= 0 && device < ndev, PMX_ERR_NO_DEVICE, "pmx_create: device %d out of range (%d devices)", device, ndev);
+    hipDeviceProp_t prop;
+    PMX_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        pmx_set_error("pmx_create: device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+        return PMX_ERR_NO_DEVICE;
+    }
+    PMX_HIP(hipSetDevice(device));
+    pmx_ctx* c = new pmx_ctx();
+    c->device = device;
+    c->max_batch = max_batch; c->max_h = max_h; c->max_w = max_w;
+    c->table = make_layer_table();
+    c->layers.resize(c->table.size());
+    for (size_t i = 0; i < c->table.size(); ++i) c->index[c->table[i].name] = (int)i;
+    PMX_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    PMX_HIP(hipEventCreate(&c->t0));
+    PMX_HIP(hipEventCreate(&c->t1));
+
+    const size_t B = max_batch, HW = (size_t)max_h * max_w, hw8 = HW / 64;
+    int rc;
+    if ((rc = dev_alloc(&c->in16, B * HW * PMX_IN_C))) return rc;
+    if ((rc = dev_alloc(&c->act0, B * HW * 64))) return rc;      // conv1_1 out is the largest activation
+    if ((rc = dev_alloc(&c->act1, B * HW * 16))) return rc;      // (H/2)(W/2) x 64 = (H/4)(W/4) x 256
+    if ((rc = dev_alloc(&c->cat, B * hw8 * PMX_CAT_C))) return rc;
+    if ((rc = dev_alloc(&c->brA, B * hw8 * 256))) return rc;
+    if ((rc = dev_alloc(&c->brB, B * hw8 * 256))) return rc;
+    if ((rc = dev_alloc(&c->brT, B * hw8 * 1024))) return rc;
+    PMX_HIP(hipMemset(c->cat, 0, B * hw8 * PMX_CAT_C * sizeof(float)));   // pad channels stay zero forever
+    c->nchw_tmp_bytes = B * HW * 3 * sizeof(float);
+    if (c->nchw_tmp_bytes < B * hw8 * 57 * sizeof(float)) c->nchw_tmp_bytes = B * hw8 * 57 * sizeof(float);
+    PMX_HIP(hipMalloc((void**)&c->nchw_tmp, c->nchw_tmp_bytes));
+    PMX_HIP(hipMalloc((void**)&c->u8_tmp, B * HW * 3));
+
+    // post-process buffers
+    PPBuffers& p = c->pp;
+    if ((rc = dev_alloc(&p.pk_raw_key, B * PMX_MAX_PEAKS))) return rc;
+    if ((rc = dev_alloc(&p.pk_raw_score, B * PMX_MAX_PEAKS))) return rc;
+    if ((rc = dev_alloc(&p.pk_count, B * PMX_N_JOINTS))) return rc;
+    if ((rc = dev_alloc(&p.pk_x, B * PMX_MAX_PEAKS))) return rc;
+    if ((rc = dev_alloc(&p.pk_y, B * PMX_MAX_PEAKS))) return rc;
+    if ((rc = dev_alloc(&p.pk_score, B * PMX_MAX_PEAKS))) return rc;
+    if ((rc = dev_alloc(&p.pk_start, B * (PMX_N_JOINTS + 1)))) return rc;
+    if ((rc = dev_alloc(&p.cn_a, B * PMX_N_LIMBS * PMX_MAX_PEAKS_PER_JOINT))) return rc;
+    if ((rc = dev_alloc(&p.cn_b, B * PMX_N_LIMBS * PMX_MAX_PEAKS_PER_JOINT))) return rc;
+    if ((rc = dev_alloc(&p.cn_score, B * PMX_N_LIMBS * PMX_MAX_PEAKS_PER_JOINT))) return rc;
+    if ((rc = dev_alloc(&p.cn_count, B * PMX_N_LIMBS))) return rc;
+    if ((rc = dev_alloc(&p.subsets, B * PMX_MAX_SUBSETS * 20))) return rc;
+    if ((rc = dev_alloc(&p.status, B))) return rc;
+    if ((rc = dev_alloc(&p.results, B))) return rc;
+    if ((rc = dev_alloc(&c->d_scale, B * 2))) return rc;
+    p.smoothed = nullptr;
+
+    // default Gaussian taps (sigma 2.5 -> radius 10); the Python binding overrides them with NumPy's values
+    {
+        const int r = (int)(4.0 * PMX_GAUSS_SIGMA + 0.5);
+        std::vector<double> g(2 * r + 1);
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = -r; i <= r; ++i) g[i + r] = exp(-0.5 / (PMX_GAUSS_SIGMA * PMX_GAUSS_SIGMA) * (double)(i * i));
+        // NumPy pairwise-sum order for n = 21: 8 running accumulators over the first 16, then the tail
+        for (int j = 0; j < 8; ++j) acc[j] = g[j];
+        for (int j = 0; j < 8; ++j) acc[j] += g[8 + j];
+        double s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        for (int i = 16; i < 2 * r + 1; ++i) s += g[i];
+        for (auto& v : g) v /= s;
+        c->gauss = g;
+    }
+    *out = c;
+    return PMX_OK;
+}
+
+extern "C" void pmx_destroy(pmx_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto& l : c->layers) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); }
+    void* ptrs[] = {c->in16, c->act0, c->act1, c->cat, c->brA, c->brB, c->brT, c->nchw_tmp, c->u8_tmp, c->ext_paf, c->ext_heat,
+                    c->pp.pk_raw_key, c->pp.pk_raw_score, c->pp.pk_count, c->pp.pk_x, c->pp.pk_y, c->pp.pk_score, c->pp.pk_start,
+                    c->pp.cn_a, c->pp.cn_b, c->pp.cn_score, c->pp.cn_count, c->pp.subsets, c->pp.status, c->pp.results,
+                    c->pp.smoothed, c->d_scale, c->tab.xi0, c->tab.xi1, c->tab.xlo, c->tab.xhi, c->tab.yi0, c->tab.yi1,
+                    c->tab.ylo, c->tab.yhi, c->tab.gauss};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& p : c->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
+    if (c->t0) (void)hipEventDestroy(c->t0);
+    if (c->t1) (void)hipEventDestroy(c->t1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+extern "C" int pmx_set_stream(pmx_ctx* c, void* s)
+{
+    PMX_CHECK(c, PMX_ERR_INVALID, "null ctx");
+    PMX_DEV(c);
+    PMX_HIP(hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return PMX_OK;
+}
+
+extern "C" int pmx_synchronize(pmx_ctx* c)
+{
+    PMX_CHECK(c, PMX_ERR_INVALID, "null ctx");
+    PMX_DEV(c);
+    PMX_HIP(hipStreamSynchronize(c->stream));
+    return PMX_OK;
+}
+
+extern "C" int pmx_set_option(pmx_ctx* c, const char* key, int value)
+{
+    PMX_CHECK(c && key, PMX_ERR_INVALID, "null arg");
+    if (!strcmp(key, "force_variant_k7")) c->opt_force[7] = value;
+    else if (!strcmp(key, "force_variant_k3")) c->opt_force[3] = value;
+    else if (!strcmp(key, "force_variant_k1")) c->opt_force[1] = value;
+    else if (!strcmp(key, "keep_smoothed")) c->opt_keep_smoothed = value;
+    else if (!strcmp(key, "stop_stage")) c->opt_stop_stage = value;
+    else { pmx_set_error("pmx_set_option: unknown key '%s'", key); return PMX_ERR_INVALID; }
+    return PMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------ weights
+extern "C" int pmx_set_layer(pmx_ctx* c, const char* name, const float* w, const float* bias, int cout, int cin, int ks)
+{
+    PMX_CHECK(c && name && w, PMX_ERR_INVALID, "pmx_set_layer: null arg");
+    PMX_DEV(c);
+    auto it = c->index.find(name);
+    PMX_CHECK(it != c->index.end(), PMX_ERR_WEIGHTS, "pmx_set_layer: unknown layer '%s'", name);
+    const LayerDesc& d = c->table[it->second];
+    PMX_CHECK(d.cin == cin && d.cout == cout && d.ks == ks, PMX_ERR_WEIGHTS,
+              "pmx_set_layer: '%s' expects (cout %d, cin %d, k %d), got (%d, %d, %d)", name, d.cout, d.cin, d.ks, cout, cin, ks);
+    PackedLayer& L = c->layers[it->second];
+    std::vector<int> cmap = (cin == 185) ? concat_map() : identity_map(cin);
+    std::vector<float> wp, bp;
+    const int cpad = cout_pad_of(cout);
+    pack_weights(w, bias, cout, cin, ks, cmap, cpad, wp, bp);
+    PMX_HIP(hipStreamSynchronize(c->stream));     // layer may be in use by queued work
+    if (!L.d_w) PMX_HIP(hipMalloc((void**)&L.d_w, wp.size() * sizeof(float)));
+    if (!L.d_b) PMX_HIP(hipMalloc((void**)&L.d_b, bp.size() * sizeof(float)));
+    PMX_HIP(hipMemcpy(L.d_w, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice));
+    PMX_HIP(hipMemcpy(L.d_b, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
+    L.set = true; L.cin = cin; L.cout = cout; L.ks = ks;
+    L.cin_pad = (int)cmap.size(); L.cout_pad = cpad; L.nch = L.cin_pad / CK;
+    return PMX_OK;
+}
+
+extern "C" int pmx_weights_missing(pmx_ctx* c, int* n)
+{
+    PMX_CHECK(c && n, PMX_ERR_INVALID, "null arg");
+    int m = 0;
+    for (auto& l : c->layers) m += l.set ? 0 : 1;
+    *n = m;
+    return PMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------ forward
+struct ConvIO { const float* in; int lda; float* out; int ldc; };
+
+// one launch of 1 or 2 groups (same geometry); in/out pointers are already offset to the group's channels
+static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float* in0, const float* in1, int lda,
+                    float* out0, float* out1, int ldc, int B, int H, int W, int relu, int pool)
+{
+    const PackedLayer& L0 = c->layers[li0];
+    const int groups = li1 >= 0 ? 2 : 1;
+    ConvArgs a;
+    memset(&a, 0, sizeof a);
+    a.g[0].in = in0; a.g[0].w = L0.d_w; a.g[0].bias = L0.d_b; a.g[0].out = out0; a.g[0].cout = L0.cout;
+    double flops = 2.0 * B * H * W * (double)L0.cout * L0.cin * L0.ks * L0.ks;
+    if (groups == 2) {
+        const PackedLayer& L1 = c->layers[li1];
+        a.g[1].in = in1; a.g[1].w = L1.d_w; a.g[1].bias = L1.d_b; a.g[1].out = out1; a.g[1].cout = L1.cout;
+        flops += 2.0 * B * H * W * (double)L1.cout * L1.cin * L1.ks * L1.ks;
+    }
+    a.B = B; a.H = H; a.W = W; a.lda = lda; a.ldc = ldc; a.nch = L0.nch; a.cout_pad = L0.cout_pad;
+    a.relu = relu; a.pool = pool;
+    const int v = conv_pick_variant(L0.ks, L0.cout_pad, H, W, B * groups, c->opt_force[L0.ks]);
+    int rc;
+    if (c->prof_on) {
+        const double bytes = 4.0 * B * H * W * ((double)L0.cin * groups + (double)L0.cout * groups / (pool ? 4 : 1));
+        if ((rc = prof_begin(c, std::string(label) + "|" + conv_variant(v).name, flops, bytes))) return rc;
+    }
+    if ((rc = conv_launch(v, a, groups, c->stream))) return rc;
+    return prof_end(c);
+}
+
+static int forward_from_in16(pmx_ctx* c, int B, int H, int W)
+{
+    auto id = [&](const char* n) { return c->index.at(n); };
+    int rc;
+    const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
+#define RUN(...) do { if ((rc = run_conv(c, __VA_ARGS__))) return rc; } while (0)
+    // stem (CocoPoseNet.py:136-151)
+    RUN("conv1_1", id("conv1_1"), -1, c->in16, nullptr, PMX_IN_C, c->act0, nullptr, 64, B, H, W, 1, 0);
+    RUN("conv1_2", id("conv1_2"), -1, c->act0, nullptr, 64, c->act1, nullptr, 64, B, H, W, 1, 1);
+    RUN("conv2_1", id("conv2_1"), -1, c->act1, nullptr, 64, c->act0, nullptr, 128, B, H2, W2, 1, 0);
+    RUN("conv2_2", id("conv2_2"), -1, c->act0, nullptr, 128, c->act1, nullptr, 128, B, H2, W2, 1, 1);
+    RUN("conv3_1", id("conv3_1"), -1, c->act1, nullptr, 128, c->act0, nullptr, 256, B, H4, W4, 1, 0);
+    RUN("conv3_2", id("conv3_2"), -1, c->act0, nullptr, 256, c->act1, nullptr, 256, B, H4, W4, 1, 0);
+    RUN("conv3_3", id("conv3_3"), -1, c->act1, nullptr, 256, c->act0, nullptr, 256, B, H4, W4, 1, 0);
+    RUN("conv3_4", id("conv3_4"), -1, c->act0, nullptr, 256, c->act1, nullptr, 256, B, H4, W4, 1, 1);
+    RUN("conv4_1", id("conv4_1"), -1, c->act1, nullptr, 256, c->act0, nullptr, 512, B, H8, W8, 1, 0);
+    RUN("conv4_2", id("conv4_2"), -1, c->act0, nullptr, 512, c->act1, nullptr, 512, B, H8, W8, 1, 0);
+    RUN("conv4_3_CPM", id("conv4_3_CPM"), -1, c->act1, nullptr, 512, c->act0, nullptr, 256, B, H8, W8, 1, 0);
+    RUN("conv4_4_CPM", id("conv4_4_CPM"), -1, c->act0, nullptr, 256, c->cat + PMX_CAT_FEAT, nullptr, PMX_CAT_C, B, H8, W8, 1, 0);
+    // stage 1 (CocoPoseNet.py:154-165); L1 = PAF branch, L2 = heat-map branch
+    float* cat = c->cat;
+    RUN("conv5_1_CPM", id("conv5_1_CPM_L1"), id("conv5_1_CPM_L2"), cat, cat, PMX_CAT_C, c->brA, c->brA + 128, 256, B, H8, W8, 1, 0);
+    RUN("conv5_2_CPM", id("conv5_2_CPM_L1"), id("conv5_2_CPM_L2"), c->brA, c->brA + 128, 256, c->brB, c->brB + 128, 256, B, H8, W8, 1, 0);
+    RUN("conv5_3_CPM", id("conv5_3_CPM_L1"), id("conv5_3_CPM_L2"), c->brB, c->brB + 128, 256, c->brA, c->brA + 128, 256, B, H8, W8, 1, 0);
+    RUN("conv5_4_CPM", id("conv5_4_CPM_L1"), id("conv5_4_CPM_L2"), c->brA, c->brA + 128, 256, c->brT, c->brT + 512, 1024, B, H8, W8, 1, 0);
+    RUN("conv5_5_CPM", id("conv5_5_CPM_L1"), id("conv5_5_CPM_L2"), c->brT, c->brT + 512, 1024, cat + PMX_CAT_PAF, cat + PMX_CAT_HEAT,
+        PMX_CAT_C, B, H8, W8, 0, 0);
+    // stages 2-6 (CocoPoseNet.py:168-260)
+    char n1[48], n2[48], lab[48];
+    for (int s = 2; s <= 6 && s <= c->opt_stop_stage; ++s) {
+        for (int i = 1; i <= 7; ++i) {
+            snprintf(n1, sizeof n1, "Mconv%d_stage%d_L1", i, s);
+            snprintf(n2, sizeof n2, "Mconv%d_stage%d_L2", i, s);
+            snprintf(lab, sizeof lab, "Mconv%d_stage%d", i, s);
+            const float *in0, *in1; float *o0, *o1; int lda, ldc;
+            if (i == 1) { in0 = cat; in1 = cat; lda = PMX_CAT_C; }
+            else if (i % 2 == 0) { in0 = c->brA; in1 = c->brA + 128; lda = 256; }
+            else { in0 = c->brB; in1 = c->brB + 128; lda = 256; }
+            if (i == 7) { o0 = cat + PMX_CAT_PAF; o1 = cat + PMX_CAT_HEAT; ldc = PMX_CAT_C; }
+            else if (i % 2 == 1) { o0 = c->brA; o1 = c->brA + 128; ldc = 256; }
+            else { o0 = c->brB; o1 = c->brB + 128; ldc = 256; }
+            RUN(lab, id(n1), id(n2), in0, in1, lda, o0, o1, ldc, B, H8, W8, i == 7 ? 0 : 1, 0);
+        }
+    }
+#undef RUN
+    c->maps_valid = true; c->maps_external = false;
+    c->cur_B = B; c->cur_fh = H8; c->cur_fw = W8;
+    c->pp_valid = false;
+    return PMX_OK;
+}
+
+static int check_forward_args(pmx_ctx* c, const void* p, int B, int H, int W)
+{
+    PMX_CHECK(c && p, PMX_ERR_INVALID, "forward: null arg");
+    PMX_CHECK(B >= 1 && B <= c->max_batch, PMX_ERR_CAPACITY, "forward: batch %d outside 1..%d", B, c->max_batch);
+    PMX_CHECK(H >= 8 && W >= 8 && H % 8 == 0 && W % 8 == 0, PMX_ERR_INVALID, "forward: H, W must be multiples of 8 (got %d x %d)", H, W);
+    PMX_CHECK((size_t)H * W <= (size_t)c->max_h * c->max_w, PMX_ERR_CAPACITY, "forward: %d x %d exceeds the context capacity %d x %d",
+              H, W, c->max_h, c->max_w);
+    int missing = 0;
+    for (auto& l : c->layers) missing += l.set ? 0 : 1;
+    PMX_CHECK(missing == 0, PMX_ERR_WEIGHTS, "forward: %d of %d layers have no weights", missing, (int)c->layers.size());
+    return PMX_OK;
+}
+
+extern "C" int pmx_forward_u8(pmx_ctx* c, const uint8_t* img, int B, int H, int W, int on_device)
+{
+    int rc = check_forward_args(c, img, B, H, W);
+    if (rc) return rc;
+    PMX_DEV(c);
+    const uint8_t* d = img;
+    if (!on_device) {
+        PMX_HIP(hipMemcpyAsync(c->u8_tmp, img, (size_t)B * H * W * 3, hipMemcpyHostToDevice, c->stream));
+        d = c->u8_tmp;
+    }
+    if ((rc = prof_begin(c, "prep_u8|prep_u8", 0, (double)B * H * W * (3 + 64)))) return rc;
+    if ((rc = launch_prep_u8(d, c->in16, B, H, W, c->stream))) return rc;
+    if ((rc = prof_end(c))) return rc;
+    return forward_from_in16(c, B, H, W);
+}
+
+extern "C" int pmx_forward_f32(pmx_ctx* c, const float* x, int B, int H, int W, int on_device)
+{
+    int rc = check_forward_args(c, x, B, H, W);
+    if (rc) return rc;
+    PMX_DEV(c);
+    const float* d = x;
+    if (!on_device) {
+        PMX_HIP(hipMemcpyAsync(c->nchw_tmp, x, (size_t)B * H * W * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        d = c->nchw_tmp;
+    }
+    if ((rc = launch_prep_f32(d, c->in16, B, H, W, c->stream))) return rc;
+    return forward_from_in16(c, B, H, W);
+}
+
+extern "C" int pmx_get_maps(pmx_ctx* c, float* paf, float* heat)
+{
+    PMX_CHECK(c, PMX_ERR_INVALID, "null ctx");
+    PMX_CHECK(c->maps_valid, PMX_ERR_STATE, "pmx_get_maps: no forward / set_maps yet");
+    PMX_DEV(c);
+    const int B = c->cur_B, fh = c->cur_fh, fw = c->cur_fw;
+    const size_t np = (size_t)B * PMX_N_PAF * fh * fw, nh = (size_t)B * PMX_N_HEAT * fh * fw;
+    if (c->maps_external) {
+        if (paf) PMX_HIP(hipMemcpyAsync(paf, c->ext_paf, np * 4, hipMemcpyDeviceToHost, c->stream));
+        if (heat) PMX_HIP(hipMemcpyAsync(heat, c->ext_heat, nh * 4, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        int rc;
+        if (paf) {
+            if ((rc = launch_nhwc_to_nchw(c->cat, c->nchw_tmp, B, PMX_N_PAF, fh, fw, PMX_CAT_C, PMX_CAT_PAF, c->stream))) return rc;
+            PMX_HIP(hipMemcpyAsync(paf, c->nchw_tmp, np * 4, hipMemcpyDeviceToHost, c->stream));
+        }
+        if (heat) {
+            float* tmp = c->nchw_tmp + np;
+            if ((rc = launch_nhwc_to_nchw(c->cat, tmp, B, PMX_N_HEAT, fh, fw, PMX_CAT_C, PMX_CAT_HEAT, c->stream))) return rc;
+            PMX_HIP(hipMemcpyAsync(heat, tmp, nh * 4, hipMemcpyDeviceToHost, c->stream));
+        }
+    }
+    PMX_HIP(hipStreamSynchronize(c->stream));
+    return PMX_OK;
+}
+
+extern "C" int pmx_set_maps(pmx_ctx* c, const float* paf, const float* heat, int B, int fh, int fw)
+{
+    PMX_CHECK(c && paf && heat, PMX_ERR_INVALID, "pmx_set_maps: null arg");
+    PMX_CHECK(B >= 1 && B <= c->max_batch, PMX_ERR_CAPACITY, "pmx_set_maps: batch %d outside 1..%d", B, c->max_batch);
+    PMX_CHECK(fh >= 1 && fw >= 1, PMX_ERR_INVALID, "pmx_set_maps: bad size");
+    PMX_DEV(c);
+    const size_t need = (size_t)B * fh * fw;
+    if (need > c->ext_cap) {
+        PMX_HIP(hipStreamSynchronize(c->stream));
+        if (c->ext_paf) (void)hipFree(c->ext_paf);
+        if (c->ext_heat) (void)hipFree(c->ext_heat);
+        c->ext_paf = c->ext_heat = nullptr;
+        PMX_HIP(hipMalloc((void**)&c->ext_paf, need * PMX_N_PAF * 4));
+        PMX_HIP(hipMalloc((void**)&c->ext_heat, need * PMX_N_HEAT * 4));
+        c->ext_cap = need;
+    }
+    PMX_HIP(hipMemcpyAsync(c->ext_paf, paf, need * PMX_N_PAF * 4, hipMemcpyHostToDevice, c->stream));
+    PMX_HIP(hipMemcpyAsync(c->ext_heat, heat, need * PMX_N_HEAT * 4, hipMemcpyHostToDevice, c->stream));
+    PMX_HIP(hipStreamSynchronize(c->stream));    // host buffers may be released by the caller
+    c->maps_valid = true; c->maps_external = true;
+    c->cur_B = B; c->cur_fh = fh; c->cur_fw = fw;
+    c->pp_valid = false;
+    return PMX_OK;
+}
+
+// ------------------------------------------------------------------------------------- post-process
+extern "C" int pmx_set_gaussian(pmx_ctx* c, const double* taps, int radius)
+{
+    PMX_CHECK(c && taps, PMX_ERR_INVALID, "null arg");
+    PMX_CHECK(radius >= 0 && radius <= PMX_GAUSS_MAX_RADIUS, PMX_ERR_INVALID, "pmx_set_gaussian: radius %d > %d", radius, PMX_GAUSS_MAX_RADIUS);
+    c->gauss.assign(taps, taps + 2 * radius + 1);
+    c->tab_in_h = -1;   // force table rebuild / upload
+    return PMX_OK;
+}
+
+// np.linspace(0, in-1, num=out) grid + the corner indices / weights of Chainer's ResizeImages (see oracle)
+static void make_grid(int in, int out, std::vector<int>& i0, std::vector<int>& i1, std::vector<double>& lo, std::vector<double>& hi)
+{
+    i0.resize(out); i1.resize(out); lo.resize(out); hi.resize(out);
+    const double start = 0.0, stop = (double)(in - 1);
+    const int div = out - 1;
+    const double delta = stop - start;
+    const double step = div > 0 ? delta / (double)div : 0.0;
+    for (int k = 0; k < out; ++k) {
+        double u;
+        if (div > 0) {
+            if (step == 0.0) u = ((double)k / (double)div) * delta + start;
+            else u = (double)k * step + start;
+            if (k == out - 1 && out > 1) u = stop;
+        } else {
+            u = start;     // num == 1 -> [start]
+        }
+        const int f = (int)floor(u);
+        const double wl = (double)(f + 1) - u, wh = u - (double)f;
+        i0[k] = f < 0 ? 0 : (f > in - 1 ? in - 1 : f);
+        i1[k] = f + 1 > in - 1 ? in - 1 : (f + 1 < 0 ? 0 : f + 1);
+        lo[k] = wl; hi[k] = wh;
+    }
+}
+
+static int ensure_tables(pmx_ctx* c, int in_h, int in_w, int out_h, int out_w)
+{
+    if (c->tab_in_h == in_h && c->tab_in_w == in_w && c->tab_out_h == out_h && c->tab_out_w == out_w) return PMX_OK;
+    const int cap = out_h > out_w ? out_h : out_w;
+    PPTables& t = c->tab;
+    if (cap > c->tab_cap) {
+        PMX_HIP(hipStreamSynchronize(c->stream));
+        void* olds[] = {t.xi0, t.xi1, t.xlo, t.xhi, t.yi0, t.yi1, t.ylo, t.yhi};
+        for (void* p : olds) if (p) (void)hipFree(p);
+        PMX_HIP(hipMalloc((void**)&t.xi0, cap * sizeof(int)));  PMX_HIP(hipMalloc((void**)&t.xi1, cap * sizeof(int)));
+        PMX_HIP(hipMalloc((void**)&t.xlo, cap * sizeof(double))); PMX_HIP(hipMalloc((void**)&t.xhi, cap * sizeof(double)));
+        PMX_HIP(hipMalloc((void**)&t.yi0, cap * sizeof(int)));  PMX_HIP(hipMalloc((void**)&t.yi1, cap * sizeof(int)));
+        PMX_HIP(hipMalloc((void**)&t.ylo, cap * sizeof(double))); PMX_HIP(hipMalloc((void**)&t.yhi, cap * sizeof(double)));
+        c->tab_cap = cap;
+    }
+    if (!t.gauss) PMX_HIP(hipMalloc((void**)&t.gauss, (2 * PMX_GAUSS_MAX_RADIUS + 1) * sizeof(double)));
+    std::vector<int> i0, i1; std::vector<double> lo, hi;
+    PMX_HIP(hipStreamSynchronize(c->stream));
+    make_grid(in_w, out_w, i0, i1, lo, hi);
+    PMX_HIP(hipMemcpy(t.xi0, i0.data(), out_w * sizeof(int), hipMemcpyHostToDevice));
+    PMX_HIP(hipMemcpy(t.xi1, i1.data(), out_w * sizeof(int), hipMemcpyHostToDevice));
+    PMX_HIP(hipMemcpy(t.xlo, lo.data(), out_w * sizeof(double), hipMemcpyHostToDevice));
+    PMX_HIP(hipMemcpy(t.xhi, hi.data(), out_w * sizeof(double), hipMemcpyHostToDevice));
+    make_grid(in_h, out_h, i0, i1, lo, hi);
+    PMX_HIP(hipMemcpy(t.yi0, i0.data(), out_h * sizeof(int), hipMemcpyHostToDevice));
+    PMX_HIP(hipMemcpy(t.yi1, i1.data(), out_h * sizeof(int), hipMemcpyHostToDevice));
+    PMX_HIP(hipMemcpy(t.ylo, lo.data(), out_h * sizeof(double), hipMemcpyHostToDevice));
+    PMX_HIP(hipMemcpy(t.yhi, hi.data(), out_h * sizeof(double), hipMemcpyHostToDevice));
+    PMX_HIP(hipMemcpy(t.gauss, c->gauss.data(), c->gauss.size() * sizeof(double), hipMemcpyHostToDevice));
+    t.radius = ((int)c->gauss.size() - 1) / 2;
+    c->tab_in_h = in_h; c->tab_in_w = in_w; c->tab_out_h = out_h; c->tab_out_w = out_w;
+    return PMX_OK;
+}
+
+extern "C" int pmx_postprocess(pmx_ctx* c, int B, int map_h, int map_w, double img_len, const double* scale_xy)
+{
+    PMX_CHECK(c, PMX_ERR_INVALID, "null ctx");
+    PMX_CHECK(c->maps_valid, PMX_ERR_STATE, "pmx_postprocess: no network output (call forward or set_maps first)");
+    PMX_CHECK(B == c->cur_B, PMX_ERR_INVALID, "pmx_postprocess: batch %d != batch of the current maps %d", B, c->cur_B);
+    PMX_CHECK(map_h >= 1 && map_w >= 1 && (long long)map_h * map_w < (1ll << 31), PMX_ERR_INVALID, "pmx_postprocess: bad map size");
+    PMX_DEV(c);
+    int rc;
+    if ((rc = ensure_tables(c, c->cur_fh, c->cur_fw, map_h, map_w))) return rc;
+    const long long fhw = (long long)c->cur_fh * c->cur_fw;
+    PPMaps m;
+    if (c->maps_external) {          // NCHW copies installed by pmx_set_maps
+        m.heat = c->ext_heat; m.paf = c->ext_paf;
+        m.sx = 1; m.sy = c->cur_fw; m.sc = fhw;
+        m.sbh = PMX_N_HEAT * fhw; m.sbp = PMX_N_PAF * fhw;
+    } else {                         // channel slices of the NHWC cat buffer written by the last stage
+        m.heat = c->cat + PMX_CAT_HEAT; m.paf = c->cat + PMX_CAT_PAF;
+        m.sc = 1; m.sx = PMX_CAT_C; m.sy = (long long)c->cur_fw * PMX_CAT_C;
+        m.sbh = m.sbp = fhw * PMX_CAT_C;
+    }
+    m.fh = c->cur_fh; m.fw = c->cur_fw;
+    if (c->opt_keep_smoothed) {
+        const size_t need = (size_t)B * PMX_N_JOINTS * map_h * map_w;
+        if (need > c->smoothed_cap) {
+            PMX_HIP(hipStreamSynchronize(c->stream));
+            if (c->pp.smoothed) (void)hipFree(c->pp.smoothed);
+            c->pp.smoothed = nullptr;
+            PMX_HIP(hipMalloc((void**)&c->pp.smoothed, need * sizeof(float)));
+            c->smoothed_cap = need;
+        }
+    }
+    const double* dscale = nullptr;
+    if (scale_xy) {
+        PMX_HIP(hipMemcpyAsync(c->d_scale, scale_xy, sizeof(double) * 2 * B, hipMemcpyHostToDevice, c->stream));
+        dscale = c->d_scale;
+    }
+    rc = pp_launch(m, c->tab, c->pp, B, map_h, map_w, img_len, dscale, c->opt_keep_smoothed && c->pp.smoothed, c->stream,
+                   c->prof_on ? pp_prof_cb : nullptr, c);
+    if (rc) return rc;
+    c->pp_valid = true; c->pp_B = B; c->pp_h = map_h; c->pp_w = map_w;
+    return PMX_OK;
+}
+
+extern "C" int pmx_detect_batch(pmx_ctx* c, const uint8_t* img, int B, int H, int W, int on_device, int map_h, int map_w,
+                                double img_len, const double* scale_xy)
+{
+    int rc = pmx_forward_u8(c, img, B, H, W, on_device);
+    if (rc) return rc;
+    return pmx_postprocess(c, B, map_h, map_w, img_len, scale_xy);
+}
+
+extern "C" int pmx_get_results(pmx_ctx* c, int B, pmx_result_record* out)
+{
+    PMX_CHECK(c && out, PMX_ERR_INVALID, "null arg");
+    PMX_CHECK(c->pp_valid && B >= 1 && B <= c->pp_B, PMX_ERR_STATE, "pmx_get_results: no post-process results for batch %d", B);
+    PMX_DEV(c);
+    PMX_HIP(hipMemcpyAsync(out, c->pp.results, sizeof(pmx_result_record) * B, hipMemcpyDeviceToHost, c->stream));
+    PMX_HIP(hipStreamSynchronize(c->stream));
+    return PMX_OK;
+}
+
+extern "C" int pmx_results_device_ptr(pmx_ctx* c, void** p, size_t* bytes)
+{
+    PMX_CHECK(c && p && bytes, PMX_ERR_INVALID, "null arg");
+    *p = c->pp.results;
+    *bytes = sizeof(pmx_result_record);
+    return PMX_OK;
+}
+
+static int check_pp_image(pmx_ctx* c, int image)
+{
+    PMX_CHECK(c, PMX_ERR_INVALID, "null ctx");
+    PMX_CHECK(c->pp_valid, PMX_ERR_STATE, "no post-process results yet");
+    PMX_CHECK(image >= 0 && image < c->pp_B, PMX_ERR_INVALID, "image %d outside 0..%d", image, c->pp_B - 1);
+    return PMX_OK;
+}
+
+extern "C" int pmx_get_peaks(pmx_ctx* c, int image, double* peaks5, int cap, int* n_rows)
+{
+    int rc = check_pp_image(c, image);
+    if (rc) return rc;
+    PMX_CHECK(peaks5 && n_rows, PMX_ERR_INVALID, "null arg");
+    PMX_DEV(c);
+    PMX_HIP(hipStreamSynchronize(c->stream));
+    int start[PMX_N_JOINTS + 1];
+    PMX_HIP(hipMemcpy(start, c->pp.pk_start + image * (PMX_N_JOINTS + 1), sizeof start, hipMemcpyDeviceToHost));
+    const int n = start[PMX_N_JOINTS];
+    *n_rows = n;
+    PMX_CHECK(n <= cap, PMX_ERR_CAPACITY, "pmx_get_peaks: %d rows > capacity %d", n, cap);
+    std::vector<int> x(n), y(n);
+    std::vector<float> s(n);
+    if (n) {
+        PMX_HIP(hipMemcpy(x.data(), c->pp.pk_x + (size_t)image * PMX_MAX_PEAKS, n * sizeof(int), hipMemcpyDeviceToHost));
+        PMX_HIP(hipMemcpy(y.data(), c->pp.pk_y + (size_t)image * PMX_MAX_PEAKS, n * sizeof(int), hipMemcpyDeviceToHost));
+        PMX_HIP(hipMemcpy(s.data(), c->pp.pk_score + (size_t)image * PMX_MAX_PEAKS, n * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    int j = 0;
+    for (int i = 0; i < n; ++i) {
+        while (j < PMX_N_JOINTS && i >= start[j + 1]) ++j;
+        peaks5[i * 5 + 0] = j; peaks5[i * 5 + 1] = x[i]; peaks5[i * 5 + 2] = y[i]; peaks5[i * 5 + 3] = (double)s[i]; peaks5[i * 5 + 4] = i;
+    }
+    return PMX_OK;
+}
+
+extern "C" int pmx_get_connections(pmx_ctx* c, int image, double* conns4, int cap, int* n_rows)
+{
+    int rc = check_pp_image(c, image);
+    if (rc) return rc;
+    PMX_CHECK(conns4 && n_rows, PMX_ERR_INVALID, "null arg");
+    PMX_DEV(c);
+    PMX_HIP(hipStreamSynchronize(c->stream));
+    int cnt[PMX_N_LIMBS];
+    PMX_HIP(hipMemcpy(cnt, c->pp.cn_count + image * PMX_N_LIMBS, sizeof cnt, hipMemcpyDeviceToHost));
+    int total = 0;
+    for (int l = 0; l < PMX_N_LIMBS; ++l) total += cnt[l];
+    *n_rows = total;
+    PMX_CHECK(total <= cap, PMX_ERR_CAPACITY, "pmx_get_connections: %d rows > capacity %d", total, cap);
+    int o = 0;
+    std::vector<int> a(PMX_MAX_PEAKS_PER_JOINT), b(PMX_MAX_PEAKS_PER_JOINT);
+    std::vector<double> s(PMX_MAX_PEAKS_PER_JOINT);
+    for (int l = 0; l < PMX_N_LIMBS; ++l) {
+        const int n = cnt[l];
+        if (!n) continue;
+        const size_t base = ((size_t)image * PMX_N_LIMBS + l) * PMX_MAX_PEAKS_PER_JOINT;
+        PMX_HIP(hipMemcpy(a.data(), c->pp.cn_a + base, n * sizeof(int), hipMemcpyDeviceToHost));
+        PMX_HIP(hipMemcpy(b.data(), c->pp.cn_b + base, n * sizeof(int), hipMemcpyDeviceToHost));
+        PMX_HIP(hipMemcpy(s.data(), c->pp.cn_score + base, n * sizeof(double), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i, ++o) {
+            conns4[o * 4 + 0] = l; conns4[o * 4 + 1] = a[i]; conns4[o * 4 + 2] = b[i]; conns4[o * 4 + 3] = s[i];
+        }
+    }
+    return PMX_OK;
+}
+
+extern "C" int pmx_get_subsets(pmx_ctx* c, int image, double* subsets20, int cap, int* n_rows)
+{
+    int rc = check_pp_image(c, image);
+    if (rc) return rc;
+    PMX_CHECK(subsets20 && n_rows, PMX_ERR_INVALID, "null arg");
+    PMX_DEV(c);
+    PMX_HIP(hipStreamSynchronize(c->stream));
+    pmx_image_info info;
+    PMX_HIP(hipMemcpy(&info, &c->pp.results[image].info, sizeof info, hipMemcpyDeviceToHost));
+    // rows kept by the final filter; n_people is clamped to PMX_MAX_PEOPLE, the subsets buffer is not
+    int n = info.n_people;
+    *n_rows = n;
+    PMX_CHECK(n <= cap, PMX_ERR_CAPACITY, "pmx_get_subsets: %d rows > capacity %d", n, cap);
+    if (n) PMX_HIP(hipMemcpy(subsets20, c->pp.subsets + (size_t)image * PMX_MAX_SUBSETS * 20, (size_t)n * 20 * sizeof(double),
+                             hipMemcpyDeviceToHost));
+    return PMX_OK;
+}
+
+extern "C" int pmx_get_smoothed(pmx_ctx* c, int image, int joint, float* out, int map_h, int map_w)
+{
+    int rc = check_pp_image(c, image);
+    if (rc) return rc;
+    PMX_CHECK(out && joint >= 0 && joint < PMX_N_JOINTS, PMX_ERR_INVALID, "bad arg");
+    PMX_CHECK(c->pp.smoothed && c->opt_keep_smoothed, PMX_ERR_STATE, "pmx_get_smoothed: option keep_smoothed was not set");
+    PMX_CHECK(map_h == c->pp_h && map_w == c->pp_w, PMX_ERR_INVALID, "pmx_get_smoothed: map size mismatch");
+    PMX_DEV(c);
+    PMX_HIP(hipStreamSynchronize(c->stream));
+    PMX_HIP(hipMemcpy(out, c->pp.smoothed + ((size_t)image * PMX_N_JOINTS + joint) * map_h * map_w, (size_t)map_h * map_w * sizeof(float),
+                      hipMemcpyDeviceToHost));
+    return PMX_OK;
+}
+
+// ------------------------------------------------------------------------------------- measurement
+extern "C" int pmx_timer_start(pmx_ctx* c)
+{
+    PMX_CHECK(c, PMX_ERR_INVALID, "null ctx");
+    PMX_DEV(c);
+    PMX_HIP(hipEventRecord(c->t0, c->stream));
+    return PMX_OK;
+}
+extern "C" int pmx_timer_stop(pmx_ctx* c, double* ms)
+{
+    PMX_CHECK(c && ms, PMX_ERR_INVALID, "null arg");
+    PMX_DEV(c);
+    PMX_HIP(hipEventRecord(c->t1, c->stream));
+    PMX_HIP(hipEventSynchronize(c->t1));
+    float f = 0.f;
+    PMX_HIP(hipEventElapsedTime(&f, c->t0, c->t1));
+    *ms = f;
+    return PMX_OK;
+}
+extern "C" int pmx_profile_enable(pmx_ctx* c, int on)
+{
+    PMX_CHECK(c, PMX_ERR_INVALID, "null ctx");
+    PMX_DEV(c);
+    int rc = prof_collect(c);
+    c->prof_on = on != 0;
+    return rc;
+}
+extern "C" int pmx_profile_reset(pmx_ctx* c)
+{
+    PMX_CHECK(c, PMX_ERR_INVALID, "null ctx");
+    PMX_DEV(c);
+    int rc = prof_collect(c);
+    c->prof.clear();
+    c->prof_index.clear();
+    return rc;
+}
+extern "C" int pmx_profile_count(pmx_ctx* c, int* n)
+{
+    PMX_CHECK(c && n, PMX_ERR_INVALID, "null arg");
+    PMX_DEV(c);
+    int rc = prof_collect(c);
+    *n = (int)c->prof.size();
+    return rc;
+}
+extern "C" int pmx_profile_entry(pmx_ctx* c, int i, char* name, int cap, double* total_ms, int64_t* launches, double* flops, double* bytes)
+{
+    PMX_CHECK(c && i >= 0 && i < (int)c->prof.size(), PMX_ERR_INVALID, "bad profile index");
+    const ProfEntry& e = c->prof[i];
+    if (name && cap > 0) { strncpy(name, e.name.c_str(), cap - 1); name[cap - 1] = 0; }
+    if (total_ms) *total_ms = e.total_ms;
+    if (launches) *launches = e.launches;
+    if (flops) *flops = e.flops;
+    if (bytes) *bytes = e.bytes;
+    return PMX_OK;
+}
+
+// ---------------------------------------------------------------------------- single-layer test entry
+extern "C" int pmx_conv2d(pmx_ctx* c, const float* x, const float* w, const float* bias, int B, int cin, int H, int W, int cout,
+                          int ks, int relu, int pool, float* y, int iters, double* avg_ms)
+{
+    PMX_CHECK(c && x && w && y, PMX_ERR_INVALID, "pmx_conv2d: null arg");
+    PMX_CHECK(ks == 1 || ks == 3 || ks == 7, PMX_ERR_INVALID, "pmx_conv2d: ksize must be 1, 3 or 7");
+    PMX_CHECK(B >= 1 && cin >= 1 && cout >= 1 && H >= 1 && W >= 1, PMX_ERR_INVALID, "pmx_conv2d: bad shape");
+    PMX_CHECK(!pool || (H % 2 == 0 && W % 2 == 0), PMX_ERR_INVALID, "pmx_conv2d: pool needs even H, W");
+    PMX_DEV(c);
+    std::vector<int> cmap = identity_map(cin);
+    const int cin_pad = (int)cmap.size(), cpad = cout_pad_of(cout);
+    std::vector<float> wp, bp;
+    pack_weights(w, bias, cout, cin, ks, cmap, cpad, wp, bp);
+    const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
+    float *d_x = nullptr, *d_xn = nullptr, *d_w = nullptr, *d_b = nullptr, *d_y = nullptr, *d_yn = nullptr;
+    const size_t nx = (size_t)B * cin * H * W, nxn = (size_t)B * H * W * cin_pad, ny = (size_t)B * cout * Ho * Wo;
+    PMX_HIP(hipMalloc((void**)&d_x, nx * 4));
+    PMX_HIP(hipMalloc((void**)&d_xn, nxn * 4));
+    PMX_HIP(hipMalloc((void**)&d_w, wp.size() * 4));
+    PMX_HIP(hipMalloc((void**)&d_b, bp.size() * 4));
+    PMX_HIP(hipMalloc((void**)&d_y, ny * 4));
+    PMX_HIP(hipMalloc((void**)&d_yn, ny * 4));
+    PMX_HIP(hipMemcpy(d_x, x, nx * 4, hipMemcpyHostToDevice));
+    PMX_HIP(hipMemset(d_xn, 0, nxn * 4));
+    PMX_HIP(hipMemcpy(d_w, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
+    PMX_HIP(hipMemcpy(d_b, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+    // poison the output so that unwritten elements are caught by the test
+    PMX_HIP(hipMemset(d_yn, 0xFF, ny * 4));
+    int rc = launch_nchw_to_nhwc(d_x, d_xn, B, cin, H, W, cin_pad, 0, c->stream);
+    ConvArgs a;
+    memset(&a, 0, sizeof a);
+    a.g[0].in = d_xn; a.g[0].w = d_w; a.g[0].bias = d_b; a.g[0].out = d_yn; a.g[0].cout = cout;
+    a.B = B; a.H = H; a.W = W; a.lda = cin_pad; a.ldc = cout; a.nch = cin_pad / CK; a.cout_pad = cpad; a.relu = relu; a.pool = pool;
+    const int v = conv_pick_variant(ks, cpad, H, W, B, c->opt_force[ks]);
+    if (!rc) rc = conv_launch(v, a, 1, c->stream);
+    if (!rc && iters > 0) {
+        hipEvent_t e0, e1;
+        PMX_HIP(hipEventCreate(&e0)); PMX_HIP(hipEventCreate(&e1));
+        PMX_HIP(hipEventRecord(e0, c->stream));
+        for (int i = 0; i < iters && !rc; ++i) rc = conv_launch(v, a, 1, c->stream);
+        PMX_HIP(hipEventRecord(e1, c->stream));
+        PMX_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        PMX_HIP(hipEventElapsedTime(&ms, e0, e1));
+        if (avg_ms) *avg_ms = ms / iters;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    if (!rc) rc = launch_nhwc_to_nchw(d_yn, d_y, B, cout, Ho, Wo, cout, 0, c->stream);
+    if (!rc) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { pmx_set_error("pmx_conv2d: %s", hipGetErrorString(e)); rc = PMX_ERR_HIP; }
+    }
+    if (!rc) {
+        hipError_t e = hipMemcpy(y, d_y, ny * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { pmx_set_error("pmx_conv2d: %s", hipGetErrorString(e)); rc = PMX_ERR_HIP; }
+    }
+    (void)hipFree(d_x); (void)hipFree(d_xn); (void)hipFree(d_w); (void)hipFree(d_b); (void)hipFree(d_y); (void)hipFree(d_yn);
+    return rc;
+}

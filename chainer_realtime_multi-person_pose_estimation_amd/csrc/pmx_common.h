@@ -1,0 +1,124 @@
+// Shared internal declarations of libpose_mi355x (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+
+#include "../../include/pose_mi355x.h"
+
+// ---- constants of the inference path (reference entity.py:71-105); the Python copy lives in entity.py --
+#define PMX_HEATMAP_PEAK_THRESH 0.05f       // entity.py:79 (compared in float32, see pose_detector.py:97)
+#define PMX_N_INTEG_POINTS 10               // entity.py:77
+#define PMX_N_INTEG_POINTS_THRESH 8         // entity.py:78
+#define PMX_INNER_PRODUCT_THRESH 0.05       // entity.py:80 (float64 compare, pose_detector.py:155)
+#define PMX_LIMB_LENGTH_RATIO 1.0           // entity.py:81
+#define PMX_LENGTH_PENALTY_VALUE 1.0        // entity.py:82
+#define PMX_N_SUBSET_LIMBS_THRESH 3.0       // entity.py:83
+#define PMX_SUBSET_SCORE_THRESH 0.2         // entity.py:84
+#define PMX_GAUSS_SIGMA 2.5                 // entity.py:75
+#define PMX_GAUSS_MAX_RADIUS 16
+
+// limb table (entity.py:85-105): joint indices (from, to) of limb i; PAF channels (2i, 2i+1) = (x, y)
+static const int PMX_LIMBS[PMX_N_LIMBS][2] = {
+    {1, 8}, {8, 9}, {9, 10}, {1, 11}, {11, 12}, {12, 13}, {1, 2}, {2, 3}, {3, 4}, {2, 16},
+    {1, 5}, {5, 6}, {6, 7}, {5, 17}, {1, 0}, {0, 14}, {0, 15}, {14, 16}, {15, 17}};
+
+// ---- activation layout -------------------------------------------------------------------------
+// All activations are NHWC float32.  The "concat" buffer that feeds stages 2-6 replaces F.concat
+// (CocoPoseNet.py:168): [feature 0..127 | PAF 128..165 | pad 166,167 | heat 168..186 | pad 187..191].
+#define PMX_CAT_C 192
+#define PMX_CAT_FEAT 0
+#define PMX_CAT_PAF 128
+#define PMX_CAT_HEAT 168
+#define PMX_IN_C 16            // network input padded 3 -> 16 channels (zeros)
+
+// ---- error handling ----------------------------------------------------------------------------
+void pmx_set_error(const char* fmt, ...);
+#define PMX_HIP(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            pmx_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return PMX_ERR_HIP;                                                                 \
+        }                                                                                       \
+    } while (0)
+#define PMX_CHECK(cond, code, ...)      \
+    do {                                \
+        if (!(cond)) {                  \
+            pmx_set_error(__VA_ARGS__); \
+            return (code);              \
+        }                               \
+    } while (0)
+
+// ---- convolution kernel interface (conv_mfma.hip) ------------------------------------------------
+struct ConvGroupArgs {
+    const float* in;    // NHWC, already offset to the group's first input channel
+    const float* w;     // packed [tap][chunk][cout_pad][CK]
+    const float* bias;  // [cout_pad]
+    float* out;         // NHWC, already offset to the group's first output channel
+    int cout;           // real output channels (<= cout_pad)
+    int pad_;
+};
+struct ConvArgs {
+    ConvGroupArgs g[2];
+    int B, H, W;        // conv input == output spatial size (before the optional 2x2 pool)
+    int lda, ldc;       // channel strides (floats) of input / output pixels
+    int nch;            // cin_pad / CK
+    int cout_pad;       // multiple of the kernel's BN
+    int tiles_x, tiles_y;
+    int relu, pool;
+};
+
+struct ConvVariant {
+    int ks, th, tw, bn, ck;
+    const char* name;
+};
+// picks a kernel variant for (ksize, cout, B*H*W); returns index into the variant table
+int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced);
+const ConvVariant& conv_variant(int idx);
+int conv_num_variants();
+// launches the variant; groups = 1 or 2 (blockIdx.z)
+int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream);
+// packed weight geometry helpers
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// other kernels (prep.hip)
+int launch_prep_u8(const uint8_t* bgr, float* out16, int B, int H, int W, hipStream_t s);
+int launch_prep_f32(const float* x_nchw, float* out16, int B, int H, int W, hipStream_t s);
+int launch_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, int ldc, int coff, hipStream_t s);
+int launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, int lda, int coff, hipStream_t s);
+
+// ---- post-process interface (postproc.hip) -------------------------------------------------------
+struct PPTables {            // device pointers, per context, sized for the largest map
+    int* xi0; int* xi1; double* xlo; double* xhi;   // per output column
+    int* yi0; int* yi1; double* ylo; double* yhi;   // per output row
+    double* gauss;                                   // 2r+1 taps
+    int radius;
+};
+struct PPMaps {              // where the low-resolution network outputs live
+    const float* heat; const float* paf;
+    long long sbh, sbp;          // batch strides (floats) of the heat / PAF maps
+    long long sy, sx, sc;        // row, column, channel strides (floats), common to both maps
+    int fh, fw;
+};
+struct PPBuffers {
+    // peaks
+    unsigned* pk_raw_key;    // [B][18][MAXPK]   y*W+x, unsorted
+    float* pk_raw_score;     // [B][18][MAXPK]
+    int* pk_count;           // [B][18] (raw, may exceed cap)
+    int* pk_x; int* pk_y; float* pk_score;   // [B][PMX_MAX_PEAKS] sorted, global ids
+    int* pk_start;           // [B][19] first id of each joint type; [18] = total
+    // connections
+    int* cn_a; int* cn_b; double* cn_score;  // [B][19][MAXPK]
+    int* cn_count;           // [B][19]
+    // grouping
+    double* subsets;         // [B][MAX_SUBSETS][20] (filtered, for parity accessors)
+    int* status;             // [B]
+    pmx_result_record* results;   // [B]
+    float* smoothed;         // optional [B][18][map_h][map_w]
+};
+int pp_launch(const PPMaps& maps, const PPTables& tab, const PPBuffers& buf, int B, int map_h, int map_w,
+              double img_len, const double* d_scale_xy, int keep_smoothed, hipStream_t stream,
+              void (*prof)(void*, const char*, int), void* prof_ctx);

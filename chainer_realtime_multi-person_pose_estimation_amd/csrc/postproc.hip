@@ -1,0 +1,504 @@
+// postproc.hip -- the reference post-process (pose_detector.py:501-517) as HIP kernels.
+//
+//   pp_peaks_kernel   F.resize_images (:501-502, corner-aligned bilinear, computed on the fly from the
+//                     low-resolution network output) + scipy gaussian_filter(sigma=2.5) semantics (:86:
+//                     separable taps, 'reflect' border, float64 accumulate per pass in SciPy's order, float32
+//                     store between passes, rows first) + 4-neighbour strict NMS against zero-padded shifts and
+//                     the 0.05 threshold (:87-102) on LDS tiles; wave-ballot compaction of the peaks.
+//   pp_sort_kernel    restores the reference's row-major peak order per joint type (:104) and assigns the
+//                     running global ids (:106-108).
+//   pp_limbs_kernel   compute_candidate_connections (:135-159): 16 lanes per candidate pair, 10 of them sample
+//                     the PAF line integral (bilinear PAF fetched on the fly), ballot for the n_valid count,
+//                     shuffle-gather + NumPy-order float64 sum; then compute_connections' greedy matching
+//                     (:172-177) as repeated block-wide arg-max over the accepted candidates (equivalent to
+//                     the stable descending sort + scan, ties resolved by the (a, b) loop order of :137-138).
+//   pp_group_kernel   grouping_key_points (:183-250) incl. the `[-2:] += score` quirk (:217), the final filter
+//                     (:248-249), the rescale to image pixels (:513-514) and subsets_to_pose_array (:252-265);
+//                     one wavefront per image, subset table in LDS, lane-parallel subset search via ballot.
+//
+// Bit-exactness: every float32 / float64 operation below is written in the operation order of the
+// reference's NumPy / SciPy code and this file is compiled with -ffp-contract=off (no FMA fusion), so peak
+// coordinates, ids, matching and grouping decisions are reproduced exactly for identical network outputs.
+#include "pmx_common.h"
+
+#pragma clang fp contract(off)
+
+#define PK_TS 32                                   // NMS output tile (pixels)
+#define PK_UW_MAX (PK_TS + 2 + 2 * PMX_GAUSS_MAX_RADIUS)   // 66
+#define PK_US (PK_UW_MAX + 1)                      // LDS row stride (floats)
+
+__constant__ int c_limbs[PMX_N_LIMBS][2] = {
+    {1, 8}, {8, 9}, {9, 10}, {1, 11}, {11, 12}, {12, 13}, {1, 2}, {2, 3}, {3, 4}, {2, 16},
+    {1, 5}, {5, 6}, {6, 7}, {5, 17}, {1, 0}, {0, 14}, {0, 15}, {14, 16}, {15, 17}};
+
+// scipy 'reflect' (d c b a | a b c d), any distance
+__device__ __forceinline__ int reflect_idx(int i, int n)
+{
+    const int p = 2 * n;
+    i %= p;
+    if (i < 0) i += p;
+    return i < n ? i : p - 1 - i;
+}
+
+// one corner-aligned bilinear sample of channel `ch` of image `b` at integer map coordinates (y, x):
+// ((w1*x00 + w2*x01) + w3*x10) + w4*x11 in float32, weights = float32(float64 product) -- see
+// oracle/postprocess_ref.py::resize_images_ref for the restated Chainer formula.
+__device__ __forceinline__ float bilinear_at(const float* __restrict__ base, long long sy, long long sx,
+                                             const PPTables& t, int y, int x)
+{
+    const int y0 = t.yi0[y], y1 = t.yi1[y], x0 = t.xi0[x], x1 = t.xi1[x];
+    const double ylo = t.ylo[y], yhi = t.yhi[y], xlo = t.xlo[x], xhi = t.xhi[x];
+    const float w1 = (float)(ylo * xlo);
+    const float w2 = (float)(ylo * xhi);
+    const float w3 = (float)(yhi * xlo);
+    const float w4 = (float)(yhi * xhi);
+    const float x00 = base[y0 * sy + x0 * sx];
+    const float x01 = base[y0 * sy + x1 * sx];
+    const float x10 = base[y1 * sy + x0 * sx];
+    const float x11 = base[y1 * sy + x1 * sx];
+    float v = w1 * x00;
+    v = v + w2 * x01;
+    v = v + w3 * x10;
+    v = v + w4 * x11;
+    return v;
+}
+
+// ============================================================================================== peaks
+__global__ __launch_bounds__(256) void pp_peaks_kernel(PPMaps maps, PPTables tab, PPBuffers buf, int map_h, int map_w,
+                                                       int tiles_x, int keep_smoothed)
+{
+    __shared__ float sU[PK_UW_MAX * PK_US];          // upsampled (+reflect) tile
+    __shared__ float sV[(PK_TS + 2) * PK_US];        // after the vertical (axis 0) pass
+    __shared__ float sS[(PK_TS + 2) * (PK_TS + 3)];  // smoothed, 1-pixel NMS halo
+    __shared__ double sG[2 * PMX_GAUSS_MAX_RADIUS + 1];
+
+    const int tid = threadIdx.x;
+    const int ch = blockIdx.y, b = blockIdx.z;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int y0 = ty * PK_TS, x0 = tx * PK_TS;
+    const int R = tab.radius;
+    const int UW = PK_TS + 2 + 2 * R;
+    const int SW = PK_TS + 3;
+
+    if (tid < 2 * R + 1) sG[tid] = tab.gauss[tid];
+
+    const float* base = maps.heat + (long long)b * maps.sbh + (long long)ch * maps.sc;
+    for (int i = tid; i < UW * UW; i += 256) {
+        const int ur = i / UW, uc = i - ur * UW;
+        const int gy = reflect_idx(y0 - 1 - R + ur, map_h);
+        const int gx = reflect_idx(x0 - 1 - R + uc, map_w);
+        sU[ur * PK_US + uc] = bilinear_at(base, maps.sy, maps.sx, tab, gy, gx);
+    }
+    __syncthreads();
+
+    // axis-0 pass (SciPy order: centre tap, then pairs from the outermost inwards), float64 accumulate
+    for (int i = tid; i < (PK_TS + 2) * UW; i += 256) {
+        const int vr = i / UW, vc = i - vr * UW;
+        const float* col = &sU[(vr + R) * PK_US + vc];
+        double acc = (double)col[0] * sG[R];
+        for (int j = R; j >= 1; --j)
+            acc = acc + ((double)col[-j * PK_US] + (double)col[j * PK_US]) * sG[R - j];
+        sV[vr * PK_US + vc] = (float)acc;
+    }
+    __syncthreads();
+
+    // axis-1 pass; positions outside the map are the NMS zero padding (pose_detector.py:87-94)
+    for (int i = tid; i < (PK_TS + 2) * (PK_TS + 2); i += 256) {
+        const int sr = i / (PK_TS + 2), sc = i - sr * (PK_TS + 2);
+        const int y = y0 - 1 + sr, x = x0 - 1 + sc;
+        float out = 0.f;
+        if (y >= 0 && y < map_h && x >= 0 && x < map_w) {
+            const float* row = &sV[sr * PK_US + sc + R];
+            double acc = (double)row[0] * sG[R];
+            for (int j = R; j >= 1; --j)
+                acc = acc + ((double)row[-j] + (double)row[j]) * sG[R - j];
+            out = (float)acc;
+            if (keep_smoothed && sr >= 1 && sr <= PK_TS && sc >= 1 && sc <= PK_TS)
+                buf.smoothed[(((long long)b * PMX_N_JOINTS + ch) * map_h + y) * map_w + x] = out;
+        }
+        sS[sr * SW + sc] = out;
+    }
+    __syncthreads();
+
+    // NMS + compaction
+    unsigned* keys = buf.pk_raw_key + ((long long)b * PMX_N_JOINTS + ch) * PMX_MAX_PEAKS_PER_JOINT;
+    float* scores = buf.pk_raw_score + ((long long)b * PMX_N_JOINTS + ch) * PMX_MAX_PEAKS_PER_JOINT;
+    int* counter = buf.pk_count + b * PMX_N_JOINTS + ch;
+    const int lane = tid & 63;
+    for (int i = tid; i < PK_TS * PK_TS; i += 256) {
+        const int r = i / PK_TS, c = i - r * PK_TS;
+        const int y = y0 + r, x = x0 + c;
+        bool peak = false;
+        float p = 0.f;
+        if (y < map_h && x < map_w) {
+            p = sS[(r + 1) * SW + (c + 1)];
+            peak = p > PMX_HEATMAP_PEAK_THRESH && p > sS[r * SW + (c + 1)] && p > sS[(r + 2) * SW + (c + 1)] &&
+                   p > sS[(r + 1) * SW + c] && p > sS[(r + 1) * SW + (c + 2)];
+        }
+        const unsigned long long m = __ballot(peak);
+        if (m) {
+            int basei = 0;
+            if (lane == 0) basei = atomicAdd(counter, __popcll(m));
+            basei = __shfl(basei, 0);
+            if (peak) {
+                const int slot = basei + __popcll(m & ((1ull << lane) - 1ull));
+                if (slot < PMX_MAX_PEAKS_PER_JOINT) {
+                    keys[slot] = (unsigned)(y * map_w + x);
+                    scores[slot] = p;
+                }
+            }
+        }
+    }
+}
+
+// ============================================================================================== sort
+__global__ __launch_bounds__(256) void pp_sort_kernel(PPBuffers buf, int map_w)
+{
+    __shared__ unsigned sKey[4][PMX_MAX_PEAKS_PER_JOINT];
+    __shared__ int sStart[PMX_N_JOINTS + 1];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int* cnt = buf.pk_count + b * PMX_N_JOINTS;
+    if (tid == 0) {
+        int s = 0, ovf = 0;
+        for (int j = 0; j < PMX_N_JOINTS; ++j) {
+            sStart[j] = s;
+            int n = cnt[j];
+            if (n > PMX_MAX_PEAKS_PER_JOINT) { n = PMX_MAX_PEAKS_PER_JOINT; ovf = 1; }
+            s += n;
+        }
+        sStart[PMX_N_JOINTS] = s;
+        if (ovf) atomicOr(buf.status + b, PMX_IMG_PEAK_OVERFLOW);
+    }
+    __syncthreads();
+    if (tid <= PMX_N_JOINTS) buf.pk_start[b * (PMX_N_JOINTS + 1) + tid] = sStart[tid];
+    for (int j = wave; j < PMX_N_JOINTS; j += 4) {     // trip count is wave-uniform
+        const int n = min(cnt[j], PMX_MAX_PEAKS_PER_JOINT);
+        const unsigned* keys = buf.pk_raw_key + ((long long)b * PMX_N_JOINTS + j) * PMX_MAX_PEAKS_PER_JOINT;
+        const float* scores = buf.pk_raw_score + ((long long)b * PMX_N_JOINTS + j) * PMX_MAX_PEAKS_PER_JOINT;
+        for (int e = lane; e < n; e += 64) sKey[wave][e] = keys[e];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (int e = lane; e < n; e += 64) {
+            const unsigned k = sKey[wave][e];
+            int rank = 0;
+            for (int o = 0; o < n; ++o) rank += (sKey[wave][o] < k) ? 1 : 0;   // keys are unique pixels
+            const int id = sStart[j] + rank;
+            buf.pk_x[b * PMX_MAX_PEAKS + id] = (int)(k % (unsigned)map_w);
+            buf.pk_y[b * PMX_MAX_PEAKS + id] = (int)(k / (unsigned)map_w);
+            buf.pk_score[b * PMX_MAX_PEAKS + id] = scores[e];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ============================================================================================= limbs
+__device__ __forceinline__ bool cand_better(double s1, unsigned i1, double s2, unsigned i2)
+{
+    return s1 > s2 || (s1 == s2 && i1 < i2);
+}
+
+__global__ __launch_bounds__(256) void pp_limbs_kernel(PPMaps maps, PPTables tab, PPBuffers buf, double img_len)
+{
+    __shared__ double sScore[PMX_MAX_CANDIDATES];
+    __shared__ unsigned sIdx[PMX_MAX_CANDIDATES];
+    __shared__ unsigned char sUsedA[PMX_MAX_PEAKS_PER_JOINT], sUsedB[PMX_MAX_PEAKS_PER_JOINT];
+    __shared__ double sRedS[4];
+    __shared__ unsigned sRedI[4];
+    __shared__ int sRedE[4];
+    __shared__ int sNC, sBestE;
+
+    const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ja = c_limbs[l][0], jb = c_limbs[l][1];
+    const int* start = buf.pk_start + b * (PMX_N_JOINTS + 1);
+    const int sA = start[ja], nA = start[ja + 1] - sA;
+    const int sB = start[jb], nB = start[jb + 1] - sB;
+    int* out_cnt = buf.cn_count + b * PMX_N_LIMBS + l;
+    if (nA == 0 || nB == 0) {        // pose_detector.py:170,179-180
+        if (tid == 0) *out_cnt = 0;
+        return;
+    }
+    if (tid == 0) sNC = 0;
+    if (tid < PMX_MAX_PEAKS_PER_JOINT) { sUsedA[tid] = 0; sUsedB[tid] = 0; }
+    __syncthreads();
+
+    const int* px = buf.pk_x + b * PMX_MAX_PEAKS;
+    const int* py = buf.pk_y + b * PMX_MAX_PEAKS;
+    const float* pafx = maps.paf + (long long)b * maps.sbp + (long long)(2 * l) * maps.sc;
+    const float* pafy = pafx + maps.sc;
+    const int P = nA * nB;
+    const int g = tid >> 4, k = tid & 15;        // 16 pair slots per block iteration, 16 lanes per pair
+    const int gl = lane & ~15;                   // first lane of my group inside the wave
+    for (int base = 0; base < P; base += 16) {   // uniform trip count
+        const int p = base + g;
+        const bool pv = p < P;
+        const int ia = pv ? p / nB : 0, ib = pv ? p - ia * nB : 0;
+        const double ax = (double)px[sA + ia], ay = (double)py[sA + ia];
+        const double bx = (double)px[sB + ib], by = (double)py[sB + ib];
+        const double vx = bx - ax, vy = by - ay;                 // :139
+        const double norm = sqrt(vx * vx + vy * vy);             // :140
+        const bool live = pv && norm != 0.0;                     // :141-142
+        double ip = 0.0;
+        if (live && k < PMX_N_INTEG_POINTS) {
+            // np.linspace(a, b, 10): step = (b-a)/9; y_k = k*step + a; y_9 = b   (:144-145)
+            const double stepx = vx / 9.0, stepy = vy / 9.0;
+            const double xs = (k == 9) ? bx : (double)k * stepx + ax;
+            const double ys = (k == 9) ? by : (double)k * stepy + ay;
+            const int xi = (int)rint(xs), yi = (int)rint(ys);    // .round().astype('i') (:146)
+            const float fx = bilinear_at(pafx, maps.sy, maps.sx, tab, yi, xi);   // paf[0][ys, xs] (:147)
+            const float fy = bilinear_at(pafy, maps.sy, maps.sx, tab, yi, xi);
+            const double ux = vx / norm, uy = vy / norm;         // :148
+            ip = (double)fx * ux + (double)fy * uy;              // :149
+        }
+        const bool valid = live && k < PMX_N_INTEG_POINTS && ip > PMX_INNER_PRODUCT_THRESH;   // :155
+        const unsigned long long m = __ballot(valid);
+        const int n_valid = __popcll((m >> gl) & 0x3FFull);
+        // gather the 10 inner products to every lane of the group; sum in NumPy's pairwise order for n = 10
+        double v[PMX_N_INTEG_POINTS];
+#pragma unroll
+        for (int j = 0; j < PMX_N_INTEG_POINTS; ++j) v[j] = __shfl(ip, gl + j);
+        if (live && k == 0) {
+            double s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            s = s + v[8];
+            s = s + v[9];
+            const double integ = s / 10.0;                                        // :151
+            double prior = PMX_LIMB_LENGTH_RATIO * img_len / norm - PMX_LENGTH_PENALTY_VALUE;   // :153
+            if (!(prior < 0.0)) prior = 0.0;
+            const double score = integ + prior;
+            if (n_valid > PMX_N_INTEG_POINTS_THRESH && score > 0.0) {              // :156
+                const int slot = atomicAdd(&sNC, 1);
+                if (slot < PMX_MAX_CANDIDATES) {
+                    sScore[slot] = score;
+                    sIdx[slot] = (unsigned)p;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    int nc = sNC;
+    if (nc > PMX_MAX_CANDIDATES) {
+        if (tid == 0) atomicOr(buf.status + b, PMX_IMG_CAND_OVERFLOW);
+        nc = PMX_MAX_CANDIDATES;
+    }
+
+    // greedy matching (:172-177): repeatedly take the best remaining candidate whose endpoints are both free
+    const int K = min(nA, nB);
+    int* oa = buf.cn_a + ((long long)b * PMX_N_LIMBS + l) * PMX_MAX_PEAKS_PER_JOINT;
+    int* ob = buf.cn_b + ((long long)b * PMX_N_LIMBS + l) * PMX_MAX_PEAKS_PER_JOINT;
+    double* os = buf.cn_score + ((long long)b * PMX_N_LIMBS + l) * PMX_MAX_PEAKS_PER_JOINT;
+    int count = 0;
+    while (count < K) {
+        double bs = -1.0;
+        unsigned bi = 0xFFFFFFFFu;
+        int be = -1;
+        for (int e = tid; e < nc; e += 256) {
+            const unsigned idx = sIdx[e];
+            const int ia = idx / nB, ib = idx - ia * nB;
+            if (!sUsedA[ia] && !sUsedB[ib]) {
+                const double s = sScore[e];
+                if (cand_better(s, idx, bs, bi)) { bs = s; bi = idx; be = e; }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double s2 = __shfl_xor(bs, off);
+            const unsigned i2 = __shfl_xor(bi, off);
+            const int e2 = __shfl_xor(be, off);
+            if (cand_better(s2, i2, bs, bi)) { bs = s2; bi = i2; be = e2; }
+        }
+        if (lane == 0) { sRedS[wave] = bs; sRedI[wave] = bi; sRedE[wave] = be; }
+        __syncthreads();
+        if (tid == 0) {
+            double s = sRedS[0]; unsigned i = sRedI[0]; int e = sRedE[0];
+            for (int w = 1; w < 4; ++w)
+                if (cand_better(sRedS[w], sRedI[w], s, i)) { s = sRedS[w]; i = sRedI[w]; e = sRedE[w]; }
+            sBestE = e;
+            if (e >= 0) {
+                const int ia = i / nB, ib = i - ia * nB;
+                sUsedA[ia] = 1;
+                sUsedB[ib] = 1;
+                oa[count] = sA + ia;        // global peak ids (:157)
+                ob[count] = sB + ib;
+                os[count] = s;
+            }
+        }
+        __syncthreads();
+        if (sBestE < 0) break;
+        ++count;
+        __syncthreads();
+    }
+    if (tid == 0) *out_cnt = count;
+}
+
+// ============================================================================================= group
+__global__ __launch_bounds__(64) void pp_group_kernel(PPBuffers buf, const double* __restrict__ scale_xy)
+{
+    __shared__ double S[PMX_MAX_SUBSETS][20];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int* start = buf.pk_start + b * (PMX_N_JOINTS + 1);
+    const int n_peaks = start[PMX_N_JOINTS];
+    const float* pscore = buf.pk_score + b * PMX_MAX_PEAKS;
+    pmx_result_record* res = buf.results + b;
+    int n = 0;            // number of live subsets (wave-uniform)
+    int status = 0;
+    bool aborted = false;
+
+    for (int l = 0; l < PMX_N_LIMBS && !aborted; ++l) {
+        const int ja = c_limbs[l][0], jb = c_limbs[l][1];
+        const int cnt = buf.cn_count[b * PMX_N_LIMBS + l];
+        const long long cbase = ((long long)b * PMX_N_LIMBS + l) * PMX_MAX_PEAKS_PER_JOINT;
+        for (int c = 0; c < cnt; ++c) {
+            const int ind_a = buf.cn_a[cbase + c], ind_b = buf.cn_b[cbase + c];
+            const double score = buf.cn_score[cbase + c];
+            const double da = (double)ind_a, db = (double)ind_b;
+            // :194-198 which subsets hold either endpoint
+            const bool m0 = lane < n && (S[lane][ja] == da || S[lane][jb] == db);
+            const bool m1 = lane + 64 < n && (S[lane + 64][ja] == da || S[lane + 64][jb] == db);
+            unsigned long long k0 = __ballot(m0), k1 = __ballot(m1);
+            const int found = __popcll(k0) + __popcll(k1);
+            if (found >= 3) {                       // reference: IndexError at :197
+                status |= PMX_IMG_TRIPLE_MATCH;
+                aborted = true;
+                break;
+            }
+            if (found == 1) {                       // :200-206
+                const int idx = k0 ? (__ffsll((long long)k0) - 1) : (64 + __ffsll((long long)k1) - 1);
+                if (lane == 0 && S[idx][jb] != db) {
+                    S[idx][jb] = db;
+                    S[idx][19] += 1.0;
+                    S[idx][18] += (double)pscore[ind_b] + score;
+                }
+            } else if (found == 2) {                // :208-235
+                int idx1, idx2;
+                if (k0) {
+                    idx1 = __ffsll((long long)k0) - 1;
+                    k0 &= k0 - 1;
+                    idx2 = k0 ? (__ffsll((long long)k0) - 1) : (64 + __ffsll((long long)k1) - 1);
+                } else {
+                    idx1 = 64 + __ffsll((long long)k1) - 1;
+                    k1 &= k1 - 1;
+                    idx2 = 64 + __ffsll((long long)k1) - 1;
+                }
+                const bool both = lane < 18 && S[idx1][lane] >= 0.0 && S[idx2][lane] >= 0.0;   // :213
+                if (__ballot(both) == 0ull) {       // merge (:214-218)
+                    __syncthreads();
+                    if (lane < 18) {
+                        S[idx1][lane] += S[idx2][lane] + 1.0;
+                    } else if (lane < 20) {
+                        S[idx1][lane] += S[idx2][lane];
+                        S[idx1][lane] += score;     // (sic) score AND count, :217
+                    }
+                    __syncthreads();
+                    if (lane < 20)
+                        for (int r = idx2; r < n - 1; ++r) S[r][lane] = S[r + 1][lane];   // np.delete (:218)
+                    n -= 1;
+                } else if (lane == 0) {             // :219-235
+                    double* s1 = S[idx1];
+                    double* s2 = S[idx2];
+                    if (s1[ja] == -1.0) {
+                        s1[ja] = da; s1[19] += 1.0; s1[18] += (double)pscore[ind_a] + score;
+                    } else if (s1[jb] == -1.0) {
+                        s1[jb] = db; s1[19] += 1.0; s1[18] += (double)pscore[ind_b] + score;
+                    }
+                    if (s2[ja] == -1.0) {
+                        s2[ja] = da; s2[19] += 1.0; s2[18] += (double)pscore[ind_a] + score;
+                    } else if (s2[jb] == -1.0) {
+                        s2[jb] = db; s2[19] += 1.0; s2[18] += (double)pscore[ind_b] + score;
+                    }
+                }
+            } else if (found == 0 && l != 9 && l != 13) {   // :237-243
+                if (n >= PMX_MAX_SUBSETS) {
+                    status |= PMX_IMG_SUBSET_OVERFLOW;
+                } else {
+                    if (lane < 20) {
+                        double v = -1.0;
+                        if (lane == ja) v = da;
+                        if (lane == jb) v = db;
+                        if (lane == 19) v = 2.0;
+                        if (lane == 18) v = ((0.0 + (double)pscore[ind_a]) + (double)pscore[ind_b]) + score;
+                        S[n][lane] = v;
+                    }
+                    n += 1;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+
+    // final filter (:248-249), rescale (:513-514), pose array (:252-265)
+    const double sx = scale_xy ? scale_xy[2 * b] : 1.0;
+    const double sy = scale_xy ? scale_xy[2 * b + 1] : 1.0;
+    const int* pkx = buf.pk_x + b * PMX_MAX_PEAKS;
+    const int* pky = buf.pk_y + b * PMX_MAX_PEAKS;
+    double* subs_out = buf.subsets + (long long)b * PMX_MAX_SUBSETS * 20;
+    int n_keep = 0;
+    if (!aborted) {
+        for (int half = 0; half < 2; ++half) {
+            const int r = lane + 64 * half;
+            const bool keep = r < n && S[r][19] >= PMX_N_SUBSET_LIMBS_THRESH &&
+                              S[r][18] / S[r][19] >= PMX_SUBSET_SCORE_THRESH;
+            const unsigned long long km = __ballot(keep);
+            if (keep) {
+                const int o = n_keep + __popcll(km & ((1ull << lane) - 1ull));
+                for (int j = 0; j < 20; ++j) subs_out[o * 20 + j] = S[r][j];
+                if (o < PMX_MAX_PEOPLE) {
+                    res->scores[o] = S[r][18];
+                    for (int j = 0; j < PMX_N_JOINTS; ++j) {
+                        const int idx = (int)S[r][j];
+                        if (idx >= 0) {
+                            res->poses[o][j][0] = (double)pkx[idx] * sx;
+                            res->poses[o][j][1] = (double)pky[idx] * sy;
+                            res->poses[o][j][2] = 2.0;
+                        } else {
+                            res->poses[o][j][0] = 0.0;
+                            res->poses[o][j][1] = 0.0;
+                            res->poses[o][j][2] = 0.0;
+                        }
+                    }
+                }
+            }
+            n_keep += __popcll(km);
+        }
+    }
+    if (lane == 0) {
+        if (n_keep > PMX_MAX_PEOPLE) status |= PMX_IMG_PEOPLE_OVERFLOW;
+        const int prev = atomicOr(buf.status + b, status);
+        res->info.n_people = min(n_keep, PMX_MAX_PEOPLE);
+        res->info.n_peaks = n_peaks;
+        res->info.status = prev | status;
+        res->info.n_subsets_raw = n;
+    }
+}
+
+// ============================================================================================== host
+int pp_launch(const PPMaps& maps, const PPTables& tab, const PPBuffers& buf, int B, int map_h, int map_w,
+              double img_len, const double* d_scale_xy, int keep_smoothed, hipStream_t stream,
+              void (*prof)(void*, const char*, int), void* prof_ctx)
+{
+    PMX_HIP(hipMemsetAsync(buf.pk_count, 0, sizeof(int) * B * PMX_N_JOINTS, stream));
+    PMX_HIP(hipMemsetAsync(buf.status, 0, sizeof(int) * B, stream));
+    const int tiles_x = (map_w + PK_TS - 1) / PK_TS, tiles_y = (map_h + PK_TS - 1) / PK_TS;
+
+    if (prof) prof(prof_ctx, "pp_peaks", 1);
+    hipLaunchKernelGGL(pp_peaks_kernel, dim3(tiles_x * tiles_y, PMX_N_JOINTS, B), dim3(256), 0, stream, maps, tab, buf,
+                       map_h, map_w, tiles_x, keep_smoothed);
+    PMX_HIP(hipGetLastError());
+    if (prof) prof(prof_ctx, "pp_peaks", 0);
+
+    if (prof) prof(prof_ctx, "pp_sort", 1);
+    hipLaunchKernelGGL(pp_sort_kernel, dim3(B), dim3(256), 0, stream, buf, map_w);
+    PMX_HIP(hipGetLastError());
+    if (prof) prof(prof_ctx, "pp_sort", 0);
+
+    if (prof) prof(prof_ctx, "pp_limbs", 1);
+    hipLaunchKernelGGL(pp_limbs_kernel, dim3(PMX_N_LIMBS, B), dim3(256), 0, stream, maps, tab, buf, img_len);
+    PMX_HIP(hipGetLastError());
+    if (prof) prof(prof_ctx, "pp_limbs", 0);
+
+    if (prof) prof(prof_ctx, "pp_group", 1);
+    hipLaunchKernelGGL(pp_group_kernel, dim3(B), dim3(64), 0, stream, buf, d_scale_xy);
+    PMX_HIP(hipGetLastError());
+    if (prof) prof(prof_ctx, "pp_group", 0);
+    return PMX_OK;
+}

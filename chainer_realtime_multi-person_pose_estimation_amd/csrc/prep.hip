@@ -1,0 +1,110 @@
+// prep.hip -- input pre-processing and layout conversion kernels (HBM-bound, coalesced float4 stores).
+//
+//   prep_u8   : PoseDetector.preprocess (pose_detector.py:426-431) fused with the NHWC-16 packing the first
+//               convolution reads: uint8 HWC BGR -> float32 (x / 255 - 0.5), channels 3..15 = 0.
+//               The two float32 operations are the reference's (`x_data /= 255; x_data -= 0.5`), applied to
+//               each of the 256 possible byte values -> exact by construction (IEEE divide, then subtract).
+//   prep_f32  : the inner seam `model(x)` (pose_detector.py:499): float32 NCHW (B,3,H,W) -> NHWC-16.
+//   nchw<->nhwc: test / accessor helpers (pmx_set_maps, pmx_get_maps, pmx_conv2d).
+#include "pmx_common.h"
+
+__global__ __launch_bounds__(256) void prep_u8_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst,
+                                                      long long npix)
+{
+    // one thread per (pixel, float4 slot of the 16 output channels)
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix * 4) return;
+    const long long p = i >> 2;
+    const int slot = (int)(i & 3);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (slot == 0) {
+        const uint8_t* s = src + p * 3;
+        v.x = (float)s[0] / 255.0f - 0.5f;   // fp-contract is off for this file: divide, then subtract
+        v.y = (float)s[1] / 255.0f - 0.5f;
+        v.z = (float)s[2] / 255.0f - 0.5f;
+    }
+    reinterpret_cast<float4*>(dst)[i] = v;
+}
+
+__global__ __launch_bounds__(256) void prep_f32_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                       int B, long long hw)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long npix = (long long)B * hw;
+    if (i >= npix * 4) return;
+    const long long p = i >> 2;
+    const int slot = (int)(i & 3);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (slot == 0) {
+        const long long b = p / hw, r = p - b * hw;
+        const float* s = src + b * 3 * hw + r;
+        v.x = s[0];
+        v.y = s[hw];
+        v.z = s[2 * hw];
+    }
+    reinterpret_cast<float4*>(dst)[i] = v;
+}
+
+// dst[(b*H*W + p) * ldc + coff + c] = src[(b*C + c) * H*W + p]
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           int B, int C, long long hw, int ldc, int coff)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)B * C * hw;
+    if (i >= total) return;
+    // thread order follows the destination (c fastest) so stores coalesce
+    const int c = (int)(i % C);
+    const long long bp = i / C;
+    const long long b = bp / hw, p = bp - b * hw;
+    dst[bp * ldc + coff + c] = src[(b * C + c) * hw + p];
+}
+
+// dst[(b*C + c) * H*W + p] = src[(b*H*W + p) * lda + coff + c]
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           int B, int C, long long hw, int lda, int coff)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)B * C * hw;
+    if (i >= total) return;
+    const long long p = i % hw;
+    const long long bc = i / hw;
+    const long long b = bc / C;
+    const int c = (int)(bc - b * C);
+    dst[i] = src[(b * hw + p) * lda + coff + c];
+}
+
+static inline unsigned nblocks(long long n) { return (unsigned)((n + 255) / 256); }
+
+int launch_prep_u8(const uint8_t* bgr, float* out16, int B, int H, int W, hipStream_t s)
+{
+    const long long npix = (long long)B * H * W;
+    hipLaunchKernelGGL(prep_u8_kernel, dim3(nblocks(npix * 4)), dim3(256), 0, s, bgr, out16, npix);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+int launch_prep_f32(const float* x_nchw, float* out16, int B, int H, int W, hipStream_t s)
+{
+    const long long hw = (long long)H * W;
+    hipLaunchKernelGGL(prep_f32_kernel, dim3(nblocks((long long)B * hw * 4)), dim3(256), 0, s, x_nchw, out16, B, hw);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+int launch_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, int ldc, int coff, hipStream_t s)
+{
+    const long long total = (long long)B * C * H * W;
+    if (total == 0) return PMX_OK;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(nblocks(total)), dim3(256), 0, s, src, dst, B, C, (long long)H * W, ldc, coff);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+int launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, int lda, int coff, hipStream_t s)
+{
+    const long long total = (long long)B * C * H * W;
+    if (total == 0) return PMX_OK;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(nblocks(total)), dim3(256), 0, s, src, dst, B, C, (long long)H * W, lda, coff);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}

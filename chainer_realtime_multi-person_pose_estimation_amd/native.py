@@ -1,0 +1,363 @@
+"""ctypes binding of libpose_mi355x.so (C ABI declared in include/pose_mi355x.h) + in-tree build.
+
+There is deliberately NO fallback: if the shared library is missing or no gfx950 device is visible, the
+calls raise -- the product path never routes through NumPy/torch or the oracle.
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB_PATH = os.path.join(CSRC, 'libpose_mi355x.so')
+HEADER = os.path.join(os.path.dirname(HERE), 'include', 'pose_mi355x.h')
+SOURCES = [('pmx_api.hip', []), ('conv_mfma.hip', []), ('prep.hip', ['-ffp-contract=off']),
+           ('postproc.hip', ['-ffp-contract=off'])]
+HEADERS = ['pmx_common.h', HEADER]
+
+N_JOINTS, N_LIMBS, N_PAF, N_HEAT = 18, 19, 38, 19
+MAX_PEAKS_PER_JOINT = 128
+MAX_PEAKS = N_JOINTS * MAX_PEAKS_PER_JOINT
+MAX_SUBSETS = 128
+MAX_PEOPLE = 64
+
+IMG_PEAK_OVERFLOW, IMG_CAND_OVERFLOW, IMG_SUBSET_OVERFLOW, IMG_TRIPLE_MATCH, IMG_PEOPLE_OVERFLOW = 1, 2, 4, 8, 16
+
+RESULT_DTYPE = np.dtype([
+    ('n_people', np.int32), ('n_peaks', np.int32), ('status', np.int32), ('n_subsets_raw', np.int32),
+    ('scores', np.float64, (MAX_PEOPLE,)), ('poses', np.float64, (MAX_PEOPLE, N_JOINTS, 3))])
+
+
+class PmxError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, 'libpose_mi355x error %d: %s' % (code, msg))
+        self.code = code
+
+
+def _hipcc():
+    for p in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if p and (os.path.isabs(p) and os.path.exists(p) or not os.path.isabs(p)):
+            return p
+    return 'hipcc'
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s, _ in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP sources for gfx950 into csrc/libpose_mi355x.so (cross-compiles without a GPU)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = _hipcc()
+    objs = []
+    base = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+    for src, extra in SOURCES:
+        obj = os.path.join(CSRC, src.replace('.hip', '.o'))
+        cmd = base + extra + ['-c', os.path.join(CSRC, src), '-o', obj]
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd, cwd=CSRC)
+        objs.append(obj)
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB_PATH
+
+
+def header_symbols():
+    """Names of every function include/pose_mi355x.h declares."""
+    txt = open(HEADER).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(pmx_[a-z0-9_]+)\s*\(', txt)))
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (building is explicit: call build() first).  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('%s not found: build it with native.build() / __graft_entry__.build(); '
+                           'there is no CPU fallback for the product path' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, ci, cd = C.c_void_p, C.c_int, C.c_double
+    fp = C.POINTER(C.c_float)
+    dp = C.POINTER(C.c_double)
+    ip = C.POINTER(C.c_int)
+    sig = {
+        'pmx_version': (C.c_char_p, []),
+        'pmx_last_error': (C.c_char_p, []),
+        'pmx_device_count': (ci, [ip]),
+        'pmx_create': (ci, [C.POINTER(vp), ci, ci, ci, ci]),
+        'pmx_destroy': (None, [vp]),
+        'pmx_set_stream': (ci, [vp, vp]),
+        'pmx_synchronize': (ci, [vp]),
+        'pmx_set_option': (ci, [vp, C.c_char_p, ci]),
+        'pmx_set_layer': (ci, [vp, C.c_char_p, vp, vp, ci, ci, ci]),
+        'pmx_weights_missing': (ci, [vp, ip]),
+        'pmx_forward_u8': (ci, [vp, vp, ci, ci, ci, ci]),
+        'pmx_forward_f32': (ci, [vp, vp, ci, ci, ci, ci]),
+        'pmx_get_maps': (ci, [vp, vp, vp]),
+        'pmx_set_maps': (ci, [vp, vp, vp, ci, ci, ci]),
+        'pmx_set_gaussian': (ci, [vp, vp, ci]),
+        'pmx_postprocess': (ci, [vp, ci, ci, ci, cd, vp]),
+        'pmx_detect_batch': (ci, [vp, vp, ci, ci, ci, ci, ci, ci, cd, vp]),
+        'pmx_get_results': (ci, [vp, ci, vp]),
+        'pmx_results_device_ptr': (ci, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+        'pmx_get_peaks': (ci, [vp, ci, vp, ci, ip]),
+        'pmx_get_connections': (ci, [vp, ci, vp, ci, ip]),
+        'pmx_get_subsets': (ci, [vp, ci, vp, ci, ip]),
+        'pmx_get_smoothed': (ci, [vp, ci, ci, vp, ci, ci]),
+        'pmx_timer_start': (ci, [vp]),
+        'pmx_timer_stop': (ci, [vp, dp]),
+        'pmx_profile_enable': (ci, [vp, ci]),
+        'pmx_profile_reset': (ci, [vp]),
+        'pmx_profile_count': (ci, [vp, ip]),
+        'pmx_profile_entry': (ci, [vp, ci, C.c_char_p, ci, dp, C.POINTER(C.c_int64), dp, dp]),
+        'pmx_conv2d': (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, dp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)     # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    lib._pmx_sig = sig
+    _lib = lib
+    return lib
+
+
+def device_count():
+    n = C.c_int(0)
+    load().pmx_device_count(C.byref(n))
+    return n.value
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def gaussian_taps(sigma, truncate=4.0):
+    """The taps scipy.ndimage.gaussian_filter(sigma) uses (scipy `_gaussian_kernel1d`, order 0), computed
+    with NumPy exactly as SciPy does at run time -- the reference calls it at pose_detector.py:86."""
+    radius = int(truncate * float(sigma) + 0.5)
+    sigma2 = sigma * sigma
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / sigma2 * x ** 2)
+    return phi / phi.sum(), radius
+
+
+class Engine(object):
+    """One libpose_mi355x context (one GPU, one stream)."""
+
+    def __init__(self, device=0, max_batch=1, max_h=368, max_w=368, gaussian_sigma=2.5):
+        self.lib = load()
+        self._ctx = C.c_void_p()
+        self._check(self.lib.pmx_create(C.byref(self._ctx), int(device), int(max_batch), int(max_h), int(max_w)))
+        self.device, self.max_batch, self.max_h, self.max_w = device, max_batch, max_h, max_w
+        taps, radius = gaussian_taps(gaussian_sigma)
+        taps = np.ascontiguousarray(taps, dtype=np.float64)
+        self._check(self.lib.pmx_set_gaussian(self._ctx, _ptr(taps), radius))
+        self._B = 0
+
+    def _check(self, rc):
+        if rc != 0:
+            raise PmxError(rc, self.lib.pmx_last_error().decode('utf-8', 'replace'))
+
+    def close(self):
+        if getattr(self, '_ctx', None) is not None and self._ctx.value:
+            self.lib.pmx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- options / weights -------------------------------------------------------------------------
+    def set_option(self, key, value):
+        self._check(self.lib.pmx_set_option(self._ctx, key.encode(), int(value)))
+
+    def set_stream(self, stream_ptr):
+        self._check(self.lib.pmx_set_stream(self._ctx, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self._check(self.lib.pmx_synchronize(self._ctx))
+
+    def set_layer(self, name, W, b):
+        W = np.ascontiguousarray(W, dtype=np.float32)
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        co, ci, kh, kw = W.shape
+        assert kh == kw and b.shape == (co,)
+        self._check(self.lib.pmx_set_layer(self._ctx, name.encode(), _ptr(W), _ptr(b), co, ci, kh))
+
+    def set_weights(self, weights):
+        for name, (W, b) in weights.items():
+            self.set_layer(name, W, b)
+
+    def weights_missing(self):
+        n = C.c_int(0)
+        self._check(self.lib.pmx_weights_missing(self._ctx, C.byref(n)))
+        return n.value
+
+    # ---- network -----------------------------------------------------------------------------------
+    def forward_u8(self, imgs=None, device_ptr=None, shape=None):
+        """imgs: (B, H, W, 3) uint8 BGR host array, or a device pointer + shape."""
+        if device_ptr is not None:
+            B, H, W = shape
+            self._check(self.lib.pmx_forward_u8(self._ctx, C.c_void_p(device_ptr), B, H, W, 1))
+        else:
+            imgs = np.ascontiguousarray(imgs, dtype=np.uint8)
+            B, H, W, c3 = imgs.shape
+            assert c3 == 3
+            self._check(self.lib.pmx_forward_u8(self._ctx, _ptr(imgs), B, H, W, 0))
+        self._B = B
+        self._fhw = (H // 8, W // 8)
+
+    def forward_f32(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        B, c3, H, W = x.shape
+        assert c3 == 3
+        self._check(self.lib.pmx_forward_f32(self._ctx, _ptr(x), B, H, W, 0))
+        self._B = B
+        self._fhw = (H // 8, W // 8)
+
+    def get_maps(self):
+        fh, fw = self._fhw
+        paf = np.empty((self._B, N_PAF, fh, fw), np.float32)
+        heat = np.empty((self._B, N_HEAT, fh, fw), np.float32)
+        self._check(self.lib.pmx_get_maps(self._ctx, _ptr(paf), _ptr(heat)))
+        return paf, heat
+
+    def set_maps(self, paf, heat):
+        paf = np.ascontiguousarray(paf, dtype=np.float32)
+        heat = np.ascontiguousarray(heat, dtype=np.float32)
+        B, cp, fh, fw = paf.shape
+        assert cp == N_PAF and heat.shape == (B, N_HEAT, fh, fw)
+        self._check(self.lib.pmx_set_maps(self._ctx, _ptr(paf), _ptr(heat), B, fh, fw))
+        self._B = B
+        self._fhw = (fh, fw)
+
+    # ---- post-process ------------------------------------------------------------------------------
+    def postprocess(self, map_h, map_w, img_len, scale_xy=None):
+        sp = None
+        if scale_xy is not None:
+            scale_xy = np.ascontiguousarray(scale_xy, dtype=np.float64).reshape(self._B, 2)
+            sp = _ptr(scale_xy)
+        self._check(self.lib.pmx_postprocess(self._ctx, self._B, int(map_h), int(map_w), float(img_len), sp))
+        self._map = (int(map_h), int(map_w))
+
+    def detect_batch(self, imgs=None, map_h=320, map_w=320, img_len=None, scale_xy=None, device_ptr=None, shape=None):
+        if device_ptr is not None:
+            B, H, W = shape
+            p, on_dev = C.c_void_p(device_ptr), 1
+        else:
+            imgs = np.ascontiguousarray(imgs, dtype=np.uint8)
+            B, H, W, _ = imgs.shape
+            p, on_dev = _ptr(imgs), 0
+        sp = None
+        if scale_xy is not None:
+            scale_xy = np.ascontiguousarray(scale_xy, dtype=np.float64).reshape(B, 2)
+            sp = _ptr(scale_xy)
+        self._check(self.lib.pmx_detect_batch(self._ctx, p, B, H, W, on_dev, int(map_h), int(map_w),
+                                              float(map_w if img_len is None else img_len), sp))
+        self._B = B
+        self._fhw = (H // 8, W // 8)
+        self._map = (int(map_h), int(map_w))
+
+    def results(self):
+        """Structured array (B,) of RESULT_DTYPE (synchronises)."""
+        out = np.zeros(self._B, dtype=RESULT_DTYPE)
+        assert out.itemsize == 16 + 8 * MAX_PEOPLE * (1 + N_JOINTS * 3)
+        self._check(self.lib.pmx_get_results(self._ctx, self._B, _ptr(out)))
+        return out
+
+    def results_device_ptr(self):
+        p = C.c_void_p()
+        n = C.c_size_t()
+        self._check(self.lib.pmx_results_device_ptr(self._ctx, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def peaks(self, image=0):
+        buf = np.empty((MAX_PEAKS, 5), np.float64)
+        n = C.c_int(0)
+        self._check(self.lib.pmx_get_peaks(self._ctx, image, _ptr(buf), MAX_PEAKS, C.byref(n)))
+        return buf[:n.value].copy()
+
+    def connections(self, image=0):
+        cap = N_LIMBS * MAX_PEAKS_PER_JOINT
+        buf = np.empty((cap, 4), np.float64)
+        n = C.c_int(0)
+        self._check(self.lib.pmx_get_connections(self._ctx, image, _ptr(buf), cap, C.byref(n)))
+        return buf[:n.value].copy()
+
+    def subsets(self, image=0):
+        buf = np.empty((MAX_SUBSETS, 20), np.float64)
+        n = C.c_int(0)
+        self._check(self.lib.pmx_get_subsets(self._ctx, image, _ptr(buf), MAX_SUBSETS, C.byref(n)))
+        return buf[:n.value].copy()
+
+    def smoothed(self, image, joint):
+        h, w = self._map
+        out = np.empty((h, w), np.float32)
+        self._check(self.lib.pmx_get_smoothed(self._ctx, image, joint, _ptr(out), h, w))
+        return out
+
+    # ---- measurement -------------------------------------------------------------------------------
+    def timer_start(self):
+        self._check(self.lib.pmx_timer_start(self._ctx))
+
+    def timer_stop(self):
+        ms = C.c_double(0)
+        self._check(self.lib.pmx_timer_stop(self._ctx, C.byref(ms)))
+        return ms.value
+
+    def profile_enable(self, on=True):
+        self._check(self.lib.pmx_profile_enable(self._ctx, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self.lib.pmx_profile_reset(self._ctx))
+
+    def profile(self):
+        """[{layer, kernel, total_ms, launches, avg_ms, flop_per_launch, bytes_per_launch}]"""
+        n = C.c_int(0)
+        self._check(self.lib.pmx_profile_count(self._ctx, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            name = C.create_string_buffer(128)
+            ms, fl, by = C.c_double(0), C.c_double(0), C.c_double(0)
+            ln = C.c_int64(0)
+            self._check(self.lib.pmx_profile_entry(self._ctx, i, name, 128, C.byref(ms), C.byref(ln), C.byref(fl), C.byref(by)))
+            layer, _, kern = name.value.decode().partition('|')
+            out.append(dict(layer=layer, kernel=kern, total_ms=ms.value, launches=ln.value,
+                            avg_ms=ms.value / max(ln.value, 1), flop_per_launch=fl.value, bytes_per_launch=by.value))
+        return out
+
+    # ---- single-layer test entry ---------------------------------------------------------------------
+    def conv2d(self, x, W, b=None, relu=False, pool=False, iters=0):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        W = np.ascontiguousarray(W, dtype=np.float32)
+        B, ci, H, Wd = x.shape
+        co, ci2, k, k2 = W.shape
+        assert ci == ci2 and k == k2
+        bp = None
+        if b is not None:
+            b = np.ascontiguousarray(b, dtype=np.float32)
+            bp = _ptr(b)
+        y = np.empty((B, co, H // 2 if pool else H, Wd // 2 if pool else Wd), np.float32)
+        ms = C.c_double(0)
+        self._check(self.lib.pmx_conv2d(self._ctx, _ptr(x), _ptr(W), bp, B, ci, H, Wd, co, k, int(relu), int(pool),
+                                        _ptr(y), int(iters), C.byref(ms)))
+        return (y, ms.value) if iters else y

@@ -1,0 +1,213 @@
+"""`PoseDetector` -- drop-in mirror of the reference class (reference `pose_detector.py:15-517`) whose
+hot path runs on one MI355X through libpose_mi355x.so (C ABI: include/pose_mi355x.h).
+
+Same constructor and call signature as the reference:
+
+    PoseDetector(arch=None, weights_file=None, model=None, device=-1, precise=False)   # pose_detector.py:16
+    poses, scores = detector(orig_img)          # orig_img: H x W x 3 uint8 BGR             pose_detector.py:484
+
+`poses` is float64 (n, 18, 3) rows [x, y, 2] / [0, 0, 0] in original-image pixels, `scores` float64 (n,);
+the "nothing found" returns have the reference's shapes (:509-510, :264).  The numerics are those of the
+reference's CPU branch (the golden one): SciPy-equivalent Gaussian, 4-neighbour strict NMS, NumPy-order
+float64 PAF scoring, greedy matching and grouping -- executed by HIP kernels.
+
+What `model=` means here (the reference's plug-in seam, :19-20):
+  * None                -> the built-in CocoPoseNet kernels with `weights_file` (Chainer NPZ) or `weights=`;
+  * dict name->(W, b)   -> the built-in kernels with these weights;
+  * a callable          -> called as `model(x)` with the float32 NCHW input exactly like the reference calls its
+                           Chain (:499); it must return `(pafs, heatmaps)` lists whose last elements are arrays
+                           of shape (1, 38, h, w) / (1, 19, h, w).  Their values are installed on the device and
+                           the post-process runs on the GPU (this is how the tests inject synthetic skeletons).
+
+`device`: GPU index; -1 (the reference's "CPU") selects GPU 0 -- there is one numerics path (the CPU-branch
+semantics) and it always runs on the MI355X; there is no CPU fallback, construction raises without a GPU.
+"""
+import math
+
+import numpy as np
+
+from . import native
+from . import weights as weights_mod
+from .entity import JointType, params
+
+
+class PoseDetector(object):
+    def __init__(self, arch=None, weights_file=None, model=None, device=-1, precise=False, weights=None,
+                 max_batch=1, max_size=None):
+        self.arch = arch
+        self.precise = precise
+        self.device = device
+        self._gpu = device if device >= 0 else 0
+        self.model = None
+        w = None
+        if callable(model):
+            self.model = model
+        elif isinstance(model, dict):
+            w = model
+        elif model is not None:
+            raise TypeError('model must be None, a weights dict or a callable returning (pafs, heatmaps)')
+        else:
+            if arch not in (None, 'posenet'):
+                raise ValueError("only arch='posenet' is on the accelerated path (got %r)" % (arch,))
+            if weights is not None:
+                w = weights
+            elif weights_file:
+                w = weights_mod.load_npz(weights_file)     # serializers.load_npz (:26)
+        size = params['inference_img_size']
+        mh, mw = (size, size) if max_size is None else max_size
+        self._cap = (max_batch, mh, mw)
+        self.engine = native.Engine(self._gpu, max_batch=max_batch, max_h=mh, max_w=mw,
+                                    gaussian_sigma=params['gaussian_sigma'])
+        if w is not None:
+            self.engine.set_weights(w)
+
+    # ---- host helpers with the reference's names and semantics -------------------------------------
+    def compute_optimal_size(self, orig_img, img_size, stride=8):
+        """reference pose_detector.py:57-73 (np.round = round-half-even; long side rounded UP to `stride`)."""
+        orig_img_h, orig_img_w, _ = orig_img.shape
+        aspect = orig_img_h / orig_img_w
+        if orig_img_h < orig_img_w:
+            img_h = img_size
+            img_w = np.round(img_size / aspect).astype(int)
+            surplus = img_w % stride
+            if surplus != 0:
+                img_w += stride - surplus
+        else:
+            img_w = img_size
+            img_h = np.round(img_size * aspect).astype(int)
+            surplus = img_h % stride
+            if surplus != 0:
+                img_h += stride - surplus
+        return (int(img_w), int(img_h))
+
+    def preprocess(self, img):
+        """reference pose_detector.py:426-431 (host version, for `model=` callables; the built-in network
+        fuses it into the first kernel)."""
+        x_data = img.astype('f')
+        x_data /= 255
+        x_data -= 0.5
+        x_data = x_data.transpose(2, 0, 1)[None]
+        return x_data
+
+    def _grow(self, batch, h, w):
+        mb, mh, mw = self._cap
+        if batch <= mb and h * w <= mh * mw:
+            return
+        raise ValueError('input batch %d x %d x %d exceeds the capacity this detector was created with '
+                         '(max_batch=%d, max_size=%dx%d)' % (batch, h, w, mb, mh, mw))
+
+    # ---- the hot path -----------------------------------------------------------------------------
+    def __call__(self, orig_img):
+        """reference pose_detector.py:484-517"""
+        orig_img = np.asarray(orig_img)
+        if self.precise:
+            return self.detect_precise(orig_img)
+        return self.detect_batch([orig_img])[0]
+
+    def detect_precise(self, orig_img):
+        raise NotImplementedError('multi-scale detect_precise (pose_detector.py:433-482) is a "next" row of the '
+                                  'scope table (SURVEY.md 8f-1) and not built yet')
+
+    def detect_batch(self, imgs):
+        """Batched `__call__`: list of H x W x 3 uint8 BGR images of ONE common size -> list of (poses, scores),
+        each identical to what `__call__` returns for that image (the reference handles one image per call)."""
+        imgs = [np.asarray(im) for im in imgs]
+        shape = imgs[0].shape
+        for im in imgs:
+            if im.shape != shape or im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
+                raise ValueError('detect_batch needs uint8 H x W x 3 images of one common size')
+        orig_h, orig_w, _ = shape
+        input_w, input_h = self.compute_optimal_size(imgs[0], params['inference_img_size'])   # :490
+        map_w, map_h = self.compute_optimal_size(imgs[0], params['heatmap_size'])            # :491
+        B = len(imgs)
+        self._grow(B, input_h, input_w)
+        if (input_h, input_w) == (orig_h, orig_w):
+            batch = np.stack(imgs)                   # cv2.resize to the same size is the identity (:493)
+        else:
+            batch = np.stack([resize_linear_u8(im, input_w, input_h) for im in imgs])
+        scale = np.tile(np.array([orig_w / map_w, orig_h / map_h], dtype=np.float64), (B, 1))   # :513-514
+        if self.model is None:
+            if self.engine.weights_missing():
+                raise RuntimeError('PoseDetector has no weights: pass weights_file=, weights= or model=')
+            self.engine.detect_batch(batch, map_h, map_w, img_len=map_w, scale_xy=scale)        # :499-516
+        else:
+            pafs, heats = [], []
+            for im in batch:
+                h1s, h2s = self.model(self.preprocess(im))                                      # :499
+                pafs.append(np.asarray(_data(h1s[-1]), dtype=np.float32)[0])
+                heats.append(np.asarray(_data(h2s[-1]), dtype=np.float32)[0])
+            self.engine.set_maps(np.stack(pafs), np.stack(heats))
+            self.engine.postprocess(map_h, map_w, img_len=map_w, scale_xy=scale)                # :501-516
+        return unpack_results(self.engine.results())
+
+    def detect_maps(self, paf, heat, map_h, map_w, img_len=None, scale_xy=None):
+        """Post-process only (pose_detector.py:501-517) on network outputs paf (B,38,h,w), heat (B,19,h,w)."""
+        self.engine.set_maps(paf, heat)
+        self.engine.postprocess(map_h, map_w, img_len=map_w if img_len is None else img_len, scale_xy=scale_xy)
+        return unpack_results(self.engine.results())
+
+
+def _data(v):
+    return getattr(v, 'data', v)      # chainer.Variable-like or plain array
+
+
+def unpack_results(records):
+    """Device result records -> [(poses, scores)] with the reference's return shapes and error behaviour."""
+    out = []
+    for r in records:
+        st = int(r['status'])
+        if st & native.IMG_TRIPLE_MATCH:
+            # the reference fails with IndexError at pose_detector.py:197 when a third subset matches
+            raise IndexError('list assignment index out of range')
+        if st & (native.IMG_PEAK_OVERFLOW | native.IMG_CAND_OVERFLOW | native.IMG_SUBSET_OVERFLOW | native.IMG_PEOPLE_OVERFLOW):
+            raise RuntimeError('pose post-process capacity exceeded (status bits 0x%x: peaks>%d/joint, candidates, '
+                               'subsets>%d or people>%d)' % (st, native.MAX_PEAKS_PER_JOINT, native.MAX_SUBSETS, native.MAX_PEOPLE))
+        n = int(r['n_people'])
+        if int(r['n_peaks']) == 0:
+            out.append((np.empty((0, len(JointType), 3)), np.empty(0)))      # :509-510
+        elif n == 0:
+            out.append((np.array([]), np.empty(0)))                          # :264 np.array([]) / :516
+        else:
+            out.append((r['poses'][:n].copy(), r['scores'][:n].copy()))
+    return out
+
+
+def resize_linear_u8(img, dst_w, dst_h):
+    """Restatement of `cv2.resize(img, (dst_w, dst_h))` (INTER_LINEAR, uint8) used at pose_detector.py:493.
+
+    OpenCV is a third-party dependency that is not vendored by the reference and not installable here, so this
+    follows OpenCV's published fixed-point algorithm (imgproc/resize.cpp: half-pixel source coordinates computed
+    in float32, 11-bit coefficients `saturate_cast<short>(c * 2048)`, horizontal pass in int32, vertical pass
+    `(((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2`).  PARITY UNPINNED (no cv2 to compare
+    against); it is the identity when the size does not change, which is the case for every 368 x 368 input.
+    Host-side NumPy: byte work of < 1 ms that the reference also does on the host before the upload (:493-497).
+    """
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    src_h, src_w, cn = img.shape
+    if (src_w, src_h) == (dst_w, dst_h):
+        return img.copy()
+
+    def coeffs(dst, src):
+        scale = 1.0 / (float(dst) / float(src))
+        d = np.arange(dst, dtype=np.float64)
+        f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = f - s.astype(np.float32)
+        lo = s < 0
+        f[lo] = 0
+        s[lo] = 0
+        hi = s >= src - 1
+        f[hi] = 0
+        s[hi] = src - 1
+        c0 = np.rint((np.float32(1.0) - f) * np.float32(2048)).astype(np.int64)
+        c1 = np.rint(f * np.float32(2048)).astype(np.int64)
+        return s, np.minimum(s + 1, src - 1), c0, c1
+
+    sx, sx1, ax0, ax1 = coeffs(dst_w, src_w)
+    sy, sy1, by0, by1 = coeffs(dst_h, src_h)
+    src = img.astype(np.int64)
+    rows = src[:, sx, :] * ax0[None, :, None] + src[:, sx1, :] * ax1[None, :, None]       # (src_h, dst_w, cn)
+    s0 = rows[sy]
+    s1 = rows[sy1]
+    out = (((by0[:, None, None] * (s0 >> 4)) >> 16) + ((by1[:, None, None] * (s1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)

@@ -7,8 +7,8 @@ the one `chainer.serializers.save_npz` writes for that Chain (`models/convert_mo
 
 No trained weights can be fetched offline (they are `wget`-ed in the reference README), so tests and
 bench use `synthetic_weights(seed)`: He-scaled Gaussian weights, which keep activations O(1) through
-all 92 layers, with the last heat-map layer shifted so that a realistic (tens, not thousands) number
-of peaks survives the 0.05 threshold.
+all 92 layers; `calibrate_head` then rescales the last (affine) PAF / heat-map layers so that a realistic
+(tens, not thousands) number of peaks survives the 0.05 threshold.
 """
 import numpy as np
 
@@ -45,7 +45,7 @@ def n_params():
     return sum(co * ci * k * k + co for _, ci, co, k in layer_table())
 
 
-def synthetic_weights(seed=0, heat_scale=0.25, heat_bias=-0.55, paf_scale=1.0):
+def synthetic_weights(seed=0):
     """{name: (W OIHW float32, b float32)} -- deterministic for a given seed (numpy PCG64)."""
     rng = np.random.default_rng(seed)
     out = {}
@@ -53,11 +53,6 @@ def synthetic_weights(seed=0, heat_scale=0.25, heat_bias=-0.55, paf_scale=1.0):
         std = np.sqrt(2.0 / (ci * k * k))
         W = (rng.standard_normal((co, ci, k, k), dtype=np.float32) * np.float32(std))
         b = (rng.standard_normal(co, dtype=np.float32) * np.float32(0.01))
-        if name == 'Mconv7_stage6_L2':
-            W *= np.float32(heat_scale)
-            b = b + np.float32(heat_bias)
-        if name == 'Mconv7_stage6_L1':
-            W *= np.float32(paf_scale)
         out[name] = (np.ascontiguousarray(W, dtype=np.float32), np.ascontiguousarray(b, dtype=np.float32))
     return out
 
@@ -82,3 +77,22 @@ def save_npz(path, weights):
         flat[name + '/W'] = W
         flat[name + '/b'] = b
     np.savez(path, **flat)
+
+
+def calibrate_head(weights, paf_raw, heat_raw, heat_s=0.1, heat_t=-0.15, paf_s=0.5):
+    """Rescale the LAST (linear, 1x1) PAF / heat-map layers of a synthetic weight set so that its outputs on the
+    calibration image have, per channel, mean `heat_t` / 0 and spatial std `heat_s` / `paf_s`.
+
+    paf_raw (38, h, w), heat_raw (19, h, w): last-stage outputs of the network with `weights` on one image
+    (from any engine).  He-initialised random weights give per-channel offsets that dwarf the spatial variation, so
+    without this either no or thousands of peaks pass the 0.05 threshold; after it a COCO-crowd-like ~8 peaks per
+    joint type survive.  Exact because the last layers are affine: y' = (y - mean) * s / std + t."""
+    out = dict(weights)
+    for name, raw, s, t in (('Mconv7_stage6_L2', heat_raw, heat_s, heat_t), ('Mconv7_stage6_L1', paf_raw, paf_s, 0.0)):
+        W, b = weights[name]
+        C = W.shape[0]
+        mean = raw.reshape(C, -1).mean(1).astype(np.float64)
+        std = raw.reshape(C, -1).std(1).astype(np.float64)
+        g = s / np.maximum(std, 1e-12)
+        out[name] = ((W * g[:, None, None, None]).astype(np.float32), ((b - mean) * g + t).astype(np.float32))
+    return out

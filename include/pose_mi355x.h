@@ -1,0 +1,163 @@
+/*
+ * pose_mi355x.h -- C ABI of the MI355X-native OpenPose inference path (libpose_mi355x.so).
+ *
+ * The reference (DeNA/Chainer_Realtime_Multi-Person_Pose_Estimation) is pure Python and has no FFI of
+ * its own: the boundary its hot path sits behind is the Python class `PoseDetector`
+ * (pose_detector.py:15-517).  This header is the C ABI a binding for that class would use; each entry
+ * point names the reference interface it replaces (file:line relative to the reference repo).
+ * The Python mirror of `PoseDetector` in this repo binds exactly these symbols through ctypes
+ * (see INTEGRATION.md for the stub).
+ *
+ * Conventions: plain pointers and sizes only (no torch / HIP types in signatures; a HIP stream is
+ * passed as void*).  Every function returns PMX_OK (0) or an error code; no exceptions cross the ABI;
+ * pmx_last_error() returns a thread-local message for the last failing call.  One context per host
+ * thread / stream; calls on a context are stream-ordered and asynchronous unless stated.
+ * There is NO CPU fallback: pmx_create fails with PMX_ERR_NO_DEVICE when no gfx950 device is present.
+ */
+#ifndef POSE_MI355X_H
+#define POSE_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMX_ABI_VERSION 1
+
+/* fixed capacities of the device-side result records (a capacity overflow is reported per image in
+ * pmx_image_info.status, never silently truncated) */
+#define PMX_N_JOINTS 18          /* entity.py:9-45 */
+#define PMX_N_LIMBS 19           /* entity.py:85-105 */
+#define PMX_N_PAF 38
+#define PMX_N_HEAT 19
+#define PMX_MAX_PEAKS_PER_JOINT 128
+#define PMX_MAX_PEAKS (PMX_N_JOINTS * PMX_MAX_PEAKS_PER_JOINT)
+#define PMX_MAX_CANDIDATES 4096  /* accepted candidate connections per limb before greedy matching */
+#define PMX_MAX_SUBSETS 128      /* live person hypotheses during grouping */
+#define PMX_MAX_PEOPLE 64        /* persons returned per image */
+
+enum pmx_status {
+    PMX_OK = 0,
+    PMX_ERR_INVALID = 1,     /* bad argument */
+    PMX_ERR_HIP = 2,         /* HIP runtime error (message in pmx_last_error) */
+    PMX_ERR_NO_DEVICE = 3,   /* no usable gfx950 GPU */
+    PMX_ERR_WEIGHTS = 4,     /* forward called before all 92 layers were set / unknown layer */
+    PMX_ERR_CAPACITY = 5,    /* batch / image larger than the context was created for */
+    PMX_ERR_STATE = 6        /* call sequence error (e.g. postprocess before forward) */
+};
+
+/* per-image status bits (pmx_image_info.status) */
+enum pmx_image_status {
+    PMX_IMG_OK = 0,
+    PMX_IMG_PEAK_OVERFLOW = 1,      /* > PMX_MAX_PEAKS_PER_JOINT peaks of one joint type */
+    PMX_IMG_CAND_OVERFLOW = 2,      /* > PMX_MAX_CANDIDATES accepted candidates for one limb */
+    PMX_IMG_SUBSET_OVERFLOW = 4,    /* > PMX_MAX_SUBSETS live subsets */
+    PMX_IMG_TRIPLE_MATCH = 8,       /* third subset matches a connection: the reference raises IndexError
+                                       (pose_detector.py:193,197); the binding re-raises it */
+    PMX_IMG_PEOPLE_OVERFLOW = 16    /* > PMX_MAX_PEOPLE persons after filtering */
+};
+
+typedef struct pmx_ctx pmx_ctx;
+
+typedef struct pmx_image_info {
+    int32_t n_people;   /* rows of poses/scores (pose_detector.py:515-516) */
+    int32_t n_peaks;    /* len(all_peaks) (pose_detector.py:508); 0 => the reference's early return :509-510 */
+    int32_t status;     /* pmx_image_status bits */
+    int32_t n_subsets_raw; /* subsets alive before the final filter (pose_detector.py:248) */
+} pmx_image_info;
+
+/* device-resident result record, one per image, contiguous: what multi-GPU runs gather with RCCL */
+typedef struct pmx_result_record {
+    pmx_image_info info;
+    double scores[PMX_MAX_PEOPLE];                       /* subsets[:, -2]   (pose_detector.py:516) */
+    double poses[PMX_MAX_PEOPLE][PMX_N_JOINTS][3];       /* [x, y, 2] | [0,0,0] (pose_detector.py:252-265) */
+} pmx_result_record;
+
+/* ---- library / device ------------------------------------------------------------------------ */
+const char* pmx_version(void);
+const char* pmx_last_error(void);
+int pmx_device_count(int* n);
+
+/* ---- context: PoseDetector.__init__ (pose_detector.py:16-35) ----------------------------------
+ * Replaces model construction (`params['archs'][arch]()`, :23), `model.to_gpu()` (:31) and the device
+ * selection (:30).  max_h/max_w bound the network input size (multiples of 8), max_batch the batch. */
+int pmx_create(pmx_ctx** out, int device, int max_batch, int max_h, int max_w);
+void pmx_destroy(pmx_ctx* ctx);
+int pmx_set_stream(pmx_ctx* ctx, void* hip_stream);   /* NULL -> the context's own stream */
+int pmx_synchronize(pmx_ctx* ctx);                    /* cuda.get_device_from_id().synchronize(), :506 */
+int pmx_set_option(pmx_ctx* ctx, const char* key, int value);
+
+/* ---- weights: serializers.load_npz (pose_detector.py:26) --------------------------------------
+ * One call per Chainer-NPZ entry pair `<layer>/W` (float32 OIHW) + `<layer>/b`; names and shapes are the
+ * 92 links of models/CocoPoseNet.py:26-129.  Host pointers; packed and uploaded immediately. */
+int pmx_set_layer(pmx_ctx* ctx, const char* name, const float* w_oihw, const float* bias,
+                  int cout, int cin, int ksize);
+int pmx_weights_missing(pmx_ctx* ctx, int* n_missing);
+
+/* ---- network forward: `self.model(x)` (pose_detector.py:499; models/CocoPoseNet.py:132-262) ----
+ * pmx_forward_u8 also fuses `preprocess` (pose_detector.py:426-431): uint8 HWC BGR -> float32, /255 - 0.5.
+ * pmx_forward_f32 is the reference's inner seam (x = float32 NCHW as produced by preprocess).
+ * `on_device` != 0: the pointer is device memory on the context's device. */
+int pmx_forward_u8(pmx_ctx* ctx, const uint8_t* bgr_nhwc, int batch, int h, int w, int on_device);
+int pmx_forward_f32(pmx_ctx* ctx, const float* x_nchw, int batch, int h, int w, int on_device);
+/* last-stage outputs h1s[-1] (PAF, B x 38 x h/8 x w/8) and h2s[-1] (heat, B x 19 x h/8 x w/8), float32 NCHW,
+ * copied to host (synchronises).  Either pointer may be NULL. */
+int pmx_get_maps(pmx_ctx* ctx, float* paf_nchw, float* heat_nchw);
+/* test seam = the reference's `model=` constructor argument (pose_detector.py:19-20): install network
+ * outputs directly (host float32 NCHW, B x 38|19 x fh x fw) instead of running the network. */
+int pmx_set_maps(pmx_ctx* ctx, const float* paf_nchw, const float* heat_nchw, int batch, int fh, int fw);
+
+/* ---- post-process (pose_detector.py:501-517) --------------------------------------------------
+ * F.resize_images to (map_h, map_w) (:501-502) + compute_peaks_from_heatmaps CPU-branch semantics
+ * (:75-110) + compute_connections (:135-181) + grouping_key_points (:183-250) + the rescale to original
+ * image pixels (:513-514) + subsets_to_pose_array (:252-265), all on the device.
+ * img_len: :511 passes map_w (fast path), :478 orig_img_w (precise path).
+ * scale_xy: per image (sx, sy) = (orig_w / map_w, orig_h / map_h) as float64, or NULL for (1, 1).
+ * gauss_w: the 2*radius+1 float64 taps scipy's gaussian_filter(sigma=2.5) uses (NULL -> computed in C). */
+int pmx_set_gaussian(pmx_ctx* ctx, const double* taps, int radius);
+int pmx_postprocess(pmx_ctx* ctx, int batch, int map_h, int map_w, double img_len, const double* scale_xy);
+
+/* fused: forward_u8 + postprocess (PoseDetector.__call__, pose_detector.py:484-517, for images already
+ * at the network input size; cv2.resize at :493 is the identity for them) */
+int pmx_detect_batch(pmx_ctx* ctx, const uint8_t* bgr_nhwc, int batch, int h, int w, int on_device,
+                     int map_h, int map_w, double img_len, const double* scale_xy);
+
+/* results: copies `batch` records to host (synchronises). */
+int pmx_get_results(pmx_ctx* ctx, int batch, pmx_result_record* out);
+/* device pointer of the record array (for RCCL gathers); valid until the context is destroyed */
+int pmx_results_device_ptr(pmx_ctx* ctx, void** dev_ptr, size_t* bytes_per_image);
+
+/* parity accessors for one image of the last post-process (host copies; synchronise).
+ * peaks: rows (type, x, y, score, id) float64 = all_peaks (pose_detector.py:76,110), BEFORE the rescale;
+ * conns: rows (limb, id_a, id_b, score) = all_connections (:161-181) flattened in limb order;
+ * subsets: rows of 20 float64 after the final filter (:248-249). */
+int pmx_get_peaks(pmx_ctx* ctx, int image, double* peaks5, int cap_rows, int* n_rows);
+int pmx_get_connections(pmx_ctx* ctx, int image, double* conns4, int cap_rows, int* n_rows);
+int pmx_get_subsets(pmx_ctx* ctx, int image, double* subsets20, int cap_rows, int* n_rows);
+/* smoothed heat map (gaussian_filter output, pose_detector.py:86) of one image/joint: only produced when
+ * option "keep_smoothed" is 1; float32 map_h x map_w. */
+int pmx_get_smoothed(pmx_ctx* ctx, int image, int joint, float* out, int map_h, int map_w);
+
+/* ---- measurement ------------------------------------------------------------------------------
+ * HIP-event timing on the stream the kernels are launched on. */
+int pmx_timer_start(pmx_ctx* ctx);
+int pmx_timer_stop(pmx_ctx* ctx, double* ms);          /* synchronises */
+int pmx_profile_enable(pmx_ctx* ctx, int on);          /* per-launch event pairs around every kernel */
+int pmx_profile_reset(pmx_ctx* ctx);
+int pmx_profile_count(pmx_ctx* ctx, int* n);
+int pmx_profile_entry(pmx_ctx* ctx, int i, char* name, int name_cap, double* total_ms,
+                      int64_t* launches, double* flop_per_launch, double* bytes_per_launch);
+
+/* ---- kernel unit-test entry (T0): one convolution layer through the product kernels -----------
+ * x: float32 NCHW host (B, cin, h, w); w: OIHW; y: NCHW host (B, cout, h', w') with h' = h/2 if pool.
+ * Semantics = L.Convolution2D(ksize, stride 1, pad ksize/2) [+ F.relu] [+ F.max_pooling_2d(2, 2)]. */
+int pmx_conv2d(pmx_ctx* ctx, const float* x_nchw, const float* w_oihw, const float* bias,
+               int batch, int cin, int h, int w, int cout, int ksize, int relu, int pool,
+               float* y_nchw, int iters, double* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POSE_MI355X_H */

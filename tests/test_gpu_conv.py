@@ -1,0 +1,79 @@
+"""GPU (T0): every convolution kernel variant through the C ABI (pmx_conv2d) against the torch-CPU fp32 reference
+of the same op (oracle/network_ref.py::conv2d_ref = L.Convolution2D semantics [+relu] [+2x2 max-pool])."""
+import numpy as np
+import pytest
+
+from oracle import network_ref as N
+
+pytestmark = pytest.mark.gpu
+
+# fp32 MFMA = exact fp32 FMA chain; the torch reference sums in a different order -> tolerance scaled by sqrt(K)
+TOL = 2e-5
+
+
+def _case(engine, B, cin, H, W, cout, k, relu, pool, seed, variant=None):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, cin, H, W)).astype('f')
+    w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype('f')
+    b = rng.standard_normal(cout).astype('f')
+    for kk in (1, 3, 7):
+        engine.set_option('force_variant_k%d' % kk, -1)
+    if variant is not None:
+        engine.set_option('force_variant_k%d' % k, variant)
+    y = engine.conv2d(x, w, b, relu=relu, pool=pool)
+    engine.set_option('force_variant_k%d' % k, -1)
+    ref = N.conv2d_ref(x, w, b, relu=relu, pool=pool)
+    assert y.shape == ref.shape
+    assert np.isfinite(y).all(), 'unwritten (poisoned) or non-finite outputs'
+    err = np.abs(y - ref).max()
+    assert err <= TOL * max(1.0, np.abs(ref).max()), (err, np.abs(ref).max())
+
+
+# variant indices: see conv_mfma.hip g_variants
+@pytest.mark.parametrize('variant,k,cout', [(0, 7, 128), (5, 7, 128), (1, 3, 128), (2, 3, 64), (6, 3, 64),
+                                            (3, 1, 128), (4, 1, 64), (7, 1, 64)])
+def test_variants_basic(engine, variant, k, cout):
+    _case(engine, 2, 32, 24, 40, cout, k, True, False, seed=variant, variant=variant)
+
+
+@pytest.mark.parametrize('k', [1, 3, 7])
+def test_asymmetric_shapes_and_edges(engine, k):
+    # H, W not multiples of the tile, odd sizes, transposition-detecting (H != W, cin != cout)
+    _case(engine, 3, 16, 13, 29, 38, k, False, False, seed=10 + k)
+    _case(engine, 1, 48, 46, 46, 19, k, True, False, seed=20 + k)
+
+
+@pytest.mark.parametrize('variant', [1, 2, 6])
+def test_fused_relu_maxpool(engine, variant):
+    _case(engine, 2, 16, 20, 36, 64 if variant != 1 else 128, 3, True, True, seed=30 + variant, variant=variant)
+
+
+def test_cin_padding_3_channels(engine):
+    _case(engine, 2, 3, 32, 48, 64, 3, True, False, seed=40)       # conv1_1 shape class (cin 3 -> 16)
+
+
+def test_cin_185_like_concat(engine):
+    _case(engine, 1, 185, 46, 46, 128, 7, True, False, seed=41)    # Mconv1 shape class (cin 185 -> 192)
+
+
+def test_deep_k_512(engine):
+    _case(engine, 1, 512, 23, 23, 256, 3, True, False, seed=42)    # conv4_3 shape class
+
+
+def test_identity_kernel_detects_layout_errors(engine):
+    # A = I check with an asymmetric weight: y[:, n] = x[:, perm[n]] exactly
+    rng = np.random.default_rng(5)
+    cin = cout = 32
+    perm = rng.permutation(cin)
+    w = np.zeros((cout, cin, 3, 3), 'f')
+    w[np.arange(cout), perm, 1, 1] = 1.0
+    x = rng.standard_normal((1, cin, 16, 32)).astype('f')
+    y = engine.conv2d(x, w, None)
+    assert np.array_equal(y, x[:, perm])
+    # shifted tap: y(y, x) = x(y + 1, x - 1) with zero padding -> checks ky/kx orientation (cross-correlation)
+    w = np.zeros((cout, cin, 3, 3), 'f')
+    w[np.arange(cout), np.arange(cin), 2, 0] = 1.0
+    y = engine.conv2d(x, w, None)
+    ref = np.zeros_like(x)
+    ref[:, :, :-1, 1:] = x[:, :, 1:, :-1]
+    assert np.array_equal(y, ref)

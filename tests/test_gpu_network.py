@@ -1,0 +1,87 @@
+"""GPU (T1/T3): the 92-layer network through the C ABI against the torch-CPU fp32 restatement, and the end-to-end
+PoseDetector on top of it."""
+import numpy as np
+import pytest
+
+from conftest import pkg
+from oracle import network_ref as N
+from oracle import postprocess_ref as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def weights():
+    return pkg('weights').synthetic_weights(0)
+
+
+def _rel_err(a, b):
+    return np.abs(a - b).max() / max(1.0, np.abs(b).max())
+
+
+def test_network_forward_matches_torch_oracle(engine, weights):
+    engine.set_weights(weights)
+    rng = np.random.default_rng(0)
+    imgs = rng.integers(0, 256, (2, 184, 248, 3), dtype=np.uint8)      # non-square, multiples of 8
+    engine.forward_u8(imgs)
+    paf, heat = engine.get_maps()
+    x = np.concatenate([P.preprocess(im) for im in imgs])
+    rpaf, rheat = N.forward(weights, x)
+    assert paf.shape == rpaf.shape == (2, 38, 23, 31) and heat.shape == rheat.shape == (2, 19, 23, 31)
+    # tolerance: fp32 accumulation-order differences through 6 stages (BASELINE tolerance for scores is 1e-4)
+    assert _rel_err(paf, rpaf) < 1e-4, _rel_err(paf, rpaf)
+    assert _rel_err(heat, rheat) < 1e-4, _rel_err(heat, rheat)
+
+
+def test_forward_f32_seam_equals_u8_path(engine, weights):
+    engine.set_weights(weights)
+    rng = np.random.default_rng(1)
+    imgs = rng.integers(0, 256, (1, 64, 96, 3), dtype=np.uint8)
+    imgs.reshape(-1)[:256] = np.arange(256)          # every byte value goes through the fused preprocess
+    engine.forward_u8(imgs)
+    paf_a, heat_a = engine.get_maps()
+    engine.forward_f32(P.preprocess(imgs[0]))
+    paf_b, heat_b = engine.get_maps()
+    assert np.array_equal(paf_a, paf_b) and np.array_equal(heat_a, heat_b)   # same kernels, same fp32 input bits
+
+
+def test_full_size_368_single_image(engine, weights):
+    engine.set_weights(weights)
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (1, 368, 368, 3), dtype=np.uint8)
+    engine.forward_u8(img)
+    paf, heat = engine.get_maps()
+    rpaf, rheat = N.forward(weights, P.preprocess(img[0]))
+    assert _rel_err(paf, rpaf) < 1e-4 and _rel_err(heat, rheat) < 1e-4
+
+
+def test_end_to_end_pose_detector(native, weights):
+    """T3: PoseDetector.__call__ == oracle network o oracle post-process on the device's own maps."""
+    W = pkg('weights')
+    PD = pkg('pose_detector')
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (368, 368, 3), dtype=np.uint8)
+    det = PD.PoseDetector(weights=weights, device=0, max_batch=2)
+    # calibrate the synthetic head so that a realistic number of peaks survives (weights stay synthetic)
+    det.engine.forward_u8(img[None])
+    paf, heat = det.engine.get_maps()
+    w2 = W.calibrate_head(weights, paf[0], heat[0])
+    det.engine.set_weights({k: w2[k] for k in ('Mconv7_stage6_L1', 'Mconv7_stage6_L2')})
+    poses, scores = det(img)
+    paf, heat = det.engine.get_maps()
+    # (a) the device's maps agree with the oracle network within tolerance
+    rpaf, rheat = N.forward(w2, P.preprocess(img))
+    assert _rel_err(paf, rpaf) < 1e-4 and _rel_err(heat, rheat) < 1e-4
+    # (b) given identical maps, everything downstream is exact
+    ref = P.postprocess_from_net_output(paf[0], heat[0], 320, 320, orig_w=368, orig_h=368)
+    assert len(ref['all_peaks']) > 20, 'calibration should leave a workload'
+    assert np.array_equal(det.engine.peaks(0), ref['all_peaks'])
+    assert np.array_equal(np.asarray(poses), np.asarray(ref['poses']))
+    assert np.allclose(scores, ref['scores'], rtol=0, atol=1e-9)
+    # (c) batched entry == per-image calls
+    img2 = rng.integers(0, 256, (368, 368, 3), dtype=np.uint8)
+    (p1, s1), (p2, s2) = det.detect_batch([img, img2])
+    assert np.array_equal(p1, poses) and np.array_equal(s1, scores)
+    q2, t2 = det(img2)
+    assert np.array_equal(p2, q2) and np.array_equal(s2, t2)
+    det.engine.close()

@@ -1,0 +1,116 @@
+"""CPU: host-side logic of the product package and the C-ABI surface (no compute calls without a GPU)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, pkg
+
+
+def test_entity_constants_match_reference_golden():
+    ent = pkg('entity')
+    g = json.load(open(os.path.join(GOLDEN, 'host_fns.json')))['entity']
+    assert {j.name: int(j) for j in ent.JointType} == g['JointType']
+    assert [[int(a), int(b)] for a, b in ent.params['limbs_point']] == g['limbs_point']
+    for k, v in g['params'].items():
+        assert ent.params[k] == v, k
+
+
+def test_c_constants_match_python_constants():
+    ent = pkg('entity')
+    native = pkg('native')
+    hdr = open(os.path.join(os.path.dirname(native.HERE), 'include', 'pose_mi355x.h')).read()
+    common = open(os.path.join(native.CSRC, 'pmx_common.h')).read()
+    import re
+
+    def define(txt, name):
+        return re.search(r'#define\s+%s\s+([^\s/]+)' % name, txt).group(1)
+    assert int(define(hdr, 'PMX_N_JOINTS')) == len(ent.JointType) == native.N_JOINTS
+    assert int(define(hdr, 'PMX_N_LIMBS')) == len(ent.params['limbs_point']) == native.N_LIMBS
+    assert int(define(hdr, 'PMX_MAX_PEAKS_PER_JOINT')) == native.MAX_PEAKS_PER_JOINT
+    assert int(define(hdr, 'PMX_MAX_SUBSETS')) == native.MAX_SUBSETS
+    assert int(define(hdr, 'PMX_MAX_PEOPLE')) == native.MAX_PEOPLE
+    assert float(define(common, 'PMX_HEATMAP_PEAK_THRESH').rstrip('f')) == ent.params['heatmap_peak_thresh']
+    assert int(define(common, 'PMX_N_INTEG_POINTS')) == ent.params['n_integ_points']
+    assert int(define(common, 'PMX_N_INTEG_POINTS_THRESH')) == ent.params['n_integ_points_thresh']
+    assert float(define(common, 'PMX_INNER_PRODUCT_THRESH')) == ent.params['inner_product_thresh']
+    assert float(define(common, 'PMX_SUBSET_SCORE_THRESH')) == ent.params['subset_score_thresh']
+    assert float(define(common, 'PMX_N_SUBSET_LIMBS_THRESH')) == ent.params['n_subset_limbs_thresh']
+    assert float(define(common, 'PMX_GAUSS_SIGMA')) == ent.params['gaussian_sigma']
+    limbs = re.search(r'PMX_LIMBS\[PMX_N_LIMBS\]\[2\] = \{(.*?)\};', common, re.S).group(1)
+    pairs = [[int(a), int(b)] for a, b in re.findall(r'\{(\d+),\s*(\d+)\}', limbs)]
+    assert pairs == [[int(a), int(b)] for a, b in ent.params['limbs_point']]
+
+
+def test_compute_optimal_size_matches_reference_golden():
+    PD = pkg('pose_detector')
+    det = PD.PoseDetector.__new__(PD.PoseDetector)     # host helper only; no engine
+    for h, w, target, rw, rh in json.load(open(os.path.join(GOLDEN, 'host_fns.json')))['compute_optimal_size']:
+        assert det.compute_optimal_size(np.zeros((h, w, 3), 'uint8'), target) == (rw, rh)
+
+
+def test_preprocess_matches_reference_golden():
+    PD = pkg('pose_detector')
+    det = PD.PoseDetector.__new__(PD.PoseDetector)
+    z = np.load(os.path.join(GOLDEN, 'preprocess.npz'))
+    assert np.array_equal(det.preprocess(z['img']), z['x'])
+
+
+def test_layer_table_and_synthetic_weights():
+    W = pkg('weights')
+    t = W.layer_table()
+    assert len(t) == 92 and W.n_params() == 52311446
+    from oracle import network_ref
+    assert sorted(t) == sorted(network_ref.layer_table())
+    w1, w2 = W.synthetic_weights(3), W.synthetic_weights(3)
+    for k in w1:
+        assert np.array_equal(w1[k][0], w2[k][0]) and np.array_equal(w1[k][1], w2[k][1])
+    assert w1['Mconv1_stage2_L1'][0].shape == (128, 185, 7, 7) and w1['conv5_5_CPM_L2'][0].shape == (19, 512, 1, 1)
+
+
+def test_npz_roundtrip(tmp_path):
+    W = pkg('weights')
+    w = W.synthetic_weights(1)
+    p = str(tmp_path / 'w.npz')
+    W.save_npz(p, w)
+    r = W.load_npz(p)
+    assert set(r) == set(w)
+    assert np.array_equal(r['conv4_2'][0], w['conv4_2'][0])
+
+
+def test_resize_linear_u8_identity_and_constant():
+    PD = pkg('pose_detector')
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (24, 32, 3), dtype=np.uint8)
+    assert np.array_equal(PD.resize_linear_u8(img, 32, 24), img)
+    flat = np.full((50, 70, 3), 137, np.uint8)
+    assert np.all(PD.resize_linear_u8(flat, 41, 33) == 137)
+    up = PD.resize_linear_u8(img, 64, 48)
+    assert up.shape == (48, 64, 3) and up.dtype == np.uint8
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol(native):
+    lib = native.load()
+    syms = native.header_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert set(syms) == set(lib._pmx_sig), set(syms) ^ set(lib._pmx_sig)
+    assert b'gfx950' in lib.pmx_version()
+    assert native.RESULT_DTYPE.itemsize == 16 + 8 * 64 * (1 + 18 * 3)
+
+
+def test_product_never_imports_oracle():
+    native = pkg('native')
+    for fn in os.listdir(native.HERE):
+        if fn.endswith('.py'):
+            src = open(os.path.join(native.HERE, fn)).read()
+            assert 'import oracle' not in src and 'from oracle' not in src, fn
+
+
+def test_no_device_fails_loudly(native):
+    if native.device_count() > 0:
+        pytest.skip('GPU present')
+    with pytest.raises(native.PmxError):
+        native.Engine(0)

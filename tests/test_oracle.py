@@ -1,0 +1,73 @@
+"""CPU: the oracle (oracle/postprocess_ref.py) against the committed golden fixtures, which were produced by the
+VERBATIM reference post-process (oracle/make_golden.py).  This is what pins the oracle on the GPU box, where
+/root/reference does not exist."""
+import numpy as np
+import pytest
+from scipy.ndimage import gaussian_filter
+
+from conftest import golden_cases, load_golden, conns_by_limb
+from oracle import postprocess_ref as P
+from oracle import fixtures as Fx
+
+
+@pytest.mark.parametrize('name', golden_cases())
+def test_oracle_reproduces_reference_golden(name):
+    g = load_golden(name)
+    map_h, map_w = [int(v) for v in g['map_hw']]
+    orig_h, orig_w = [int(v) for v in g['orig_hw']]
+    out = P.postprocess_from_net_output(g['paf_lo'], g['heat_lo'], map_h, map_w, orig_w=orig_w, orig_h=orig_h)
+    # integer / index work: bit-exact
+    assert np.array_equal(out['all_peaks'], g['all_peaks'].reshape(-1, 5))
+    ref_conns = conns_by_limb(g['connections'])
+    for l in range(19):
+        mine = np.asarray(out['connections'][l]).reshape(-1, 3)
+        assert mine.shape == ref_conns[l].shape, 'limb %d' % l
+        assert np.array_equal(mine[:, :2], ref_conns[l][:, :2]), 'limb %d ids' % l
+        # PAF scores: tolerance 1e-4 per BASELINE.json (observed <= 1e-12; np.dot vs explicit mul-add)
+        assert np.allclose(mine[:, 2], ref_conns[l][:, 2], rtol=0, atol=1e-9)
+    assert out['subsets'].shape == g['subsets'].shape
+    assert np.array_equal(out['subsets'][:, :18], g['subsets'][:, :18])
+    assert np.allclose(out['subsets'][:, 18:], g['subsets'][:, 18:], rtol=0, atol=1e-9)
+    poses = np.asarray(out['poses'], dtype=np.float64)
+    assert poses.shape == g['poses'].shape
+    assert np.array_equal(poses, g['poses'])
+    assert np.allclose(out['scores'], g['scores'], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize('shape', [(320, 320), (40, 56), (21, 21), (12, 9), (5, 7)])
+def test_gaussian_restatement_bit_exact_vs_scipy(shape):
+    rng = np.random.default_rng(0)
+    a = (rng.random(shape) * 2 - 0.5).astype('f')
+    assert np.array_equal(gaussian_filter(a, sigma=2.5), P.gaussian_filter_ref(a))
+
+
+def test_gaussian_taps_match_scipy_internal():
+    from scipy.ndimage import _filters
+    w = _filters._gaussian_kernel1d(2.5, 0, 10)
+    assert np.array_equal(w, P.gaussian_kernel1d(2.5))
+    assert len(w) == 21
+
+
+def test_resize_is_identity_for_same_size_and_corner_aligned():
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((3, 9, 11)).astype('f')
+    assert np.array_equal(P.resize_images_ref(x, 9, 11), x)
+    y = P.resize_images_ref(x, 33, 41)       # (out-1) = 4 * (in-1): every 4th sample is an input sample
+    assert np.array_equal(y[:, ::4, ::4], x)
+    import torch
+    t = torch.nn.functional.interpolate(torch.from_numpy(x)[None], size=(33, 41), mode='bilinear', align_corners=True)[0].numpy()
+    assert np.allclose(y, t, atol=2e-6)
+
+
+def test_np_sum10_is_numpys_order():
+    rng = np.random.default_rng(2)
+    for _ in range(200):
+        v = rng.standard_normal(10) * 10.0 ** rng.integers(-8, 8, 10)
+        assert P._np_sum10(v) == v.sum()
+
+
+def test_fixture_renderer_shapes():
+    heat, paf, poses = Fx.synthetic_maps(3, 2, 46, 46, 1.0, 0.9)
+    assert heat.shape == (19, 46, 46) and paf.shape == (38, 46, 46) and poses.shape == (2, 18, 3)
+    assert heat.dtype == np.float32 and paf.dtype == np.float32
+    assert np.all(heat[:18] >= 0) and np.all(heat[:18] <= 1)
