@@ -29,8 +29,9 @@ template <int KS, int TH, int TW, int BN, int CK, int WM, int WN>
 struct ConvCfg {
     static constexpr int T = KS * KS;
     static constexpr int PADK = KS / 2;
-    static constexpr int M = TH * TW;
-    static constexpr int MTILES = M / 32;
+    static constexpr int M = TH * TW;                 // real pixels per tile
+    static constexpr int MTILES = (M + 31) / 32;      // 32-row MFMA tiles (rows >= M are masked)
+    static constexpr bool MASK_M = (M % 32) != 0;
     static constexpr int NTILES = BN / 32;
     static constexpr int MT = MTILES / WM;   // 32-row tiles per wave
     static constexpr int NT = NTILES / WN;   // 32-col tiles per wave
@@ -42,7 +43,8 @@ struct ConvCfg {
     static constexpr int LDS_BYTES = (IN_ELEMS + 2 * W_ELEMS) * 4;
     static constexpr int WREGS = (BN * CK / 4 + 255) / 256;   // float4 per thread per weight panel (1 or 2)
     static_assert(WM * WN == 4, "4 waves per block");
-    static_assert(M % 32 == 0 && BN % 32 == 0, "tile must be a multiple of the 32x32 MFMA");
+    static_assert(BN % 32 == 0, "BN must be a multiple of the 32x32 MFMA");
+    static_assert(M % 4 == 0, "whole 2x2 windows");
     static_assert(MTILES % WM == 0 && NTILES % WN == 0, "wave grid must divide the tile grid");
     static_assert(TH % 2 == 0 && TW % 2 == 0, "2x2 window mapping");
     static_assert(CK % 8 == 0, "k8 steps");
@@ -87,7 +89,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
     int a_base[C::MT];
 #pragma unroll
     for (int t = 0; t < C::MT; ++t) {
-        const int m = (wm * C::MT + t) * 32 + li;
+        int m = (wm * C::MT + t) * 32 + li;
+        if (C::MASK_M && m >= C::M) m = C::M - 1;     // padded rows recompute the last pixel; never stored
         const int q = m >> 2, r = m & 3;
         const int wy = q / (TW / 2), wx = q % (TW / 2);
         const int py = 2 * wy + (r >> 1), px = 2 * wx + (r & 1);
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
                     const int gy = y0 + 2 * wy + (r >> 1), gx = x0 + 2 * wx + (r & 1);
                     float v = acc[t][u][reg] + bias;
                     if (a.relu) v = fmaxf(v, 0.f);
-                    if (nok && gy < H && gx < W) out_b[((size_t)gy * W + gx) * a.ldc + n] = v;
+                    if (nok && (!C::MASK_M || m < C::M) && gy < H && gx < W) out_b[((size_t)gy * W + gx) * a.ldc + n] = v;
                 }
             } else {
                 const int Hp = H >> 1, Wp = W >> 1;
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
                     const int q = (wm * C::MT + t) * 8 + 2 * g4 + kh;
                     const int wy = q / (TW / 2), wx = q % (TW / 2);
                     const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
-                    if (nok && oy < Hp && ox < Wp) out_b[((size_t)oy * Wp + ox) * a.ldc + n] = v;
+                    if (nok && (!C::MASK_M || q < C::M / 4) && oy < Hp && ox < Wp) out_b[((size_t)oy * Wp + ox) * a.ldc + n] = v;
                 }
             }
         }
@@ -239,6 +242,8 @@ static const ConvVariant g_variants[] = {
     {7, 8, 8, 64, 16, "conv7x7_t8x8_n64"},        // 5: small batches (more blocks)
     {3, 8, 8, 64, 16, "conv3x3_t8x8_n64"},        // 6
     {1, 8, 8, 64, 16, "conv1x1_t8x8_n64"},        // 7
+    {7, 2, 46, 128, 16, "conv7x7_t2x46_n128"},    // 8: zero-waste row strips for 46-wide maps (368x368 input)
+    {3, 2, 46, 128, 16, "conv3x3_t2x46_n128"},    // 9
 };
 
 int conv_num_variants() { return (int)(sizeof(g_variants) / sizeof(g_variants[0])); }
@@ -250,8 +255,9 @@ int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced)
     // enough 8x16 tiles to fill 256 CUs a few times over?  otherwise use the small tiles
     const long tiles816 = (long)((H + 7) / 8) * ((W + 15) / 16) * B;
     const bool small = tiles816 * ((cout + 127) / 128) < 512;
-    if (ks == 7) return small ? 5 : 0;
-    if (ks == 3) return small ? 6 : (cout <= 64 ? 2 : 1);
+    const bool strip = (W == 46) && (cout % 128 == 0) && ((long)((H + 1) / 2) * B * (cout / 128) >= 512);
+    if (ks == 7) return strip ? 8 : (small ? 5 : 0);
+    if (ks == 3) return strip ? 9 : (small ? 6 : (cout <= 64 ? 2 : 1));
     return small ? 7 : (cout <= 64 ? 4 : 3);
 }
 
@@ -288,6 +294,8 @@ int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream)
         case 5: return launch_cfg<7, 8, 8, 64, 16, 2, 2>(a, groups, stream);
         case 6: return launch_cfg<3, 8, 8, 64, 16, 2, 2>(a, groups, stream);
         case 7: return launch_cfg<1, 8, 8, 64, 16, 2, 2>(a, groups, stream);
+        case 8: return launch_cfg<7, 2, 46, 128, 16, 1, 4>(a, groups, stream);
+        case 9: return launch_cfg<3, 2, 46, 128, 16, 1, 4>(a, groups, stream);
     }
     pmx_set_error("conv_launch: unknown variant %d", variant);
     return PMX_ERR_INVALID;

@@ -36,6 +36,13 @@ def test_variants_basic(engine, variant, k, cout):
     _case(engine, 2, 32, 24, 40, cout, k, True, False, seed=variant, variant=variant)
 
 
+@pytest.mark.parametrize('variant,k', [(8, 7), (9, 3)])
+@pytest.mark.parametrize('hw', [(46, 46), (10, 46), (7, 30), (6, 100)])
+def test_row_strip_variants(engine, variant, k, hw):
+    # 2 x 46 strips: 92 real pixels padded to 96 MFMA rows (masked); also widths != 46 and odd heights
+    _case(engine, 2, 32, hw[0], hw[1], 128, k, True, False, seed=50 + variant + hw[0], variant=variant)
+
+
 @pytest.mark.parametrize('k', [1, 3, 7])
 def test_asymmetric_shapes_and_edges(engine, k):
     # H, W not multiples of the tile, odd sizes, transposition-detecting (H != W, cin != cout)

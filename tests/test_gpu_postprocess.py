@@ -89,9 +89,9 @@ def test_vs_oracle_seeded(engine, seed, n, hw, mapsz):
     engine.set_option('keep_smoothed', 1)
     engine.set_maps(paf[None], heat[None])
     engine.postprocess(mapsz[0], mapsz[1], img_len=mapsz[1], scale_xy=[[2.0, 3.0]])
-    engine.set_option('keep_smoothed', 0)
     for j in (0, 7, 17):
         assert np.array_equal(engine.smoothed(0, j), ref['smoothed'][j]), 'smoothed heat map %d not bit-exact' % j
+    engine.set_option('keep_smoothed', 0)
     rec = engine.results()[0]
     _compare(engine, 0, ref['all_peaks'], ref['connections'], ref['subsets'], ref['poses'], ref['scores'], rec)
 
