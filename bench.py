@@ -33,7 +33,29 @@ sys.path.insert(0, ROOT)
 PKG = 'chainer_realtime_multi-person_pose_estimation_amd'
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 FLOP_PER_FRAME = 271868013568          # 2 x MACs of the 92 convs at 368 x 368
-DOMINANT_KERNEL = 'conv7x7_t8x16_n128'
+DOMINANT_LAYERS = ('Mconv2_', 'Mconv3_', 'Mconv4_', 'Mconv5_')   # 7x7 128->128, 20 launches per step
+
+
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the newest committed PMC summary (profiles/rNN_pmc_summary.json,
+    written by tools/summarize_profiles.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same
+    workload; (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md).  Median over the launches of the
+    kernel (20 of its 25 launches per step are the dominant 128->128 layers).  None if no summary exists."""
+    import glob
+    import re
+    m = re.match(r'conv(\d)x\d_t(\d+)x(\d+)_n(\d+)', kernel_name)
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_summary.json')))
+    if not m or not files:
+        return None, None
+    sig = 'conv_mfma_kernel<%s, %s, %s, %s,' % m.groups()
+    try:
+        d = json.load(open(files[-1]))
+        for k, e in d['kernels'].items():
+            if sig in k and 'hbm_bytes_per_launch_median' in e.get('derived', {}):
+                return e['derived']['hbm_bytes_per_launch_median'], os.path.basename(files[-1])
+    except Exception:
+        pass
+    return None, None
 
 
 def parse():
@@ -184,16 +206,17 @@ def main():
         }
         roof = None
         if prof:
-            dom = [p for p in prof if p['kernel'] == DOMINANT_KERNEL and p['layer'].startswith('Mconv')
-                   and not p['layer'].startswith('Mconv1_')]
+            dom = [p for p in prof if p['layer'].startswith(DOMINANT_LAYERS)]
             if dom:
                 launches = sum(p['launches'] for p in dom)
                 total_ms = sum(p['total_ms'] for p in dom)
                 flop = dom[0]['flop_per_launch']
                 avg_ms = total_ms / launches
                 ach = flop / (avg_ms * 1e-3) / 1e12
-                roof = {'kernel': DOMINANT_KERNEL, 'bound': 'mfma', 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS,
-                        'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                traffic, traffic_src = pmc_traffic(dom[0]['kernel'])
+                roof = {'kernel': dom[0]['kernel'], 'bound': 'mfma', 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS,
+                        'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
+                        'traffic_source': traffic_src,
                         'flop_per_launch': flop, 'avg_launch_ms': avg_ms, 'launches_timed': launches,
                         'note': '7x7 128->128 conv at 46x46, both branch groups per launch, B=%d; HIP events on the launch stream' % B}
             conv_ms = sum(p['total_ms'] for p in prof if p['kernel'].startswith('conv'))

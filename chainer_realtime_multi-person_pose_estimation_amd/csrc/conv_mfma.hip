@@ -251,7 +251,8 @@ const ConvVariant& conv_variant(int idx) { return g_variants[idx]; }
 
 int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced)
 {
-    if (forced >= 0 && forced < conv_num_variants() && g_variants[forced].ks == ks) return forced;
+    if (forced >= 0 && forced < conv_num_variants() && g_variants[forced].ks == ks && cout % g_variants[forced].bn == 0)
+        return forced;   // (cout here is the padded channel count)
     // enough 8x16 tiles to fill 256 CUs a few times over?  otherwise use the small tiles
     const long tiles816 = (long)((H + 7) / 8) * ((W + 15) / 16) * B;
     const bool small = tiles816 * ((cout + 127) / 128) < 512;

@@ -1,0 +1,82 @@
+#!/usr/bin/env python
+"""Condense the rocprofv3 outputs of tools/gpu_round_run.sh (gpurun_out/) into small tracked files under profiles/.
+
+    python tools/summarize_profiles.py r01
+
+Writes profiles/<round>_kernel_stats.csv   (rocprofv3 --kernel-trace --stats summary, verbatim)
+       profiles/<round>_pmc_summary.json   (per-kernel means of every PMC pass + derived figures)
+       profiles/<round>_layer_profile.json (per-layer HIP-event table dumped by bench.py)
+       profiles/<round>_bench.json         (the bench line)
+PMC handling follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are
+collected in separate passes, are in KiB, and on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide
+(16 B/lane) coalesced reads, so the read side is doubled: hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
+"""
+import collections
+import csv
+import json
+import os
+import shutil
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, 'gpurun_out')
+P = os.path.join(ROOT, 'profiles')
+rnd = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+os.makedirs(P, exist_ok=True)
+
+shutil.copy(os.path.join(G, 'rp_stats', 'drv_kernel_stats.csv'), os.path.join(P, rnd + '_kernel_stats.csv'))
+
+summary = {'source': 'rocprofv3 --pmc <counters> --kernel-trace -- python tools/profile_driver.py --batch 32 --steps 1 '
+                     '(one pass per counter group); rocprofv3 --kernel-trace --stats for durations',
+           'units': {'FETCH_SIZE': 'KiB (uncorrected)', 'WRITE_SIZE': 'KiB', 'SQ_*': 'summed over the chip',
+                     'GRBM_GUI_ACTIVE': 'summed over 8 XCDs'},
+           'kernels': {}}
+for d in sorted(os.listdir(G)):
+    f = os.path.join(G, d, 'drv_counter_collection.csv')
+    if not d.startswith('pmc_') or not os.path.exists(f):
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        agg[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
+        agg[r['Kernel_Name']]['_dur_ns_' + d].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
+    for k, cs in agg.items():
+        if 'conv_mfma' not in k and not k.startswith('pp_') and 'prep' not in k:
+            continue
+        e = summary['kernels'].setdefault(k, {})
+        for c, vals in cs.items():
+            e[c] = {'n': len(vals), 'mean': statistics.mean(vals), 'median': statistics.median(vals), 'min': min(vals), 'max': max(vals)}
+
+N_SIMD = 256 * 4
+for k, e in summary['kernels'].items():
+    der = {}
+    if 'FETCH_SIZE' in e and 'WRITE_SIZE' in e:
+        der['hbm_bytes_per_launch_min'] = (2 * e['FETCH_SIZE']['min'] + e['WRITE_SIZE']['min']) * 1024
+        der['hbm_bytes_per_launch_mean'] = (2 * e['FETCH_SIZE']['mean'] + e['WRITE_SIZE']['mean']) * 1024
+        der['hbm_bytes_per_launch_median'] = (2 * e['FETCH_SIZE']['median'] + e['WRITE_SIZE']['median']) * 1024
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in e and 'GRBM_GUI_ACTIVE' in e:
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over all 1024 SIMDs
+        der['mfma_busy_frac'] = (e['SQ_VALU_MFMA_BUSY_CYCLES']['mean'] / N_SIMD) / (e['GRBM_GUI_ACTIVE']['mean'] / 8)
+        dur = e.get('_dur_ns_pmc_SQ_VALU_MFMA_BUSY_CYCLES')
+        if dur:
+            der['effective_clock_ghz'] = e['GRBM_GUI_ACTIVE']['mean'] / 8 / dur['mean']
+    if 'SQ_LDS_BANK_CONFLICT' in e and 'SQ_LDS_IDX_ACTIVE' in e and e['SQ_LDS_IDX_ACTIVE']['mean'] > 0:
+        der['lds_conflict_frac'] = e['SQ_LDS_BANK_CONFLICT']['mean'] / e['SQ_LDS_IDX_ACTIVE']['mean']
+    if 'SQ_WAVE_CYCLES' in e:
+        w = e['SQ_WAVE_CYCLES']['mean']
+        for c in ('SQ_WAIT_INST_ANY', 'SQ_WAIT_ANY', 'SQ_ACTIVE_INST_ANY'):
+            if c in e:
+                der[c.lower() + '_frac'] = e[c]['mean'] / w
+    e['derived'] = der
+json.dump(summary, open(os.path.join(P, rnd + '_pmc_summary.json'), 'w'), indent=1)
+
+for src, dst in (('prof_bench.json', '_layer_profile.json'),):
+    if os.path.exists(os.path.join(G, src)):
+        shutil.copy(os.path.join(G, src), os.path.join(P, rnd + dst))
+bl = os.path.join(G, 'bench.log')
+if os.path.exists(bl):
+    lines = [l for l in open(bl) if l.startswith('{')]
+    if lines:
+        json.dump(json.loads(lines[-1]), open(os.path.join(P, rnd + '_bench.json'), 'w'), indent=1)
+for k, e in summary['kernels'].items():
+    print(k[:60], json.dumps(e['derived']))
