@@ -43,11 +43,11 @@ def pmc_traffic(kernel_name):
     kernel (20 of its 25 launches per step are the dominant 128->128 layers).  None if no summary exists."""
     import glob
     import re
-    m = re.match(r'conv(\d)x\d_t(\d+)x(\d+)_n(\d+)', kernel_name)
+    m = re.match(r'conv(\d)x\d(_v2)?_t(\d+)x(\d+)_n(\d+)', kernel_name)
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_summary.json')))
     if not m or not files:
         return None, None
-    sig = 'conv_mfma_kernel<%s, %s, %s, %s,' % m.groups()
+    sig = 'conv_mfma%s_kernel<%s, %s, %s, %s,' % (m.group(2) or '', m.group(1), m.group(3), m.group(4), m.group(5))
     try:
         d = json.load(open(files[-1]))
         for k, e in d['kernels'].items():
@@ -69,6 +69,8 @@ def parse():
     ap.add_argument('--cpu-budget', type=float, default=20.0, help='seconds of CPU-baseline sampling')
     ap.add_argument('--no-profile', action='store_true', help='skip the per-launch HIP events (roofline object null)')
     ap.add_argument('--dump-profile', default=None, help='write the per-layer table to this JSON file')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N > 1 ('nccl' = RCCL; 'gloo' only "
+                    "for the single-GPU multi-rank smoke test, where all ranks share device 0)")
     return ap.parse_args()
 
 
@@ -132,11 +134,17 @@ def main():
     if native.needs_build():
         if local_rank == 0:
             native.build()
+    if a.backend != 'nccl':
+        local_rank = local_rank % max(1, torch.cuda.device_count())    # smoke mode: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        if a.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
         dist.barrier()
     dev = torch.device('cuda', local_rank)
+    coll_dev = dev if a.backend == 'nccl' else torch.device('cpu')
     B, S = a.batch, a.size
     map_s = 320 if S == 368 else (S * 320) // 368 // 8 * 8
 
@@ -158,7 +166,7 @@ def main():
         eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(B, S, S), map_h=map_s, map_w=map_s)
         rec = eng.results()                           # stream sync + D2H of the fixed-size records
         if world > 1:
-            rec = dist_mod.gather_records(rec, device=dev)     # RCCL all_gather (the only collective)
+            rec = dist_mod.gather_records(rec, device=coll_dev)     # RCCL all_gather (the only collective)
         return rec
 
     for _ in range(a.warmup):
@@ -180,7 +188,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

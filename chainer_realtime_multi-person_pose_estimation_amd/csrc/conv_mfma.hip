@@ -232,6 +232,227 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
     }
 }
 
+// =============================================================================================================
+// v2: weights stream L2 -> registers (no weight panel in LDS, no barrier inside a channel chunk)
+//
+// With the waves of a block split along N (WN = 4: each wave owns 32 output channels x all pixels of the tile) the
+// B (weight) fragment of a wave is private to it, so staging it through LDS only adds a write, a read and a
+// block-wide barrier per tap.  Here every lane loads its own fragment -- 16 B = 4 channels of one output channel for
+// one tap -- directly from the packed weight array (the same global_load_dwordx4 count per lane as the LDS staging
+// needed), double-buffered in registers one tap ahead so the L2 latency hides under the current tap's MFMAs.  LDS
+// holds only the input halo tile (read-only during a chunk): barriers remain at chunk boundaries only (every KS*KS
+// taps), and the smaller LDS footprint admits 4 blocks per CU.  For KS == 1 the A operand has no tap reuse either, so
+// it is loaded straight from global memory too: no LDS and no barrier at all.
+// The block index is remapped so that consecutive tiles (neighbouring strips of one image, which share halo rows)
+// run on the same XCD and hit in its L2 (blocks are dispatched round-robin over the 8 XCDs).
+template <int KS, int TH, int TW, int BN, int CK, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_mfma_v2_kernel(const ConvArgs a)
+{
+    using C = ConvCfg<KS, TH, TW, BN, CK, WM, WN>;
+    static_assert(CK == 16, "v2 is written for 16-channel chunks (two k8 steps per tap)");
+    extern __shared__ float4 smem4[];
+    float* const s_in = reinterpret_cast<float*>(smem4);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31;
+    const int kh = lane >> 5;
+
+    const bool g1 = blockIdx.z != 0;
+    ConvGroupArgs G;
+    G.in = g1 ? a.g[1].in : a.g[0].in;
+    G.w = g1 ? a.g[1].w : a.g[0].w;
+    G.bias = g1 ? a.g[1].bias : a.g[0].bias;
+    G.out = g1 ? a.g[1].out : a.g[0].out;
+    G.cout = g1 ? a.g[1].cout : a.g[0].cout;
+    const int H = a.H, W = a.W;
+
+    // XCD-aware tile order (bijective for any grid size)
+    int tile;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int bimg = tile / tiles_per_img;
+    const int trem = tile - bimg * tiles_per_img;
+    const int y0 = (trem / a.tiles_x) * TH;
+    const int x0 = (trem % a.tiles_x) * TW;
+    const int n0 = blockIdx.y * BN;
+    const float* in_b = G.in + (size_t)bimg * H * W * a.lda;
+
+    // A fragment addressing: LDS offsets (KS > 1) or global float offsets (KS == 1)
+    int a_base[C::MT];
+#pragma unroll
+    for (int t = 0; t < C::MT; ++t) {
+        int m = (wm * C::MT + t) * 32 + li;
+        if (C::MASK_M && m >= C::M) m = C::M - 1;
+        const int q = m >> 2, r = m & 3;
+        const int wy = q / (TW / 2), wx = q % (TW / 2);
+        const int py = 2 * wy + (r >> 1), px = 2 * wx + (r & 1);
+        if constexpr (KS == 1) {
+            const int gy = min(y0 + py, H - 1), gx = min(x0 + px, W - 1);   // clamped; masked at the store
+            a_base[t] = (gy * W + gx) * a.lda + kh * 4;
+        } else {
+            a_base[t] = (py * C::HALO_W + px) * C::LDP + kh * 4;
+        }
+    }
+    // B fragment pointers: packed weights [tap][chunk][cout_pad][16]
+    const float* b_ptr[C::NT];
+#pragma unroll
+    for (int u = 0; u < C::NT; ++u) b_ptr[u] = G.w + (size_t)(n0 + (wn * C::NT + u) * 32 + li) * CK + kh * 4;
+    const size_t w_panel_stride = (size_t)a.cout_pad * CK;
+
+    f32x16 acc[C::MT][C::NT];
+#pragma unroll
+    for (int t = 0; t < C::MT; ++t)
+#pragma unroll
+        for (int u = 0; u < C::NT; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
+
+    float4 bc[C::NT][2], bn[C::NT][2];       // current / next tap's B fragments (two k8 steps each)
+#pragma unroll
+    for (int u = 0; u < C::NT; ++u) {
+        bc[u][0] = *reinterpret_cast<const float4*>(b_ptr[u]);
+        bc[u][1] = *reinterpret_cast<const float4*>(b_ptr[u] + 8);
+    }
+
+    if constexpr (KS == 1) {
+        // ---- pointwise: A and B straight from global memory, one "tap" per 16-channel chunk, no LDS ----
+        float4 ac[C::MT][2], an[C::MT][2];
+#pragma unroll
+        for (int t = 0; t < C::MT; ++t) {
+            ac[t][0] = *reinterpret_cast<const float4*>(in_b + a_base[t]);
+            ac[t][1] = *reinterpret_cast<const float4*>(in_b + a_base[t] + 8);
+        }
+#pragma unroll 1
+        for (int ch = 0; ch < a.nch; ++ch) {
+            const int cn = (ch + 1 < a.nch) ? ch + 1 : ch;
+#pragma unroll
+            for (int u = 0; u < C::NT; ++u) {
+                bn[u][0] = *reinterpret_cast<const float4*>(b_ptr[u] + (size_t)cn * w_panel_stride);
+                bn[u][1] = *reinterpret_cast<const float4*>(b_ptr[u] + (size_t)cn * w_panel_stride + 8);
+            }
+#pragma unroll
+            for (int t = 0; t < C::MT; ++t) {
+                an[t][0] = *reinterpret_cast<const float4*>(in_b + a_base[t] + cn * CK);
+                an[t][1] = *reinterpret_cast<const float4*>(in_b + a_base[t] + cn * CK + 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int t = 0; t < C::MT; ++t)
+#pragma unroll
+                    for (int u = 0; u < C::NT; ++u) {
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][s].x, bc[u][s].x, acc[t][u], 0, 0, 0);
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][s].y, bc[u][s].y, acc[t][u], 0, 0, 0);
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][s].z, bc[u][s].z, acc[t][u], 0, 0, 0);
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][s].w, bc[u][s].w, acc[t][u], 0, 0, 0);
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < C::NT; ++u) { bc[u][0] = bn[u][0]; bc[u][1] = bn[u][1]; }
+#pragma unroll
+            for (int t = 0; t < C::MT; ++t) { ac[t][0] = an[t][0]; ac[t][1] = an[t][1]; }
+        }
+    } else {
+        for (int ch = 0; ch < a.nch; ++ch) {
+            __syncthreads();   // everyone is done reading the previous chunk's halo tile
+            for (int f = tid; f < C::HALO_H * C::HALO_W * (CK / 4); f += 256) {
+                const int hp = f / (CK / 4), c4 = f % (CK / 4);
+                const int hy = hp / C::HALO_W, hx = hp - hy * C::HALO_W;
+                const int gy = y0 + hy - C::PADK, gx = x0 + hx - C::PADK;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+                    v = *reinterpret_cast<const float4*>(in_b + ((size_t)gy * W + gx) * a.lda + ch * CK + c4 * 4);
+                *reinterpret_cast<float4*>(&s_in[hp * C::LDP + c4 * 4]) = v;
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int tap = 0; tap < C::T; ++tap) {
+                // prefetch the next (tap, chunk) weight fragments: next tap, or tap 0 of the next chunk
+                int tn = tap + 1, cn = ch;
+                if (tn == C::T) {
+                    if (ch + 1 < a.nch) { tn = 0; cn = ch + 1; }
+                    else tn = tap;
+                }
+                const size_t poff = ((size_t)tn * a.nch + cn) * w_panel_stride;
+#pragma unroll
+                for (int u = 0; u < C::NT; ++u) {
+                    bn[u][0] = *reinterpret_cast<const float4*>(b_ptr[u] + poff);
+                    bn[u][1] = *reinterpret_cast<const float4*>(b_ptr[u] + poff + 8);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int ky = tap / KS, kx = tap - ky * KS;
+                const int tapoff = (ky * C::HALO_W + kx) * C::LDP;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float4 av[C::MT];
+#pragma unroll
+                    for (int t = 0; t < C::MT; ++t)
+                        av[t] = *reinterpret_cast<const float4*>(&s_in[a_base[t] + tapoff + s * 8]);
+#pragma unroll
+                    for (int t = 0; t < C::MT; ++t)
+#pragma unroll
+                        for (int u = 0; u < C::NT; ++u) {
+                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].x, bc[u][s].x, acc[t][u], 0, 0, 0);
+                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].y, bc[u][s].y, acc[t][u], 0, 0, 0);
+                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].z, bc[u][s].z, acc[t][u], 0, 0, 0);
+                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].w, bc[u][s].w, acc[t][u], 0, 0, 0);
+                        }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < C::NT; ++u) { bc[u][0] = bn[u][0]; bc[u][1] = bn[u][1]; }
+            }
+        }
+    }
+
+    // ---- epilogue (identical to v1) ----
+#pragma unroll
+    for (int t = 0; t < C::MT; ++t) {
+#pragma unroll
+        for (int u = 0; u < C::NT; ++u) {
+            const int n = n0 + (wn * C::NT + u) * 32 + li;
+            const bool nok = n < G.cout;
+            const float bias = G.bias[n];
+            if (!a.pool) {
+                float* out_b = G.out + (size_t)bimg * H * W * a.ldc;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                    const int m = (wm * C::MT + t) * 32 + row;
+                    const int q = m >> 2, r = m & 3;
+                    const int wy = q / (TW / 2), wx = q % (TW / 2);
+                    const int gy = y0 + 2 * wy + (r >> 1), gx = x0 + 2 * wx + (r & 1);
+                    float v = acc[t][u][reg] + bias;
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (nok && (!C::MASK_M || m < C::M) && gy < H && gx < W) out_b[((size_t)gy * W + gx) * a.ldc + n] = v;
+                }
+            } else {
+                const int Hp = H >> 1, Wp = W >> 1;
+                float* out_b = G.out + (size_t)bimg * Hp * Wp * a.ldc;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float v = fmaxf(fmaxf(acc[t][u][4 * g4 + 0], acc[t][u][4 * g4 + 1]),
+                                    fmaxf(acc[t][u][4 * g4 + 2], acc[t][u][4 * g4 + 3]));
+                    v += bias;
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    const int q = (wm * C::MT + t) * 8 + 2 * g4 + kh;
+                    const int wy = q / (TW / 2), wx = q % (TW / 2);
+                    const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
+                    if (nok && (!C::MASK_M || q < C::M / 4) && oy < Hp && ox < Wp) out_b[((size_t)oy * Wp + ox) * a.ldc + n] = v;
+                }
+            }
+        }
+    }
+}
+
 // ---- variant table ---------------------------------------------------------------------------------------
 static const ConvVariant g_variants[] = {
     {7, 8, 16, 128, 16, "conv7x7_t8x16_n128"},    // 0: stages 2-6, the dominant kernel
@@ -244,19 +465,39 @@ static const ConvVariant g_variants[] = {
     {1, 8, 8, 64, 16, "conv1x1_t8x8_n64"},        // 7
     {7, 2, 46, 128, 16, "conv7x7_t2x46_n128"},    // 8: zero-waste row strips for 46-wide maps (368x368 input)
     {3, 2, 46, 128, 16, "conv3x3_t2x46_n128"},    // 9
+    // v2 kernels: weights L2 -> registers, no per-tap barrier (see conv_mfma_v2_kernel)
+    {7, 2, 46, 128, 16, "conv7x7_v2_t2x46_n128"},  // 10
+    {3, 2, 46, 128, 16, "conv3x3_v2_t2x46_n128"},  // 11
+    {7, 8, 16, 128, 16, "conv7x7_v2_t8x16_n128"},  // 12
+    {3, 8, 16, 128, 16, "conv3x3_v2_t8x16_n128"},  // 13
+    {3, 8, 16, 64, 16, "conv3x3_v2_t8x16_n64"},    // 14
+    {1, 8, 16, 128, 16, "conv1x1_v2_t8x16_n128"},  // 15
+    {1, 8, 16, 64, 16, "conv1x1_v2_t8x16_n64"},    // 16
+    {1, 2, 46, 128, 16, "conv1x1_v2_t2x46_n128"},  // 17
 };
 
 int conv_num_variants() { return (int)(sizeof(g_variants) / sizeof(g_variants[0])); }
 const ConvVariant& conv_variant(int idx) { return g_variants[idx]; }
 
-int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced)
+int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen)
 {
+    // `cout` is the padded channel count of the layer
     if (forced >= 0 && forced < conv_num_variants() && g_variants[forced].ks == ks && cout % g_variants[forced].bn == 0)
-        return forced;   // (cout here is the padded channel count)
+        return forced;
     // enough 8x16 tiles to fill 256 CUs a few times over?  otherwise use the small tiles
     const long tiles816 = (long)((H + 7) / 8) * ((W + 15) / 16) * B;
     const bool small = tiles816 * ((cout + 127) / 128) < 512;
     const bool strip = (W == 46) && (cout % 128 == 0) && ((long)((H + 1) / 2) * B * (cout / 128) >= 512);
+    if (gen >= 3) {      // every layer on the v2 kernels (A/B measurements only)
+        if (ks == 7) return strip ? 10 : (small ? 5 : 12);
+        if (ks == 3) return strip ? 11 : (small ? 6 : (cout <= 64 ? 14 : 13));
+        return strip ? 17 : (small ? 7 : (cout <= 64 ? 16 : 15));
+    }
+    if (gen == 2) {      // default: v2 (weights L2 -> registers) where it measured faster: 3x3 / 7x7 with cout >= 128
+        if (ks == 7) return strip ? 10 : (small ? 5 : 12);
+        if (ks == 3) return strip ? 11 : (small ? 6 : (cout <= 64 ? 2 : 13));
+        return small ? 7 : (cout <= 64 ? 4 : 3);
+    }
     if (ks == 7) return strip ? 8 : (small ? 5 : 0);
     if (ks == 3) return strip ? 9 : (small ? 6 : (cout <= 64 ? 2 : 1));
     return small ? 7 : (cout <= 64 ? 4 : 3);
@@ -284,6 +525,29 @@ static int launch_cfg(const ConvArgs& a0, int groups, hipStream_t stream)
     return PMX_OK;
 }
 
+template <int KS, int TH, int TW, int BN, int CK, int WM, int WN>
+static int launch_v2(const ConvArgs& a0, int groups, hipStream_t stream)
+{
+    using C = ConvCfg<KS, TH, TW, BN, CK, WM, WN>;
+    ConvArgs a = a0;
+    a.tiles_x = (a.W + TW - 1) / TW;
+    a.tiles_y = (a.H + TH - 1) / TH;
+    PMX_CHECK(a.cout_pad % BN == 0, PMX_ERR_INVALID, "conv: cout_pad %d not a multiple of BN %d", a.cout_pad, BN);
+    PMX_CHECK(!a.pool || (a.H % 2 == 0 && a.W % 2 == 0), PMX_ERR_INVALID, "conv: pooled layer needs even H, W");
+    PMX_CHECK((long long)a.H * a.W * a.lda < (1ll << 31), PMX_ERR_INVALID, "conv: image too large for 32-bit offsets");
+    auto kern = conv_mfma_v2_kernel<KS, TH, TW, BN, CK, WM, WN>;
+    const int lds = KS == 1 ? 0 : C::IN_ELEMS * 4;
+    static bool attr_set = false;
+    if (!attr_set && lds > 0) {
+        PMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / BN), (unsigned)groups);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
 int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream)
 {
     switch (variant) {
@@ -297,6 +561,14 @@ int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream)
         case 7: return launch_cfg<1, 8, 8, 64, 16, 2, 2>(a, groups, stream);
         case 8: return launch_cfg<7, 2, 46, 128, 16, 1, 4>(a, groups, stream);
         case 9: return launch_cfg<3, 2, 46, 128, 16, 1, 4>(a, groups, stream);
+        case 10: return launch_v2<7, 2, 46, 128, 16, 1, 4>(a, groups, stream);
+        case 11: return launch_v2<3, 2, 46, 128, 16, 1, 4>(a, groups, stream);
+        case 12: return launch_v2<7, 8, 16, 128, 16, 1, 4>(a, groups, stream);
+        case 13: return launch_v2<3, 8, 16, 128, 16, 1, 4>(a, groups, stream);
+        case 14: return launch_v2<3, 8, 16, 64, 16, 2, 2>(a, groups, stream);
+        case 15: return launch_v2<1, 8, 16, 128, 16, 1, 4>(a, groups, stream);
+        case 16: return launch_v2<1, 8, 16, 64, 16, 2, 2>(a, groups, stream);
+        case 17: return launch_v2<1, 2, 46, 128, 16, 1, 4>(a, groups, stream);
     }
     pmx_set_error("conv_launch: unknown variant %d", variant);
     return PMX_ERR_INVALID;

@@ -36,6 +36,39 @@ def test_variants_basic(engine, variant, k, cout):
     _case(engine, 2, 32, 24, 40, cout, k, True, False, seed=variant, variant=variant)
 
 
+@pytest.mark.parametrize('variant,k,cout', [(10, 7, 128), (11, 3, 128), (12, 7, 128), (13, 3, 256), (14, 3, 64), (15, 1, 128),
+                                            (16, 1, 38), (17, 1, 128)])
+@pytest.mark.parametrize('hw', [(46, 46), (9, 21)])
+def test_v2_variants(engine, variant, k, cout, hw):
+    # v2 kernels: weights streamed L2 -> registers, XCD-aware tile order, no LDS for 1x1
+    _case(engine, 3, 48, hw[0], hw[1], cout, k, True, False, seed=70 + variant, variant=variant)
+
+
+@pytest.mark.parametrize('variant', [13, 14])
+def test_v2_fused_relu_maxpool(engine, variant):
+    _case(engine, 2, 32, 24, 40, 64 if variant == 14 else 128, 3, True, True, seed=90 + variant, variant=variant)
+
+
+def test_v2_network_equals_v1_network_bitwise(engine):
+    """Both kernel generations compute the same fp32 FMA chains in the same K order -> identical bits."""
+    from conftest import pkg
+    w = pkg('weights').synthetic_weights(0)
+    engine.set_weights(w)
+    img = np.random.default_rng(5).integers(0, 256, (2, 184, 184, 3), dtype=np.uint8)
+    engine.set_option('kernel_gen', 1)
+    engine.forward_u8(img)
+    p1, h1 = engine.get_maps()
+    engine.set_option('kernel_gen', 2)
+    engine.forward_u8(img)
+    p2, h2 = engine.get_maps()
+    engine.set_option('kernel_gen', 3)
+    engine.forward_u8(img)
+    p3, h3 = engine.get_maps()
+    engine.set_option('kernel_gen', 2)      # library default
+    assert np.array_equal(p1, p2) and np.array_equal(h1, h2)
+    assert np.array_equal(p1, p3) and np.array_equal(h1, h3)
+
+
 @pytest.mark.parametrize('variant,k', [(8, 7), (9, 3)])
 @pytest.mark.parametrize('hw', [(46, 46), (10, 46), (7, 30), (6, 100)])
 def test_row_strip_variants(engine, variant, k, hw):

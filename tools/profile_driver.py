@@ -21,6 +21,7 @@ ap.add_argument('--steps', type=int, default=3)
 ap.add_argument('--size', type=int, default=368)
 ap.add_argument('--k7', type=int, default=-1, help='force a 7x7 kernel variant')
 ap.add_argument('--k3', type=int, default=-1)
+ap.add_argument('--gen', type=int, default=0, help='kernel generation (0 = library default)')
 ap.add_argument('--profile-json', default=None)
 a = ap.parse_args()
 native = importlib.import_module(PKG + '.native')
@@ -36,6 +37,8 @@ w = weights_mod.calibrate_head(w, paf[0], heat[0])
 eng.set_weights({k: w[k] for k in ('Mconv7_stage6_L1', 'Mconv7_stage6_L2')})
 eng.set_option('force_variant_k7', a.k7)
 eng.set_option('force_variant_k3', a.k3)
+if a.gen:
+    eng.set_option('kernel_gen', a.gen)
 imgs = np.random.default_rng(1).integers(0, 256, (B, S, S, 3), dtype=np.uint8)
 if a.profile_json:
     eng.profile_enable(True)
