@@ -363,6 +363,7 @@ __global__ __launch_bounds__(256) void conv_mfma_v2_kernel(const ConvArgs a)
     } else {
         for (int ch = 0; ch < a.nch; ++ch) {
             __syncthreads();   // everyone is done reading the previous chunk's halo tile
+            if (!(a.dbg & 1) || ch == 0)
             for (int f = tid; f < C::HALO_H * C::HALO_W * (CK / 4); f += 256) {
                 const int hp = f / (CK / 4), c4 = f % (CK / 4);
                 const int hy = hp / C::HALO_W, hx = hp - hy * C::HALO_W;
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256) void conv_mfma_v2_kernel(const ConvArgs a)
                     if (ch + 1 < a.nch) { tn = 0; cn = ch + 1; }
                     else tn = tap;
                 }
-                const size_t poff = ((size_t)tn * a.nch + cn) * w_panel_stride;
+                const size_t poff = (a.dbg & 2) ? 0 : ((size_t)tn * a.nch + cn) * w_panel_stride;
 #pragma unroll
                 for (int u = 0; u < C::NT; ++u) {
                     bn[u][0] = *reinterpret_cast<const float4*>(b_ptr[u] + poff);
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(256) void conv_mfma_v2_kernel(const ConvArgs a)
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const int ky = tap / KS, kx = tap - ky * KS;
-                const int tapoff = (ky * C::HALO_W + kx) * C::LDP;
+                const int tapoff = (a.dbg & 8) ? 0 : (ky * C::HALO_W + kx) * C::LDP;
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     float4 av[C::MT];
@@ -410,6 +411,230 @@ __global__ __launch_bounds__(256) void conv_mfma_v2_kernel(const ConvArgs a)
 #pragma unroll
                 for (int u = 0; u < C::NT; ++u) { bc[u][0] = bn[u][0]; bc[u][1] = bn[u][1]; }
             }
+        }
+    }
+
+    if ((a.dbg & 4) && acc[0][0][0] != 12345.678f) return;   // ablation: drop the stores but keep the accumulators live
+    // ---- epilogue (identical to v1) ----
+#pragma unroll
+    for (int t = 0; t < C::MT; ++t) {
+#pragma unroll
+        for (int u = 0; u < C::NT; ++u) {
+            const int n = n0 + (wn * C::NT + u) * 32 + li;
+            const bool nok = n < G.cout;
+            const float bias = G.bias[n];
+            if (!a.pool) {
+                float* out_b = G.out + (size_t)bimg * H * W * a.ldc;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                    const int m = (wm * C::MT + t) * 32 + row;
+                    const int q = m >> 2, r = m & 3;
+                    const int wy = q / (TW / 2), wx = q % (TW / 2);
+                    const int gy = y0 + 2 * wy + (r >> 1), gx = x0 + 2 * wx + (r & 1);
+                    float v = acc[t][u][reg] + bias;
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (nok && (!C::MASK_M || m < C::M) && gy < H && gx < W) out_b[((size_t)gy * W + gx) * a.ldc + n] = v;
+                }
+            } else {
+                const int Hp = H >> 1, Wp = W >> 1;
+                float* out_b = G.out + (size_t)bimg * Hp * Wp * a.ldc;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float v = fmaxf(fmaxf(acc[t][u][4 * g4 + 0], acc[t][u][4 * g4 + 1]),
+                                    fmaxf(acc[t][u][4 * g4 + 2], acc[t][u][4 * g4 + 3]));
+                    v += bias;
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    const int q = (wm * C::MT + t) * 8 + 2 * g4 + kh;
+                    const int wy = q / (TW / 2), wx = q % (TW / 2);
+                    const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
+                    if (nok && (!C::MASK_M || q < C::M / 4) && oy < Hp && ox < Wp) out_b[((size_t)oy * Wp + ox) * a.ldc + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// =============================================================================================================
+// v3: software-pipelined for TWO waves per SIMD
+//
+// Measured on MI355X (tools/mfma_peak2.hip, profiles/): a pure v_mfma_f32_32x32x2_f32 loop sustains 98 % of the
+// 157.3 TFLOP/s peak with 1 or 2 waves per SIMD but only 75-79 % with 3 or 4 -- co-resident waves lose a fifth of the
+// matrix pipe in arbitration.  v1/v2 hide LDS and L2 latency with 3-4 blocks per CU and therefore top out at ~80 %.
+// v3 keeps the v2 data flow (weights L2 -> registers one tap ahead, halo tile in LDS) but hides latency inside the
+// wave instead, and asks for enough LDS that at most 2 blocks (2 waves per SIMD) are resident:
+//   * A fragments are double-buffered in registers: the ds_read_b128s of k-step q+1 are issued before the MFMAs of
+//     k-step q (two register sets, the tap loop body handles the two k8 steps of a 16-channel chunk explicitly);
+//   * the next chunk's halo tile is fetched into registers at the start of a chunk and written to the SECOND LDS halo
+//     buffer at its end: one barrier per chunk (every KS*KS taps) and no exposed global-memory latency.
+template <int KS, int TH, int TW, int BN, int CK, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_mfma_v3_kernel(const ConvArgs a)
+{
+    using C = ConvCfg<KS, TH, TW, BN, CK, WM, WN>;
+    static_assert(CK == 16 && KS > 1, "v3: 16-channel chunks, spatial kernels");
+    constexpr int NHF = (C::HALO_H * C::HALO_W * (CK / 4) + 255) / 256;   // halo float4 per thread
+    extern __shared__ float4 smem4[];
+    float* const s_in = reinterpret_cast<float*>(smem4);                  // two halo buffers of IN_ELEMS floats
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31;
+    const int kh = lane >> 5;
+
+    const bool g1 = blockIdx.z != 0;
+    ConvGroupArgs G;
+    G.in = g1 ? a.g[1].in : a.g[0].in;
+    G.w = g1 ? a.g[1].w : a.g[0].w;
+    G.bias = g1 ? a.g[1].bias : a.g[0].bias;
+    G.out = g1 ? a.g[1].out : a.g[0].out;
+    G.cout = g1 ? a.g[1].cout : a.g[0].cout;
+    const int H = a.H, W = a.W;
+
+    int tile;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int bimg = tile / tiles_per_img;
+    const int trem = tile - bimg * tiles_per_img;
+    const int y0 = (trem / a.tiles_x) * TH;
+    const int x0 = (trem % a.tiles_x) * TW;
+    const int n0 = blockIdx.y * BN;
+    const float* in_b = G.in + (size_t)bimg * H * W * a.lda;
+
+    int a_base[C::MT];
+#pragma unroll
+    for (int t = 0; t < C::MT; ++t) {
+        int m = (wm * C::MT + t) * 32 + li;
+        if (C::MASK_M && m >= C::M) m = C::M - 1;
+        const int q = m >> 2, r = m & 3;
+        const int wy = q / (TW / 2), wx = q % (TW / 2);
+        const int py = 2 * wy + (r >> 1), px = 2 * wx + (r & 1);
+        a_base[t] = (py * C::HALO_W + px) * C::LDP + kh * 4;
+    }
+    const float* b_ptr[C::NT];
+#pragma unroll
+    for (int u = 0; u < C::NT; ++u) b_ptr[u] = G.w + (size_t)(n0 + (wn * C::NT + u) * 32 + li) * CK + kh * 4;
+    const size_t w_panel_stride = (size_t)a.cout_pad * CK;
+
+    // halo staging slots of this thread: LDS offset, clamped global offset, in-bounds flag (same for every chunk)
+    int h_lds[NHF], h_goff[NHF];
+    bool h_ok[NHF];
+#pragma unroll
+    for (int r = 0; r < NHF; ++r) {
+        const int f = tid + r * 256;
+        const bool slot = f < C::HALO_H * C::HALO_W * (CK / 4);
+        const int hp = slot ? f / (CK / 4) : 0, c4 = f % (CK / 4);
+        const int hy = hp / C::HALO_W, hx = hp - hy * C::HALO_W;
+        const int gy = y0 + hy - C::PADK, gx = x0 + hx - C::PADK;
+        const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+        h_lds[r] = slot ? hp * C::LDP + c4 * 4 : -1;
+        h_goff[r] = (cy * W + cx) * a.lda + c4 * 4;
+        h_ok[r] = inb;
+    }
+
+    f32x16 acc[C::MT][C::NT];
+#pragma unroll
+    for (int t = 0; t < C::MT; ++t)
+#pragma unroll
+        for (int u = 0; u < C::NT; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
+
+    // ---- prologue: chunk 0 halo -> buffer 0, first weight fragments, first A fragments ----
+    float4 bc[C::NT][2], bn[C::NT][2];
+#pragma unroll
+    for (int u = 0; u < C::NT; ++u) {
+        bc[u][0] = *reinterpret_cast<const float4*>(b_ptr[u]);
+        bc[u][1] = *reinterpret_cast<const float4*>(b_ptr[u] + 8);
+    }
+#pragma unroll
+    for (int r = 0; r < NHF; ++r) {
+        float4 v = *reinterpret_cast<const float4*>(in_b + h_goff[r]);
+        if (!h_ok[r]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (h_lds[r] >= 0) *reinterpret_cast<float4*>(&s_in[h_lds[r]]) = v;
+    }
+    __syncthreads();
+    float4 av0[C::MT], av1[C::MT];
+#pragma unroll
+    for (int t = 0; t < C::MT; ++t) av0[t] = *reinterpret_cast<const float4*>(&s_in[a_base[t]]);
+
+    for (int ch = 0; ch < a.nch; ++ch) {
+        const float* cur = s_in + (ch & 1) * C::IN_ELEMS;
+        float* nxt = s_in + ((ch + 1) & 1) * C::IN_ELEMS;
+        const bool more_ch = ch + 1 < a.nch;
+        // next chunk's halo: global -> registers now, registers -> LDS after the last tap
+        float4 hreg[NHF];
+        {
+            const int cn = more_ch ? ch + 1 : ch;
+#pragma unroll
+            for (int r = 0; r < NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + cn * CK);
+        }
+#pragma unroll 1
+        for (int tap = 0; tap < C::T; ++tap) {
+            int tn = tap + 1, cn = ch;
+            if (tn == C::T) {
+                if (more_ch) { tn = 0; cn = ch + 1; }
+                else tn = tap;
+            }
+            const size_t poff = ((size_t)tn * a.nch + cn) * w_panel_stride;
+#pragma unroll
+            for (int u = 0; u < C::NT; ++u) {
+                bn[u][0] = *reinterpret_cast<const float4*>(b_ptr[u] + poff);
+                bn[u][1] = *reinterpret_cast<const float4*>(b_ptr[u] + poff + 8);
+            }
+            const int ky = tap / KS, kx = tap - ky * KS;
+            const int tapoff = (ky * C::HALO_W + kx) * C::LDP;
+            // k8 step 0: prefetch step 1's A fragments, then the MFMAs of step 0
+#pragma unroll
+            for (int t = 0; t < C::MT; ++t) av1[t] = *reinterpret_cast<const float4*>(&cur[a_base[t] + tapoff + 8]);
+            __builtin_amdgcn_sched_barrier(0);   // loads above are issued before the MFMAs below (pins the prefetch distance)
+#pragma unroll
+            for (int t = 0; t < C::MT; ++t)
+#pragma unroll
+                for (int u = 0; u < C::NT; ++u) {
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t].x, bc[u][0].x, acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t].y, bc[u][0].y, acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t].z, bc[u][0].z, acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t].w, bc[u][0].w, acc[t][u], 0, 0, 0);
+                }
+            // k8 step 1: prefetch the next tap's step-0 fragments (clamped to this tap on the chunk's last one)
+            {
+                const int t2 = (tap + 1 < C::T) ? tap + 1 : tap;
+                const int ky2 = t2 / KS, kx2 = t2 - ky2 * KS;
+                const int tapoff2 = (ky2 * C::HALO_W + kx2) * C::LDP;
+#pragma unroll
+                for (int t = 0; t < C::MT; ++t) av0[t] = *reinterpret_cast<const float4*>(&cur[a_base[t] + tapoff2]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < C::MT; ++t)
+#pragma unroll
+                for (int u = 0; u < C::NT; ++u) {
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t].x, bc[u][1].x, acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t].y, bc[u][1].y, acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t].z, bc[u][1].z, acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t].w, bc[u][1].w, acc[t][u], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < C::NT; ++u) { bc[u][0] = bn[u][0]; bc[u][1] = bn[u][1]; }
+        }
+        if (more_ch) {
+#pragma unroll
+            for (int r = 0; r < NHF; ++r) {
+                float4 v = hreg[r];
+                if (!h_ok[r]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (h_lds[r] >= 0) *reinterpret_cast<float4*>(&nxt[h_lds[r]]) = v;
+            }
+            __syncthreads();   // next halo visible; nobody still reads the buffer that the chunk after next will overwrite
+#pragma unroll
+            for (int t = 0; t < C::MT; ++t) av0[t] = *reinterpret_cast<const float4*>(&nxt[a_base[t]]);
         }
     }
 
@@ -453,6 +678,11 @@ __global__ __launch_bounds__(256) void conv_mfma_v2_kernel(const ConvArgs a)
     }
 }
 
+// minimum dynamic LDS per block: caps the number of co-resident blocks per CU (the fp32 MFMA pipe
+// loses ~20% with 3+ waves per SIMD)
+static int g_min_lds = 0;
+void conv_set_min_lds(int bytes) { g_min_lds = bytes; }
+
 // ---- variant table ---------------------------------------------------------------------------------------
 static const ConvVariant g_variants[] = {
     {7, 8, 16, 128, 16, "conv7x7_t8x16_n128"},    // 0: stages 2-6, the dominant kernel
@@ -474,6 +704,12 @@ static const ConvVariant g_variants[] = {
     {1, 8, 16, 128, 16, "conv1x1_v2_t8x16_n128"},  // 15
     {1, 8, 16, 64, 16, "conv1x1_v2_t8x16_n64"},    // 16
     {1, 2, 46, 128, 16, "conv1x1_v2_t2x46_n128"},  // 17
+    // v3 kernels: software-pipelined, 2 blocks per CU (see conv_mfma_v3_kernel)
+    {7, 2, 46, 128, 16, "conv7x7_v3_t2x46_n128"},  // 18
+    {3, 2, 46, 128, 16, "conv3x3_v3_t2x46_n128"},  // 19
+    {7, 8, 16, 128, 16, "conv7x7_v3_t8x16_n128"},  // 20
+    {3, 8, 16, 128, 16, "conv3x3_v3_t8x16_n128"},  // 21
+    {3, 8, 16, 64, 16, "conv3x3_v3_t8x16_n64"},    // 22
 };
 
 int conv_num_variants() { return (int)(sizeof(g_variants) / sizeof(g_variants[0])); }
@@ -515,12 +751,12 @@ static int launch_cfg(const ConvArgs& a0, int groups, hipStream_t stream)
     auto kern = conv_mfma_kernel<KS, TH, TW, BN, CK, WM, WN>;
     static bool attr_set = false;
     if (!attr_set) {
-        PMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        PMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
+    const int lds = C::LDS_BYTES > g_min_lds ? C::LDS_BYTES : g_min_lds;
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / BN), (unsigned)groups);
-    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
@@ -536,10 +772,39 @@ static int launch_v2(const ConvArgs& a0, int groups, hipStream_t stream)
     PMX_CHECK(!a.pool || (a.H % 2 == 0 && a.W % 2 == 0), PMX_ERR_INVALID, "conv: pooled layer needs even H, W");
     PMX_CHECK((long long)a.H * a.W * a.lda < (1ll << 31), PMX_ERR_INVALID, "conv: image too large for 32-bit offsets");
     auto kern = conv_mfma_v2_kernel<KS, TH, TW, BN, CK, WM, WN>;
-    const int lds = KS == 1 ? 0 : C::IN_ELEMS * 4;
+    int lds = KS == 1 ? 0 : C::IN_ELEMS * 4;
+    if (lds < g_min_lds) lds = g_min_lds;
     static bool attr_set = false;
-    if (!attr_set && lds > 0) {
-        PMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if (!attr_set) {
+        PMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / BN), (unsigned)groups);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+static int g_v3_lds = 56 * 1024;     // dynamic LDS floor of the v3 kernels: 3 x 56 KB > 160 KB -> at most 2 blocks per CU
+void conv_set_v3_lds(int bytes) { g_v3_lds = bytes; }
+
+template <int KS, int TH, int TW, int BN, int CK, int WM, int WN>
+static int launch_v3(const ConvArgs& a0, int groups, hipStream_t stream)
+{
+    using C = ConvCfg<KS, TH, TW, BN, CK, WM, WN>;
+    ConvArgs a = a0;
+    a.tiles_x = (a.W + TW - 1) / TW;
+    a.tiles_y = (a.H + TH - 1) / TH;
+    PMX_CHECK(a.cout_pad % BN == 0, PMX_ERR_INVALID, "conv: cout_pad %d not a multiple of BN %d", a.cout_pad, BN);
+    PMX_CHECK(!a.pool || (a.H % 2 == 0 && a.W % 2 == 0), PMX_ERR_INVALID, "conv: pooled layer needs even H, W");
+    PMX_CHECK((long long)a.H * a.W * a.lda < (1ll << 31), PMX_ERR_INVALID, "conv: image too large for 32-bit offsets");
+    auto kern = conv_mfma_v3_kernel<KS, TH, TW, BN, CK, WM, WN>;
+    int lds = 2 * C::IN_ELEMS * 4;
+    if (lds < g_v3_lds) lds = g_v3_lds;
+    if (lds < g_min_lds) lds = g_min_lds;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / BN), (unsigned)groups);
@@ -569,6 +834,11 @@ int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream)
         case 15: return launch_v2<1, 8, 16, 128, 16, 1, 4>(a, groups, stream);
         case 16: return launch_v2<1, 8, 16, 64, 16, 2, 2>(a, groups, stream);
         case 17: return launch_v2<1, 2, 46, 128, 16, 1, 4>(a, groups, stream);
+        case 18: return launch_v3<7, 2, 46, 128, 16, 1, 4>(a, groups, stream);
+        case 19: return launch_v3<3, 2, 46, 128, 16, 1, 4>(a, groups, stream);
+        case 20: return launch_v3<7, 8, 16, 128, 16, 1, 4>(a, groups, stream);
+        case 21: return launch_v3<3, 8, 16, 128, 16, 1, 4>(a, groups, stream);
+        case 22: return launch_v3<3, 8, 16, 64, 16, 2, 2>(a, groups, stream);
     }
     pmx_set_error("conv_launch: unknown variant %d", variant);
     return PMX_ERR_INVALID;

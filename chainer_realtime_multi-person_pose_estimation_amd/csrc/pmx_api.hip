@@ -148,7 +148,7 @@ struct pmx_ctx {
     size_t smoothed_cap = 0;
     // options
     int opt_force[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // by ksize
-    int opt_keep_smoothed = 0, opt_stop_stage = 6, opt_kernel_gen = 2;
+    int opt_keep_smoothed = 0, opt_stop_stage = 6, opt_kernel_gen = 2, opt_conv_dbg = 0;
     // timing / profiling
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool prof_on = false;
@@ -343,6 +343,8 @@ extern "C" int pmx_set_option(pmx_ctx* c, const char* key, int value)
     else if (!strcmp(key, "keep_smoothed")) c->opt_keep_smoothed = value;
     else if (!strcmp(key, "stop_stage")) c->opt_stop_stage = value;
     else if (!strcmp(key, "kernel_gen")) c->opt_kernel_gen = value;
+    else if (!strcmp(key, "conv_dbg")) c->opt_conv_dbg = value;
+    else if (!strcmp(key, "conv_min_lds")) conv_set_min_lds(value);
     else { pmx_set_error("pmx_set_option: unknown key '%s'", key); return PMX_ERR_INVALID; }
     return PMX_OK;
 }
@@ -880,6 +882,7 @@ extern "C" int pmx_conv2d(pmx_ctx* c, const float* x, const float* w, const floa
     memset(&a, 0, sizeof a);
     a.g[0].in = d_xn; a.g[0].w = d_w; a.g[0].bias = d_b; a.g[0].out = d_yn; a.g[0].cout = cout;
     a.B = B; a.H = H; a.W = W; a.lda = cin_pad; a.ldc = cout; a.nch = cin_pad / CK; a.cout_pad = cpad; a.relu = relu; a.pool = pool;
+    a.dbg = c->opt_conv_dbg;
     const int v = conv_pick_variant(ks, cpad, H, W, B, c->opt_force[ks], c->opt_kernel_gen);
     if (!rc) rc = conv_launch(v, a, 1, c->stream);
     if (!rc && iters > 0) {

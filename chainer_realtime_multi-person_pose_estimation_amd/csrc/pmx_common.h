@@ -69,6 +69,7 @@ struct ConvArgs {
     int cout_pad;       // multiple of the kernel's BN
     int tiles_x, tiles_y;
     int relu, pool;
+    int dbg;            // ablation flags (tools/conv_ablate.py): 1 skip re-staging, 2 no weight streaming, 4 no stores, 8 one A read
 };
 
 struct ConvVariant {
@@ -81,6 +82,7 @@ const ConvVariant& conv_variant(int idx);
 int conv_num_variants();
 // launches the variant; groups = 1 or 2 (blockIdx.z)
 int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream);
+void conv_set_min_lds(int bytes);
 // packed weight geometry helpers
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
