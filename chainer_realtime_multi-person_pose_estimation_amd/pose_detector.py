@@ -55,11 +55,18 @@ class PoseDetector(object):
                 w = weights_mod.load_npz(weights_file)     # serializers.load_npz (:26)
         size = params['inference_img_size']
         mh, mw = (size, size) if max_size is None else max_size
+        self._weights = w
+        self.engine = None
+        self._make_engine(max_batch, mh, mw)
+
+    def _make_engine(self, max_batch, mh, mw):
+        if self.engine is not None:
+            self.engine.close()
         self._cap = (max_batch, mh, mw)
         self.engine = native.Engine(self._gpu, max_batch=max_batch, max_h=mh, max_w=mw,
                                     gaussian_sigma=params['gaussian_sigma'])
-        if w is not None:
-            self.engine.set_weights(w)
+        if self._weights is not None:
+            self.engine.set_weights(self._weights)
 
     # ---- host helpers with the reference's names and semantics -------------------------------------
     def compute_optimal_size(self, orig_img, img_size, stride=8):
@@ -90,11 +97,11 @@ class PoseDetector(object):
         return x_data
 
     def _grow(self, batch, h, w):
+        """Re-create the device context when an input exceeds its capacity (buffers are sized at creation)."""
         mb, mh, mw = self._cap
         if batch <= mb and h * w <= mh * mw:
             return
-        raise ValueError('input batch %d x %d x %d exceeds the capacity this detector was created with '
-                         '(max_batch=%d, max_size=%dx%d)' % (batch, h, w, mb, mh, mw))
+        self._make_engine(max(mb, batch), max(mh, h), max(mw, w))
 
     # ---- the hot path -----------------------------------------------------------------------------
     def __call__(self, orig_img):
@@ -104,9 +111,60 @@ class PoseDetector(object):
             return self.detect_precise(orig_img)
         return self.detect_batch([orig_img])[0]
 
+    def pad_image(self, img, stride, pad_value):
+        """reference pose_detector.py:46-55: pad bottom / right to a multiple of `stride`."""
+        h, w, _ = img.shape
+        pad = [0] * 2
+        pad[0] = (stride - (h % stride)) % stride  # down
+        pad[1] = (stride - (w % stride)) % stride  # right
+        img_padded = np.empty((h + pad[0], w + pad[1], 3), np.uint8)
+        img_padded[...] = np.asarray(pad_value, dtype=np.uint8)
+        img_padded[:h, :w, :] = img
+        return img_padded, pad
+
     def detect_precise(self, orig_img):
-        raise NotImplementedError('multi-scale detect_precise (pose_detector.py:433-482) is a "next" row of the '
-                                  'scope table (SURVEY.md 8f-1) and not built yet')
+        """reference pose_detector.py:433-482: average the network outputs over `inference_scales`, resized
+        (cv2 INTER_CUBIC, restated in resize_cubic_*) to the ORIGINAL resolution, then the same post-process at that
+        resolution with img_len = orig_img_w (:478) and no coordinate rescale.  The four forward passes and the
+        full-resolution post-process run on the GPU; the cubic resizes are host code as in the reference."""
+        orig_img = np.ascontiguousarray(orig_img, dtype=np.uint8)
+        orig_img_h, orig_img_w, _ = orig_img.shape
+        pafs_sum = 0
+        heatmaps_sum = 0
+        for scale in params['inference_scales']:
+            multiplier = scale * params['inference_img_size'] / min(orig_img.shape[:2])            # :442
+            img = resize_cubic_u8(orig_img, math.ceil(orig_img_w * multiplier), math.ceil(orig_img_h * multiplier))
+            padded_img, pad = self.pad_image(img, params['downscale'], (104, 117, 123))              # :445
+            p_h, p_w = padded_img.shape[:2]
+            if self.model is None:
+                if self._weights is None:
+                    raise RuntimeError('PoseDetector has no weights: pass weights_file=, weights= or model=')
+                self._grow(1, p_h, p_w)
+                self.engine.forward_u8(padded_img[None])                                             # :451
+                paf, heat = self.engine.get_maps()
+                paf, heat = paf[0], heat[0]
+            else:
+                h1s, h2s = self.model(self.preprocess(padded_img))
+                paf = np.asarray(_data(h1s[-1]), dtype=np.float32)[0]
+                heat = np.asarray(_data(h2s[-1]), dtype=np.float32)[0]
+            tmp_paf = np.ascontiguousarray(paf.transpose(1, 2, 0))                                   # :453
+            tmp_heatmap = np.ascontiguousarray(heat.transpose(1, 2, 0))                              # :454
+            tmp_paf = resize_cubic_f32(tmp_paf, p_w, p_h)                                            # :461
+            tmp_paf = tmp_paf[:p_h - pad[0], :p_w - pad[1], :]                                       # :462
+            pafs_sum = pafs_sum + resize_cubic_f32(tmp_paf, orig_img_w, orig_img_h)                  # :463
+            ds = params['downscale']
+            tmp_heatmap = resize_cubic_f32(tmp_heatmap, tmp_heatmap.shape[1] * ds, tmp_heatmap.shape[0] * ds)   # :465
+            tmp_heatmap = tmp_heatmap[:p_h - pad[0], :p_w - pad[1], :]                               # :466
+            heatmaps_sum = heatmaps_sum + resize_cubic_f32(tmp_heatmap, orig_img_w, orig_img_h)      # :467
+        n = len(params['inference_scales'])
+        self.pafs = (pafs_sum / n).transpose(2, 0, 1)                                                # :469
+        self.heatmaps = (heatmaps_sum / n).transpose(2, 0, 1)                                        # :470
+        # post-process at the original resolution on the device (resize to the same size is the identity)
+        self._grow(1, 8, 8)
+        self.engine.set_maps(np.ascontiguousarray(self.pafs)[None], np.ascontiguousarray(self.heatmaps)[None])
+        self.engine.postprocess(orig_img_h, orig_img_w, img_len=orig_img_w, scale_xy=None)           # :475-481
+        self.all_peaks = self.engine.peaks(0)
+        return unpack_results(self.engine.results())[0]
 
     def detect_batch(self, imgs):
         """Batched `__call__`: list of H x W x 3 uint8 BGR images of ONE common size -> list of (poses, scores),
@@ -210,4 +268,61 @@ def resize_linear_u8(img, dst_w, dst_h):
     s0 = rows[sy]
     s1 = rows[sy1]
     out = (((by0[:, None, None] * (s0 >> 4)) >> 16) + ((by1[:, None, None] * (s1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+# ---- cv2.resize(..., interpolation=cv2.INTER_CUBIC) restated (used by detect_precise only) ---------------------------
+def _cubic_taps(dst, src):
+    """Source indices (4 taps, replicate border) and float32 coefficients of OpenCV's bicubic (A = -0.75):
+    fx = float((dx + 0.5) * scale - 0.5), scale = 1 / (dst / src) in double; sx = floor(fx); taps sx-1 .. sx+2."""
+    scale = 1.0 / (float(dst) / float(src))
+    d = np.arange(dst, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    x = (f - s.astype(np.float32)).astype(np.float32)
+    A = np.float32(-0.75)
+    one = np.float32(1.0)
+    c0 = ((A * (x + one) - np.float32(5) * A) * (x + one) + np.float32(8) * A) * (x + one) - np.float32(4) * A
+    c1 = ((A + np.float32(2)) * x - (A + np.float32(3))) * x * x + one
+    c2 = ((A + np.float32(2)) * (one - x) - (A + np.float32(3))) * (one - x) * (one - x) + one
+    c3 = one - c0 - c1 - c2
+    idx = np.stack([np.clip(s + k, 0, src - 1) for k in (-1, 0, 1, 2)])
+    return idx, np.stack([c0, c1, c2, c3]).astype(np.float32)
+
+
+def resize_cubic_f32(img, dst_w, dst_h):
+    """`cv2.resize(float32 H x W x C, (dst_w, dst_h), interpolation=cv2.INTER_CUBIC)` restated (pose_detector.py:461-467):
+    horizontal 4-tap pass then vertical 4-tap pass, float32 products summed left to right.  PARITY UNPINNED: OpenCV is
+    not installable here (its SIMD paths may fuse multiply-adds)."""
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    src_h, src_w = img.shape[:2]
+    if (src_w, src_h) == (dst_w, dst_h):
+        return img.copy()
+    ix, cx = _cubic_taps(dst_w, src_w)
+    iy, cy = _cubic_taps(dst_h, src_h)
+    rows = img[:, ix[0]] * cx[0][None, :, None]
+    for k in (1, 2, 3):
+        rows = rows + img[:, ix[k]] * cx[k][None, :, None]
+    out = rows[iy[0]] * cy[0][:, None, None]
+    for k in (1, 2, 3):
+        out = out + rows[iy[k]] * cy[k][:, None, None]
+    return out
+
+
+def resize_cubic_u8(img, dst_w, dst_h):
+    """`cv2.resize(uint8 image, (dst_w, dst_h), interpolation=cv2.INTER_CUBIC)` restated (pose_detector.py:443): OpenCV's
+    fixed-point path -- coefficients `saturate_cast<short>(c * 2048)`, int32 horizontal pass, vertical pass
+    `(sum + (1 << 21)) >> 22`, saturated to uint8.  PARITY UNPINNED (no cv2 to compare against)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    src_h, src_w = img.shape[:2]
+    if (src_w, src_h) == (dst_w, dst_h):
+        return img.copy()
+    ix, cx = _cubic_taps(dst_w, src_w)
+    iy, cy = _cubic_taps(dst_h, src_h)
+    ax = np.clip(np.rint(cx * np.float32(2048)), -32768, 32767).astype(np.int64)
+    ay = np.clip(np.rint(cy * np.float32(2048)), -32768, 32767).astype(np.int64)
+    src = img.astype(np.int64)
+    rows = sum(src[:, ix[k]] * ax[k][None, :, None] for k in range(4))
+    out = sum(rows[iy[k]] * ay[k][:, None, None] for k in range(4))
+    out = (out + (1 << 21)) >> 22
     return np.clip(out, 0, 255).astype(np.uint8)

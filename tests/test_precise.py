@@ -1,0 +1,109 @@
+"""detect_precise (reference pose_detector.py:433-482): CPU tests of the restated cv2 cubic resizes, GPU test of the
+multi-scale path through the drop-in class."""
+import numpy as np
+import pytest
+
+from conftest import pkg
+from oracle import precise_ref as R
+from oracle import postprocess_ref as P
+from oracle import fixtures as Fx
+
+
+def test_cubic_f32_product_equals_independent_oracle():
+    PD = pkg('pose_detector')
+    rng = np.random.default_rng(0)
+    for (h, w, c, dh, dw) in [(6, 9, 5, 48, 72), (23, 31, 3, 17, 40), (10, 10, 2, 10, 25), (46, 46, 4, 368, 368)]:
+        a = rng.standard_normal((h, w, c)).astype('f')
+        assert np.array_equal(PD.resize_cubic_f32(a, dw, dh), R.resize_cubic_f32_ref(a, dw, dh))
+
+
+def test_cubic_u8_product_equals_independent_oracle_and_is_sane():
+    PD = pkg('pose_detector')
+    rng = np.random.default_rng(1)
+    for (h, w, dh, dw) in [(20, 30, 31, 45), (48, 64, 24, 32), (37, 29, 100, 64)]:
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        assert np.array_equal(PD.resize_cubic_u8(a, dw, dh), R.resize_cubic_u8_ref(a, dw, dh))
+    flat = np.full((9, 7, 3), 200, np.uint8)
+    assert np.all(PD.resize_cubic_u8(flat, 20, 33) == 200)
+    # against torch's bicubic (same A = -0.75, half-pixel centres): float path to rounding, uint8 path to +-1
+    import torch
+    a = rng.standard_normal((10, 12, 3)).astype('f')
+    t = torch.nn.functional.interpolate(torch.from_numpy(a.transpose(2, 0, 1))[None], size=(80, 96), mode='bicubic',
+                                        align_corners=False)[0].numpy().transpose(1, 2, 0)
+    assert np.abs(PD.resize_cubic_f32(a, 96, 80) - t).max() < 1e-5
+
+
+def test_pad_image_matches_reference_semantics():
+    PD = pkg('pose_detector')
+    det = PD.PoseDetector.__new__(PD.PoseDetector)
+    img = np.arange(5 * 11 * 3, dtype=np.uint8).reshape(5, 11, 3)
+    p, pad = det.pad_image(img, 8, (104, 117, 123))
+    q, pad2 = R.pad_image(img, 8, (104, 117, 123))
+    assert pad == pad2 == [3, 5] and np.array_equal(p, q)
+    assert p.shape == (8, 16, 3) and tuple(p[7, 15]) == (104, 117, 123)
+
+
+@pytest.mark.gpu
+def test_detect_precise_with_model_seam(native):
+    """Synthetic skeleton maps injected through the reference's `model=` seam at every scale; the averaged maps and
+    the final poses must equal the oracle's (same restated cubic; post-process exact on identical maps)."""
+    PD = pkg('pose_detector')
+    H, W = 96, 128                     # original image
+    rng = np.random.default_rng(4)
+    poses = Fx.random_poses(rng, 3, H, W, height_range=(0.5, 0.8), drop_prob=0.1)
+
+    def model(x):
+        # network-output-shaped maps for whatever padded input size the scale loop produced
+        h8, w8 = x.shape[2] // 8, x.shape[3] // 8
+        sp = poses.copy()
+        sp[:, :, 0] *= w8 / W
+        sp[:, :, 1] *= h8 / H
+        heat = Fx.render_heatmaps((h8, w8), sp, max(0.6, 0.02 * h8))
+        paf = Fx.render_pafs((h8, w8), sp, max(0.6, 0.015 * h8))
+        return [paf[None]], [heat[None]]
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    det = PD.PoseDetector(model=model, device=0, precise=True)
+    got_poses, got_scores = det(img)
+    ref_paf, ref_heat, sizes = R.averaged_maps(lambda x: tuple(m[-1] for m in model(x)), img)
+    assert sizes[0][0] % 8 == 0 and len(sizes) == 4
+    assert np.array_equal(det.pafs, ref_paf) and np.array_equal(det.heatmaps, ref_heat)
+    ref = R.detect_precise_from_maps(ref_paf, ref_heat)
+    assert np.array_equal(det.all_peaks, ref['all_peaks'])
+    assert len(ref['subsets']) >= 2, 'fixture should find people'
+    assert np.array_equal(np.asarray(got_poses), np.asarray(ref['poses']))
+    assert np.allclose(got_scores, ref['scores'], rtol=0, atol=1e-9)
+    det.engine.close()
+
+
+@pytest.mark.gpu
+def test_detect_precise_native_network(native):
+    """The four forward passes run on the GPU kernels (sizes 0.5x..2x); averaged maps vs the oracle network within
+    tolerance, post-process exact on the device's own averaged maps."""
+    PD = pkg('pose_detector')
+    W_ = pkg('weights')
+    from oracle import network_ref as N
+    weights = W_.synthetic_weights(0)
+    rng = np.random.default_rng(6)
+    img = rng.integers(0, 256, (120, 152, 3), dtype=np.uint8)
+    det = PD.PoseDetector(weights=weights, device=0, precise=True, max_size=(368, 472))
+    # calibrate the synthetic head on the scale-1 input so that a sane number of peaks survives at full resolution
+    cal = PD.resize_cubic_u8(img, 467, 368)
+    cal, _ = det.pad_image(cal, 8, (104, 117, 123))
+    det.engine.forward_u8(cal[None])
+    paf0, heat0 = det.engine.get_maps()
+    weights = W_.calibrate_head(weights, paf0[0], heat0[0], heat_s=0.1, heat_t=-0.2)
+    det._weights = weights
+    det.engine.set_weights({k: weights[k] for k in ('Mconv7_stage6_L1', 'Mconv7_stage6_L2')})
+    poses, scores = det(img)
+    ref_paf, ref_heat, sizes = R.averaged_maps(lambda x: N.forward(weights, x), img)
+    assert sizes[-1][0] >= 2 * 368
+    scale = max(1.0, np.abs(ref_heat).max(), np.abs(ref_paf).max())
+    assert np.abs(det.pafs - ref_paf).max() < 2e-4 * scale
+    assert np.abs(det.heatmaps - ref_heat).max() < 2e-4 * scale
+    try:
+        ref = R.detect_precise_from_maps(det.pafs, det.heatmaps)
+    except IndexError:
+        pytest.skip('reference raises IndexError on this random field')
+    assert np.array_equal(det.all_peaks, ref['all_peaks'])
+    assert np.array_equal(np.asarray(poses), np.asarray(ref['poses']))
+    det.engine.close()
