@@ -132,8 +132,7 @@ def main():
     weights_mod = importlib.import_module(PKG + '.weights')
     dist_mod = importlib.import_module(PKG + '.dist')
     if native.needs_build():
-        if local_rank == 0:
-            native.build()
+        native.build()          # serialised across ranks by a lock file
     if a.backend != 'nccl':
         local_rank = local_rank % max(1, torch.cuda.device_count())    # smoke mode: ranks may share a GPU
     torch.cuda.set_device(local_rank)

@@ -57,6 +57,19 @@ def build(force=False, verbose=False):
     """Compile the HIP sources for gfx950 into csrc/libpose_mi355x.so (cross-compiles without a GPU)."""
     if not force and not needs_build():
         return LIB_PATH
+    # several ranks of one node may get here at once: serialise on a lock file, re-check under the lock
+    import fcntl
+    with open(os.path.join(CSRC, '.build.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():
+                return LIB_PATH
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose):
     hipcc = _hipcc()
     objs = []
     base = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
