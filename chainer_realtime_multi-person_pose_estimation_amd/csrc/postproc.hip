@@ -478,6 +478,7 @@ int pp_launch(const PPMaps& maps, const PPTables& tab, const PPBuffers& buf, int
 {
     PMX_HIP(hipMemsetAsync(buf.pk_count, 0, sizeof(int) * B * PMX_N_JOINTS, stream));
     PMX_HIP(hipMemsetAsync(buf.status, 0, sizeof(int) * B, stream));
+    PMX_HIP(hipMemsetAsync(buf.results, 0, sizeof(pmx_result_record) * B, stream));   // unused rows of a record are zero
     const int tiles_x = (map_w + PK_TS - 1) / PK_TS, tiles_y = (map_h + PK_TS - 1) / PK_TS;
 
     if (prof) prof(prof_ctx, "pp_peaks", 1);
