@@ -710,6 +710,8 @@ static const ConvVariant g_variants[] = {
     {7, 8, 16, 128, 16, "conv7x7_v3_t8x16_n128"},  // 20
     {3, 8, 16, 128, 16, "conv3x3_v3_t8x16_n128"},  // 21
     {3, 8, 16, 64, 16, "conv3x3_v3_t8x16_n64"},    // 22
+    {7, 8, 8, 64, 16, "conv7x7_v3_t8x8_n64"},      // 23: small launches (single images): one wave per SIMD, pipelined
+    {3, 8, 8, 64, 16, "conv3x3_v3_t8x8_n64"},      // 24
 };
 
 int conv_num_variants() { return (int)(sizeof(g_variants) / sizeof(g_variants[0])); }
@@ -730,9 +732,13 @@ int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen
         if (ks == 3) return strip ? 11 : (small ? 6 : (cout <= 64 ? 14 : 13));
         return strip ? 17 : (small ? 7 : (cout <= 64 ? 16 : 15));
     }
-    if (gen == 2) {      // default: v2 (weights L2 -> registers) where it measured faster: 3x3 / 7x7 with cout >= 128
-        if (ks == 7) return strip ? 10 : (small ? 5 : 12);
-        if (ks == 3) return strip ? 11 : (small ? 6 : (cout <= 64 ? 2 : 13));
+    if (gen == 2) {      // default: v2 (weights L2 -> registers) where it measured faster: 3x3 / 7x7 with cout >= 128;
+                         // small launches (few blocks, one wave per SIMD) use the software-pipelined v3 small tiles
+        // (v3 small tiles only while there is at most ~1 block per CU; with more blocks the v1 small tiles win)
+        const long blocks88 = (long)((H + 7) / 8) * ((W + 7) / 8) * B * ((cout + 63) / 64);
+        const bool tiny = blocks88 <= 320;
+        if (ks == 7) return strip ? 10 : (small ? (tiny ? 23 : 5) : 12);
+        if (ks == 3) return strip ? 11 : (small ? (tiny ? 24 : 6) : (cout <= 64 ? 2 : 13));
         return small ? 7 : (cout <= 64 ? 4 : 3);
     }
     if (ks == 7) return strip ? 8 : (small ? 5 : 0);
@@ -840,6 +846,8 @@ int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream)
         case 20: return launch_v3<7, 8, 16, 128, 16, 1, 4>(a, groups, stream);
         case 21: return launch_v3<3, 8, 16, 128, 16, 1, 4>(a, groups, stream);
         case 22: return launch_v3<3, 8, 16, 64, 16, 2, 2>(a, groups, stream);
+        case 23: return launch_v3<7, 8, 8, 64, 16, 2, 2>(a, groups, stream);
+        case 24: return launch_v3<3, 8, 8, 64, 16, 2, 2>(a, groups, stream);
     }
     pmx_set_error("conv_launch: unknown variant %d", variant);
     return PMX_ERR_INVALID;

@@ -44,7 +44,8 @@ def test_v2_variants(engine, variant, k, cout, hw):
     _case(engine, 3, 48, hw[0], hw[1], cout, k, True, False, seed=70 + variant, variant=variant)
 
 
-@pytest.mark.parametrize('variant,k,cout', [(18, 7, 128), (19, 3, 128), (20, 7, 128), (21, 3, 256), (22, 3, 64)])
+@pytest.mark.parametrize('variant,k,cout', [(18, 7, 128), (19, 3, 128), (20, 7, 128), (21, 3, 256), (22, 3, 64), (23, 7, 128),
+                                            (24, 3, 38)])
 @pytest.mark.parametrize('hw,cin', [((46, 46), 48), ((9, 21), 16), ((20, 50), 185)])
 def test_v3_variants(engine, variant, k, cout, hw, cin):
     # v3: software-pipelined (A fragments one k-step ahead, halo double-buffered), 1..12 channel chunks
