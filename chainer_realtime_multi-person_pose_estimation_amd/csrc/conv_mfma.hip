@@ -678,6 +678,468 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v3_kernel(const ConvArgs a)
     }
 }
 
+// =============================================================================================================
+// v4: v3 with the memory instructions interleaved into the MFMA stream
+//
+// Compile-time ablations of v3 (profiles/r01_conv_ablate3.txt) showed that the tap loop without any memory
+// instruction reaches the structural ceiling (~85 % of peak: row padding, block quantisation, DVFS), and that the two
+// weight loads (-9 %) and six LDS reads (-7 %) per tap cost far more than their latency: a wave issues in order, so
+// when the loads of a tap are issued in one clump only the first 64 cycles of that issue time are covered by the MFMA
+// in flight and the matrix pipe idles for the rest.  v4 therefore issues exactly one memory instruction in the gap
+// after each of the first MFMAs of a k-step (the 64-cycle MFMA hides a 1 KB load issue), keeps the prefetch distances
+// of v3 (weights one tap ahead, A fragments one k-step ahead, halo one chunk ahead) and ping-pongs two named weight
+// register sets across an unrolled-by-two tap loop so that no register copies are left in the loop.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <typename C, int KS>
+struct TapBody {
+    // one tap = two k8 steps.  bc: this tap's weight fragments; bn: filled with the next tap's (prefetch).
+    // av0: this tap's step-0 A fragments (prefetched); on return holds the next tap's step-0 fragments.
+    static __device__ __forceinline__ void run(f32x16 (&acc)[C::MT][C::NT], f32x4 (&av0)[C::MT], f32x4 (&av1)[C::MT],
+                                               const f32x4 (&bc)[C::NT][2], f32x4 (&bn)[C::NT][2],
+                                               const float* const (&b_ptr)[C::NT], size_t poff_next, const float* cur,
+                                               const int (&a_base)[C::MT], int tapoff, int tapoff_next)
+    {
+        constexpr int NM = 4 * C::MT * C::NT;     // MFMAs per k8 step
+        constexpr int NB = 2 * C::NT;             // weight loads per tap
+        static_assert(NM >= NB + C::MT, "not enough MFMA gaps for the memory instructions of a k-step");
+        // ---- k8 step 0: + weight prefetch (NB loads) + A fragments of step 1 (MT LDS reads) ----
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            const int e = i / (C::MT * C::NT), t = (i / C::NT) % C::MT, u = i % C::NT;
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t][e], bc[u][0][e], acc[t][u], 0, 0, 0);
+            if (i < NB) {
+                bn[i >> 1][i & 1] = *reinterpret_cast<const f32x4*>(b_ptr[i >> 1] + poff_next + (i & 1) * 8);
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (i < NB + C::MT) {
+                av1[i - NB] = *reinterpret_cast<const f32x4*>(&cur[a_base[i - NB] + tapoff + 8]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- k8 step 1: + A fragments of the next tap's step 0 ----
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            const int e = i / (C::MT * C::NT), t = (i / C::NT) % C::MT, u = i % C::NT;
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t][e], bc[u][1][e], acc[t][u], 0, 0, 0);
+            if (i < C::MT) {
+                // (the read replaces av0[i], whose last use was in step 0)
+                av0[i] = *reinterpret_cast<const f32x4*>(&cur[a_base[i] + tapoff_next]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+};
+
+template <int KS, int TH, int TW, int BN, int CK, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_mfma_v4_kernel(const ConvArgs a)
+{
+    using C = ConvCfg<KS, TH, TW, BN, CK, WM, WN>;
+    static_assert(CK == 16 && KS > 1 && (KS * KS) % 2 == 1, "v4: 16-channel chunks, odd number of taps");
+    constexpr int NHF = (C::HALO_H * C::HALO_W * (CK / 4) + 255) / 256;
+    extern __shared__ float4 smem4[];
+    float* const s_in = reinterpret_cast<float*>(smem4);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31;
+    const int kh = lane >> 5;
+
+    const bool g1 = blockIdx.z != 0;
+    ConvGroupArgs G;
+    G.in = g1 ? a.g[1].in : a.g[0].in;
+    G.w = g1 ? a.g[1].w : a.g[0].w;
+    G.bias = g1 ? a.g[1].bias : a.g[0].bias;
+    G.out = g1 ? a.g[1].out : a.g[0].out;
+    G.cout = g1 ? a.g[1].cout : a.g[0].cout;
+    const int H = a.H, W = a.W;
+
+    int tile;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int bimg = tile / tiles_per_img;
+    const int trem = tile - bimg * tiles_per_img;
+    const int y0 = (trem / a.tiles_x) * TH;
+    const int x0 = (trem % a.tiles_x) * TW;
+    const int n0 = blockIdx.y * BN;
+    const float* in_b = G.in + (size_t)bimg * H * W * a.lda;
+
+    int a_base[C::MT];
+#pragma unroll
+    for (int t = 0; t < C::MT; ++t) {
+        int m = (wm * C::MT + t) * 32 + li;
+        if (C::MASK_M && m >= C::M) m = C::M - 1;
+        const int q = m >> 2, r = m & 3;
+        const int wy = q / (TW / 2), wx = q % (TW / 2);
+        const int py = 2 * wy + (r >> 1), px = 2 * wx + (r & 1);
+        a_base[t] = (py * C::HALO_W + px) * C::LDP + kh * 4;
+    }
+    const float* b_ptr[C::NT];
+#pragma unroll
+    for (int u = 0; u < C::NT; ++u) b_ptr[u] = G.w + (size_t)(n0 + (wn * C::NT + u) * 32 + li) * CK + kh * 4;
+    const size_t w_panel_stride = (size_t)a.cout_pad * CK;
+
+    int h_lds[NHF], h_goff[NHF];
+    bool h_ok[NHF];
+#pragma unroll
+    for (int r = 0; r < NHF; ++r) {
+        const int f = tid + r * 256;
+        const bool slot = f < C::HALO_H * C::HALO_W * (CK / 4);
+        const int hp = slot ? f / (CK / 4) : 0, c4 = f % (CK / 4);
+        const int hy = hp / C::HALO_W, hx = hp - hy * C::HALO_W;
+        const int gy = y0 + hy - C::PADK, gx = x0 + hx - C::PADK;
+        const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+        h_lds[r] = slot ? hp * C::LDP + c4 * 4 : -1;
+        h_goff[r] = (cy * W + cx) * a.lda + c4 * 4;
+        h_ok[r] = inb;
+    }
+
+    f32x16 acc[C::MT][C::NT];
+#pragma unroll
+    for (int t = 0; t < C::MT; ++t)
+#pragma unroll
+        for (int u = 0; u < C::NT; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
+
+    f32x4 bA[C::NT][2], bB[C::NT][2];      // ping-pong weight fragment sets
+#pragma unroll
+    for (int u = 0; u < C::NT; ++u) {
+        bA[u][0] = *reinterpret_cast<const f32x4*>(b_ptr[u]);
+        bA[u][1] = *reinterpret_cast<const f32x4*>(b_ptr[u] + 8);
+    }
+#pragma unroll
+    for (int r = 0; r < NHF; ++r) {
+        float4 v = *reinterpret_cast<const float4*>(in_b + h_goff[r]);
+        if (!h_ok[r]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (h_lds[r] >= 0) *reinterpret_cast<float4*>(&s_in[h_lds[r]]) = v;
+    }
+    __syncthreads();
+    f32x4 av0[C::MT], av1[C::MT];
+#pragma unroll
+    for (int t = 0; t < C::MT; ++t) av0[t] = *reinterpret_cast<const f32x4*>(&s_in[a_base[t]]);
+
+    for (int ch = 0; ch < a.nch; ++ch) {
+        const float* cur = s_in + (ch & 1) * C::IN_ELEMS;
+        float* nxt = s_in + ((ch + 1) & 1) * C::IN_ELEMS;
+        const bool more_ch = ch + 1 < a.nch;
+        float4 hreg[NHF];
+        {
+            const int cn = more_ch ? ch + 1 : ch;
+#pragma unroll
+            for (int r = 0; r < NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + cn * CK);
+        }
+        const size_t chunk_off = (size_t)ch * w_panel_stride;
+        const size_t tap_stride = (size_t)a.nch * w_panel_stride;
+        // taps 0 .. T-2 in pairs (A -> B -> A), then the last tap (A -> B) and one copy B -> A per chunk.
+        // LDS tap offsets and weight panel offsets advance incrementally (no divisions / 64-bit multiplies in the loop).
+        size_t pnext = chunk_off + tap_stride;       // panel of tap 1
+        int toff = 0, kx = 0;                        // LDS offset of the current tap, its column
+        auto advance = [&](int off, int& col) {      // offset of the following tap
+            if (col + 1 == KS) { col = 0; return off + (C::HALO_W - KS + 1) * C::LDP; }
+            col += 1;
+            return off + C::LDP;
+        };
+#pragma unroll 1
+        for (int tap = 0; tap + 1 < C::T; tap += 2) {
+            const int toff1 = advance(toff, kx);
+            TapBody<C, KS>::run(acc, av0, av1, bA, bB, b_ptr, pnext, cur, a_base, toff, toff1);
+            pnext += tap_stride;
+            const int toff2 = advance(toff1, kx);
+            TapBody<C, KS>::run(acc, av0, av1, bB, bA, b_ptr, pnext, cur, a_base, toff1, toff2);
+            pnext += tap_stride;
+            toff = toff2;
+        }
+        {
+            // last tap: prefetch tap 0 of the next chunk (or re-read this panel on the very last chunk)
+            const size_t plast = more_ch ? chunk_off + w_panel_stride : (size_t)(C::T - 1) * tap_stride + chunk_off;
+            TapBody<C, KS>::run(acc, av0, av1, bA, bB, b_ptr, plast, cur, a_base, toff, toff);
+#pragma unroll
+            for (int u = 0; u < C::NT; ++u) { bA[u][0] = bB[u][0]; bA[u][1] = bB[u][1]; }
+        }
+        if (more_ch) {
+#pragma unroll
+            for (int r = 0; r < NHF; ++r) {
+                float4 v = hreg[r];
+                if (!h_ok[r]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (h_lds[r] >= 0) *reinterpret_cast<float4*>(&nxt[h_lds[r]]) = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < C::MT; ++t) av0[t] = *reinterpret_cast<const f32x4*>(&nxt[a_base[t]]);
+        }
+    }
+
+    // ---- epilogue (identical to v1) ----
+#pragma unroll
+    for (int t = 0; t < C::MT; ++t) {
+#pragma unroll
+        for (int u = 0; u < C::NT; ++u) {
+            const int n = n0 + (wn * C::NT + u) * 32 + li;
+            const bool nok = n < G.cout;
+            const float bias = G.bias[n];
+            if (!a.pool) {
+                float* out_b = G.out + (size_t)bimg * H * W * a.ldc;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                    const int m = (wm * C::MT + t) * 32 + row;
+                    const int q = m >> 2, r = m & 3;
+                    const int wy = q / (TW / 2), wx = q % (TW / 2);
+                    const int gy = y0 + 2 * wy + (r >> 1), gx = x0 + 2 * wx + (r & 1);
+                    float v = acc[t][u][reg] + bias;
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (nok && (!C::MASK_M || m < C::M) && gy < H && gx < W) out_b[((size_t)gy * W + gx) * a.ldc + n] = v;
+                }
+            } else {
+                const int Hp = H >> 1, Wp = W >> 1;
+                float* out_b = G.out + (size_t)bimg * Hp * Wp * a.ldc;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float v = fmaxf(fmaxf(acc[t][u][4 * g4 + 0], acc[t][u][4 * g4 + 1]),
+                                    fmaxf(acc[t][u][4 * g4 + 2], acc[t][u][4 * g4 + 3]));
+                    v += bias;
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    const int q = (wm * C::MT + t) * 8 + 2 * g4 + kh;
+                    const int wy = q / (TW / 2), wx = q % (TW / 2);
+                    const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
+                    if (nok && (!C::MASK_M || q < C::M / 4) && oy < Hp && ox < Wp) out_b[((size_t)oy * Wp + ox) * a.ldc + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// Ablation twin of v3 (timing experiments only, results are wrong when ABL != 0): ABL bit0 = weight fragments loaded
+// once (no per-tap global loads), bit1 = A fragments read once per chunk (no per-step ds_reads), bit2 = halo staged
+// once (no per-chunk global loads / LDS writes / barrier), bit3 = no B register copies (prefetch into bc directly).
+template <int KS, int TH, int TW, int BN, int CK, int WM, int WN, int ABL>
+__global__ __launch_bounds__(256, 2) void conv_mfma_v3abl_kernel(const ConvArgs a)
+{
+    using C = ConvCfg<KS, TH, TW, BN, CK, WM, WN>;
+    static_assert(CK == 16 && KS > 1, "v3: 16-channel chunks, spatial kernels");
+    constexpr int NHF = (C::HALO_H * C::HALO_W * (CK / 4) + 255) / 256;   // halo float4 per thread
+    extern __shared__ float4 smem4[];
+    float* const s_in = reinterpret_cast<float*>(smem4);                  // two halo buffers of IN_ELEMS floats
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31;
+    const int kh = lane >> 5;
+
+    const bool g1 = blockIdx.z != 0;
+    ConvGroupArgs G;
+    G.in = g1 ? a.g[1].in : a.g[0].in;
+    G.w = g1 ? a.g[1].w : a.g[0].w;
+    G.bias = g1 ? a.g[1].bias : a.g[0].bias;
+    G.out = g1 ? a.g[1].out : a.g[0].out;
+    G.cout = g1 ? a.g[1].cout : a.g[0].cout;
+    const int H = a.H, W = a.W;
+
+    int tile;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int bimg = tile / tiles_per_img;
+    const int trem = tile - bimg * tiles_per_img;
+    const int y0 = (trem / a.tiles_x) * TH;
+    const int x0 = (trem % a.tiles_x) * TW;
+    const int n0 = blockIdx.y * BN;
+    const float* in_b = G.in + (size_t)bimg * H * W * a.lda;
+
+    int a_base[C::MT];
+#pragma unroll
+    for (int t = 0; t < C::MT; ++t) {
+        int m = (wm * C::MT + t) * 32 + li;
+        if (C::MASK_M && m >= C::M) m = C::M - 1;
+        const int q = m >> 2, r = m & 3;
+        const int wy = q / (TW / 2), wx = q % (TW / 2);
+        const int py = 2 * wy + (r >> 1), px = 2 * wx + (r & 1);
+        a_base[t] = (py * C::HALO_W + px) * C::LDP + kh * 4;
+    }
+    const float* b_ptr[C::NT];
+#pragma unroll
+    for (int u = 0; u < C::NT; ++u) b_ptr[u] = G.w + (size_t)(n0 + (wn * C::NT + u) * 32 + li) * CK + kh * 4;
+    const size_t w_panel_stride = (size_t)a.cout_pad * CK;
+
+    // halo staging slots of this thread: LDS offset, clamped global offset, in-bounds flag (same for every chunk)
+    int h_lds[NHF], h_goff[NHF];
+    bool h_ok[NHF];
+#pragma unroll
+    for (int r = 0; r < NHF; ++r) {
+        const int f = tid + r * 256;
+        const bool slot = f < C::HALO_H * C::HALO_W * (CK / 4);
+        const int hp = slot ? f / (CK / 4) : 0, c4 = f % (CK / 4);
+        const int hy = hp / C::HALO_W, hx = hp - hy * C::HALO_W;
+        const int gy = y0 + hy - C::PADK, gx = x0 + hx - C::PADK;
+        const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+        h_lds[r] = slot ? hp * C::LDP + c4 * 4 : -1;
+        h_goff[r] = (cy * W + cx) * a.lda + c4 * 4;
+        h_ok[r] = inb;
+    }
+
+    f32x16 acc[C::MT][C::NT];
+#pragma unroll
+    for (int t = 0; t < C::MT; ++t)
+#pragma unroll
+        for (int u = 0; u < C::NT; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
+
+    // ---- prologue: chunk 0 halo -> buffer 0, first weight fragments, first A fragments ----
+    float4 bc[C::NT][2], bn[C::NT][2];
+#pragma unroll
+    for (int u = 0; u < C::NT; ++u) {
+        bc[u][0] = *reinterpret_cast<const float4*>(b_ptr[u]);
+        bc[u][1] = *reinterpret_cast<const float4*>(b_ptr[u] + 8);
+    }
+#pragma unroll
+    for (int r = 0; r < NHF; ++r) {
+        float4 v = *reinterpret_cast<const float4*>(in_b + h_goff[r]);
+        if (!h_ok[r]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (h_lds[r] >= 0) *reinterpret_cast<float4*>(&s_in[h_lds[r]]) = v;
+    }
+    __syncthreads();
+    float4 av0[C::MT], av1[C::MT];
+#pragma unroll
+    for (int t = 0; t < C::MT; ++t) { av0[t] = *reinterpret_cast<const float4*>(&s_in[a_base[t]]); av1[t] = *reinterpret_cast<const float4*>(&s_in[a_base[t] + 8]); }
+
+    for (int ch = 0; ch < a.nch; ++ch) {
+        const float* cur = s_in + ((ABL & 4) ? 0 : (ch & 1)) * C::IN_ELEMS;
+        float* nxt = s_in + ((ch + 1) & 1) * C::IN_ELEMS;
+        const bool more_ch = ch + 1 < a.nch;
+        // next chunk's halo: global -> registers now, registers -> LDS after the last tap
+        float4 hreg[NHF];
+        if constexpr (!(ABL & 4)) {
+            const int cn = more_ch ? ch + 1 : ch;
+#pragma unroll
+            for (int r = 0; r < NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + cn * CK);
+        }
+#pragma unroll 1
+        for (int tap = 0; tap < C::T; ++tap) {
+            int tn = tap + 1, cn = ch;
+            if (tn == C::T) {
+                if (more_ch) { tn = 0; cn = ch + 1; }
+                else tn = tap;
+            }
+            const size_t poff = ((size_t)tn * a.nch + cn) * w_panel_stride;
+            if constexpr (!(ABL & 1)) {
+#pragma unroll
+            for (int u = 0; u < C::NT; ++u) {
+                bn[u][0] = *reinterpret_cast<const float4*>(b_ptr[u] + poff);
+                bn[u][1] = *reinterpret_cast<const float4*>(b_ptr[u] + poff + 8);
+            }
+            }
+            const int ky = tap / KS, kx = tap - ky * KS;
+            const int tapoff = (ky * C::HALO_W + kx) * C::LDP;
+            // k8 step 0: prefetch step 1's A fragments, then the MFMAs of step 0
+            if constexpr (!(ABL & 2) )
+#pragma unroll
+            for (int t = 0; t < C::MT; ++t) av1[t] = *reinterpret_cast<const float4*>(&cur[a_base[t] + tapoff + 8]);
+            __builtin_amdgcn_sched_barrier(0);   // loads above are issued before the MFMAs below (pins the prefetch distance)
+#pragma unroll
+            for (int t = 0; t < C::MT; ++t)
+#pragma unroll
+                for (int u = 0; u < C::NT; ++u) {
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t].x, bc[u][0].x, acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t].y, bc[u][0].y, acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t].z, bc[u][0].z, acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t].w, bc[u][0].w, acc[t][u], 0, 0, 0);
+                }
+            // k8 step 1: prefetch the next tap's step-0 fragments (clamped to this tap on the chunk's last one)
+            {
+                const int t2 = (tap + 1 < C::T) ? tap + 1 : tap;
+                const int ky2 = t2 / KS, kx2 = t2 - ky2 * KS;
+                const int tapoff2 = (ky2 * C::HALO_W + kx2) * C::LDP;
+                if constexpr (!(ABL & 2))
+#pragma unroll
+                for (int t = 0; t < C::MT; ++t) av0[t] = *reinterpret_cast<const float4*>(&cur[a_base[t] + tapoff2]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < C::MT; ++t)
+#pragma unroll
+                for (int u = 0; u < C::NT; ++u) {
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t].x, bc[u][1].x, acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t].y, bc[u][1].y, acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t].z, bc[u][1].z, acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t].w, bc[u][1].w, acc[t][u], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(ABL & 1) && !(ABL & 8)) {
+#pragma unroll
+            for (int u = 0; u < C::NT; ++u) { bc[u][0] = bn[u][0]; bc[u][1] = bn[u][1]; }
+            }
+            if constexpr ((ABL & 8) && !(ABL & 1)) {      // keep the loads alive without the copies
+#pragma unroll
+                for (int u = 0; u < C::NT; ++u) asm volatile("" ::"v"(bn[u][0].x), "v"(bn[u][1].x));
+            }
+        }
+        if (more_ch && !(ABL & 4)) {
+#pragma unroll
+            for (int r = 0; r < NHF; ++r) {
+                float4 v = hreg[r];
+                if (!h_ok[r]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (h_lds[r] >= 0) *reinterpret_cast<float4*>(&nxt[h_lds[r]]) = v;
+            }
+            __syncthreads();   // next halo visible; nobody still reads the buffer that the chunk after next will overwrite
+#pragma unroll
+            for (int t = 0; t < C::MT; ++t) av0[t] = *reinterpret_cast<const float4*>(&nxt[a_base[t]]);
+        }
+    }
+
+    // ---- epilogue (identical to v1) ----
+#pragma unroll
+    for (int t = 0; t < C::MT; ++t) {
+#pragma unroll
+        for (int u = 0; u < C::NT; ++u) {
+            const int n = n0 + (wn * C::NT + u) * 32 + li;
+            const bool nok = n < G.cout;
+            const float bias = G.bias[n];
+            if (!a.pool) {
+                float* out_b = G.out + (size_t)bimg * H * W * a.ldc;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                    const int m = (wm * C::MT + t) * 32 + row;
+                    const int q = m >> 2, r = m & 3;
+                    const int wy = q / (TW / 2), wx = q % (TW / 2);
+                    const int gy = y0 + 2 * wy + (r >> 1), gx = x0 + 2 * wx + (r & 1);
+                    float v = acc[t][u][reg] + bias;
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (nok && (!C::MASK_M || m < C::M) && gy < H && gx < W) out_b[((size_t)gy * W + gx) * a.ldc + n] = v;
+                }
+            } else {
+                const int Hp = H >> 1, Wp = W >> 1;
+                float* out_b = G.out + (size_t)bimg * Hp * Wp * a.ldc;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float v = fmaxf(fmaxf(acc[t][u][4 * g4 + 0], acc[t][u][4 * g4 + 1]),
+                                    fmaxf(acc[t][u][4 * g4 + 2], acc[t][u][4 * g4 + 3]));
+                    v += bias;
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    const int q = (wm * C::MT + t) * 8 + 2 * g4 + kh;
+                    const int wy = q / (TW / 2), wx = q % (TW / 2);
+                    const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
+                    if (nok && (!C::MASK_M || q < C::M / 4) && oy < Hp && ox < Wp) out_b[((size_t)oy * Wp + ox) * a.ldc + n] = v;
+                }
+            }
+        }
+    }
+}
+
 // minimum dynamic LDS per block: caps the number of co-resident blocks per CU (the fp32 MFMA pipe
 // loses ~20% with 3+ waves per SIMD)
 static int g_min_lds = 0;
@@ -712,6 +1174,14 @@ static const ConvVariant g_variants[] = {
     {3, 8, 16, 64, 16, "conv3x3_v3_t8x16_n64"},    // 22
     {7, 8, 8, 64, 16, "conv7x7_v3_t8x8_n64"},      // 23: small launches (single images): one wave per SIMD, pipelined
     {3, 8, 8, 64, 16, "conv3x3_v3_t8x8_n64"},      // 24
+    // v4 kernels: v3 + memory instructions interleaved into the MFMA stream (see conv_mfma_v4_kernel)
+    {7, 2, 46, 128, 16, "conv7x7_v4_t2x46_n128"},  // 25
+    {3, 2, 46, 128, 16, "conv3x3_v4_t2x46_n128"},  // 26
+    {7, 8, 16, 128, 16, "conv7x7_v4_t8x16_n128"},  // 27
+    {3, 8, 16, 128, 16, "conv3x3_v4_t8x16_n128"},  // 28
+    {3, 8, 16, 64, 16, "conv3x3_v4_t8x16_n64"},    // 29
+    {7, 8, 8, 64, 16, "conv7x7_v4_t8x8_n64"},      // 30
+    {3, 8, 8, 64, 16, "conv3x3_v4_t8x8_n64"},      // 31
 };
 
 int conv_num_variants() { return (int)(sizeof(g_variants) / sizeof(g_variants[0])); }
@@ -720,6 +1190,7 @@ const ConvVariant& conv_variant(int idx) { return g_variants[idx]; }
 int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen)
 {
     // `cout` is the padded channel count of the layer
+    if (forced >= 100 && ks == 7) return forced;      // ablation kernels
     if (forced >= 0 && forced < conv_num_variants() && g_variants[forced].ks == ks && cout % g_variants[forced].bn == 0)
         return forced;
     // enough 8x16 tiles to fill 256 CUs a few times over?  otherwise use the small tiles
@@ -727,7 +1198,14 @@ int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen
     const bool small = tiles816 * ((cout + 127) / 128) < 512;
     // 2 x 46 row strips tile 46-wide maps exactly (8 x 16 tiles waste 8.9 %); on 92-wide maps they measured neutral
     const bool strip = (W == 46) && (cout % 128 == 0) && ((long)((H + 1) / 2) * B * (cout / 128) >= 512);
-    if (gen >= 3) {      // every layer on the v2 kernels (A/B measurements only)
+    if (gen == 4) {      // v4 kernels (interleaved memory instructions, 2 blocks per CU) for 3x3 / 7x7
+        const long blocks88 = (long)((H + 7) / 8) * ((W + 7) / 8) * B * ((cout + 63) / 64);
+        const bool tiny = blocks88 <= 320;
+        if (ks == 7) return strip ? 25 : (small ? (tiny ? 30 : 5) : 27);
+        if (ks == 3) return strip ? 26 : (small ? (tiny ? 31 : 6) : (cout <= 64 ? 2 : 28));
+        return small ? 7 : (cout <= 64 ? 4 : 3);
+    }
+    if (gen == 3) {      // every layer on the v2 kernels (A/B measurements only)
         if (ks == 7) return strip ? 10 : (small ? 5 : 12);
         if (ks == 3) return strip ? 11 : (small ? 6 : (cout <= 64 ? 14 : 13));
         return strip ? 17 : (small ? 7 : (cout <= 64 ? 16 : 15));
@@ -795,7 +1273,7 @@ static int launch_v2(const ConvArgs& a0, int groups, hipStream_t stream)
 static int g_v3_lds = 56 * 1024;     // dynamic LDS floor of the v3 kernels: 3 x 56 KB > 160 KB -> at most 2 blocks per CU
 void conv_set_v3_lds(int bytes) { g_v3_lds = bytes; }
 
-template <int KS, int TH, int TW, int BN, int CK, int WM, int WN>
+template <int KS, int TH, int TW, int BN, int CK, int WM, int WN, int GEN = 3>
 static int launch_v3(const ConvArgs& a0, int groups, hipStream_t stream)
 {
     using C = ConvCfg<KS, TH, TW, BN, CK, WM, WN>;
@@ -805,7 +1283,7 @@ static int launch_v3(const ConvArgs& a0, int groups, hipStream_t stream)
     PMX_CHECK(a.cout_pad % BN == 0, PMX_ERR_INVALID, "conv: cout_pad %d not a multiple of BN %d", a.cout_pad, BN);
     PMX_CHECK(!a.pool || (a.H % 2 == 0 && a.W % 2 == 0), PMX_ERR_INVALID, "conv: pooled layer needs even H, W");
     PMX_CHECK((long long)a.H * a.W * a.lda < (1ll << 31), PMX_ERR_INVALID, "conv: image too large for 32-bit offsets");
-    auto kern = conv_mfma_v3_kernel<KS, TH, TW, BN, CK, WM, WN>;
+    auto kern = GEN == 4 ? conv_mfma_v4_kernel<KS, TH, TW, BN, CK, WM, WN> : conv_mfma_v3_kernel<KS, TH, TW, BN, CK, WM, WN>;
     int lds = 2 * C::IN_ELEMS * 4;
     if (lds < g_v3_lds) lds = g_v3_lds;
     if (lds < g_min_lds) lds = g_min_lds;
@@ -820,8 +1298,40 @@ static int launch_v3(const ConvArgs& a0, int groups, hipStream_t stream)
     return PMX_OK;
 }
 
+template <int ABL>
+static int launch_v3abl(const ConvArgs& a0, int groups, hipStream_t stream)
+{
+    using C = ConvCfg<7, 2, 46, 128, 16, 1, 4>;
+    ConvArgs a = a0;
+    a.tiles_x = (a.W + 46 - 1) / 46;
+    a.tiles_y = (a.H + 2 - 1) / 2;
+    auto kern = conv_mfma_v3abl_kernel<7, 2, 46, 128, 16, 1, 4, ABL>;
+    int lds = 2 * C::IN_ELEMS * 4;
+    if (lds < g_v3_lds) lds = g_v3_lds;
+    if (lds < g_min_lds) lds = g_min_lds;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / 128), (unsigned)groups);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
 int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream)
 {
+    switch (variant) {     // ablation twins of the v3 7x7 strip kernel (tools/conv_ablate3.py)
+        case 100: return launch_v3abl<0>(a, groups, stream);
+        case 101: return launch_v3abl<1>(a, groups, stream);
+        case 102: return launch_v3abl<2>(a, groups, stream);
+        case 103: return launch_v3abl<3>(a, groups, stream);
+        case 104: return launch_v3abl<4>(a, groups, stream);
+        case 107: return launch_v3abl<7>(a, groups, stream);
+        case 108: return launch_v3abl<8>(a, groups, stream);
+        case 115: return launch_v3abl<15>(a, groups, stream);
+    }
     switch (variant) {
         case 0: return launch_cfg<7, 8, 16, 128, 16, 2, 2>(a, groups, stream);
         case 1: return launch_cfg<3, 8, 16, 128, 16, 2, 2>(a, groups, stream);
@@ -848,6 +1358,13 @@ int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream)
         case 22: return launch_v3<3, 8, 16, 64, 16, 2, 2>(a, groups, stream);
         case 23: return launch_v3<7, 8, 8, 64, 16, 2, 2>(a, groups, stream);
         case 24: return launch_v3<3, 8, 8, 64, 16, 2, 2>(a, groups, stream);
+        case 25: return launch_v3<7, 2, 46, 128, 16, 1, 4, 4>(a, groups, stream);
+        case 26: return launch_v3<3, 2, 46, 128, 16, 1, 4, 4>(a, groups, stream);
+        case 27: return launch_v3<7, 8, 16, 128, 16, 1, 4, 4>(a, groups, stream);
+        case 28: return launch_v3<3, 8, 16, 128, 16, 1, 4, 4>(a, groups, stream);
+        case 29: return launch_v3<3, 8, 16, 64, 16, 2, 2, 4>(a, groups, stream);
+        case 30: return launch_v3<7, 8, 8, 64, 16, 2, 2, 4>(a, groups, stream);
+        case 31: return launch_v3<3, 8, 8, 64, 16, 2, 2, 4>(a, groups, stream);
     }
     pmx_set_error("conv_launch: unknown variant %d", variant);
     return PMX_ERR_INVALID;

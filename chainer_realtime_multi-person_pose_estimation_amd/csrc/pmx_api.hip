@@ -148,7 +148,7 @@ struct pmx_ctx {
     size_t smoothed_cap = 0;
     // options
     int opt_force[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // by ksize
-    int opt_keep_smoothed = 0, opt_stop_stage = 6, opt_kernel_gen = 2, opt_conv_dbg = 0;
+    int opt_keep_smoothed = 0, opt_stop_stage = 6, opt_kernel_gen = 4, opt_conv_dbg = 0;
     // timing / profiling
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool prof_on = false;

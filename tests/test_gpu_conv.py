@@ -52,6 +52,19 @@ def test_v3_variants(engine, variant, k, cout, hw, cin):
     _case(engine, 3, cin, hw[0], hw[1], cout, k, True, False, seed=170 + variant, variant=variant)
 
 
+@pytest.mark.parametrize('variant,k,cout', [(25, 7, 128), (26, 3, 128), (27, 7, 128), (28, 3, 256), (29, 3, 64), (30, 7, 128),
+                                            (31, 3, 38)])
+@pytest.mark.parametrize('hw,cin', [((46, 46), 48), ((9, 21), 16), ((20, 50), 185)])
+def test_v4_variants(engine, variant, k, cout, hw, cin):
+    # v4: memory instructions interleaved into the MFMA stream, ping-pong weight registers; 1..12 channel chunks
+    _case(engine, 3, cin, hw[0], hw[1], cout, k, True, False, seed=270 + variant, variant=variant)
+
+
+@pytest.mark.parametrize('variant', [28, 29])
+def test_v4_fused_relu_maxpool(engine, variant):
+    _case(engine, 2, 32, 24, 40, 64 if variant == 29 else 128, 3, True, True, seed=290 + variant, variant=variant)
+
+
 @pytest.mark.parametrize('variant', [21, 22])
 def test_v3_fused_relu_maxpool(engine, variant):
     _case(engine, 2, 32, 24, 40, 64 if variant == 22 else 128, 3, True, True, seed=190 + variant, variant=variant)
@@ -77,9 +90,13 @@ def test_v2_network_equals_v1_network_bitwise(engine):
     engine.set_option('kernel_gen', 3)
     engine.forward_u8(img)
     p3, h3 = engine.get_maps()
-    engine.set_option('kernel_gen', 2)      # library default
+    engine.set_option('kernel_gen', 4)
+    engine.forward_u8(img)
+    p4, h4 = engine.get_maps()
+    engine.set_option('kernel_gen', 4)      # library default
     assert np.array_equal(p1, p2) and np.array_equal(h1, h2)
     assert np.array_equal(p1, p3) and np.array_equal(h1, h3)
+    assert np.array_equal(p1, p4) and np.array_equal(h1, h4)
 
 
 @pytest.mark.parametrize('variant,k', [(8, 7), (9, 3)])
