@@ -51,6 +51,66 @@ struct ConvCfg {
     static_assert((BN * CK / 4) % 256 == 0 && WREGS <= 2, "weight panel must be 1 or 2 float4 per thread");
 };
 
+
+// ---- shared epilogue: bias + ReLU (+ 2x2 max-pool) + masked NHWC store ----------------------------------------
+// C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+// `biasv` is loaded in the kernel prologue: a load inside the guarded store blocks makes the compiler drain the
+// memory queue (s_waitcnt vmcnt(0)) in front of every one of the 16*MT*NT stores, serialising the store latencies.
+template <typename C, int TW>
+__device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[C::MT][C::NT], const float (&biasv)[C::NT], const ConvArgs& a,
+                                              float* gout, int cout, int bimg, int y0, int x0, int n0, int wm, int wn, int li, int kh)
+{
+    const int H = a.H, W = a.W;
+#pragma unroll
+    for (int t = 0; t < C::MT; ++t) {
+#pragma unroll
+        for (int u = 0; u < C::NT; ++u) {
+            const int n = n0 + (wn * C::NT + u) * 32 + li;
+            const bool nok = n < cout;
+            const float bias = biasv[u];
+            if (!a.pool) {
+                float* out_b = gout + (size_t)bimg * H * W * a.ldc + n;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                    const int m = (wm * C::MT + t) * 32 + row;
+                    const int q = m >> 2, r = m & 3;
+                    const int wy = q / (TW / 2), wx = q % (TW / 2);
+                    const int gy = y0 + 2 * wy + (r >> 1), gx = x0 + 2 * wx + (r & 1);
+                    float v = acc[t][u][reg] + bias;
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (nok && (!C::MASK_M || m < C::M) && gy < H && gx < W) out_b[(size_t)(gy * W + gx) * a.ldc] = v;
+                }
+            } else {
+                const int Hp = H >> 1, Wp = W >> 1;
+                float* out_b = gout + (size_t)bimg * Hp * Wp * a.ldc + n;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float v = fmaxf(fmaxf(acc[t][u][4 * g4 + 0], acc[t][u][4 * g4 + 1]),
+                                    fmaxf(acc[t][u][4 * g4 + 2], acc[t][u][4 * g4 + 3]));
+                    v += bias;
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    const int q = (wm * C::MT + t) * 8 + 2 * g4 + kh;
+                    const int wy = q / (TW / 2), wx = q % (TW / 2);
+                    const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
+                    if (nok && (!C::MASK_M || q < C::M / 4) && oy < Hp && ox < Wp) out_b[(size_t)(oy * Wp + ox) * a.ldc] = v;
+                }
+            }
+        }
+    }
+}
+
+// bias of this lane's output channels, fetched up front and pinned in registers (see conv_epilogue)
+template <typename C>
+__device__ __forceinline__ void conv_load_bias(float (&biasv)[C::NT], const float* gbias, int n0, int wn, int li)
+{
+#pragma unroll
+    for (int u = 0; u < C::NT; ++u) {
+        biasv[u] = gbias[n0 + (wn * C::NT + u) * 32 + li];     // bias is padded to cout_pad
+        asm volatile("" : "+v"(biasv[u]));                      // materialise now, not at the first use
+    }
+}
+
 template <int KS, int TH, int TW, int BN, int CK, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
 {
@@ -84,6 +144,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
     const int n0 = blockIdx.y * BN;
 
     const float* in_b = G.in + (size_t)bimg * H * W * a.lda;
+    float biasv[C::NT];
+    conv_load_bias<C>(biasv, G.bias, n0, wn, li);
 
     // per-lane LDS offsets of the A (pixel) and B (weight) fragments
     int a_base[C::MT];
@@ -193,43 +255,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
 
     // ---- epilogue: bias + ReLU (+ 2x2 max-pool) + masked NHWC store ----
     // C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-#pragma unroll
-    for (int t = 0; t < C::MT; ++t) {
-#pragma unroll
-        for (int u = 0; u < C::NT; ++u) {
-            const int n = n0 + (wn * C::NT + u) * 32 + li;
-            const bool nok = n < G.cout;
-            const float bias = G.bias[n];      // bias is padded to cout_pad
-            if (!a.pool) {
-                float* out_b = G.out + (size_t)bimg * H * W * a.ldc;
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
-                    const int m = (wm * C::MT + t) * 32 + row;
-                    const int q = m >> 2, r = m & 3;
-                    const int wy = q / (TW / 2), wx = q % (TW / 2);
-                    const int gy = y0 + 2 * wy + (r >> 1), gx = x0 + 2 * wx + (r & 1);
-                    float v = acc[t][u][reg] + bias;
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    if (nok && (!C::MASK_M || m < C::M) && gy < H && gx < W) out_b[((size_t)gy * W + gx) * a.ldc + n] = v;
-                }
-            } else {
-                const int Hp = H >> 1, Wp = W >> 1;
-                float* out_b = G.out + (size_t)bimg * Hp * Wp * a.ldc;
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    float v = fmaxf(fmaxf(acc[t][u][4 * g4 + 0], acc[t][u][4 * g4 + 1]),
-                                    fmaxf(acc[t][u][4 * g4 + 2], acc[t][u][4 * g4 + 3]));
-                    v += bias;
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    const int q = (wm * C::MT + t) * 8 + 2 * g4 + kh;
-                    const int wy = q / (TW / 2), wx = q % (TW / 2);
-                    const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
-                    if (nok && (!C::MASK_M || q < C::M / 4) && oy < Hp && ox < Wp) out_b[((size_t)oy * Wp + ox) * a.ldc + n] = v;
-                }
-            }
-        }
-    }
+conv_epilogue<C, TW>(acc, biasv, a, G.out, G.cout, bimg, y0, x0, n0, wm, wn, li, kh);
 }
 
 // =============================================================================================================
@@ -283,6 +309,8 @@ __global__ __launch_bounds__(256) void conv_mfma_v2_kernel(const ConvArgs a)
     const int x0 = (trem % a.tiles_x) * TW;
     const int n0 = blockIdx.y * BN;
     const float* in_b = G.in + (size_t)bimg * H * W * a.lda;
+    float biasv[C::NT];
+    conv_load_bias<C>(biasv, G.bias, n0, wn, li);
 
     // A fragment addressing: LDS offsets (KS > 1) or global float offsets (KS == 1)
     int a_base[C::MT];
@@ -416,43 +444,7 @@ __global__ __launch_bounds__(256) void conv_mfma_v2_kernel(const ConvArgs a)
 
     if ((a.dbg & 4) && acc[0][0][0] != 12345.678f) return;   // ablation: drop the stores but keep the accumulators live
     // ---- epilogue (identical to v1) ----
-#pragma unroll
-    for (int t = 0; t < C::MT; ++t) {
-#pragma unroll
-        for (int u = 0; u < C::NT; ++u) {
-            const int n = n0 + (wn * C::NT + u) * 32 + li;
-            const bool nok = n < G.cout;
-            const float bias = G.bias[n];
-            if (!a.pool) {
-                float* out_b = G.out + (size_t)bimg * H * W * a.ldc;
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
-                    const int m = (wm * C::MT + t) * 32 + row;
-                    const int q = m >> 2, r = m & 3;
-                    const int wy = q / (TW / 2), wx = q % (TW / 2);
-                    const int gy = y0 + 2 * wy + (r >> 1), gx = x0 + 2 * wx + (r & 1);
-                    float v = acc[t][u][reg] + bias;
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    if (nok && (!C::MASK_M || m < C::M) && gy < H && gx < W) out_b[((size_t)gy * W + gx) * a.ldc + n] = v;
-                }
-            } else {
-                const int Hp = H >> 1, Wp = W >> 1;
-                float* out_b = G.out + (size_t)bimg * Hp * Wp * a.ldc;
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    float v = fmaxf(fmaxf(acc[t][u][4 * g4 + 0], acc[t][u][4 * g4 + 1]),
-                                    fmaxf(acc[t][u][4 * g4 + 2], acc[t][u][4 * g4 + 3]));
-                    v += bias;
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    const int q = (wm * C::MT + t) * 8 + 2 * g4 + kh;
-                    const int wy = q / (TW / 2), wx = q % (TW / 2);
-                    const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
-                    if (nok && (!C::MASK_M || q < C::M / 4) && oy < Hp && ox < Wp) out_b[((size_t)oy * Wp + ox) * a.ldc + n] = v;
-                }
-            }
-        }
-    }
+conv_epilogue<C, TW>(acc, biasv, a, G.out, G.cout, bimg, y0, x0, n0, wm, wn, li, kh);
 }
 
 // =============================================================================================================
@@ -505,6 +497,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v3_kernel(const ConvArgs a)
     const int x0 = (trem % a.tiles_x) * TW;
     const int n0 = blockIdx.y * BN;
     const float* in_b = G.in + (size_t)bimg * H * W * a.lda;
+    float biasv[C::NT];
+    conv_load_bias<C>(biasv, G.bias, n0, wn, li);
 
     int a_base[C::MT];
 #pragma unroll
@@ -639,43 +633,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v3_kernel(const ConvArgs a)
     }
 
     // ---- epilogue (identical to v1) ----
-#pragma unroll
-    for (int t = 0; t < C::MT; ++t) {
-#pragma unroll
-        for (int u = 0; u < C::NT; ++u) {
-            const int n = n0 + (wn * C::NT + u) * 32 + li;
-            const bool nok = n < G.cout;
-            const float bias = G.bias[n];
-            if (!a.pool) {
-                float* out_b = G.out + (size_t)bimg * H * W * a.ldc;
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
-                    const int m = (wm * C::MT + t) * 32 + row;
-                    const int q = m >> 2, r = m & 3;
-                    const int wy = q / (TW / 2), wx = q % (TW / 2);
-                    const int gy = y0 + 2 * wy + (r >> 1), gx = x0 + 2 * wx + (r & 1);
-                    float v = acc[t][u][reg] + bias;
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    if (nok && (!C::MASK_M || m < C::M) && gy < H && gx < W) out_b[((size_t)gy * W + gx) * a.ldc + n] = v;
-                }
-            } else {
-                const int Hp = H >> 1, Wp = W >> 1;
-                float* out_b = G.out + (size_t)bimg * Hp * Wp * a.ldc;
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    float v = fmaxf(fmaxf(acc[t][u][4 * g4 + 0], acc[t][u][4 * g4 + 1]),
-                                    fmaxf(acc[t][u][4 * g4 + 2], acc[t][u][4 * g4 + 3]));
-                    v += bias;
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    const int q = (wm * C::MT + t) * 8 + 2 * g4 + kh;
-                    const int wy = q / (TW / 2), wx = q % (TW / 2);
-                    const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
-                    if (nok && (!C::MASK_M || q < C::M / 4) && oy < Hp && ox < Wp) out_b[((size_t)oy * Wp + ox) * a.ldc + n] = v;
-                }
-            }
-        }
-    }
+conv_epilogue<C, TW>(acc, biasv, a, G.out, G.cout, bimg, y0, x0, n0, wm, wn, li, kh);
 }
 
 // =============================================================================================================
@@ -691,7 +649,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v3_kernel(const ConvArgs a)
 // register sets across an unrolled-by-two tap loop so that no register copies are left in the loop.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <typename C, int KS>
+template <typename C, int KS, int ABL = 0>
 struct TapBody {
     // one tap = two k8 steps.  bc: this tap's weight fragments; bn: filled with the next tap's (prefetch).
     // av0: this tap's step-0 A fragments (prefetched); on return holds the next tap's step-0 fragments.
@@ -709,11 +667,15 @@ struct TapBody {
             const int e = i / (C::MT * C::NT), t = (i / C::NT) % C::MT, u = i % C::NT;
             acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t][e], bc[u][0][e], acc[t][u], 0, 0, 0);
             if (i < NB) {
-                bn[i >> 1][i & 1] = *reinterpret_cast<const f32x4*>(b_ptr[i >> 1] + poff_next + (i & 1) * 8);
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!(ABL & 1)) {
+                    bn[i >> 1][i & 1] = *reinterpret_cast<const f32x4*>(b_ptr[i >> 1] + poff_next + (i & 1) * 8);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             } else if (i < NB + C::MT) {
-                av1[i - NB] = *reinterpret_cast<const f32x4*>(&cur[a_base[i - NB] + tapoff + 8]);
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!(ABL & 2)) {
+                    av1[i - NB] = *reinterpret_cast<const f32x4*>(&cur[a_base[i - NB] + tapoff + 8]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         // ---- k8 step 1: + A fragments of the next tap's step 0 ----
@@ -723,14 +685,16 @@ struct TapBody {
             acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t][e], bc[u][1][e], acc[t][u], 0, 0, 0);
             if (i < C::MT) {
                 // (the read replaces av0[i], whose last use was in step 0)
-                av0[i] = *reinterpret_cast<const f32x4*>(&cur[a_base[i] + tapoff_next]);
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!(ABL & 2)) {
+                    av0[i] = *reinterpret_cast<const f32x4*>(&cur[a_base[i] + tapoff_next]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
     }
 };
 
-template <int KS, int TH, int TW, int BN, int CK, int WM, int WN>
+template <int KS, int TH, int TW, int BN, int CK, int WM, int WN, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_mfma_v4_kernel(const ConvArgs a)
 {
     using C = ConvCfg<KS, TH, TW, BN, CK, WM, WN>;
@@ -768,6 +732,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v4_kernel(const ConvArgs a)
     const int x0 = (trem % a.tiles_x) * TW;
     const int n0 = blockIdx.y * BN;
     const float* in_b = G.in + (size_t)bimg * H * W * a.lda;
+    float biasv[C::NT];
+    conv_load_bias<C>(biasv, G.bias, n0, wn, li);
 
     int a_base[C::MT];
 #pragma unroll
@@ -813,6 +779,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v4_kernel(const ConvArgs a)
     for (int u = 0; u < C::NT; ++u) {
         bA[u][0] = *reinterpret_cast<const f32x4*>(b_ptr[u]);
         bA[u][1] = *reinterpret_cast<const f32x4*>(b_ptr[u] + 8);
+        if constexpr (ABL & 1) { bB[u][0] = bA[u][0]; bB[u][1] = bA[u][1]; }
     }
 #pragma unroll
     for (int r = 0; r < NHF; ++r) {
@@ -823,14 +790,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v4_kernel(const ConvArgs a)
     __syncthreads();
     f32x4 av0[C::MT], av1[C::MT];
 #pragma unroll
-    for (int t = 0; t < C::MT; ++t) av0[t] = *reinterpret_cast<const f32x4*>(&s_in[a_base[t]]);
+    for (int t = 0; t < C::MT; ++t) {
+        av0[t] = *reinterpret_cast<const f32x4*>(&s_in[a_base[t]]);
+        if constexpr (ABL & 2) av1[t] = *reinterpret_cast<const f32x4*>(&s_in[a_base[t] + 8]);
+    }
 
     for (int ch = 0; ch < a.nch; ++ch) {
-        const float* cur = s_in + (ch & 1) * C::IN_ELEMS;
+        const float* cur = s_in + ((ABL & 4) ? 0 : (ch & 1)) * C::IN_ELEMS;
         float* nxt = s_in + ((ch + 1) & 1) * C::IN_ELEMS;
         const bool more_ch = ch + 1 < a.nch;
         float4 hreg[NHF];
-        {
+        if constexpr (!(ABL & 4)) {
             const int cn = more_ch ? ch + 1 : ch;
 #pragma unroll
             for (int r = 0; r < NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + cn * CK);
@@ -849,21 +819,21 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v4_kernel(const ConvArgs a)
 #pragma unroll 1
         for (int tap = 0; tap + 1 < C::T; tap += 2) {
             const int toff1 = advance(toff, kx);
-            TapBody<C, KS>::run(acc, av0, av1, bA, bB, b_ptr, pnext, cur, a_base, toff, toff1);
+            TapBody<C, KS, ABL>::run(acc, av0, av1, bA, bB, b_ptr, pnext, cur, a_base, toff, toff1);
             pnext += tap_stride;
             const int toff2 = advance(toff1, kx);
-            TapBody<C, KS>::run(acc, av0, av1, bB, bA, b_ptr, pnext, cur, a_base, toff1, toff2);
+            TapBody<C, KS, ABL>::run(acc, av0, av1, bB, bA, b_ptr, pnext, cur, a_base, toff1, toff2);
             pnext += tap_stride;
             toff = toff2;
         }
         {
             // last tap: prefetch tap 0 of the next chunk (or re-read this panel on the very last chunk)
             const size_t plast = more_ch ? chunk_off + w_panel_stride : (size_t)(C::T - 1) * tap_stride + chunk_off;
-            TapBody<C, KS>::run(acc, av0, av1, bA, bB, b_ptr, plast, cur, a_base, toff, toff);
+            TapBody<C, KS, ABL>::run(acc, av0, av1, bA, bB, b_ptr, plast, cur, a_base, toff, toff);
 #pragma unroll
             for (int u = 0; u < C::NT; ++u) { bA[u][0] = bB[u][0]; bA[u][1] = bB[u][1]; }
         }
-        if (more_ch) {
+        if (more_ch && !(ABL & 4)) {
 #pragma unroll
             for (int r = 0; r < NHF; ++r) {
                 float4 v = hreg[r];
@@ -877,43 +847,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v4_kernel(const ConvArgs a)
     }
 
     // ---- epilogue (identical to v1) ----
-#pragma unroll
-    for (int t = 0; t < C::MT; ++t) {
-#pragma unroll
-        for (int u = 0; u < C::NT; ++u) {
-            const int n = n0 + (wn * C::NT + u) * 32 + li;
-            const bool nok = n < G.cout;
-            const float bias = G.bias[n];
-            if (!a.pool) {
-                float* out_b = G.out + (size_t)bimg * H * W * a.ldc;
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
-                    const int m = (wm * C::MT + t) * 32 + row;
-                    const int q = m >> 2, r = m & 3;
-                    const int wy = q / (TW / 2), wx = q % (TW / 2);
-                    const int gy = y0 + 2 * wy + (r >> 1), gx = x0 + 2 * wx + (r & 1);
-                    float v = acc[t][u][reg] + bias;
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    if (nok && (!C::MASK_M || m < C::M) && gy < H && gx < W) out_b[((size_t)gy * W + gx) * a.ldc + n] = v;
-                }
-            } else {
-                const int Hp = H >> 1, Wp = W >> 1;
-                float* out_b = G.out + (size_t)bimg * Hp * Wp * a.ldc;
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    float v = fmaxf(fmaxf(acc[t][u][4 * g4 + 0], acc[t][u][4 * g4 + 1]),
-                                    fmaxf(acc[t][u][4 * g4 + 2], acc[t][u][4 * g4 + 3]));
-                    v += bias;
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    const int q = (wm * C::MT + t) * 8 + 2 * g4 + kh;
-                    const int wy = q / (TW / 2), wx = q % (TW / 2);
-                    const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
-                    if (nok && (!C::MASK_M || q < C::M / 4) && oy < Hp && ox < Wp) out_b[((size_t)oy * Wp + ox) * a.ldc + n] = v;
-                }
-            }
-        }
-    }
+conv_epilogue<C, TW>(acc, biasv, a, G.out, G.cout, bimg, y0, x0, n0, wm, wn, li, kh);
 }
 
 // Ablation twin of v3 (timing experiments only, results are wrong when ABL != 0): ABL bit0 = weight fragments loaded
@@ -957,6 +891,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v3abl_kernel(const ConvArgs 
     const int x0 = (trem % a.tiles_x) * TW;
     const int n0 = blockIdx.y * BN;
     const float* in_b = G.in + (size_t)bimg * H * W * a.lda;
+    float biasv[C::NT];
+    conv_load_bias<C>(biasv, G.bias, n0, wn, li);
 
     int a_base[C::MT];
 #pragma unroll
@@ -1101,43 +1037,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v3abl_kernel(const ConvArgs 
     }
 
     // ---- epilogue (identical to v1) ----
-#pragma unroll
-    for (int t = 0; t < C::MT; ++t) {
-#pragma unroll
-        for (int u = 0; u < C::NT; ++u) {
-            const int n = n0 + (wn * C::NT + u) * 32 + li;
-            const bool nok = n < G.cout;
-            const float bias = G.bias[n];
-            if (!a.pool) {
-                float* out_b = G.out + (size_t)bimg * H * W * a.ldc;
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
-                    const int m = (wm * C::MT + t) * 32 + row;
-                    const int q = m >> 2, r = m & 3;
-                    const int wy = q / (TW / 2), wx = q % (TW / 2);
-                    const int gy = y0 + 2 * wy + (r >> 1), gx = x0 + 2 * wx + (r & 1);
-                    float v = acc[t][u][reg] + bias;
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    if (nok && (!C::MASK_M || m < C::M) && gy < H && gx < W) out_b[((size_t)gy * W + gx) * a.ldc + n] = v;
-                }
-            } else {
-                const int Hp = H >> 1, Wp = W >> 1;
-                float* out_b = G.out + (size_t)bimg * Hp * Wp * a.ldc;
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    float v = fmaxf(fmaxf(acc[t][u][4 * g4 + 0], acc[t][u][4 * g4 + 1]),
-                                    fmaxf(acc[t][u][4 * g4 + 2], acc[t][u][4 * g4 + 3]));
-                    v += bias;
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    const int q = (wm * C::MT + t) * 8 + 2 * g4 + kh;
-                    const int wy = q / (TW / 2), wx = q % (TW / 2);
-                    const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
-                    if (nok && (!C::MASK_M || q < C::M / 4) && oy < Hp && ox < Wp) out_b[((size_t)oy * Wp + ox) * a.ldc + n] = v;
-                }
-            }
-        }
-    }
+conv_epilogue<C, TW>(acc, biasv, a, G.out, G.cout, bimg, y0, x0, n0, wm, wn, li, kh);
 }
 
 // minimum dynamic LDS per block: caps the number of co-resident blocks per CU (the fp32 MFMA pipe
@@ -1299,6 +1199,28 @@ static int launch_v3(const ConvArgs& a0, int groups, hipStream_t stream)
 }
 
 template <int ABL>
+static int launch_v4abl(const ConvArgs& a0, int groups, hipStream_t stream)
+{
+    using C = ConvCfg<7, 2, 46, 128, 16, 1, 4>;
+    ConvArgs a = a0;
+    a.tiles_x = (a.W + 46 - 1) / 46;
+    a.tiles_y = (a.H + 2 - 1) / 2;
+    auto kern = conv_mfma_v4_kernel<7, 2, 46, 128, 16, 1, 4, ABL>;
+    int lds = 2 * C::IN_ELEMS * 4;
+    if (lds < g_v3_lds) lds = g_v3_lds;
+    if (lds < g_min_lds) lds = g_min_lds;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / 128), (unsigned)groups);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+template <int ABL>
 static int launch_v3abl(const ConvArgs& a0, int groups, hipStream_t stream)
 {
     using C = ConvCfg<7, 2, 46, 128, 16, 1, 4>;
@@ -1322,7 +1244,13 @@ static int launch_v3abl(const ConvArgs& a0, int groups, hipStream_t stream)
 
 int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream)
 {
-    switch (variant) {     // ablation twins of the v3 7x7 strip kernel (tools/conv_ablate3.py)
+    switch (variant) {     // ablation twins of the v3 / v4 7x7 strip kernels (tools/conv_ablate3.py)
+        case 120: return launch_v4abl<0>(a, groups, stream);
+        case 121: return launch_v4abl<1>(a, groups, stream);
+        case 122: return launch_v4abl<2>(a, groups, stream);
+        case 123: return launch_v4abl<3>(a, groups, stream);
+        case 124: return launch_v4abl<4>(a, groups, stream);
+        case 127: return launch_v4abl<7>(a, groups, stream);
         case 100: return launch_v3abl<0>(a, groups, stream);
         case 101: return launch_v3abl<1>(a, groups, stream);
         case 102: return launch_v3abl<2>(a, groups, stream);

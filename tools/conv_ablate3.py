@@ -11,10 +11,10 @@ B = 128
 x = np.maximum(rng.standard_normal((B, 128, 46, 46)), 0).astype('f')
 w = (rng.standard_normal((128, 128, 7, 7)) / np.sqrt(128 * 49)).astype('f')
 b = np.zeros(128, 'f')
-names = {25: 'v4', 10: 'v2', 100: 'full v3', 101: 'no B loads', 102: 'no A reads', 103: 'no A, no B', 104: 'halo staged once', 107: 'no A/B/staging',
+names = {120: 'v4 twin', 121: 'v4 no B loads', 122: 'v4 no A reads', 123: 'v4 no A, no B', 124: 'v4 halo once', 127: 'v4 no A/B/staging', 25: 'v4', 10: 'v2', 100: 'full v3', 101: 'no B loads', 102: 'no A reads', 103: 'no A, no B', 104: 'halo staged once', 107: 'no A/B/staging',
          108: 'no B reg copies', 115: 'pure MFMA loop', 18: 'v3 (product)'}
 for lds in (0, 84 * 1024):
-    for v in (25, 18, 10, 115):
+    for v in (25, 120, 121, 122, 123, 124, 127, 115):
         eng.set_option('force_variant_k7', v)
         eng.set_option('conv_min_lds', lds)
         y, ms = eng.conv2d(x, w, b, relu=True, iters=8)
