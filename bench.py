@@ -43,7 +43,7 @@ def pmc_traffic(kernel_name):
     kernel (20 of its 25 launches per step are the dominant 128->128 layers).  None if no summary exists."""
     import glob
     import re
-    m = re.match(r'conv(\d)x\d(_v2)?_t(\d+)x(\d+)_n(\d+)', kernel_name)
+    m = re.match(r'conv(\d)x\d(_v\d)?_t(\d+)x(\d+)_n(\d+)', kernel_name)
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_summary.json')))
     if not m or not files:
         return None, None
