@@ -345,6 +345,7 @@ extern "C" int pmx_set_option(pmx_ctx* c, const char* key, int value)
     else if (!strcmp(key, "kernel_gen")) c->opt_kernel_gen = value;
     else if (!strcmp(key, "conv_dbg")) c->opt_conv_dbg = value;
     else if (!strcmp(key, "conv_min_lds")) conv_set_min_lds(value);
+    else if (!strcmp(key, "pp_generic")) pp_set_generic(value);
     else { pmx_set_error("pmx_set_option: unknown key '%s'", key); return PMX_ERR_INVALID; }
     return PMX_OK;
 }

@@ -121,6 +121,7 @@ struct PPBuffers {
     pmx_result_record* results;   // [B]
     float* smoothed;         // optional [B][18][map_h][map_w]
 };
+void pp_set_generic(int on);
 int pp_launch(const PPMaps& maps, const PPTables& tab, const PPBuffers& buf, int B, int map_h, int map_w,
               double img_len, const double* d_scale_xy, int keep_smoothed, hipStream_t stream,
               void (*prof)(void*, const char*, int), void* prof_ctx);

@@ -151,6 +151,170 @@ __global__ __launch_bounds__(256) void pp_peaks_kernel(PPMaps maps, PPTables tab
     }
 }
 
+// ------------------------------------------------------------------------------------------ peaks (fast path)
+// Same arithmetic as pp_peaks_kernel, specialised for a compile-time Gaussian radius R (10 for sigma 2.5):
+//   * the tile's row / column resize tables (corner indices, float64 weights, reflect applied) are staged in LDS once,
+//     so a bilinear sample costs 4 map loads instead of 4 + 12 table loads from global memory;
+//   * both 1-D passes use a sliding window: a thread produces SEG consecutive outputs of one column (row) from
+//     SEG + 2R LDS reads held in registers instead of 2R + 1 reads per output.
+// The float32 / float64 operation order per output is unchanged (SciPy's: centre tap, then pairs from the outermost
+// inwards), so the results are bit-identical to the generic kernel (tests compare both against the oracle).
+template <int R>
+__global__ __launch_bounds__(256) void pp_peaks_fast_kernel(PPMaps maps, PPTables tab, PPBuffers buf, int map_h, int map_w,
+                                                            int tiles_x, int keep_smoothed)
+{
+    constexpr int UW = PK_TS + 2 + 2 * R;        // 54
+    constexpr int US = UW + 1;
+    constexpr int VR = PK_TS + 2;                // 34 rows/cols that feed the NMS
+    constexpr int SEG = 9;                       // outputs per thread and pass
+    constexpr int NSEG = (VR + SEG - 1) / SEG;   // 4
+    constexpr int SW = PK_TS + 3;
+    __shared__ float sU[UW * US];
+    __shared__ float sV[VR * US];
+    __shared__ float sS[VR * SW];
+    __shared__ double sG[2 * R + 1];
+    __shared__ double sYlo[UW], sYhi[UW], sXlo[UW], sXhi[UW];
+    __shared__ int sY0[UW], sY1[UW], sX0[UW], sX1[UW];
+    constexpr int PW = 56;                       // low-resolution patch staged in LDS (rows x cols), covers in == out
+    __shared__ float sP[PW * PW];
+    __shared__ int sBox[4];                      // patch origin (row, col) and extent
+
+    const int tid = threadIdx.x;
+    const int ch = blockIdx.y, b = blockIdx.z;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int y0 = ty * PK_TS, x0 = tx * PK_TS;
+
+    if (tid < 2 * R + 1) sG[tid] = tab.gauss[tid];
+    if (tid < UW) {
+        const int gy = reflect_idx(y0 - 1 - R + tid, map_h);
+        sY0[tid] = tab.yi0[gy]; sY1[tid] = tab.yi1[gy]; sYlo[tid] = tab.ylo[gy]; sYhi[tid] = tab.yhi[gy];
+    } else if (tid >= 64 && tid < 64 + UW) {
+        const int k = tid - 64;
+        const int gx = reflect_idx(x0 - 1 - R + k, map_w);
+        sX0[k] = tab.xi0[gx]; sX1[k] = tab.xi1[gx]; sXlo[k] = tab.xlo[gx]; sXhi[k] = tab.xhi[gx];
+    }
+    __syncthreads();
+
+    const float* base = maps.heat + (long long)b * maps.sbh + (long long)ch * maps.sc;
+    // bounding box of the low-resolution pixels this tile samples (a 7x upsampled tile touches ~10 x 10 of them):
+    // stage it in LDS once instead of 4 scattered global loads per full-resolution sample
+    if (tid < 64) {
+        int lo_y = 1 << 30, hi_y = -1, lo_x = 1 << 30, hi_x = -1;
+        if (tid < UW) { lo_y = sY0[tid]; hi_y = sY1[tid]; lo_x = sX0[tid]; hi_x = sX1[tid]; }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            lo_y = min(lo_y, __shfl_xor(lo_y, off)); hi_y = max(hi_y, __shfl_xor(hi_y, off));
+            lo_x = min(lo_x, __shfl_xor(lo_x, off)); hi_x = max(hi_x, __shfl_xor(hi_x, off));
+        }
+        if (tid == 0) { sBox[0] = lo_y; sBox[1] = lo_x; sBox[2] = hi_y - lo_y + 1; sBox[3] = hi_x - lo_x + 1; }
+    }
+    __syncthreads();
+    const int py0 = sBox[0], px0 = sBox[1], ph = sBox[2], pw = sBox[3];
+    const bool patched = ph <= PW && pw <= PW;       // block-uniform
+    if (patched) {
+        for (int i = tid; i < ph * pw; i += 256) {
+            const int r = i / pw, c = i - r * pw;
+            sP[r * PW + c] = base[(long long)(py0 + r) * maps.sy + (long long)(px0 + c) * maps.sx];
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < UW * UW; i += 256) {
+        const int ur = i / UW, uc = i - ur * UW;
+        const double ylo = sYlo[ur], yhi = sYhi[ur], xlo = sXlo[uc], xhi = sXhi[uc];
+        const float w1 = (float)(ylo * xlo), w2 = (float)(ylo * xhi), w3 = (float)(yhi * xlo), w4 = (float)(yhi * xhi);
+        float x00, x01, x10, x11;
+        if (patched) {
+            const int r0 = (sY0[ur] - py0) * PW, r1 = (sY1[ur] - py0) * PW, c0 = sX0[uc] - px0, c1 = sX1[uc] - px0;
+            x00 = sP[r0 + c0]; x01 = sP[r0 + c1]; x10 = sP[r1 + c0]; x11 = sP[r1 + c1];
+        } else {
+            const long long r0 = sY0[ur] * maps.sy, r1 = sY1[ur] * maps.sy, c0 = sX0[uc] * maps.sx, c1 = sX1[uc] * maps.sx;
+            x00 = base[r0 + c0]; x01 = base[r0 + c1]; x10 = base[r1 + c0]; x11 = base[r1 + c1];
+        }
+        float v = w1 * x00;
+        v = v + w2 * x01;
+        v = v + w3 * x10;
+        v = v + w4 * x11;
+        sU[ur * US + uc] = v;
+    }
+    __syncthreads();
+
+    // axis-0 pass: thread = (column, segment of SEG rows)
+    for (int i = tid; i < UW * NSEG; i += 256) {
+        const int vc = i % UW, sg = i / UW;
+        const int r0 = sg * SEG;
+        float win[SEG + 2 * R];
+#pragma unroll
+        for (int k = 0; k < SEG + 2 * R; ++k) win[k] = (r0 + k < UW) ? sU[(r0 + k) * US + vc] : 0.f;
+#pragma unroll
+        for (int o = 0; o < SEG; ++o) {
+            if (r0 + o < VR) {
+                double acc = (double)win[o + R] * sG[R];
+#pragma unroll
+                for (int j = R; j >= 1; --j) acc = acc + ((double)win[o + R - j] + (double)win[o + R + j]) * sG[R - j];
+                sV[(r0 + o) * US + vc] = (float)acc;
+            }
+        }
+    }
+    __syncthreads();
+
+    // axis-1 pass: thread = (row, segment of SEG columns); positions outside the map are the NMS zero padding
+    for (int i = tid; i < VR * NSEG; i += 256) {
+        const int sr = i % VR, sg = i / VR;
+        const int c0 = sg * SEG;
+        const int y = y0 - 1 + sr;
+        float win[SEG + 2 * R];
+#pragma unroll
+        for (int k = 0; k < SEG + 2 * R; ++k) win[k] = (c0 + k < UW) ? sV[sr * US + c0 + k] : 0.f;
+#pragma unroll
+        for (int o = 0; o < SEG; ++o) {
+            const int sc = c0 + o;
+            if (sc < VR) {
+                const int x = x0 - 1 + sc;
+                float out = 0.f;
+                if (y >= 0 && y < map_h && x >= 0 && x < map_w) {
+                    double acc = (double)win[o + R] * sG[R];
+#pragma unroll
+                    for (int j = R; j >= 1; --j) acc = acc + ((double)win[o + R - j] + (double)win[o + R + j]) * sG[R - j];
+                    out = (float)acc;
+                    if (keep_smoothed && sr >= 1 && sr <= PK_TS && sc >= 1 && sc <= PK_TS)
+                        buf.smoothed[(((long long)b * PMX_N_JOINTS + ch) * map_h + y) * map_w + x] = out;
+                }
+                sS[sr * SW + sc] = out;
+            }
+        }
+    }
+    __syncthreads();
+
+    unsigned* keys = buf.pk_raw_key + ((long long)b * PMX_N_JOINTS + ch) * PMX_MAX_PEAKS_PER_JOINT;
+    float* scores = buf.pk_raw_score + ((long long)b * PMX_N_JOINTS + ch) * PMX_MAX_PEAKS_PER_JOINT;
+    int* counter = buf.pk_count + b * PMX_N_JOINTS + ch;
+    const int lane = tid & 63;
+    for (int i = tid; i < PK_TS * PK_TS; i += 256) {
+        const int r = i / PK_TS, c = i - r * PK_TS;
+        const int y = y0 + r, x = x0 + c;
+        bool peak = false;
+        float p = 0.f;
+        if (y < map_h && x < map_w) {
+            p = sS[(r + 1) * SW + (c + 1)];
+            peak = p > PMX_HEATMAP_PEAK_THRESH && p > sS[r * SW + (c + 1)] && p > sS[(r + 2) * SW + (c + 1)] &&
+                   p > sS[(r + 1) * SW + c] && p > sS[(r + 1) * SW + (c + 2)];
+        }
+        const unsigned long long m = __ballot(peak);
+        if (m) {
+            int basei = 0;
+            if (lane == 0) basei = atomicAdd(counter, __popcll(m));
+            basei = __shfl(basei, 0);
+            if (peak) {
+                const int slot = basei + __popcll(m & ((1ull << lane) - 1ull));
+                if (slot < PMX_MAX_PEAKS_PER_JOINT) {
+                    keys[slot] = (unsigned)(y * map_w + x);
+                    scores[slot] = p;
+                }
+            }
+        }
+    }
+}
+
 // ============================================================================================== sort
 __global__ __launch_bounds__(256) void pp_sort_kernel(PPBuffers buf, int map_w)
 {
@@ -472,6 +636,9 @@ __global__ __launch_bounds__(64) void pp_group_kernel(PPBuffers buf, const doubl
 }
 
 // ============================================================================================== host
+static int g_pp_generic = 0;      // 1: always use the generic-radius peaks kernel (tests compare both paths)
+void pp_set_generic(int on) { g_pp_generic = on; }
+
 int pp_launch(const PPMaps& maps, const PPTables& tab, const PPBuffers& buf, int B, int map_h, int map_w,
               double img_len, const double* d_scale_xy, int keep_smoothed, hipStream_t stream,
               void (*prof)(void*, const char*, int), void* prof_ctx)
@@ -482,8 +649,12 @@ int pp_launch(const PPMaps& maps, const PPTables& tab, const PPBuffers& buf, int
     const int tiles_x = (map_w + PK_TS - 1) / PK_TS, tiles_y = (map_h + PK_TS - 1) / PK_TS;
 
     if (prof) prof(prof_ctx, "pp_peaks", 1);
-    hipLaunchKernelGGL(pp_peaks_kernel, dim3(tiles_x * tiles_y, PMX_N_JOINTS, B), dim3(256), 0, stream, maps, tab, buf,
-                       map_h, map_w, tiles_x, keep_smoothed);
+    if (tab.radius == 10 && !g_pp_generic)
+        hipLaunchKernelGGL(pp_peaks_fast_kernel<10>, dim3(tiles_x * tiles_y, PMX_N_JOINTS, B), dim3(256), 0, stream, maps, tab, buf,
+                           map_h, map_w, tiles_x, keep_smoothed);
+    else
+        hipLaunchKernelGGL(pp_peaks_kernel, dim3(tiles_x * tiles_y, PMX_N_JOINTS, B), dim3(256), 0, stream, maps, tab, buf,
+                           map_h, map_w, tiles_x, keep_smoothed);
     PMX_HIP(hipGetLastError());
     if (prof) prof(prof_ctx, "pp_peaks", 0);
 

@@ -134,3 +134,24 @@ def test_peak_capacity_overflow_is_reported_not_truncated(engine, native):
             PD.unpack_results(np.array([rec]))
     else:
         assert rec['status'] == 0
+
+
+def test_fast_and_generic_peak_kernels_agree(engine):
+    """The radius-10 fast path (LDS tables, sliding windows) and the generic-radius kernel: identical smoothed maps
+    and peaks (both are also compared with the oracle elsewhere)."""
+    heat, paf, _ = Fx.synthetic_maps(21, 7, 46, 46, 1.0, 0.9, noise=0.03)
+    out = {}
+    for generic in (0, 1):
+        engine.set_option('pp_generic', generic)
+        engine.set_option('keep_smoothed', 1)
+        engine.set_maps(paf[None], heat[None])
+        engine.postprocess(333, 301, img_len=301)
+        out[generic] = (engine.peaks(0), [engine.smoothed(0, j) for j in (0, 5, 17)], engine.results()[0].copy())
+    engine.set_option('pp_generic', 0)
+    engine.set_option('keep_smoothed', 0)
+    assert np.array_equal(out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert np.array_equal(a, b)
+    assert out[0][2]['n_people'] == out[1][2]['n_people'] and np.array_equal(out[0][2]['poses'], out[1][2]['poses'])
+    ref = P.postprocess_from_net_output(paf, heat, 333, 301)
+    assert np.array_equal(out[0][0], ref['all_peaks'])
