@@ -107,3 +107,42 @@ def test_detect_precise_native_network(native):
     assert np.array_equal(det.all_peaks, ref['all_peaks'])
     assert np.array_equal(np.asarray(poses), np.asarray(ref['poses']))
     det.engine.close()
+
+
+@pytest.mark.gpu
+def test_detect_precise_crowd_config5(native):
+    """BASELINE config 5: multi-scale (0.5/1.0/1.5/2.0) crowd image -- 22 synthetic people at 482 x 642 (dinner.png's
+    size), full PAF grouping stress at the ORIGINAL resolution.  Maps enter through the `model=` seam at every scale;
+    poses must equal the oracle's exactly (identical restated cubic resizes -> identical averaged maps)."""
+    PD = pkg('pose_detector')
+    H, W = 482, 642
+    rng = np.random.default_rng(12)
+    poses = Fx.random_poses(rng, 22, H, W, height_range=(0.25, 0.5), drop_prob=0.1)
+
+    def model(x):
+        h8, w8 = x.shape[2] // 8, x.shape[3] // 8
+        sp = poses.copy()
+        sp[:, :, 0] *= w8 / W
+        sp[:, :, 1] *= h8 / H
+        heat = Fx.render_heatmaps((h8, w8), sp, max(0.7, 0.012 * h8))
+        paf = Fx.render_pafs((h8, w8), sp, max(0.7, 0.01 * h8))
+        return [paf[None]], [heat[None]]
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    det = PD.PoseDetector(model=model, device=0, precise=True)
+    got_poses, got_scores = det(img)
+    ref_paf, ref_heat, sizes = R.averaged_maps(lambda x: tuple(m[-1] for m in model(x)), img)
+    assert np.array_equal(det.pafs, ref_paf) and np.array_equal(det.heatmaps, ref_heat)
+    ref = R.detect_precise_from_maps(ref_paf, ref_heat)
+    assert len(ref['subsets']) >= 15, 'crowd fixture should recover most of the 22 people (got %d)' % len(ref['subsets'])
+    assert np.array_equal(det.all_peaks, ref['all_peaks'])
+    assert np.array_equal(np.asarray(got_poses), np.asarray(ref['poses']))
+    assert np.allclose(got_scores, ref['scores'], rtol=0, atol=1e-9)
+    # recovered people sit on the ground-truth skeletons: keypoints within tolerance of the rendered joints (the 1/8
+    # resolution rendering + cubic up-sampling shifts peaks by ~5 px at this size; fragments of mixed people are rare)
+    gp = np.asarray(got_poses)
+    ds = []
+    for person in gp:
+        vis = person[:, 2] > 0
+        ds.append(min(np.mean(np.hypot(person[vis, 0] - q[vis, 0], person[vis, 1] - q[vis, 1])) for q in poses))
+    assert np.median(ds) < 8.0, np.median(ds)
+    det.engine.close()
