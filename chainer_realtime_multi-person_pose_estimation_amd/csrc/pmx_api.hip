@@ -131,6 +131,10 @@ struct pmx_ctx {
     float* nchw_tmp = nullptr;       // staging for NCHW host <-> NHWC device conversions
     size_t nchw_tmp_bytes = 0;
     uint8_t* u8_tmp = nullptr;
+    uint8_t* u8_src = nullptr;       // original-size images awaiting the on-device resize
+    size_t u8_src_cap = 0;
+    int* rs_tab = nullptr;           // resize tables: x (4 * dw ints) then y (4 * dh ints)
+    size_t rs_tab_cap = 0;
     // state of the last forward / set_maps
     bool maps_valid = false, maps_external = false;
     int cur_B = 0, cur_fh = 0, cur_fw = 0;
@@ -304,7 +308,7 @@ extern "C" void pmx_destroy(pmx_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (auto& l : c->layers) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); }
-    void* ptrs[] = {c->in16, c->act0, c->act1, c->cat, c->brA, c->brB, c->brT, c->nchw_tmp, c->u8_tmp, c->ext_paf, c->ext_heat,
+    void* ptrs[] = {c->u8_src, c->rs_tab, c->in16, c->act0, c->act1, c->cat, c->brA, c->brB, c->brT, c->nchw_tmp, c->u8_tmp, c->ext_paf, c->ext_heat,
                     c->pp.pk_raw_key, c->pp.pk_raw_score, c->pp.pk_count, c->pp.pk_x, c->pp.pk_y, c->pp.pk_score, c->pp.pk_start,
                     c->pp.cn_a, c->pp.cn_b, c->pp.cn_score, c->pp.cn_count, c->pp.subsets, c->pp.status, c->pp.results,
                     c->pp.smoothed, c->d_scale, c->tab.xi0, c->tab.xi1, c->tab.xlo, c->tab.xhi, c->tab.yi0, c->tab.yi1,
@@ -506,6 +510,77 @@ extern "C" int pmx_forward_f32(pmx_ctx* c, const float* x, int B, int H, int W, 
     }
     if ((rc = launch_prep_f32(d, c->in16, B, H, W, c->stream))) return rc;
     return forward_from_in16(c, B, H, W);
+}
+
+// OpenCV INTER_LINEAR uint8 tables for one axis: [idx0 | idx1 | coef0 | coef1], each `dst` ints.
+// fx = float((d + 0.5) * scale - 0.5) with scale = 1 / (dst / src) in double; s = floor(fx); fx -= s;
+// s < 0 -> (0, fx = 0); s >= src - 1 -> (src - 1, fx = 0); coefficients cvRound((1 - fx) * 2048), cvRound(fx * 2048).
+static void make_resize_table(int dst, int src, int* tab)
+{
+    const double scale = 1.0 / ((double)dst / (double)src);
+    for (int d = 0; d < dst; ++d) {
+        float f = (float)(((double)d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f = f - (float)s;
+        if (s < 0) { s = 0; f = 0.f; }
+        if (s >= src - 1) { s = src - 1; f = 0.f; }
+        tab[d] = s;
+        tab[dst + d] = s + 1 < src - 1 ? s + 1 : src - 1;
+        tab[2 * dst + d] = (int)lrintf((1.0f - f) * 2048.0f);
+        tab[3 * dst + d] = (int)lrintf(f * 2048.0f);
+    }
+}
+
+// uint8 images of one original size -> cv2.resize(..., (w, h)) on the device -> network forward
+extern "C" int pmx_forward_u8_resized(pmx_ctx* c, const uint8_t* img, int B, int src_h, int src_w, int h, int w, int on_device)
+{
+    if (src_h == h && src_w == w) return pmx_forward_u8(c, img, B, h, w, on_device);     // identity (pose_detector.py:493)
+    int rc = check_forward_args(c, img, B, h, w);
+    if (rc && rc != PMX_ERR_WEIGHTS) return rc;      // without weights the resize still runs (pmx_get_resized), then
+                                                     // pmx_forward_u8 below reports PMX_ERR_WEIGHTS
+    PMX_CHECK(src_h >= 1 && src_w >= 1, PMX_ERR_INVALID, "forward_u8_resized: bad source size");
+    PMX_DEV(c);
+    const size_t nsrc = (size_t)B * src_h * src_w * 3;
+    const uint8_t* d = img;
+    if (!on_device) {
+        if (nsrc > c->u8_src_cap) {
+            PMX_HIP(hipStreamSynchronize(c->stream));
+            if (c->u8_src) (void)hipFree(c->u8_src);
+            c->u8_src = nullptr;
+            PMX_HIP(hipMalloc((void**)&c->u8_src, nsrc));
+            c->u8_src_cap = nsrc;
+        }
+        PMX_HIP(hipMemcpyAsync(c->u8_src, img, nsrc, hipMemcpyHostToDevice, c->stream));
+        d = c->u8_src;
+    }
+    const size_t ntab = (size_t)4 * (w + h);
+    if (ntab > c->rs_tab_cap) {
+        PMX_HIP(hipStreamSynchronize(c->stream));
+        if (c->rs_tab) (void)hipFree(c->rs_tab);
+        c->rs_tab = nullptr;
+        PMX_HIP(hipMalloc((void**)&c->rs_tab, ntab * sizeof(int)));
+        c->rs_tab_cap = ntab;
+    }
+    std::vector<int> tab(ntab);
+    make_resize_table(w, src_w, tab.data());
+    make_resize_table(h, src_h, tab.data() + 4 * w);
+    PMX_HIP(hipStreamSynchronize(c->stream));     // the table buffer may still be in use by a queued resize
+    PMX_HIP(hipMemcpy(c->rs_tab, tab.data(), ntab * sizeof(int), hipMemcpyHostToDevice));
+    if ((rc = prof_begin(c, "resize_u8|resize_linear_u8", 0, (double)nsrc + (double)B * h * w * 3))) return rc;
+    if ((rc = launch_resize_linear_u8(d, c->u8_tmp, c->rs_tab, c->rs_tab + 4 * w, B, src_h, src_w, h, w, c->stream))) return rc;
+    if ((rc = prof_end(c))) return rc;
+    return pmx_forward_u8(c, c->u8_tmp, B, h, w, 1);
+}
+
+// test / parity accessor: the resized uint8 batch of the last pmx_forward_u8_resized (B x h x w x 3)
+extern "C" int pmx_get_resized(pmx_ctx* c, uint8_t* out, int B, int h, int w)
+{
+    PMX_CHECK(c && out, PMX_ERR_INVALID, "null arg");
+    PMX_CHECK(B >= 1 && B <= c->max_batch && (size_t)h * w <= (size_t)c->max_h * c->max_w, PMX_ERR_CAPACITY, "pmx_get_resized: size");
+    PMX_DEV(c);
+    PMX_HIP(hipMemcpyAsync(out, c->u8_tmp, (size_t)B * h * w * 3, hipMemcpyDeviceToHost, c->stream));
+    PMX_HIP(hipStreamSynchronize(c->stream));
+    return PMX_OK;
 }
 
 extern "C" int pmx_get_maps(pmx_ctx* c, float* paf, float* heat)

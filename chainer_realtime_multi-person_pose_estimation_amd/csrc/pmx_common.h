@@ -89,6 +89,8 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // other kernels (prep.hip)
 int launch_prep_u8(const uint8_t* bgr, float* out16, int B, int H, int W, hipStream_t s);
 int launch_prep_f32(const float* x_nchw, float* out16, int B, int H, int W, hipStream_t s);
+int launch_resize_linear_u8(const uint8_t* src, uint8_t* dst, const int* xtab, const int* ytab, int B, int sh, int sw, int dh, int dw,
+                            hipStream_t s);
 int launch_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, int ldc, int coff, hipStream_t s);
 int launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, int lda, int coff, hipStream_t s);
 

@@ -73,6 +73,37 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
     dst[i] = src[(b * hw + p) * lda + coff + c];
 }
 
+// cv2.resize(img, (dw, dh)) for uint8 HWC images, INTER_LINEAR (reference pose_detector.py:493) -- OpenCV's fixed-point
+// algorithm: horizontal pass S = s[sx]*a0 + s[sx1]*a1 (11-bit coefficients, int32), vertical pass
+// (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.  One thread per output pixel (3 channels), HBM-bound
+// byte work; the per-axis tables (source indices, coefficients) are built on the host exactly as the restatement in
+// oracle/resize_ref.py does (float32 coordinate math, round-half-even).
+__global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                               const int* __restrict__ xtab, const int* __restrict__ ytab,
+                                                               int B, int sh, int sw, int dh, int dw)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long npix = (long long)B * dh * dw;
+    if (i >= npix) return;
+    const int x = (int)(i % dw);
+    const long long t = i / dw;
+    const int y = (int)(t % dh);
+    const long long b = t / dh;
+    const int sx0 = xtab[x], sx1 = xtab[dw + x], a0 = xtab[2 * dw + x], a1 = xtab[3 * dw + x];
+    const int sy0 = ytab[y], sy1 = ytab[dh + y], b0 = ytab[2 * dh + y], b1 = ytab[3 * dh + y];
+    const uint8_t* r0 = src + ((b * sh + sy0) * sw) * 3;
+    const uint8_t* r1 = src + ((b * sh + sy1) * sw) * 3;
+    uint8_t* o = dst + i * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int S0 = (int)r0[sx0 * 3 + c] * a0 + (int)r0[sx1 * 3 + c] * a1;
+        const int S1 = (int)r1[sx0 * 3 + c] * a0 + (int)r1[sx1 * 3 + c] * a1;
+        int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        o[c] = (uint8_t)v;
+    }
+}
+
 static inline unsigned nblocks(long long n) { return (unsigned)((n + 255) / 256); }
 
 int launch_prep_u8(const uint8_t* bgr, float* out16, int B, int H, int W, hipStream_t s)
@@ -105,6 +136,15 @@ int launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W
     const long long total = (long long)B * C * H * W;
     if (total == 0) return PMX_OK;
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(nblocks(total)), dim3(256), 0, s, src, dst, B, C, (long long)H * W, lda, coff);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+int launch_resize_linear_u8(const uint8_t* src, uint8_t* dst, const int* xtab, const int* ytab, int B, int sh, int sw, int dh, int dw,
+                            hipStream_t s)
+{
+    const long long npix = (long long)B * dh * dw;
+    hipLaunchKernelGGL(resize_linear_u8_kernel, dim3(nblocks(npix)), dim3(256), 0, s, src, dst, xtab, ytab, B, sh, sw, dh, dw);
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }

@@ -123,6 +123,8 @@ def load():
         'pmx_weights_missing': (ci, [vp, ip]),
         'pmx_forward_u8': (ci, [vp, vp, ci, ci, ci, ci]),
         'pmx_forward_f32': (ci, [vp, vp, ci, ci, ci, ci]),
+        'pmx_forward_u8_resized': (ci, [vp, vp, ci, ci, ci, ci, ci, ci]),
+        'pmx_get_resized': (ci, [vp, vp, ci, ci, ci]),
         'pmx_get_maps': (ci, [vp, vp, vp]),
         'pmx_set_maps': (ci, [vp, vp, vp, ci, ci, ci]),
         'pmx_set_gaussian': (ci, [vp, vp, ci]),
@@ -238,6 +240,31 @@ class Engine(object):
             self._check(self.lib.pmx_forward_u8(self._ctx, _ptr(imgs), B, H, W, 0))
         self._B = B
         self._fhw = (H // 8, W // 8)
+
+    def forward_u8_resized(self, imgs, h, w):
+        """imgs (B, H0, W0, 3) uint8 -> cv2.resize(INTER_LINEAR)-equivalent to (h, w) on the device -> forward."""
+        imgs = np.ascontiguousarray(imgs, dtype=np.uint8)
+        B, H0, W0, c3 = imgs.shape
+        assert c3 == 3
+        self._check(self.lib.pmx_forward_u8_resized(self._ctx, _ptr(imgs), B, H0, W0, int(h), int(w), 0))
+        self._B = B
+        self._fhw = (int(h) // 8, int(w) // 8)
+
+    def get_resized(self, h, w):
+        out = np.empty((self._B, int(h), int(w), 3), np.uint8)
+        self._check(self.lib.pmx_get_resized(self._ctx, _ptr(out), self._B, int(h), int(w)))
+        return out
+
+    def resize_u8(self, imgs, h, w):
+        """Device resize only needs a context with weights for the forward that follows it in forward_u8_resized; for
+        the `model=` seam (no weights) run the resize kernel through the same entry and fetch the resized batch."""
+        imgs = np.ascontiguousarray(imgs, dtype=np.uint8)
+        B, H0, W0, _ = imgs.shape
+        rc = self.lib.pmx_forward_u8_resized(self._ctx, _ptr(imgs), B, H0, W0, int(h), int(w), 0)
+        if rc not in (0, 4):          # 4 = PMX_ERR_WEIGHTS: resize done, network skipped (no weights loaded)
+            self._check(rc)
+        self._B = B
+        return self.get_resized(h, w)
 
     def forward_f32(self, x):
         x = np.ascontiguousarray(x, dtype=np.float32)

@@ -179,17 +179,18 @@ class PoseDetector(object):
         map_w, map_h = self.compute_optimal_size(imgs[0], params['heatmap_size'])            # :491
         B = len(imgs)
         self._grow(B, input_h, input_w)
-        if (input_h, input_w) == (orig_h, orig_w):
-            batch = np.stack(imgs)                   # cv2.resize to the same size is the identity (:493)
-        else:
-            batch = np.stack([resize_linear_u8(im, input_w, input_h) for im in imgs])
+        batch = np.stack(imgs)
         scale = np.tile(np.array([orig_w / map_w, orig_h / map_h], dtype=np.float64), (B, 1))   # :513-514
         if self.model is None:
             if self.engine.weights_missing():
                 raise RuntimeError('PoseDetector has no weights: pass weights_file=, weights= or model=')
-            self.engine.detect_batch(batch, map_h, map_w, img_len=map_w, scale_xy=scale)        # :499-516
+            # cv2.resize (:493, identity when the size is unchanged) + preprocess + network + post-process, all on the GPU
+            self.engine.forward_u8_resized(batch, input_h, input_w)                              # :493-499
+            self.engine.postprocess(map_h, map_w, img_len=map_w, scale_xy=scale)                 # :501-516
         else:
             pafs, heats = [], []
+            if (input_h, input_w) != (orig_h, orig_w):
+                batch = self.engine.resize_u8(batch, input_h, input_w)                           # :493 on the device
             for im in batch:
                 h1s, h2s = self.model(self.preprocess(im))                                      # :499
                 pafs.append(np.asarray(_data(h1s[-1]), dtype=np.float32)[0])
@@ -228,47 +229,6 @@ def unpack_results(records):
         else:
             out.append((r['poses'][:n].copy(), r['scores'][:n].copy()))
     return out
-
-
-def resize_linear_u8(img, dst_w, dst_h):
-    """Restatement of `cv2.resize(img, (dst_w, dst_h))` (INTER_LINEAR, uint8) used at pose_detector.py:493.
-
-    OpenCV is a third-party dependency that is not vendored by the reference and not installable here, so this
-    follows OpenCV's published fixed-point algorithm (imgproc/resize.cpp: half-pixel source coordinates computed
-    in float32, 11-bit coefficients `saturate_cast<short>(c * 2048)`, horizontal pass in int32, vertical pass
-    `(((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2`).  PARITY UNPINNED (no cv2 to compare
-    against); it is the identity when the size does not change, which is the case for every 368 x 368 input.
-    Host-side NumPy: byte work of < 1 ms that the reference also does on the host before the upload (:493-497).
-    """
-    img = np.ascontiguousarray(img, dtype=np.uint8)
-    src_h, src_w, cn = img.shape
-    if (src_w, src_h) == (dst_w, dst_h):
-        return img.copy()
-
-    def coeffs(dst, src):
-        scale = 1.0 / (float(dst) / float(src))
-        d = np.arange(dst, dtype=np.float64)
-        f = ((d + 0.5) * scale - 0.5).astype(np.float32)
-        s = np.floor(f).astype(np.int64)
-        f = f - s.astype(np.float32)
-        lo = s < 0
-        f[lo] = 0
-        s[lo] = 0
-        hi = s >= src - 1
-        f[hi] = 0
-        s[hi] = src - 1
-        c0 = np.rint((np.float32(1.0) - f) * np.float32(2048)).astype(np.int64)
-        c1 = np.rint(f * np.float32(2048)).astype(np.int64)
-        return s, np.minimum(s + 1, src - 1), c0, c1
-
-    sx, sx1, ax0, ax1 = coeffs(dst_w, src_w)
-    sy, sy1, by0, by1 = coeffs(dst_h, src_h)
-    src = img.astype(np.int64)
-    rows = src[:, sx, :] * ax0[None, :, None] + src[:, sx1, :] * ax1[None, :, None]       # (src_h, dst_w, cn)
-    s0 = rows[sy]
-    s1 = rows[sy1]
-    out = (((by0[:, None, None] * (s0 >> 4)) >> 16) + ((by1[:, None, None] * (s1 >> 4)) >> 16) + 2) >> 2
-    return np.clip(out, 0, 255).astype(np.uint8)
 
 
 # ---- cv2.resize(..., interpolation=cv2.INTER_CUBIC) restated (used by detect_precise only) ---------------------------

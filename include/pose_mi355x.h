@@ -102,6 +102,10 @@ int pmx_weights_missing(pmx_ctx* ctx, int* n_missing);
  * `on_device` != 0: the pointer is device memory on the context's device. */
 int pmx_forward_u8(pmx_ctx* ctx, const uint8_t* bgr_nhwc, int batch, int h, int w, int on_device);
 int pmx_forward_f32(pmx_ctx* ctx, const float* x_nchw, int batch, int h, int w, int on_device);
+/* `cv2.resize(orig_img, (w, h))` (pose_detector.py:493; INTER_LINEAR uint8, OpenCV's fixed-point algorithm restated) on
+ * the device, then pmx_forward_u8.  All images of the batch share one source size; identity when the sizes agree. */
+int pmx_forward_u8_resized(pmx_ctx* ctx, const uint8_t* bgr_nhwc, int batch, int src_h, int src_w, int h, int w, int on_device);
+int pmx_get_resized(pmx_ctx* ctx, uint8_t* out_nhwc, int batch, int h, int w);   /* parity accessor */
 /* last-stage outputs h1s[-1] (PAF, B x 38 x h/8 x w/8) and h2s[-1] (heat, B x 19 x h/8 x w/8), float32 NCHW,
  * copied to host (synchronises).  Either pointer may be NULL. */
 int pmx_get_maps(pmx_ctx* ctx, float* paf_nchw, float* heat_nchw);

@@ -79,15 +79,20 @@ def test_npz_roundtrip(tmp_path):
     assert np.array_equal(r['conv4_2'][0], w['conv4_2'][0])
 
 
-def test_resize_linear_u8_identity_and_constant():
-    PD = pkg('pose_detector')
+def test_resize_linear_u8_oracle_identity_constant_and_torch():
+    from oracle import resize_ref as RR
     rng = np.random.default_rng(0)
     img = rng.integers(0, 256, (24, 32, 3), dtype=np.uint8)
-    assert np.array_equal(PD.resize_linear_u8(img, 32, 24), img)
+    assert np.array_equal(RR.resize_linear_u8(img, 32, 24), img)
     flat = np.full((50, 70, 3), 137, np.uint8)
-    assert np.all(PD.resize_linear_u8(flat, 41, 33) == 137)
-    up = PD.resize_linear_u8(img, 64, 48)
+    assert np.all(RR.resize_linear_u8(flat, 41, 33) == 137)
+    up = RR.resize_linear_u8(img, 64, 48)
     assert up.shape == (48, 64, 3) and up.dtype == np.uint8
+    # same geometry as torch's half-pixel bilinear; the 11-bit fixed-point result stays within 1 grey level of it
+    import torch
+    t = torch.nn.functional.interpolate(torch.from_numpy(img.astype('f').transpose(2, 0, 1))[None], size=(48, 64),
+                                        mode='bilinear', align_corners=False)[0].numpy().transpose(1, 2, 0)
+    assert np.abs(up.astype('f') - t).max() <= 1.0
 
 
 def test_library_builds_loads_and_exports_every_declared_symbol(native):
