@@ -1098,11 +1098,10 @@ int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen
     const bool small = tiles816 * ((cout + 127) / 128) < 512;
     // 2 x 46 row strips tile 46-wide maps exactly (8 x 16 tiles waste 8.9 %); on 92-wide maps they measured neutral
     const bool strip = (W == 46) && (cout % 128 == 0) && ((long)((H + 1) / 2) * B * (cout / 128) >= 512);
-    if (gen == 4) {      // v4 kernels (interleaved memory instructions, 2 blocks per CU) for 3x3 / 7x7
-        const long blocks88 = (long)((H + 7) / 8) * ((W + 7) / 8) * B * ((cout + 63) / 64);
-        const bool tiny = blocks88 <= 320;
-        if (ks == 7) return strip ? 25 : (small ? (tiny ? 30 : 5) : 27);
-        if (ks == 3) return strip ? 26 : (small ? (tiny ? 31 : 6) : (cout <= 64 ? 2 : 28));
+    if (gen == 4) {      // v4 kernels (interleaved memory instructions, 2 blocks per CU) for 3x3 / 7x7; launches that
+                         // would not fill the chip with 8x16 tiles use the v4 8x8 / BN64 tiles (measured best for B = 1..16)
+        if (ks == 7) return strip ? 25 : (small ? 30 : 27);
+        if (ks == 3) return strip ? 26 : (small ? 31 : (cout <= 64 ? 2 : 28));
         return small ? 7 : (cout <= 64 ? 4 : 3);
     }
     if (gen == 3) {      // every layer on the v2 kernels (A/B measurements only)

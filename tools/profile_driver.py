@@ -42,11 +42,15 @@ if a.gen:
 imgs = np.random.default_rng(1).integers(0, 256, (B, S, S, 3), dtype=np.uint8)
 if a.profile_json:
     eng.profile_enable(True)
+import time
+eng.detect_batch(imgs, 320 * S // 368 // 8 * 8 if S != 368 else 320, 320 * S // 368 // 8 * 8 if S != 368 else 320); eng.results()
+_t0 = time.perf_counter()
 for _ in range(a.steps):
     eng.detect_batch(imgs, 320 * S // 368 // 8 * 8 if S != 368 else 320, 320 * S // 368 // 8 * 8 if S != 368 else 320)
     rec = eng.results()
 if a.profile_json:
     import json
     json.dump({'batch': B, 'steps': a.steps, 'entries': eng.profile()}, open(a.profile_json, 'w'), indent=1)
+print('B=%d k7=%d k3=%d gen=%d: %.3f ms/step  %.3f ms/frame' % (B, a.k7, a.k3, a.gen, (time.perf_counter() - _t0) / a.steps * 1e3, (time.perf_counter() - _t0) / a.steps * 1e3 / B))
 print('people/frame %.2f peaks/frame %.1f status %d' % (rec['n_people'].mean(), rec['n_peaks'].mean(), int(np.bitwise_or.reduce(rec['status']))))
 eng.close()
