@@ -286,3 +286,98 @@ def resize_cubic_u8(img, dst_w, dst_h):
     out = sum(rows[iy[k]] * ay[k][:, None, None] for k in range(4))
     out = (out + (1 << 21)) >> 22
     return np.clip(out, 0, 255).astype(np.uint8)
+
+
+# ---- visualisation + CLI (reference pose_detector.py:520-579); host-only, no compute on the hot path ---------------------
+LIMB_COLORS = [
+    [0, 255, 0], [0, 255, 85], [0, 255, 170], [0, 255, 255], [0, 170, 255],
+    [0, 85, 255], [255, 0, 0], [255, 85, 0], [255, 170, 0], [255, 255, 0],
+    [255, 0, 85], [170, 255, 0], [85, 255, 0], [170, 0, 255], [0, 0, 255],
+    [0, 0, 255], [255, 0, 255], [170, 0, 255], [255, 0, 170]]
+JOINT_COLORS = [
+    [255, 0, 0], [255, 85, 0], [255, 170, 0], [255, 255, 0], [170, 255, 0],
+    [85, 255, 0], [0, 255, 0], [0, 255, 85], [0, 255, 170], [0, 255, 255],
+    [0, 170, 255], [0, 85, 255], [0, 0, 255], [85, 0, 255], [170, 0, 255],
+    [255, 0, 255], [255, 0, 170], [255, 0, 85]]
+
+
+def _draw_line(canvas, p1, p2, color, thickness=2):
+    """All pixels within thickness/2 of the segment p1-p2 (stands in for cv2.line; OpenCV's exact raster is unpinned)."""
+    h, w = canvas.shape[:2]
+    x1, y1, x2, y2 = float(p1[0]), float(p1[1]), float(p2[0]), float(p2[1])
+    r = thickness / 2.0
+    xa, xb = int(max(0, math.floor(min(x1, x2) - r))), int(min(w - 1, math.ceil(max(x1, x2) + r)))
+    ya, yb = int(max(0, math.floor(min(y1, y2) - r))), int(min(h - 1, math.ceil(max(y1, y2) + r)))
+    if xa > xb or ya > yb:
+        return
+    ys, xs = np.mgrid[ya:yb + 1, xa:xb + 1]
+    dx, dy = x2 - x1, y2 - y1
+    L2 = dx * dx + dy * dy
+    t = np.clip(((xs - x1) * dx + (ys - y1) * dy) / L2, 0, 1) if L2 > 0 else np.zeros_like(xs, dtype=float)
+    d2 = (xs - (x1 + t * dx)) ** 2 + (ys - (y1 + t * dy)) ** 2
+    canvas[ya:yb + 1, xa:xb + 1][d2 <= r * r + 0.25] = color
+
+
+def _draw_disc(canvas, c, radius, color):
+    h, w = canvas.shape[:2]
+    cx, cy = int(c[0]), int(c[1])
+    xa, xb, ya, yb = max(0, cx - radius), min(w - 1, cx + radius), max(0, cy - radius), min(h - 1, cy + radius)
+    if xa > xb or ya > yb:
+        return
+    ys, xs = np.mgrid[ya:yb + 1, xa:xb + 1]
+    canvas[ya:yb + 1, xa:xb + 1][(xs - cx) ** 2 + (ys - cy) ** 2 <= radius * radius] = color
+
+
+def draw_person_pose(orig_img, poses):
+    """reference pose_detector.py:520-553: limbs (thickness 2, shoulder-ear limbs 9 and 13 skipped) then joints (discs
+    of radius 3) on a copy of the BGR image."""
+    if len(poses) == 0:
+        return orig_img
+    canvas = np.array(orig_img, copy=True)
+    rounded = np.asarray(poses).round().astype('i')
+    for pose in rounded:
+        for i, (limb, color) in enumerate(zip(params['limbs_point'], LIMB_COLORS)):
+            if i != 9 and i != 13:
+                a, b = pose[int(limb[0])], pose[int(limb[1])]
+                if a[2] != 0 and b[2] != 0:
+                    _draw_line(canvas, a[:2], b[:2], color, 2)
+    for pose in rounded:
+        for (x, y, v), color in zip(pose, JOINT_COLORS):
+            if v != 0:
+                _draw_disc(canvas, (x, y), 3, color)
+    return canvas
+
+
+def imread_bgr(path):
+    """cv2.imread equivalent for the CLI: 8-bit BGR, alpha dropped (pose_detector.py:571)."""
+    from PIL import Image
+    return np.ascontiguousarray(np.asarray(Image.open(path).convert('RGB'))[:, :, ::-1])
+
+
+def imwrite_bgr(path, img):
+    from PIL import Image
+    Image.fromarray(np.ascontiguousarray(img[:, :, ::-1])).save(path)
+
+
+def main(argv=None):
+    """`python -m <package>.pose_detector posenet weights.npz --img X [--gpu N] [--precise]` (reference :555-579)."""
+    import argparse
+    parser = argparse.ArgumentParser(description='Pose detector')
+    parser.add_argument('arch', choices=['posenet'], default='posenet', help='Model architecture')
+    parser.add_argument('weights', help='weights file path (Chainer NPZ)')
+    parser.add_argument('--img', '-i', default=None, help='image file path')
+    parser.add_argument('--gpu', '-g', type=int, default=-1, help='GPU ID (negative value selects GPU 0: there is no CPU path)')
+    parser.add_argument('--precise', action='store_true', help='do precise inference')
+    parser.add_argument('--out', '-o', default='result.png', help='output image path')
+    args = parser.parse_args(argv)
+    pose_detector = PoseDetector(args.arch, args.weights, device=args.gpu, precise=args.precise)
+    img = imread_bgr(args.img)
+    poses, _ = pose_detector(img)
+    img = draw_person_pose(img, poses)
+    print('Saving result into %s...' % args.out)
+    imwrite_bgr(args.out, img)
+    return 0
+
+
+if __name__ == '__main__':
+    raise SystemExit(main())

@@ -121,3 +121,28 @@ def test_pose_detector_non_square_input_resized_on_device(native, weights):
     rpaf, rheat = N.forward(weights, P.preprocess(resized))
     assert _rel_err(paf, rpaf) < 1e-4 and _rel_err(heat, rheat) < 1e-4
     det.engine.close()
+
+
+def test_cli_end_to_end_with_npz_weights(native, weights, tmp_path):
+    """`pose_detector.py posenet weights.npz --img X --gpu 0` (reference :555-579) through the Chainer-NPZ reader."""
+    W = pkg('weights')
+    PD = pkg('pose_detector')
+    rng = np.random.default_rng(10)
+    img = rng.integers(0, 256, (368, 368, 3), dtype=np.uint8)
+    eng = native.Engine(0, max_batch=1, max_h=368, max_w=368)
+    eng.set_weights(weights)
+    eng.forward_u8(img[None])
+    paf, heat = eng.get_maps()
+    eng.close()
+    w2 = W.calibrate_head(weights, paf[0], heat[0])
+    npz = str(tmp_path / 'coco_posenet.npz')
+    W.save_npz(npz, w2)
+    png_in, png_out = str(tmp_path / 'in.png'), str(tmp_path / 'result.png')
+    PD.imwrite_bgr(png_in, img)
+    assert PD.main(['posenet', npz, '--img', png_in, '--gpu', '0', '--out', png_out]) == 0
+    drawn = PD.imread_bgr(png_out)
+    det = PD.PoseDetector('posenet', npz, device=0)
+    poses, scores = det(img)
+    assert len(poses) > 0
+    assert np.array_equal(drawn, PD.draw_person_pose(img, poses))
+    det.engine.close()

@@ -119,3 +119,23 @@ def test_no_device_fails_loudly(native):
         pytest.skip('GPU present')
     with pytest.raises(native.PmxError):
         native.Engine(0)
+
+
+def test_draw_person_pose_and_image_io(tmp_path):
+    PD = pkg('pose_detector')
+    img = np.zeros((120, 160, 3), np.uint8)
+    assert PD.draw_person_pose(img, np.empty((0, 18, 3))) is img            # reference :521-522
+    pose = np.zeros((1, 18, 3))
+    pose[0, 1] = [80, 30, 2]     # neck
+    pose[0, 8] = [70, 90, 2]     # right waist   (limb 0: neck -> right waist, colour [0, 255, 0])
+    pose[0, 2] = [60, 32, 2]     # right shoulder
+    pose[0, 16] = [55, 12, 2]    # right ear     (limb 9 shoulder -> ear is NOT drawn)
+    out = PD.draw_person_pose(img, pose)
+    assert out is not img and not img.any()
+    assert tuple(out[60, 75]) == (0, 255, 0)                                  # a point on the neck-waist segment
+    assert tuple(out[30, 80]) == tuple(PD.JOINT_COLORS[1])                    # joint disc drawn over the limb
+    assert not out[22, 57].any()                                              # shoulder-ear limb skipped (:542)
+    assert (out.reshape(-1, 3).any(axis=1)).sum() > 150
+    p = str(tmp_path / 'x.png')
+    PD.imwrite_bgr(p, out)
+    assert np.array_equal(PD.imread_bgr(p), out)
