@@ -152,6 +152,7 @@ struct pmx_ctx {
     size_t smoothed_cap = 0;
     // options
     int opt_force[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // by ksize
+    int opt_gpu_branch_peaks = 0;    // reference GPU-branch peak extraction (non-golden variant)
     int opt_keep_smoothed = 0, opt_stop_stage = 6, opt_kernel_gen = 4, opt_conv_dbg = 0;
     // timing / profiling
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -350,6 +351,7 @@ extern "C" int pmx_set_option(pmx_ctx* c, const char* key, int value)
     else if (!strcmp(key, "conv_dbg")) c->opt_conv_dbg = value;
     else if (!strcmp(key, "conv_min_lds")) conv_set_min_lds(value);
     else if (!strcmp(key, "pp_generic")) pp_set_generic(value);
+    else if (!strcmp(key, "peaks_gpu_branch")) { c->opt_gpu_branch_peaks = value; c->tab_in_h = -1; }
     else { pmx_set_error("pmx_set_option: unknown key '%s'", key); return PMX_ERR_INVALID; }
     return PMX_OK;
 }
@@ -697,8 +699,19 @@ static int ensure_tables(pmx_ctx* c, int in_h, int in_w, int out_h, int out_w)
     PMX_HIP(hipMemcpy(t.yi1, i1.data(), out_h * sizeof(int), hipMemcpyHostToDevice));
     PMX_HIP(hipMemcpy(t.ylo, lo.data(), out_h * sizeof(double), hipMemcpyHostToDevice));
     PMX_HIP(hipMemcpy(t.yhi, hi.data(), out_h * sizeof(double), hipMemcpyHostToDevice));
-    PMX_HIP(hipMemcpy(t.gauss, c->gauss.data(), c->gauss.size() * sizeof(double), hipMemcpyHostToDevice));
-    t.radius = ((int)c->gauss.size() - 1) / 2;
+    if (c->opt_gpu_branch_peaks) {
+        // create_gaussian_kernel(sigma, ksize = 17) (pose_detector.py:38-44): 1/(2 pi sigma^2) exp(-d^2 / 2 sigma^2), NOT
+        // normalised to sum 1, applied as a 17x17 zero-padded convolution (:112-113); separable factor per axis
+        const int r = 8;
+        std::vector<double> g(2 * r + 1);
+        const double s2 = PMX_GAUSS_SIGMA * PMX_GAUSS_SIGMA;
+        for (int i = -r; i <= r; ++i) g[i + r] = sqrt(1.0 / (s2 * 2.0 * M_PI)) * exp(-0.5 * (double)(i * i) / s2);
+        PMX_HIP(hipMemcpy(t.gauss, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice));
+        t.radius = r; t.border_zero = 1; t.nms_ge = 1;
+    } else {
+        PMX_HIP(hipMemcpy(t.gauss, c->gauss.data(), c->gauss.size() * sizeof(double), hipMemcpyHostToDevice));
+        t.radius = ((int)c->gauss.size() - 1) / 2; t.border_zero = 0; t.nms_ge = 0;
+    }
     c->tab_in_h = in_h; c->tab_in_w = in_w; c->tab_out_h = out_h; c->tab_out_w = out_w;
     return PMX_OK;
 }

@@ -100,6 +100,8 @@ struct PPTables {            // device pointers, per context, sized for the larg
     int* yi0; int* yi1; double* ylo; double* yhi;   // per output row
     double* gauss;                                   // 2r+1 taps
     int radius;
+    int border_zero;   // 0: scipy 'reflect' (CPU branch, golden); 1: zero padding (reference GPU branch, :112-113)
+    int nms_ge;        // 0: strict '>' against the 4 neighbours (:98-101); 1: '>=' (GPU branch, :123-126)
 };
 struct PPMaps {              // where the low-resolution network outputs live
     const float* heat; const float* paf;

@@ -85,9 +85,14 @@ __global__ __launch_bounds__(256) void pp_peaks_kernel(PPMaps maps, PPTables tab
     const float* base = maps.heat + (long long)b * maps.sbh + (long long)ch * maps.sc;
     for (int i = tid; i < UW * UW; i += 256) {
         const int ur = i / UW, uc = i - ur * UW;
-        const int gy = reflect_idx(y0 - 1 - R + ur, map_h);
-        const int gx = reflect_idx(x0 - 1 - R + uc, map_w);
-        sU[ur * PK_US + uc] = bilinear_at(base, maps.sy, maps.sx, tab, gy, gx);
+        const int ry = y0 - 1 - R + ur, rx = x0 - 1 - R + uc;
+        float v;
+        if (tab.border_zero) {      // reference GPU branch: F.convolution_2d zero padding (:112-113)
+            v = (ry >= 0 && ry < map_h && rx >= 0 && rx < map_w) ? bilinear_at(base, maps.sy, maps.sx, tab, ry, rx) : 0.f;
+        } else {
+            v = bilinear_at(base, maps.sy, maps.sx, tab, reflect_idx(ry, map_h), reflect_idx(rx, map_w));
+        }
+        sU[ur * PK_US + uc] = v;
     }
     __syncthreads();
 
@@ -132,8 +137,9 @@ __global__ __launch_bounds__(256) void pp_peaks_kernel(PPMaps maps, PPTables tab
         float p = 0.f;
         if (y < map_h && x < map_w) {
             p = sS[(r + 1) * SW + (c + 1)];
-            peak = p > PMX_HEATMAP_PEAK_THRESH && p > sS[r * SW + (c + 1)] && p > sS[(r + 2) * SW + (c + 1)] &&
-                   p > sS[(r + 1) * SW + c] && p > sS[(r + 1) * SW + (c + 2)];
+            const float up = sS[r * SW + (c + 1)], dn = sS[(r + 2) * SW + (c + 1)], lf = sS[(r + 1) * SW + c], rt = sS[(r + 1) * SW + (c + 2)];
+            peak = tab.nms_ge ? (p > PMX_HEATMAP_PEAK_THRESH && p >= up && p >= dn && p >= lf && p >= rt)
+                              : (p > PMX_HEATMAP_PEAK_THRESH && p > up && p > dn && p > lf && p > rt);
         }
         const unsigned long long m = __ballot(peak);
         if (m) {
@@ -649,7 +655,7 @@ int pp_launch(const PPMaps& maps, const PPTables& tab, const PPBuffers& buf, int
     const int tiles_x = (map_w + PK_TS - 1) / PK_TS, tiles_y = (map_h + PK_TS - 1) / PK_TS;
 
     if (prof) prof(prof_ctx, "pp_peaks", 1);
-    if (tab.radius == 10 && !g_pp_generic)
+    if (tab.radius == 10 && !g_pp_generic && !tab.border_zero && !tab.nms_ge)
         hipLaunchKernelGGL(pp_peaks_fast_kernel<10>, dim3(tiles_x * tiles_y, PMX_N_JOINTS, B), dim3(256), 0, stream, maps, tab, buf,
                            map_h, map_w, tiles_x, keep_smoothed);
     else

@@ -33,7 +33,7 @@ from .entity import JointType, params
 
 class PoseDetector(object):
     def __init__(self, arch=None, weights_file=None, model=None, device=-1, precise=False, weights=None,
-                 max_batch=1, max_size=None):
+                 max_batch=1, max_size=None, gpu_branch_peaks=False):
         self.arch = arch
         self.precise = precise
         self.device = device
@@ -56,6 +56,7 @@ class PoseDetector(object):
         size = params['inference_img_size']
         mh, mw = (size, size) if max_size is None else max_size
         self._weights = w
+        self._gpu_branch_peaks = bool(gpu_branch_peaks)
         self.engine = None
         self._make_engine(max_batch, mh, mw)
 
@@ -67,6 +68,10 @@ class PoseDetector(object):
                                     gaussian_sigma=params['gaussian_sigma'])
         if self._weights is not None:
             self.engine.set_weights(self._weights)
+        if self._gpu_branch_peaks:
+            # the reference's own GPU branch of compute_peaks_from_heatmaps (:111-133): 17x17 un-normalised kernel, zero
+            # padding, '>=' NMS -- NOT the golden CPU semantics; off by default
+            self.engine.set_option('peaks_gpu_branch', 1)
 
     # ---- host helpers with the reference's names and semantics -------------------------------------
     def compute_optimal_size(self, orig_img, img_size, stride=8):

@@ -155,3 +155,27 @@ def test_fast_and_generic_peak_kernels_agree(engine):
     assert out[0][2]['n_people'] == out[1][2]['n_people'] and np.array_equal(out[0][2]['poses'], out[1][2]['poses'])
     ref = P.postprocess_from_net_output(paf, heat, 333, 301)
     assert np.array_equal(out[0][0], ref['all_peaks'])
+
+
+def test_reference_gpu_branch_peaks_variant(engine):
+    """Documented NON-golden variant: the reference's own GPU branch (pose_detector.py:111-133) -- un-normalised 17x17
+    kernel, zero padding, '>=' NMS.  Scores to float32 rounding (cuDNN order is undefined), coordinates exact on a
+    fixture without near-ties."""
+    heat, paf, _ = Fx.synthetic_maps(31, 5, 46, 46, 1.0, 0.9)
+    up = P.resize_images_ref(heat, 320, 320)
+    ref_peaks, ref_sm = P.compute_peaks_gpu_branch(up)
+    engine.set_option('peaks_gpu_branch', 1)
+    engine.set_option('keep_smoothed', 1)
+    engine.set_maps(paf[None], heat[None])
+    engine.postprocess(320, 320, img_len=320)
+    got = engine.peaks(0)
+    sm0 = engine.smoothed(0, 0)
+    engine.set_option('keep_smoothed', 0)
+    engine.set_option('peaks_gpu_branch', 0)
+    assert np.abs(sm0 - ref_sm[0]).max() < 2e-6 * max(1.0, np.abs(ref_sm[0]).max())
+    assert got.shape == ref_peaks.shape
+    assert np.array_equal(got[:, [0, 1, 2, 4]], ref_peaks[:, [0, 1, 2, 4]])
+    assert np.allclose(got[:, 3], ref_peaks[:, 3], rtol=0, atol=2e-6)
+    # and it is really a different result from the golden CPU branch (scores are not normalised the same way)
+    cpu, _ = P.compute_peaks_from_heatmaps(up)
+    assert cpu.shape != got.shape or not np.array_equal(cpu[:, 3], got[:, 3])
