@@ -38,6 +38,28 @@ extern "C" int pmx_device_count(int* n)
 // -------------------------------------------------------------------------------------- layer table
 struct LayerDesc { std::string name; int cin, cout, ks; };
 
+enum NetKind { NET_POSE = 0, NET_FACE = 1, NET_HAND = 2 };     // params['archs'] (entity.py:50-54)
+static int net_out_channels(int kind) { return kind == NET_FACE ? 71 : (kind == NET_HAND ? 22 : 19); }
+
+// FaceNet / HandNet (models/FaceNet.py:12-75, models/HandNet.py): VGG-19 stem to conv5_2, conv5_3_CPM, single-branch 6-stage CPM
+static std::vector<LayerDesc> make_cpm_table(int C)
+{
+    std::vector<LayerDesc> t = {
+        {"conv1_1", 3, 64, 3}, {"conv1_2", 64, 64, 3}, {"conv2_1", 64, 128, 3}, {"conv2_2", 128, 128, 3},
+        {"conv3_1", 128, 256, 3}, {"conv3_2", 256, 256, 3}, {"conv3_3", 256, 256, 3}, {"conv3_4", 256, 256, 3},
+        {"conv4_1", 256, 512, 3}, {"conv4_2", 512, 512, 3}, {"conv4_3", 512, 512, 3}, {"conv4_4", 512, 512, 3},
+        {"conv5_1", 512, 512, 3}, {"conv5_2", 512, 512, 3}, {"conv5_3_CPM", 512, 128, 3},
+        {"conv6_1_CPM", 128, 512, 1}, {"conv6_2_CPM", 512, C, 1}};
+    char buf[64];
+    for (int s = 2; s <= 6; ++s) {
+        snprintf(buf, sizeof buf, "Mconv1_stage%d", s); t.push_back({buf, C + 128, 128, 7});
+        for (int i = 2; i <= 5; ++i) { snprintf(buf, sizeof buf, "Mconv%d_stage%d", i, s); t.push_back({buf, 128, 128, 7}); }
+        snprintf(buf, sizeof buf, "Mconv6_stage%d", s); t.push_back({buf, 128, 128, 1});
+        snprintf(buf, sizeof buf, "Mconv7_stage%d", s); t.push_back({buf, 128, C, 1});
+    }
+    return t;
+}
+
 static std::vector<LayerDesc> make_layer_table()   // models/CocoPoseNet.py:26-129
 {
     std::vector<LayerDesc> t = {
@@ -109,6 +131,16 @@ static std::vector<int> concat_map()
     return m;
 }
 
+// F.concat((h, feature_map)) of FaceNet / HandNet (models/FaceNet.py:107): reference channel c (0..C-1 heat, C..C+127
+// feature) lives at cat-buffer channel: feature -> 0..127, heat -> 128..128+C-1, zero pad up to a multiple of 16
+static std::vector<int> concat_map_cpm(int C)
+{
+    std::vector<int> m(round_up(128 + C, CK), -1);
+    for (int i = 0; i < 128; ++i) m[i] = C + i;
+    for (int i = 0; i < C; ++i) m[128 + i] = i;
+    return m;
+}
+
 // ------------------------------------------------------------------------------------------ profiler
 struct ProfEntry {
     std::string name;
@@ -120,6 +152,12 @@ struct ProfPending { int entry; hipEvent_t e0, e1; };
 
 // ------------------------------------------------------------------------------------------- context
 struct pmx_ctx {
+    int kind = NET_POSE;             // architecture: posenet | facenet | handnet
+    int n_heat = PMX_N_HEAT;         // heat-map channels of the last layer (19 | 71 | 22)
+    int cat_c = PMX_CAT_C;           // channels of the cat buffer (192 | 208 | 160)
+    int cat_heat = PMX_CAT_HEAT;     // first heat-map channel in the cat buffer (168 | 128 | 128)
+    double* d_kp = nullptr;          // key-point records of pmx_keypoints
+    size_t kp_cap = 0;
     int device = 0;
     hipStream_t stream = nullptr, own_stream = nullptr;
     int max_batch = 0, max_h = 0, max_w = 0;
@@ -220,10 +258,21 @@ static int dev_alloc(T** p, size_t count)
     return PMX_OK;
 }
 
+extern "C" int pmx_create_net(pmx_ctx** out, const char* arch, int device, int max_batch, int max_h, int max_w);
 extern "C" int pmx_create(pmx_ctx** out, int device, int max_batch, int max_h, int max_w)
 {
-    PMX_CHECK(out, PMX_ERR_INVALID, "pmx_create: null out");
+    return pmx_create_net(out, "posenet", device, max_batch, max_h, max_w);
+}
+
+extern "C" int pmx_create_net(pmx_ctx** out, const char* arch, int device, int max_batch, int max_h, int max_w)
+{
+    PMX_CHECK(out && arch, PMX_ERR_INVALID, "pmx_create: null arg");
     *out = nullptr;
+    int kind;
+    if (!strcmp(arch, "posenet")) kind = NET_POSE;
+    else if (!strcmp(arch, "facenet")) kind = NET_FACE;
+    else if (!strcmp(arch, "handnet")) kind = NET_HAND;
+    else { pmx_set_error("pmx_create_net: unknown arch '%s' (posenet | facenet | handnet)", arch); return PMX_ERR_INVALID; }
     PMX_CHECK(max_batch >= 1 && max_h >= 8 && max_w >= 8 && max_h % 8 == 0 && max_w % 8 == 0, PMX_ERR_INVALID,
               "pmx_create: max_batch >= 1 and max_h/max_w positive multiples of 8 required (got %d, %d, %d)", max_batch, max_h, max_w);
     int ndev = 0;
@@ -243,7 +292,10 @@ extern "C" int pmx_create(pmx_ctx** out, int device, int max_batch, int max_h, i
     pmx_ctx* c = new pmx_ctx();
     c->device = device;
     c->max_batch = max_batch; c->max_h = max_h; c->max_w = max_w;
-    c->table = make_layer_table();
+    c->kind = kind;
+    c->n_heat = net_out_channels(kind);
+    if (kind != NET_POSE) { c->cat_c = round_up(128 + c->n_heat, CK); c->cat_heat = 128; }
+    c->table = kind == NET_POSE ? make_layer_table() : make_cpm_table(c->n_heat);
     c->layers.resize(c->table.size());
     for (size_t i = 0; i < c->table.size(); ++i) c->index[c->table[i].name] = (int)i;
     PMX_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -256,13 +308,13 @@ extern "C" int pmx_create(pmx_ctx** out, int device, int max_batch, int max_h, i
     if ((rc = dev_alloc(&c->in16, B * HW * PMX_IN_C))) return rc;
     if ((rc = dev_alloc(&c->act0, B * HW * 64))) return rc;      // conv1_1 out is the largest activation
     if ((rc = dev_alloc(&c->act1, B * HW * 16))) return rc;      // (H/2)(W/2) x 64 = (H/4)(W/4) x 256
-    if ((rc = dev_alloc(&c->cat, B * hw8 * PMX_CAT_C))) return rc;
+    if ((rc = dev_alloc(&c->cat, B * hw8 * c->cat_c))) return rc;
     if ((rc = dev_alloc(&c->brA, B * hw8 * 256))) return rc;
     if ((rc = dev_alloc(&c->brB, B * hw8 * 256))) return rc;
     if ((rc = dev_alloc(&c->brT, B * hw8 * 1024))) return rc;
-    PMX_HIP(hipMemset(c->cat, 0, B * hw8 * PMX_CAT_C * sizeof(float)));   // pad channels stay zero forever
+    PMX_HIP(hipMemset(c->cat, 0, B * hw8 * c->cat_c * sizeof(float)));   // pad channels stay zero forever
     c->nchw_tmp_bytes = B * HW * 3 * sizeof(float);
-    if (c->nchw_tmp_bytes < B * hw8 * 57 * sizeof(float)) c->nchw_tmp_bytes = B * hw8 * 57 * sizeof(float);
+    if (c->nchw_tmp_bytes < B * hw8 * 80 * sizeof(float)) c->nchw_tmp_bytes = B * hw8 * 80 * sizeof(float);
     PMX_HIP(hipMalloc((void**)&c->nchw_tmp, c->nchw_tmp_bytes));
     PMX_HIP(hipMalloc((void**)&c->u8_tmp, B * HW * 3));
 
@@ -309,7 +361,7 @@ extern "C" void pmx_destroy(pmx_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (auto& l : c->layers) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); }
-    void* ptrs[] = {c->u8_src, c->rs_tab, c->in16, c->act0, c->act1, c->cat, c->brA, c->brB, c->brT, c->nchw_tmp, c->u8_tmp, c->ext_paf, c->ext_heat,
+    void* ptrs[] = {c->d_kp, c->u8_src, c->rs_tab, c->in16, c->act0, c->act1, c->cat, c->brA, c->brB, c->brT, c->nchw_tmp, c->u8_tmp, c->ext_paf, c->ext_heat,
                     c->pp.pk_raw_key, c->pp.pk_raw_score, c->pp.pk_count, c->pp.pk_x, c->pp.pk_y, c->pp.pk_score, c->pp.pk_start,
                     c->pp.cn_a, c->pp.cn_b, c->pp.cn_score, c->pp.cn_count, c->pp.subsets, c->pp.status, c->pp.results,
                     c->pp.smoothed, c->d_scale, c->tab.xi0, c->tab.xi1, c->tab.xlo, c->tab.xhi, c->tab.yi0, c->tab.yi1,
@@ -367,7 +419,8 @@ extern "C" int pmx_set_layer(pmx_ctx* c, const char* name, const float* w, const
     PMX_CHECK(d.cin == cin && d.cout == cout && d.ks == ks, PMX_ERR_WEIGHTS,
               "pmx_set_layer: '%s' expects (cout %d, cin %d, k %d), got (%d, %d, %d)", name, d.cout, d.cin, d.ks, cout, cin, ks);
     PackedLayer& L = c->layers[it->second];
-    std::vector<int> cmap = (cin == 185) ? concat_map() : identity_map(cin);
+    std::vector<int> cmap = (c->kind == NET_POSE && cin == 185) ? concat_map()
+                            : (c->kind != NET_POSE && cin == c->n_heat + 128) ? concat_map_cpm(c->n_heat) : identity_map(cin);
     std::vector<float> wp, bp;
     const int cpad = cout_pad_of(cout);
     pack_weights(w, bias, cout, cin, ks, cmap, cpad, wp, bp);
@@ -420,8 +473,58 @@ static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float
     return prof_end(c);
 }
 
+// FaceNet / HandNet forward (models/FaceNet.py:78-160): one branch, groups = 1 everywhere
+static int forward_cpm(pmx_ctx* c, int B, int H, int W)
+{
+    auto id = [&](const char* n) { return c->index.at(n); };
+    int rc;
+    const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
+    const int CC = c->cat_c;
+    float* cat = c->cat;
+    float* heat = cat + c->cat_heat;
+#define RUN1(name, in, lda, out, ldc, h, w, relu, pool) \
+    do { if ((rc = run_conv(c, name, id(name), -1, in, nullptr, lda, out, nullptr, ldc, B, h, w, relu, pool))) return rc; } while (0)
+    RUN1("conv1_1", c->in16, PMX_IN_C, c->act0, 64, H, W, 1, 0);
+    RUN1("conv1_2", c->act0, 64, c->act1, 64, H, W, 1, 1);
+    RUN1("conv2_1", c->act1, 64, c->act0, 128, H2, W2, 1, 0);
+    RUN1("conv2_2", c->act0, 128, c->act1, 128, H2, W2, 1, 1);
+    RUN1("conv3_1", c->act1, 128, c->act0, 256, H4, W4, 1, 0);
+    RUN1("conv3_2", c->act0, 256, c->act1, 256, H4, W4, 1, 0);
+    RUN1("conv3_3", c->act1, 256, c->act0, 256, H4, W4, 1, 0);
+    RUN1("conv3_4", c->act0, 256, c->act1, 256, H4, W4, 1, 1);
+    RUN1("conv4_1", c->act1, 256, c->act0, 512, H8, W8, 1, 0);
+    RUN1("conv4_2", c->act0, 512, c->act1, 512, H8, W8, 1, 0);
+    RUN1("conv4_3", c->act1, 512, c->act0, 512, H8, W8, 1, 0);
+    RUN1("conv4_4", c->act0, 512, c->act1, 512, H8, W8, 1, 0);
+    RUN1("conv5_1", c->act1, 512, c->act0, 512, H8, W8, 1, 0);
+    RUN1("conv5_2", c->act0, 512, c->act1, 512, H8, W8, 1, 0);
+    RUN1("conv5_3_CPM", c->act1, 512, cat, CC, H8, W8, 1, 0);               // feature_map -> cat[:, 0:128]
+    RUN1("conv6_1_CPM", cat, CC, c->brT, 512, H8, W8, 1, 0);                  // reads the 128 feature channels
+    RUN1("conv6_2_CPM", c->brT, 512, heat, CC, H8, W8, 0, 0);                 // stage-1 heat maps -> cat[:, 128:128+C]
+    char nm[48];
+    for (int s = 2; s <= 6 && s <= c->opt_stop_stage; ++s) {
+        for (int i = 1; i <= 7; ++i) {
+            snprintf(nm, sizeof nm, "Mconv%d_stage%d", i, s);
+            const float* in; float* out; int lda, ldc;
+            if (i == 1) { in = cat; lda = CC; }
+            else if (i % 2 == 0) { in = c->brA; lda = 128; }
+            else { in = c->brB; lda = 128; }
+            if (i == 7) { out = heat; ldc = CC; }
+            else if (i % 2 == 1) { out = c->brA; ldc = 128; }
+            else { out = c->brB; ldc = 128; }
+            RUN1(nm, in, lda, out, ldc, H8, W8, i == 7 ? 0 : 1, 0);
+        }
+    }
+#undef RUN1
+    c->maps_valid = true; c->maps_external = false;
+    c->cur_B = B; c->cur_fh = H8; c->cur_fw = W8;
+    c->pp_valid = false;
+    return PMX_OK;
+}
+
 static int forward_from_in16(pmx_ctx* c, int B, int H, int W)
 {
+    if (c->kind != NET_POSE) return forward_cpm(c, B, H, W);
     auto id = [&](const char* n) { return c->index.at(n); };
     int rc;
     const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
@@ -495,7 +598,7 @@ extern "C" int pmx_forward_u8(pmx_ctx* c, const uint8_t* img, int B, int H, int 
         d = c->u8_tmp;
     }
     if ((rc = prof_begin(c, "prep_u8|prep_u8", 0, (double)B * H * W * (3 + 64)))) return rc;
-    if ((rc = launch_prep_u8(d, c->in16, B, H, W, c->stream))) return rc;
+    if ((rc = launch_prep_u8(d, c->in16, B, H, W, c->kind == NET_POSE ? 255.0f : 256.0f, c->stream))) return rc;
     if ((rc = prof_end(c))) return rc;
     return forward_from_in16(c, B, H, W);
 }
@@ -591,7 +694,8 @@ extern "C" int pmx_get_maps(pmx_ctx* c, float* paf, float* heat)
     PMX_CHECK(c->maps_valid, PMX_ERR_STATE, "pmx_get_maps: no forward / set_maps yet");
     PMX_DEV(c);
     const int B = c->cur_B, fh = c->cur_fh, fw = c->cur_fw;
-    const size_t np = (size_t)B * PMX_N_PAF * fh * fw, nh = (size_t)B * PMX_N_HEAT * fh * fw;
+    PMX_CHECK(c->kind == NET_POSE || !paf, PMX_ERR_INVALID, "pmx_get_maps: facenet / handnet have no PAF output (pass NULL)");
+    const size_t np = c->kind == NET_POSE ? (size_t)B * PMX_N_PAF * fh * fw : 0, nh = (size_t)B * c->n_heat * fh * fw;
     if (c->maps_external) {
         if (paf) PMX_HIP(hipMemcpyAsync(paf, c->ext_paf, np * 4, hipMemcpyDeviceToHost, c->stream));
         if (heat) PMX_HIP(hipMemcpyAsync(heat, c->ext_heat, nh * 4, hipMemcpyDeviceToHost, c->stream));
@@ -603,7 +707,7 @@ extern "C" int pmx_get_maps(pmx_ctx* c, float* paf, float* heat)
         }
         if (heat) {
             float* tmp = c->nchw_tmp + np;
-            if ((rc = launch_nhwc_to_nchw(c->cat, tmp, B, PMX_N_HEAT, fh, fw, PMX_CAT_C, PMX_CAT_HEAT, c->stream))) return rc;
+            if ((rc = launch_nhwc_to_nchw(c->cat, tmp, B, c->n_heat, fh, fw, c->cat_c, c->cat_heat, c->stream))) return rc;
             PMX_HIP(hipMemcpyAsync(heat, tmp, nh * 4, hipMemcpyDeviceToHost, c->stream));
         }
     }
@@ -613,7 +717,7 @@ extern "C" int pmx_get_maps(pmx_ctx* c, float* paf, float* heat)
 
 extern "C" int pmx_set_maps(pmx_ctx* c, const float* paf, const float* heat, int B, int fh, int fw)
 {
-    PMX_CHECK(c && paf && heat, PMX_ERR_INVALID, "pmx_set_maps: null arg");
+    PMX_CHECK(c && heat && (paf || c->kind != NET_POSE), PMX_ERR_INVALID, "pmx_set_maps: null arg");
     PMX_CHECK(B >= 1 && B <= c->max_batch, PMX_ERR_CAPACITY, "pmx_set_maps: batch %d outside 1..%d", B, c->max_batch);
     PMX_CHECK(fh >= 1 && fw >= 1, PMX_ERR_INVALID, "pmx_set_maps: bad size");
     PMX_DEV(c);
@@ -624,11 +728,11 @@ extern "C" int pmx_set_maps(pmx_ctx* c, const float* paf, const float* heat, int
         if (c->ext_heat) (void)hipFree(c->ext_heat);
         c->ext_paf = c->ext_heat = nullptr;
         PMX_HIP(hipMalloc((void**)&c->ext_paf, need * PMX_N_PAF * 4));
-        PMX_HIP(hipMalloc((void**)&c->ext_heat, need * PMX_N_HEAT * 4));
+        PMX_HIP(hipMalloc((void**)&c->ext_heat, need * c->n_heat * 4));
         c->ext_cap = need;
     }
-    PMX_HIP(hipMemcpyAsync(c->ext_paf, paf, need * PMX_N_PAF * 4, hipMemcpyHostToDevice, c->stream));
-    PMX_HIP(hipMemcpyAsync(c->ext_heat, heat, need * PMX_N_HEAT * 4, hipMemcpyHostToDevice, c->stream));
+    if (paf) PMX_HIP(hipMemcpyAsync(c->ext_paf, paf, need * PMX_N_PAF * 4, hipMemcpyHostToDevice, c->stream));
+    PMX_HIP(hipMemcpyAsync(c->ext_heat, heat, need * c->n_heat * 4, hipMemcpyHostToDevice, c->stream));
     PMX_HIP(hipStreamSynchronize(c->stream));    // host buffers may be released by the caller
     c->maps_valid = true; c->maps_external = true;
     c->cur_B = B; c->cur_fh = fh; c->cur_fw = fw;
@@ -719,6 +823,7 @@ static int ensure_tables(pmx_ctx* c, int in_h, int in_w, int out_h, int out_w)
 extern "C" int pmx_postprocess(pmx_ctx* c, int B, int map_h, int map_w, double img_len, const double* scale_xy)
 {
     PMX_CHECK(c, PMX_ERR_INVALID, "null ctx");
+    PMX_CHECK(c->kind == NET_POSE, PMX_ERR_STATE, "pmx_postprocess: posenet only (use pmx_keypoints for facenet / handnet)");
     PMX_CHECK(c->maps_valid, PMX_ERR_STATE, "pmx_postprocess: no network output (call forward or set_maps first)");
     PMX_CHECK(B == c->cur_B, PMX_ERR_INVALID, "pmx_postprocess: batch %d != batch of the current maps %d", B, c->cur_B);
     PMX_CHECK(map_h >= 1 && map_w >= 1 && (long long)map_h * map_w < (1ll << 31), PMX_ERR_INVALID, "pmx_postprocess: bad map size");
@@ -756,6 +861,51 @@ extern "C" int pmx_postprocess(pmx_ctx* c, int B, int map_h, int map_w, double i
                    c->prof_on ? pp_prof_cb : nullptr, c);
     if (rc) return rc;
     c->pp_valid = true; c->pp_B = B; c->pp_h = map_h; c->pp_w = map_w;
+    return PMX_OK;
+}
+
+// FaceDetector / HandDetector.__call__ post-process (face_detector.py:37-38,58-68; hand_detector.py:41,68-78):
+// F.resize_images(hs[-1], (out_h, out_w)) + gaussian_filter + per-channel arg-max over the n_heat - 1 key-point channels.
+// out: batch x (n_heat - 1) x 4 float64 rows (x, y, confidence, valid); valid = 0 where the reference appends None.
+extern "C" int pmx_keypoints(pmx_ctx* c, int B, int out_h, int out_w, double thresh, double* out)
+{
+    PMX_CHECK(c && out, PMX_ERR_INVALID, "null arg");
+    PMX_CHECK(c->kind != NET_POSE, PMX_ERR_STATE, "pmx_keypoints: facenet / handnet only");
+    PMX_CHECK(c->maps_valid && B == c->cur_B, PMX_ERR_STATE, "pmx_keypoints: no network output for batch %d", B);
+    PMX_CHECK(out_h >= 1 && out_w >= 1 && (long long)out_h * out_w < (1ll << 31), PMX_ERR_INVALID, "pmx_keypoints: bad size");
+    PMX_DEV(c);
+    int rc;
+    if ((rc = ensure_tables(c, c->cur_fh, c->cur_fw, out_h, out_w))) return rc;
+    const int n_ch = c->n_heat - 1;
+    const long long fhw = (long long)c->cur_fh * c->cur_fw;
+    PPMaps m;
+    if (c->maps_external) {
+        m.heat = c->ext_heat; m.paf = nullptr; m.sx = 1; m.sy = c->cur_fw; m.sc = fhw; m.sbh = c->n_heat * fhw; m.sbp = 0;
+    } else {
+        m.heat = c->cat + c->cat_heat; m.paf = nullptr; m.sc = 1; m.sx = c->cat_c; m.sy = (long long)c->cur_fw * c->cat_c;
+        m.sbh = fhw * c->cat_c; m.sbp = 0;
+    }
+    m.fh = c->cur_fh; m.fw = c->cur_fw;
+    const size_t need = (size_t)B * n_ch * out_h * out_w;
+    if (need > c->smoothed_cap) {
+        PMX_HIP(hipStreamSynchronize(c->stream));
+        if (c->pp.smoothed) (void)hipFree(c->pp.smoothed);
+        c->pp.smoothed = nullptr;
+        PMX_HIP(hipMalloc((void**)&c->pp.smoothed, need * sizeof(float)));
+        c->smoothed_cap = need;
+    }
+    const size_t nkp = (size_t)B * n_ch * 4;
+    if (nkp > c->kp_cap) {
+        PMX_HIP(hipStreamSynchronize(c->stream));
+        if (c->d_kp) (void)hipFree(c->d_kp);
+        c->d_kp = nullptr;
+        PMX_HIP(hipMalloc((void**)&c->d_kp, nkp * sizeof(double)));
+        c->kp_cap = nkp;
+    }
+    if ((rc = pp_keypoints_launch(m, c->tab, c->pp, B, n_ch, out_h, out_w, thresh, c->d_kp, c->stream))) return rc;
+    PMX_HIP(hipMemcpyAsync(out, c->d_kp, nkp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PMX_HIP(hipStreamSynchronize(c->stream));
+    c->pp_valid = true; c->pp_B = B; c->pp_h = out_h; c->pp_w = out_w;
     return PMX_OK;
 }
 
@@ -872,12 +1022,13 @@ extern "C" int pmx_get_smoothed(pmx_ctx* c, int image, int joint, float* out, in
 {
     int rc = check_pp_image(c, image);
     if (rc) return rc;
-    PMX_CHECK(out && joint >= 0 && joint < PMX_N_JOINTS, PMX_ERR_INVALID, "bad arg");
-    PMX_CHECK(c->pp.smoothed && c->opt_keep_smoothed, PMX_ERR_STATE, "pmx_get_smoothed: option keep_smoothed was not set");
+    const int n_ch = c->kind == NET_POSE ? PMX_N_JOINTS : c->n_heat - 1;
+    PMX_CHECK(out && joint >= 0 && joint < n_ch, PMX_ERR_INVALID, "bad arg");
+    PMX_CHECK(c->pp.smoothed && (c->opt_keep_smoothed || c->kind != NET_POSE), PMX_ERR_STATE, "pmx_get_smoothed: option keep_smoothed was not set");
     PMX_CHECK(map_h == c->pp_h && map_w == c->pp_w, PMX_ERR_INVALID, "pmx_get_smoothed: map size mismatch");
     PMX_DEV(c);
     PMX_HIP(hipStreamSynchronize(c->stream));
-    PMX_HIP(hipMemcpy(out, c->pp.smoothed + ((size_t)image * PMX_N_JOINTS + joint) * map_h * map_w, (size_t)map_h * map_w * sizeof(float),
+    PMX_HIP(hipMemcpy(out, c->pp.smoothed + ((size_t)image * n_ch + joint) * map_h * map_w, (size_t)map_h * map_w * sizeof(float),
                       hipMemcpyDeviceToHost));
     return PMX_OK;
 }

@@ -87,7 +87,7 @@ void conv_set_min_lds(int bytes);
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // other kernels (prep.hip)
-int launch_prep_u8(const uint8_t* bgr, float* out16, int B, int H, int W, hipStream_t s);
+int launch_prep_u8(const uint8_t* bgr, float* out16, int B, int H, int W, float divisor, hipStream_t s);
 int launch_prep_f32(const float* x_nchw, float* out16, int B, int H, int W, hipStream_t s);
 int launch_resize_linear_u8(const uint8_t* src, uint8_t* dst, const int* xtab, const int* ytab, int B, int sh, int sw, int dh, int dw,
                             hipStream_t s);
@@ -126,6 +126,8 @@ struct PPBuffers {
     float* smoothed;         // optional [B][18][map_h][map_w]
 };
 void pp_set_generic(int on);
+int pp_keypoints_launch(const PPMaps& maps, const PPTables& tab, const PPBuffers& buf, int B, int n_ch, int map_h, int map_w,
+                        double thresh, double* d_out, hipStream_t stream);
 int pp_launch(const PPMaps& maps, const PPTables& tab, const PPBuffers& buf, int B, int map_h, int map_w,
               double img_len, const double* d_scale_xy, int keep_smoothed, hipStream_t stream,
               void (*prof)(void*, const char*, int), void* prof_ctx);

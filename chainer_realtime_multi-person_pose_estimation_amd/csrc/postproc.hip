@@ -65,7 +65,7 @@ __device__ __forceinline__ float bilinear_at(const float* __restrict__ base, lon
 
 // ============================================================================================== peaks
 __global__ __launch_bounds__(256) void pp_peaks_kernel(PPMaps maps, PPTables tab, PPBuffers buf, int map_h, int map_w,
-                                                       int tiles_x, int keep_smoothed)
+                                                       int tiles_x, int keep_smoothed, int n_ch, int do_nms)
 {
     __shared__ float sU[PK_UW_MAX * PK_US];          // upsampled (+reflect) tile
     __shared__ float sV[(PK_TS + 2) * PK_US];        // after the vertical (axis 0) pass
@@ -119,12 +119,13 @@ __global__ __launch_bounds__(256) void pp_peaks_kernel(PPMaps maps, PPTables tab
                 acc = acc + ((double)row[-j] + (double)row[j]) * sG[R - j];
             out = (float)acc;
             if (keep_smoothed && sr >= 1 && sr <= PK_TS && sc >= 1 && sc <= PK_TS)
-                buf.smoothed[(((long long)b * PMX_N_JOINTS + ch) * map_h + y) * map_w + x] = out;
+                buf.smoothed[(((long long)b * n_ch + ch) * map_h + y) * map_w + x] = out;
         }
         sS[sr * SW + sc] = out;
     }
     __syncthreads();
 
+    if (!do_nms) return;      // smoothing-only mode (face / hand key points)
     // NMS + compaction
     unsigned* keys = buf.pk_raw_key + ((long long)b * PMX_N_JOINTS + ch) * PMX_MAX_PEAKS_PER_JOINT;
     float* scores = buf.pk_raw_score + ((long long)b * PMX_N_JOINTS + ch) * PMX_MAX_PEAKS_PER_JOINT;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void pp_peaks_kernel(PPMaps maps, PPTables tab
 // inwards), so the results are bit-identical to the generic kernel (tests compare both against the oracle).
 template <int R>
 __global__ __launch_bounds__(256) void pp_peaks_fast_kernel(PPMaps maps, PPTables tab, PPBuffers buf, int map_h, int map_w,
-                                                            int tiles_x, int keep_smoothed)
+                                                            int tiles_x, int keep_smoothed, int n_ch, int do_nms)
 {
     constexpr int UW = PK_TS + 2 + 2 * R;        // 54
     constexpr int US = UW + 1;
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(256) void pp_peaks_fast_kernel(PPMaps maps, PPTable
                     for (int j = R; j >= 1; --j) acc = acc + ((double)win[o + R - j] + (double)win[o + R + j]) * sG[R - j];
                     out = (float)acc;
                     if (keep_smoothed && sr >= 1 && sr <= PK_TS && sc >= 1 && sc <= PK_TS)
-                        buf.smoothed[(((long long)b * PMX_N_JOINTS + ch) * map_h + y) * map_w + x] = out;
+                        buf.smoothed[(((long long)b * n_ch + ch) * map_h + y) * map_w + x] = out;
                 }
                 sS[sr * SW + sc] = out;
             }
@@ -291,6 +292,7 @@ __global__ __launch_bounds__(256) void pp_peaks_fast_kernel(PPMaps maps, PPTable
     }
     __syncthreads();
 
+    if (!do_nms) return;      // smoothing-only mode (face / hand key points)
     unsigned* keys = buf.pk_raw_key + ((long long)b * PMX_N_JOINTS + ch) * PMX_MAX_PEAKS_PER_JOINT;
     float* scores = buf.pk_raw_score + ((long long)b * PMX_N_JOINTS + ch) * PMX_MAX_PEAKS_PER_JOINT;
     int* counter = buf.pk_count + b * PMX_N_JOINTS + ch;
@@ -657,10 +659,10 @@ int pp_launch(const PPMaps& maps, const PPTables& tab, const PPBuffers& buf, int
     if (prof) prof(prof_ctx, "pp_peaks", 1);
     if (tab.radius == 10 && !g_pp_generic && !tab.border_zero && !tab.nms_ge)
         hipLaunchKernelGGL(pp_peaks_fast_kernel<10>, dim3(tiles_x * tiles_y, PMX_N_JOINTS, B), dim3(256), 0, stream, maps, tab, buf,
-                           map_h, map_w, tiles_x, keep_smoothed);
+                           map_h, map_w, tiles_x, keep_smoothed, PMX_N_JOINTS, 1);
     else
         hipLaunchKernelGGL(pp_peaks_kernel, dim3(tiles_x * tiles_y, PMX_N_JOINTS, B), dim3(256), 0, stream, maps, tab, buf,
-                           map_h, map_w, tiles_x, keep_smoothed);
+                           map_h, map_w, tiles_x, keep_smoothed, PMX_N_JOINTS, 1);
     PMX_HIP(hipGetLastError());
     if (prof) prof(prof_ctx, "pp_peaks", 0);
 
@@ -678,5 +680,80 @@ int pp_launch(const PPMaps& maps, const PPTables& tab, const PPBuffers& buf, int
     hipLaunchKernelGGL(pp_group_kernel, dim3(B), dim3(64), 0, stream, buf, d_scale_xy);
     PMX_HIP(hipGetLastError());
     if (prof) prof(prof_ctx, "pp_group", 0);
+    return PMX_OK;
+}
+
+
+// ======================================================================================= face / hand key points
+// FaceDetector / HandDetector.compute_peaks_from_heatmaps, CPU branch (face_detector.py:58-68, hand_detector.py:68-78):
+// per channel (background excluded) gaussian_filter(sigma) of the resized heat map, max_value = heatmap.max(); if it
+// exceeds the threshold the key point is `np.array(np.where(heatmap == max_value)).flatten()` -> [coords[1], coords[0]]:
+// (x, y) of the maximum when it is unique; with k > 1 equal maxima the flattened array is [y0, y1, .., x0, x1, ..], so the
+// reference returns (y1, y0) -- reproduced here.
+struct ArgMax { float v; int cnt; int i0; int i1; };   // max value, multiplicity, two smallest row-major indices
+
+__device__ __forceinline__ ArgMax argmax_merge(const ArgMax& a, const ArgMax& b)
+{
+    if (a.v > b.v) return a;
+    if (b.v > a.v) return b;
+    ArgMax r;
+    r.v = a.v;
+    r.cnt = a.cnt + b.cnt;
+    // two smallest of {a.i0, a.i1, b.i0, b.i1} (INT_MAX = empty)
+    const int lo = min(a.i0, b.i0), hi = max(a.i0, b.i0);
+    r.i0 = lo;
+    r.i1 = min(hi, min(a.i1, b.i1));
+    return r;
+}
+
+__global__ __launch_bounds__(256) void pp_argmax_kernel(const float* __restrict__ smoothed, int n_ch, int map_h, int map_w,
+                                                        double thresh, double* __restrict__ out)
+{
+    __shared__ ArgMax sred[4];
+    const int ch = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* m = smoothed + ((long long)b * n_ch + ch) * map_h * map_w;
+    const int n = map_h * map_w;
+    ArgMax a;
+    a.v = -INFINITY; a.cnt = 0; a.i0 = 0x7fffffff; a.i1 = 0x7fffffff;
+    for (int i = tid; i < n; i += 256) {
+        const float v = m[i];
+        if (v > a.v) { a.v = v; a.cnt = 1; a.i0 = i; a.i1 = 0x7fffffff; }
+        else if (v == a.v) { a.cnt += 1; if (a.i1 == 0x7fffffff) a.i1 = i; }     // own indices ascend
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        ArgMax o;
+        o.v = __shfl_xor(a.v, off); o.cnt = __shfl_xor(a.cnt, off); o.i0 = __shfl_xor(a.i0, off); o.i1 = __shfl_xor(a.i1, off);
+        a = argmax_merge(a, o);
+    }
+    if (lane == 0) sred[wave] = a;
+    __syncthreads();
+    if (tid == 0) {
+        ArgMax r = sred[0];
+        for (int w = 1; w < 4; ++w) r = argmax_merge(r, sred[w]);
+        double* o = out + ((long long)b * n_ch + ch) * 4;
+        const bool valid = (double)r.v > thresh;        // np.float32 scalar > python float: float64 comparison
+        int x = r.i0 % map_w, y = r.i0 / map_w;
+        if (r.cnt >= 2) { x = r.i1 / map_w; }            // (sic) coords[1] is the SECOND maximum's row when k >= 2
+        o[0] = valid ? (double)x : 0.0;
+        o[1] = valid ? (double)y : 0.0;
+        o[2] = (double)r.v;
+        o[3] = valid ? 1.0 : 0.0;
+    }
+}
+
+int pp_keypoints_launch(const PPMaps& maps, const PPTables& tab, const PPBuffers& buf, int B, int n_ch, int map_h, int map_w,
+                        double thresh, double* d_out, hipStream_t stream)
+{
+    const int tiles_x = (map_w + PK_TS - 1) / PK_TS, tiles_y = (map_h + PK_TS - 1) / PK_TS;
+    if (tab.radius == 10 && !g_pp_generic && !tab.border_zero)
+        hipLaunchKernelGGL(pp_peaks_fast_kernel<10>, dim3(tiles_x * tiles_y, n_ch, B), dim3(256), 0, stream, maps, tab, buf, map_h, map_w,
+                           tiles_x, 1, n_ch, 0);
+    else
+        hipLaunchKernelGGL(pp_peaks_kernel, dim3(tiles_x * tiles_y, n_ch, B), dim3(256), 0, stream, maps, tab, buf, map_h, map_w,
+                           tiles_x, 1, n_ch, 0);
+    PMX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(pp_argmax_kernel, dim3(n_ch, B), dim3(256), 0, stream, buf.smoothed, n_ch, map_h, map_w, thresh, d_out);
+    PMX_HIP(hipGetLastError());
     return PMX_OK;
 }

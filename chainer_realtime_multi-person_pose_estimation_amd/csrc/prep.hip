@@ -9,7 +9,7 @@
 #include "pmx_common.h"
 
 __global__ __launch_bounds__(256) void prep_u8_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst,
-                                                      long long npix)
+                                                      long long npix, float divisor)
 {
     // one thread per (pixel, float4 slot of the 16 output channels)
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -19,9 +19,10 @@ __global__ __launch_bounds__(256) void prep_u8_kernel(const uint8_t* __restrict_
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (slot == 0) {
         const uint8_t* s = src + p * 3;
-        v.x = (float)s[0] / 255.0f - 0.5f;   // fp-contract is off for this file: divide, then subtract
-        v.y = (float)s[1] / 255.0f - 0.5f;
-        v.z = (float)s[2] / 255.0f - 0.5f;
+        // pose: /255 (pose_detector.py:428); face / hand: /256 (face_detector.py:32, hand_detector.py:36)
+        v.x = (float)s[0] / divisor - 0.5f;   // fp-contract is off for this file: divide, then subtract
+        v.y = (float)s[1] / divisor - 0.5f;
+        v.z = (float)s[2] / divisor - 0.5f;
     }
     reinterpret_cast<float4*>(dst)[i] = v;
 }
@@ -106,10 +107,10 @@ __global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __
 
 static inline unsigned nblocks(long long n) { return (unsigned)((n + 255) / 256); }
 
-int launch_prep_u8(const uint8_t* bgr, float* out16, int B, int H, int W, hipStream_t s)
+int launch_prep_u8(const uint8_t* bgr, float* out16, int B, int H, int W, float divisor, hipStream_t s)
 {
     const long long npix = (long long)B * H * W;
-    hipLaunchKernelGGL(prep_u8_kernel, dim3(nblocks(npix * 4)), dim3(256), 0, s, bgr, out16, npix);
+    hipLaunchKernelGGL(prep_u8_kernel, dim3(nblocks(npix * 4)), dim3(256), 0, s, bgr, out16, npix, divisor);
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }

@@ -74,8 +74,20 @@ params = {
         [_J.RightEye, _J.RightEar],
         [_J.LeftEye, _J.LeftEar],
     ],
-    # name -> network; only 'posenet' is on the hot path (reference entity.py:50-54)
-    'archs': {},
+    # face / hand key-point detectors (reference entity.py:126-151)
+    'face_inference_img_size': 368,
+    'face_heatmap_peak_thresh': 0.1,
+    'hand_inference_img_size': 368,
+    'hand_heatmap_peak_thresh': 0.1,
+    'fingers_indices': [
+        [[0, 1], [1, 2], [2, 3], [3, 4]],
+        [[0, 5], [5, 6], [6, 7], [7, 8]],
+        [[0, 9], [9, 10], [10, 11], [11, 12]],
+        [[0, 13], [13, 14], [14, 15], [15, 16]],
+        [[0, 17], [17, 18], [18, 19], [19, 20]],
+    ],
+    # name -> network architecture handled by the native library (reference entity.py:50-54)
+    'archs': {'posenet': 'posenet', 'facenet': 'facenet', 'handnet': 'handnet'},
 }
 
 N_JOINTS = len(JointType)          # 18

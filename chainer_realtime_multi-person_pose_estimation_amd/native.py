@@ -115,6 +115,8 @@ def load():
         'pmx_last_error': (C.c_char_p, []),
         'pmx_device_count': (ci, [ip]),
         'pmx_create': (ci, [C.POINTER(vp), ci, ci, ci, ci]),
+        'pmx_create_net': (ci, [C.POINTER(vp), C.c_char_p, ci, ci, ci, ci]),
+        'pmx_keypoints': (ci, [vp, ci, ci, ci, cd, vp]),
         'pmx_destroy': (None, [vp]),
         'pmx_set_stream': (ci, [vp, vp]),
         'pmx_synchronize': (ci, [vp]),
@@ -176,10 +178,14 @@ def gaussian_taps(sigma, truncate=4.0):
 class Engine(object):
     """One libpose_mi355x context (one GPU, one stream)."""
 
-    def __init__(self, device=0, max_batch=1, max_h=368, max_w=368, gaussian_sigma=2.5):
+    N_MAPS = {'posenet': 19, 'facenet': 71, 'handnet': 22}
+
+    def __init__(self, device=0, max_batch=1, max_h=368, max_w=368, gaussian_sigma=2.5, arch='posenet'):
         self.lib = load()
         self._ctx = C.c_void_p()
-        self._check(self.lib.pmx_create(C.byref(self._ctx), int(device), int(max_batch), int(max_h), int(max_w)))
+        self.arch = arch
+        self.n_heat = self.N_MAPS[arch]
+        self._check(self.lib.pmx_create_net(C.byref(self._ctx), arch.encode(), int(device), int(max_batch), int(max_h), int(max_w)))
         self.device, self.max_batch, self.max_h, self.max_w = device, max_batch, max_h, max_w
         taps, radius = gaussian_taps(gaussian_sigma)
         taps = np.ascontiguousarray(taps, dtype=np.float64)
@@ -275,11 +281,31 @@ class Engine(object):
         self._fhw = (H // 8, W // 8)
 
     def get_maps(self):
+        """posenet: (paf, heat); facenet / handnet: heat only (B, 71 | 22, h, w)."""
         fh, fw = self._fhw
+        heat = np.empty((self._B, self.n_heat, fh, fw), np.float32)
+        if self.arch != 'posenet':
+            self._check(self.lib.pmx_get_maps(self._ctx, None, _ptr(heat)))
+            return heat
         paf = np.empty((self._B, N_PAF, fh, fw), np.float32)
-        heat = np.empty((self._B, N_HEAT, fh, fw), np.float32)
         self._check(self.lib.pmx_get_maps(self._ctx, _ptr(paf), _ptr(heat)))
         return paf, heat
+
+    def set_heat(self, heat):
+        """facenet / handnet test seam: install last-stage heat maps (B, 71 | 22, h, w)."""
+        heat = np.ascontiguousarray(heat, dtype=np.float32)
+        B, c, fh, fw = heat.shape
+        assert c == self.n_heat and self.arch != 'posenet'
+        self._check(self.lib.pmx_set_maps(self._ctx, None, _ptr(heat), B, fh, fw))
+        self._B = B
+        self._fhw = (fh, fw)
+
+    def keypoints(self, out_h, out_w, thresh):
+        """facenet / handnet: (B, maps - 1, 4) float64 rows (x, y, confidence, valid)."""
+        out = np.empty((self._B, self.n_heat - 1, 4), np.float64)
+        self._check(self.lib.pmx_keypoints(self._ctx, self._B, int(out_h), int(out_w), float(thresh), _ptr(out)))
+        self._map = (int(out_h), int(out_w))
+        return out
 
     def set_maps(self, paf, heat):
         paf = np.ascontiguousarray(paf, dtype=np.float32)

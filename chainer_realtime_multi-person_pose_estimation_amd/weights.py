@@ -15,8 +15,29 @@ import numpy as np
 N_LAYERS = 92
 
 
-def layer_table():
-    """[(name, cin, cout, ksize)] -- 92 convolutions, reference declaration order."""
+def cpm_layer_table(n_maps):
+    """FaceNet (71 maps, models/FaceNet.py:12-75) / HandNet (22 maps, models/HandNet.py): VGG-19 stem to conv5_2,
+    conv5_3_CPM, one-branch 6-stage CPM on concat((heat, feature))."""
+    t = [('conv1_1', 3, 64, 3), ('conv1_2', 64, 64, 3), ('conv2_1', 64, 128, 3), ('conv2_2', 128, 128, 3),
+         ('conv3_1', 128, 256, 3), ('conv3_2', 256, 256, 3), ('conv3_3', 256, 256, 3), ('conv3_4', 256, 256, 3),
+         ('conv4_1', 256, 512, 3), ('conv4_2', 512, 512, 3), ('conv4_3', 512, 512, 3), ('conv4_4', 512, 512, 3),
+         ('conv5_1', 512, 512, 3), ('conv5_2', 512, 512, 3), ('conv5_3_CPM', 512, 128, 3),
+         ('conv6_1_CPM', 128, 512, 1), ('conv6_2_CPM', 512, n_maps, 1)]
+    for s in range(2, 7):
+        t.append(('Mconv1_stage%d' % s, n_maps + 128, 128, 7))
+        for i in range(2, 6):
+            t.append(('Mconv%d_stage%d' % (i, s), 128, 128, 7))
+        t.append(('Mconv6_stage%d' % s, 128, 128, 1))
+        t.append(('Mconv7_stage%d' % s, 128, n_maps, 1))
+    return t
+
+
+def layer_table(arch='posenet'):
+    """[(name, cin, cout, ksize)] -- posenet: 92 convolutions, reference declaration order."""
+    if arch == 'facenet':
+        return cpm_layer_table(71)
+    if arch == 'handnet':
+        return cpm_layer_table(22)
     t = [
         ('conv1_1', 3, 64, 3), ('conv1_2', 64, 64, 3),
         ('conv2_1', 64, 128, 3), ('conv2_2', 128, 128, 3),
@@ -41,15 +62,15 @@ def layer_table():
     return t
 
 
-def n_params():
-    return sum(co * ci * k * k + co for _, ci, co, k in layer_table())
+def n_params(arch='posenet'):
+    return sum(co * ci * k * k + co for _, ci, co, k in layer_table(arch))
 
 
-def synthetic_weights(seed=0):
+def synthetic_weights(seed=0, arch='posenet'):
     """{name: (W OIHW float32, b float32)} -- deterministic for a given seed (numpy PCG64)."""
     rng = np.random.default_rng(seed)
     out = {}
-    for name, ci, co, k in layer_table():
+    for name, ci, co, k in layer_table(arch):
         std = np.sqrt(2.0 / (ci * k * k))
         W = (rng.standard_normal((co, ci, k, k), dtype=np.float32) * np.float32(std))
         b = (rng.standard_normal(co, dtype=np.float32) * np.float32(0.01))
@@ -57,11 +78,11 @@ def synthetic_weights(seed=0):
     return out
 
 
-def load_npz(path):
-    """Chainer NPZ (`<layer>/W`, `<layer>/b`) -> {name: (W, b)}; every one of the 92 layers must be present."""
+def load_npz(path, arch='posenet'):
+    """Chainer NPZ (`<layer>/W`, `<layer>/b`) -> {name: (W, b)}; every layer of the architecture must be present."""
     out = {}
     with np.load(path) as z:
-        for name, ci, co, k in layer_table():
+        for name, ci, co, k in layer_table(arch):
             W = np.ascontiguousarray(z[name + '/W'], dtype=np.float32)
             b = np.ascontiguousarray(z[name + '/b'], dtype=np.float32)
             if W.shape != (co, ci, k, k) or b.shape != (co,):

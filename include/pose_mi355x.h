@@ -84,6 +84,9 @@ int pmx_device_count(int* n);
  * Replaces model construction (`params['archs'][arch]()`, :23), `model.to_gpu()` (:31) and the device
  * selection (:30).  max_h/max_w bound the network input size (multiples of 8), max_batch the batch. */
 int pmx_create(pmx_ctx** out, int device, int max_batch, int max_h, int max_w);
+/* `params['archs'][arch]()` (entity.py:50-54; pose_detector.py:23, face_detector.py:15, hand_detector.py:15):
+ * arch = "posenet" (models/CocoPoseNet.py), "facenet" (models/FaceNet.py, 71 maps) or "handnet" (models/HandNet.py, 22 maps). */
+int pmx_create_net(pmx_ctx** out, const char* arch, int device, int max_batch, int max_h, int max_w);
 void pmx_destroy(pmx_ctx* ctx);
 int pmx_set_stream(pmx_ctx* ctx, void* hip_stream);   /* NULL -> the context's own stream */
 int pmx_synchronize(pmx_ctx* ctx);                    /* cuda.get_device_from_id().synchronize(), :506 */
@@ -122,6 +125,11 @@ int pmx_set_maps(pmx_ctx* ctx, const float* paf_nchw, const float* heat_nchw, in
  * gauss_w: the 2*radius+1 float64 taps scipy's gaussian_filter(sigma=2.5) uses (NULL -> computed in C). */
 int pmx_set_gaussian(pmx_ctx* ctx, const double* taps, int radius);
 int pmx_postprocess(pmx_ctx* ctx, int batch, int map_h, int map_w, double img_len, const double* scale_xy);
+
+/* FaceDetector / HandDetector post-process (face_detector.py:37-38,58-68; hand_detector.py:41,68-78) for facenet / handnet
+ * contexts: F.resize_images(hs[-1], (out_h, out_w)) + gaussian_filter + per-channel arg-max.  out: batch x (maps - 1) x 4
+ * float64 rows (x, y, confidence, valid); valid = 0 where the reference appends None.  Synchronises. */
+int pmx_keypoints(pmx_ctx* ctx, int batch, int out_h, int out_w, double thresh, double* out);
 
 /* fused: forward_u8 + postprocess (PoseDetector.__call__, pose_detector.py:484-517, for images already
  * at the network input size; cv2.resize at :493 is the identity for them) */

@@ -60,7 +60,7 @@ def test_preprocess_matches_reference_golden():
 def test_layer_table_and_synthetic_weights():
     W = pkg('weights')
     t = W.layer_table()
-    assert len(t) == 92 and W.n_params() == 52311446
+    assert len(t) == 92 and sum(co * ci * k * k + co for _, ci, co, k in t) == 52311446
     from oracle import network_ref
     assert sorted(t) == sorted(network_ref.layer_table())
     w1, w2 = W.synthetic_weights(3), W.synthetic_weights(3)
