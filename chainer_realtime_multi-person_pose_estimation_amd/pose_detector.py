@@ -171,6 +171,76 @@ class PoseDetector(object):
         self.all_peaks = self.engine.peaks(0)
         return unpack_results(self.engine.results())[0]
 
+    # ---- demo-chain helpers (reference pose_detector.py:267-424): host geometry that feeds the face / hand detectors -------
+    _UNIT_BASE_LIMBS = (14, 3, 0, 13, 9)            # nose-neck, neck-left hip, neck-right hip, shoulder-ear (left, right)
+    _UNIT_BASE_RATIO = (0.85, 2.2, 2.2, 0.85, 0.85)
+    _UNIT_ALL_RATIO = (2.2, 1.7, 1.7, 2.2, 1.7, 1.7, 0.6, 0.93, 0.65, 0.85, 0.6, 0.93, 0.65, 0.85, 1, 0.2, 0.2, 0.25, 0.25)
+
+    def compute_limbs_length(self, joints):
+        """reference :267-277 -- per-limb length (0 where an endpoint is None) and the endpoint pairs."""
+        pairs, lengths = [], np.zeros(len(params['limbs_point']))
+        for i, (ja, jb) in enumerate(params['limbs_point']):
+            a, b = joints[ja], joints[jb]
+            if a is None or b is None:
+                pairs.append(None)
+                continue
+            pairs.append([a, b])
+            lengths[i] = np.linalg.norm(b[:-1] - a[:-1])
+        return lengths, pairs
+
+    def compute_unit_length(self, limbs_len):
+        """reference :279-291 -- body 'unit length' from limb-length ratios; torso/head limbs are preferred."""
+        base = limbs_len[list(self._UNIT_BASE_LIMBS)]
+        known = base > 0
+        if known.any():
+            ratio = np.array(self._UNIT_BASE_RATIO)
+            return np.sum(base[known] / ratio[known]) / np.count_nonzero(known)
+        ratio = np.array(self._UNIT_ALL_RATIO)
+        known = limbs_len > 0
+        return np.sum(limbs_len[known] / ratio[known]) / np.count_nonzero(known)
+
+    def get_unit_length(self, person_pose):
+        """reference :293-297 (called by demo.py:32)"""
+        return self.compute_unit_length(self.compute_limbs_length(person_pose)[0])
+
+    def crop_image(self, img, bbox):
+        """reference :401-424 -- crop with zero padding where the box leaves the image."""
+        left, top, right, bottom = bbox
+        h, w, ch = img.shape
+        out = np.zeros((bottom - top, right - left, ch), dtype=np.uint8)
+        x0, y0, x1, y1 = max(0, left), max(0, top), min(w, right), min(h, bottom)
+        if x1 > x0 and y1 > y0:
+            out[y0 - top:y1 - top, x0 - left:x1 - left] = img[y0:y1, x0:x1]
+        return out
+
+    def crop_around_keypoint(self, img, keypoint, crop_size):
+        """reference :299-309"""
+        x, y = keypoint
+        bbox = (int(x - crop_size), int(y - crop_size), int(x + crop_size), int(y + crop_size))
+        return self.crop_image(img, bbox), bbox
+
+    def crop_face(self, img, person_pose, unit_length):
+        """reference :354-369 (demo.py:36): box around the nose, 1.2 units up, 0.8 down, 1 unit to each side."""
+        nose = person_pose[JointType.Nose]
+        if not nose[2] > 0:
+            return None, None
+        bbox = (int(nose[0] - unit_length), int(nose[1] - unit_length * 1.2),
+                int(nose[0] + unit_length), int(nose[1] + unit_length * 0.8))
+        return self.crop_image(img, bbox), bbox
+
+    def crop_hands(self, img, person_pose, unit_length):
+        """reference :371-399 (demo.py:44): a 0.95-unit box centred 30 % past the wrist along the forearm."""
+        hands = {"left": None, "right": None}
+        for side, wrist_j, elbow_j in (("left", JointType.LeftHand, JointType.LeftElbow),
+                                       ("right", JointType.RightHand, JointType.RightElbow)):
+            if person_pose[wrist_j][2] > 0:
+                center = person_pose[wrist_j][:-1]          # a view, updated in place exactly as the reference does
+                if person_pose[elbow_j][2] > 0:
+                    center += (0.3 * (person_pose[wrist_j][:-1] - person_pose[elbow_j][:-1])).astype(center.dtype)
+                hand_img, bbox = self.crop_around_keypoint(img, center, unit_length * 0.95)
+                hands[side] = {"img": hand_img, "bbox": bbox}
+        return hands
+
     def detect_batch(self, imgs):
         """Batched `__call__`: list of H x W x 3 uint8 BGR images of ONE common size -> list of (poses, scores),
         each identical to what `__call__` returns for that image (the reference handles one image per call)."""

@@ -45,3 +45,37 @@ def test_host_helpers_match_reference():
             assert (int(rw), int(rh)) == P.compute_optimal_size(h, w, t)
     img = rng.integers(0, 256, (9, 13, 3), dtype=np.uint8)
     assert np.array_equal(det.preprocess(img), P.preprocess(img))
+
+
+def test_demo_chain_helpers_match_reference():
+    """get_unit_length / crop_face / crop_hands (pose_detector.py:267-424) of the product class vs the verbatim reference
+    on random poses.  The reference raises ValueError when a crop box lies entirely outside the image (negative slice
+    sizes at :423); the mirror returns the all-zero crop there -- those cases are skipped."""
+    from conftest import pkg
+    _, _, det_ref, _ = R.import_reference()
+    PD = pkg('pose_detector')
+    mine = PD.PoseDetector.__new__(PD.PoseDetector)
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (200, 300, 3), dtype=np.uint8)
+    compared = 0
+    for _ in range(300):
+        pose = np.zeros((18, 3))
+        pose[:, :2] = rng.uniform(-20, 320, (18, 2))
+        pose[:, 2] = (rng.random(18) > 0.3) * 2
+        ul_r, ul_m = det_ref.get_unit_length(pose.copy()), mine.get_unit_length(pose.copy())
+        assert ul_r == ul_m or (np.isnan(ul_r) and np.isnan(ul_m))
+        u = ul_r if np.isfinite(ul_r) and ul_r > 1 else 20.0
+        try:
+            fr = det_ref.crop_face(img, pose.copy(), u)
+            hr = det_ref.crop_hands(img, pose.copy(), 25.0)
+        except ValueError:
+            continue
+        fm = mine.crop_face(img, pose.copy(), u)
+        hm = mine.crop_hands(img, pose.copy(), 25.0)
+        assert fr[1] == fm[1] and ((fr[0] is None and fm[0] is None) or np.array_equal(fr[0], fm[0]))
+        for side in ('left', 'right'):
+            assert (hr[side] is None) == (hm[side] is None)
+            if hr[side] is not None:
+                assert hr[side]['bbox'] == hm[side]['bbox'] and np.array_equal(hr[side]['img'], hm[side]['img'])
+        compared += 1
+    assert compared > 100
