@@ -156,6 +156,10 @@ struct pmx_ctx {
     int n_heat = PMX_N_HEAT;         // heat-map channels of the last layer (19 | 71 | 22)
     int cat_c = PMX_CAT_C;           // channels of the cat buffer (192 | 208 | 160)
     int cat_heat = PMX_CAT_HEAT;     // first heat-map channel in the cat buffer (168 | 128 | 128)
+    // detect_precise accumulation state (pmx_precise_*)
+    int pr_h = 0, pr_w = 0, pr_scales = 0;
+    float* pr_tmp = nullptr; size_t pr_tmp_cap = 0;      // x8 up-sampled maps of one scale, NHWC-57
+    void* pr_tab = nullptr; size_t pr_tab_cap = 0;       // cubic tables of the current resize
     double* d_kp = nullptr;          // key-point records of pmx_keypoints
     size_t kp_cap = 0;
     int device = 0;
@@ -361,7 +365,7 @@ extern "C" void pmx_destroy(pmx_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (auto& l : c->layers) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); }
-    void* ptrs[] = {c->d_kp, c->u8_src, c->rs_tab, c->in16, c->act0, c->act1, c->cat, c->brA, c->brB, c->brT, c->nchw_tmp, c->u8_tmp, c->ext_paf, c->ext_heat,
+    void* ptrs[] = {c->pr_tmp, c->pr_tab, c->d_kp, c->u8_src, c->rs_tab, c->in16, c->act0, c->act1, c->cat, c->brA, c->brB, c->brT, c->nchw_tmp, c->u8_tmp, c->ext_paf, c->ext_heat,
                     c->pp.pk_raw_key, c->pp.pk_raw_score, c->pp.pk_count, c->pp.pk_x, c->pp.pk_y, c->pp.pk_score, c->pp.pk_start,
                     c->pp.cn_a, c->pp.cn_b, c->pp.cn_score, c->pp.cn_count, c->pp.subsets, c->pp.status, c->pp.results,
                     c->pp.smoothed, c->d_scale, c->tab.xi0, c->tab.xi1, c->tab.xlo, c->tab.xhi, c->tab.yi0, c->tab.yi1,
@@ -861,6 +865,173 @@ extern "C" int pmx_postprocess(pmx_ctx* c, int B, int map_h, int map_w, double i
                    c->prof_on ? pp_prof_cb : nullptr, c);
     if (rc) return rc;
     c->pp_valid = true; c->pp_B = B; c->pp_h = map_h; c->pp_w = map_w;
+    return PMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------- detect_precise on the device
+// OpenCV bicubic tables for one axis (A = -0.75): idx[k][d] (clamped, replicate border) and coef[k][d] float32, k = 0..3.
+// Same float32 expression order as pose_detector.py::_cubic_taps / oracle/precise_ref.py::_coeffs.
+#pragma clang fp contract(off)
+static void make_cubic_table(int dst, int src, int* idx, float* coef)
+{
+    const double scale = 1.0 / ((double)dst / (double)src);
+    const float A = -0.75f;
+    for (int d = 0; d < dst; ++d) {
+        const float f = (float)(((double)d + 0.5) * scale - 0.5);
+        const int s = (int)floorf(f);
+        const float x = f - (float)s;
+        const float x1 = x + 1.0f, xm = 1.0f - x;
+        float c0 = A * x1;  c0 = c0 - 5.0f * A;  c0 = c0 * x1;  c0 = c0 + 8.0f * A;  c0 = c0 * x1;  c0 = c0 - 4.0f * A;
+        float c1 = (A + 2.0f) * x;  c1 = c1 - (A + 3.0f);  c1 = c1 * x;  c1 = c1 * x;  c1 = c1 + 1.0f;
+        float c2 = (A + 2.0f) * xm;  c2 = c2 - (A + 3.0f);  c2 = c2 * xm;  c2 = c2 * xm;  c2 = c2 + 1.0f;
+        float c3 = 1.0f - c0;  c3 = c3 - c1;  c3 = c3 - c2;
+        const float cs[4] = {c0, c1, c2, c3};
+        for (int k = 0; k < 4; ++k) {
+            int i = s - 1 + k;
+            i = i < 0 ? 0 : (i > src - 1 ? src - 1 : i);
+            idx[k * dst + d] = i;
+            coef[k * dst + d] = cs[k];
+        }
+    }
+}
+
+// uploads [xi | yi | xc | yc] (or fixed-point coefficients when `fixed`) for a (sh, sw) -> (dh, dw) cubic resize
+static int upload_cubic_tables(pmx_ctx* c, int sh, int sw, int dh, int dw, bool fixed, int** xi, void** xc, int** yi, void** yc)
+{
+    const size_t n = (size_t)4 * (dw + dh);
+    const size_t bytes = n * 2 * sizeof(int);
+    if (bytes > c->pr_tab_cap) {
+        PMX_HIP(hipStreamSynchronize(c->stream));
+        if (c->pr_tab) (void)hipFree(c->pr_tab);
+        c->pr_tab = nullptr;
+        PMX_HIP(hipMalloc(&c->pr_tab, bytes));
+        c->pr_tab_cap = bytes;
+    }
+    std::vector<int> hi(n);
+    std::vector<float> hc(n);
+    make_cubic_table(dw, sw, hi.data(), hc.data());
+    make_cubic_table(dh, sh, hi.data() + 4 * dw, hc.data() + 4 * dw);
+    PMX_HIP(hipStreamSynchronize(c->stream));     // previous resize may still read the table buffer
+    int* d_i = (int*)c->pr_tab;
+    PMX_HIP(hipMemcpy(d_i, hi.data(), n * sizeof(int), hipMemcpyHostToDevice));
+    if (fixed) {
+        std::vector<int> ha(n);
+        for (size_t k = 0; k < n; ++k) {
+            long v = lrintf(hc[k] * 2048.0f);      // saturate_cast<short>(coef * INTER_RESIZE_COEF_SCALE)
+            ha[k] = (int)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+        }
+        PMX_HIP(hipMemcpy(d_i + n, ha.data(), n * sizeof(int), hipMemcpyHostToDevice));
+    } else {
+        PMX_HIP(hipMemcpy(d_i + n, hc.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    }
+    *xi = d_i; *yi = d_i + 4 * dw;
+    *xc = (void*)(d_i + n); *yc = (void*)((int*)(d_i + n) + 4 * dw);
+    return PMX_OK;
+}
+
+// detect_precise (pose_detector.py:433-470) accumulated on the device.  begin: zero the per-channel sums at the original size.
+extern "C" int pmx_precise_begin(pmx_ctx* c, int orig_h, int orig_w)
+{
+    PMX_CHECK(c && c->kind == NET_POSE, PMX_ERR_INVALID, "pmx_precise_begin: posenet context required");
+    PMX_CHECK(orig_h >= 1 && orig_w >= 1, PMX_ERR_INVALID, "pmx_precise_begin: bad size");
+    PMX_DEV(c);
+    const size_t need = (size_t)orig_h * orig_w;
+    if (need > c->ext_cap) {
+        PMX_HIP(hipStreamSynchronize(c->stream));
+        if (c->ext_paf) (void)hipFree(c->ext_paf);
+        if (c->ext_heat) (void)hipFree(c->ext_heat);
+        c->ext_paf = c->ext_heat = nullptr;
+        PMX_HIP(hipMalloc((void**)&c->ext_paf, need * PMX_N_PAF * 4));
+        PMX_HIP(hipMalloc((void**)&c->ext_heat, need * PMX_N_HEAT * 4));
+        c->ext_cap = need;
+    }
+    PMX_HIP(hipMemsetAsync(c->ext_paf, 0, need * PMX_N_PAF * 4, c->stream));
+    PMX_HIP(hipMemsetAsync(c->ext_heat, 0, need * PMX_N_HEAT * 4, c->stream));
+    c->pr_h = orig_h; c->pr_w = orig_w; c->pr_scales = 0;
+    c->maps_valid = false;
+    return PMX_OK;
+}
+
+// one scale of the loop at :441-467: cubic resize of the uint8 image to (scaled_h, scaled_w) (:443), pad to a multiple of 8
+// with (104, 117, 123) (:445), forward (:451), x8 cubic up-sampling of both outputs (:461,465), crop of the padding
+// (:462,466), cubic resize to the original size and accumulation (:463,467).  `img`: host uint8 orig_h x orig_w x 3.
+extern "C" int pmx_precise_add_scale(pmx_ctx* c, const uint8_t* img, int scaled_h, int scaled_w)
+{
+    PMX_CHECK(c && img && c->pr_h > 0, PMX_ERR_STATE, "pmx_precise_add_scale: call pmx_precise_begin first");
+    PMX_CHECK(scaled_h >= 1 && scaled_w >= 1, PMX_ERR_INVALID, "bad size");
+    PMX_DEV(c);
+    const int oh = c->pr_h, ow = c->pr_w;
+    const int ph = round_up(scaled_h, 8), pw = round_up(scaled_w, 8);
+    PMX_CHECK((size_t)ph * pw <= (size_t)c->max_h * c->max_w && c->max_batch >= 1, PMX_ERR_CAPACITY,
+              "pmx_precise_add_scale: padded size %d x %d exceeds the context capacity %d x %d", ph, pw, c->max_h, c->max_w);
+    int missing = 0;
+    for (auto& l : c->layers) missing += l.set ? 0 : 1;
+    PMX_CHECK(missing == 0, PMX_ERR_WEIGHTS, "pmx_precise_add_scale: %d layers have no weights", missing);
+    int rc;
+    // original image -> device
+    const size_t nsrc = (size_t)oh * ow * 3;
+    if (nsrc > c->u8_src_cap) {
+        PMX_HIP(hipStreamSynchronize(c->stream));
+        if (c->u8_src) (void)hipFree(c->u8_src);
+        c->u8_src = nullptr;
+        PMX_HIP(hipMalloc((void**)&c->u8_src, nsrc));
+        c->u8_src_cap = nsrc;
+    }
+    PMX_HIP(hipMemcpyAsync(c->u8_src, img, nsrc, hipMemcpyHostToDevice, c->stream));
+    int *xi, *yi; void *xc, *yc;
+    // (1) uint8 cubic resize into the padded image
+    if ((rc = launch_fill_bgr(c->u8_tmp, (long long)ph * pw, 104, 117, 123, c->stream))) return rc;
+    if (scaled_h == oh && scaled_w == ow) {
+        PMX_HIP(hipMemcpy2DAsync(c->u8_tmp, (size_t)pw * 3, c->u8_src, (size_t)ow * 3, (size_t)ow * 3, oh, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        if ((rc = upload_cubic_tables(c, oh, ow, scaled_h, scaled_w, true, &xi, &xc, &yi, &yc))) return rc;
+        if ((rc = launch_resize_cubic_u8(c->u8_src, ow, c->u8_tmp, scaled_h, scaled_w, pw, xi, (const int*)xc, yi, (const int*)yc, c->stream))) return rc;
+    }
+    // (2) network
+    if ((rc = launch_prep_u8(c->u8_tmp, c->in16, 1, ph, pw, 255.0f, c->stream))) return rc;
+    if ((rc = forward_from_in16(c, 1, ph, pw))) return rc;
+    const int fh = ph / 8, fw = pw / 8;
+    // (3) x8 cubic up-sampling of PAF (38) and heat (19) channels into NHWC-57
+    const size_t ntmp = (size_t)ph * pw * 57;
+    if (ntmp > c->pr_tmp_cap) {
+        PMX_HIP(hipStreamSynchronize(c->stream));
+        if (c->pr_tmp) (void)hipFree(c->pr_tmp);
+        c->pr_tmp = nullptr;
+        PMX_HIP(hipMalloc((void**)&c->pr_tmp, ntmp * sizeof(float)));
+        c->pr_tmp_cap = ntmp;
+    }
+    if ((rc = upload_cubic_tables(c, fh, fw, ph, pw, false, &xi, &xc, &yi, &yc))) return rc;
+    const long long sy = (long long)fw * PMX_CAT_C, sx = PMX_CAT_C;
+    // PAF and heat are separate arrays in the reference (two cv2.resize calls); here two launches into one NHWC-57 buffer
+    // would need a strided destination, so each map set gets its own dense NHWC temp region: [ph*pw*38 | ph*pw*19]
+    float* t_paf = c->pr_tmp;
+    float* t_heat = c->pr_tmp + (size_t)ph * pw * PMX_N_PAF;
+    if ((rc = launch_resize_cubic_f32(c->cat + PMX_CAT_PAF, sy, sx, 1, PMX_N_PAF, t_paf, ph, pw, xi, (const float*)xc, yi, (const float*)yc, 0, 0, c->stream))) return rc;
+    if ((rc = launch_resize_cubic_f32(c->cat + PMX_CAT_HEAT, sy, sx, 1, PMX_N_HEAT, t_heat, ph, pw, xi, (const float*)xc, yi, (const float*)yc, 0, 0, c->stream))) return rc;
+    // (4) crop the padding (source extent scaled_h x scaled_w of the padded maps) and cubic resize to the original size, accumulating
+    if ((rc = upload_cubic_tables(c, scaled_h, scaled_w, oh, ow, false, &xi, &xc, &yi, &yc))) return rc;
+    if ((rc = launch_resize_cubic_f32(t_paf, (long long)pw * PMX_N_PAF, PMX_N_PAF, 1, PMX_N_PAF, c->ext_paf, oh, ow, xi, (const float*)xc, yi,
+                                      (const float*)yc, 1, 0, c->stream))) return rc;
+    if ((rc = launch_resize_cubic_f32(t_heat, (long long)pw * PMX_N_HEAT, PMX_N_HEAT, 1, PMX_N_HEAT, c->ext_heat, oh, ow, xi, (const float*)xc, yi,
+                                      (const float*)yc, 1, 0, c->stream))) return rc;
+    c->pr_scales += 1;
+    c->maps_valid = false;       // the cat buffer holds one scale only; the averaged maps become valid in pmx_precise_finish
+    return PMX_OK;
+}
+
+// :469-470: divide the sums by the number of scales and install them as the maps of a batch of one at the original size
+extern "C" int pmx_precise_finish(pmx_ctx* c)
+{
+    PMX_CHECK(c && c->pr_h > 0 && c->pr_scales > 0, PMX_ERR_STATE, "pmx_precise_finish: nothing accumulated");
+    PMX_DEV(c);
+    int rc;
+    const long long n = (long long)c->pr_h * c->pr_w;
+    if ((rc = launch_scale_f32(c->ext_paf, n * PMX_N_PAF, (float)c->pr_scales, c->stream))) return rc;
+    if ((rc = launch_scale_f32(c->ext_heat, n * PMX_N_HEAT, (float)c->pr_scales, c->stream))) return rc;
+    c->maps_valid = true; c->maps_external = true;
+    c->cur_B = 1; c->cur_fh = c->pr_h; c->cur_fw = c->pr_w;
+    c->pp_valid = false;
+    c->pr_scales = 0;
     return PMX_OK;
 }
 

@@ -91,6 +91,12 @@ int launch_prep_u8(const uint8_t* bgr, float* out16, int B, int H, int W, float 
 int launch_prep_f32(const float* x_nchw, float* out16, int B, int H, int W, hipStream_t s);
 int launch_resize_linear_u8(const uint8_t* src, uint8_t* dst, const int* xtab, const int* ytab, int B, int sh, int sw, int dh, int dw,
                             hipStream_t s);
+int launch_resize_cubic_f32(const float* src, long long sy, long long sx, long long sc, int C, float* dst, int dh, int dw,
+                            const int* xi, const float* xc, const int* yi, const float* yc, int accumulate, int dst_c0, hipStream_t s);
+int launch_resize_cubic_u8(const uint8_t* src, int sw, uint8_t* dst, int dh, int dw, int dpitch, const int* xi, const int* xa,
+                           const int* yi, const int* ya, hipStream_t s);
+int launch_fill_bgr(uint8_t* dst, long long npix, int b, int g, int r, hipStream_t s);
+int launch_scale_f32(float* p, long long n, float divisor, hipStream_t s);
 int launch_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, int ldc, int coff, hipStream_t s);
 int launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, int lda, int coff, hipStream_t s);
 

@@ -105,6 +105,87 @@ __global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __
     }
 }
 
+// ---- cv2.resize(..., interpolation=cv2.INTER_CUBIC) restated (detect_precise, reference pose_detector.py:443,461-467) ----
+// Tables per axis (host, pmx_api.hip::make_cubic_table): 4 clamped source indices and 4 float32 coefficients (OpenCV's
+// bicubic, A = -0.75) per destination coordinate, laid out [k][dst].  Arithmetic order = the NumPy restatement
+// (pose_detector.py::resize_cubic_*, oracle/precise_ref.py): horizontal 4-tap sums for the 4 source rows, then the
+// vertical 4-tap sum, float32 products added left to right (this file is compiled with -ffp-contract=off).
+
+// float32: src(y, x, c) = src[y * sy + x * sx + c * sc], C channels; dst either NHWC (dst[(y * dw + x) * C + c], accumulate = 0)
+// or planar with accumulation (dst[(c * dh + y) * dw + x] += v, accumulate = 1; the per-scale sums of :463,467)
+__global__ __launch_bounds__(256) void resize_cubic_f32_kernel(const float* __restrict__ src, long long sy, long long sx, long long sc,
+                                                               int C, float* __restrict__ dst, int dh, int dw,
+                                                               const int* __restrict__ xi, const float* __restrict__ xc,
+                                                               const int* __restrict__ yi, const float* __restrict__ yc,
+                                                               int accumulate, int dst_c0)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n = (long long)dh * dw * C;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    const long long p = i / C;
+    const int x = (int)(p % dw), y = (int)(p / dw);
+    const float* s = src + (long long)c * sc;
+    float rows[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float* r = s + (long long)yi[k * dh + y] * sy;
+        float a = r[(long long)xi[x] * sx] * xc[x];
+        a = a + r[(long long)xi[dw + x] * sx] * xc[dw + x];
+        a = a + r[(long long)xi[2 * dw + x] * sx] * xc[2 * dw + x];
+        a = a + r[(long long)xi[3 * dw + x] * sx] * xc[3 * dw + x];
+        rows[k] = a;
+    }
+    float v = rows[0] * yc[y];
+    v = v + rows[1] * yc[dh + y];
+    v = v + rows[2] * yc[2 * dh + y];
+    v = v + rows[3] * yc[3 * dh + y];
+    if (accumulate) {
+        float* d = dst + ((long long)(dst_c0 + c) * dh + y) * dw + x;
+        *d = *d + v;
+    } else {
+        dst[p * C + c] = v;
+    }
+}
+
+// uint8 HWC, 11-bit fixed point: rows = sum(src * ax) (int32), out = (sum(rows * ay) + (1 << 21)) >> 22, saturated.
+// dst has row pitch `dpitch` pixels (the resized image is written into the top-left corner of the padded image, :445)
+__global__ __launch_bounds__(256) void resize_cubic_u8_kernel(const uint8_t* __restrict__ src, int sw, uint8_t* __restrict__ dst,
+                                                              int dh, int dw, int dpitch, const int* __restrict__ xi,
+                                                              const int* __restrict__ xa, const int* __restrict__ yi, const int* __restrict__ ya)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)dh * dw) return;
+    const int x = (int)(i % dw), y = (int)(i / dw);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        long long acc = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint8_t* r = src + ((long long)yi[k * dh + y] * sw) * 3 + c;
+            const long long row = (long long)r[xi[x] * 3] * xa[x] + (long long)r[xi[dw + x] * 3] * xa[dw + x] +
+                                  (long long)r[xi[2 * dw + x] * 3] * xa[2 * dw + x] + (long long)r[xi[3 * dw + x] * 3] * xa[3 * dw + x];
+            acc += row * ya[k * dh + y];
+        }
+        long long v = (acc + (1ll << 21)) >> 22;
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        dst[((long long)y * dpitch + x) * 3 + c] = (uint8_t)v;
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_bgr_kernel(uint8_t* __restrict__ dst, long long npix, int b, int g, int r)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    dst[i * 3] = (uint8_t)b; dst[i * 3 + 1] = (uint8_t)g; dst[i * 3 + 2] = (uint8_t)r;
+}
+
+__global__ __launch_bounds__(256) void scale_f32_kernel(float* __restrict__ p, long long n, float divisor)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = p[i] / divisor;
+}
+
 static inline unsigned nblocks(long long n) { return (unsigned)((n + 255) / 256); }
 
 int launch_prep_u8(const uint8_t* bgr, float* out16, int B, int H, int W, float divisor, hipStream_t s)
@@ -146,6 +227,38 @@ int launch_resize_linear_u8(const uint8_t* src, uint8_t* dst, const int* xtab, c
 {
     const long long npix = (long long)B * dh * dw;
     hipLaunchKernelGGL(resize_linear_u8_kernel, dim3(nblocks(npix)), dim3(256), 0, s, src, dst, xtab, ytab, B, sh, sw, dh, dw);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+int launch_resize_cubic_f32(const float* src, long long sy, long long sx, long long sc, int C, float* dst, int dh, int dw,
+                            const int* xi, const float* xc, const int* yi, const float* yc, int accumulate, int dst_c0, hipStream_t s)
+{
+    const long long n = (long long)dh * dw * C;
+    hipLaunchKernelGGL(resize_cubic_f32_kernel, dim3(nblocks(n)), dim3(256), 0, s, src, sy, sx, sc, C, dst, dh, dw, xi, xc, yi, yc,
+                       accumulate, dst_c0);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+int launch_resize_cubic_u8(const uint8_t* src, int sw, uint8_t* dst, int dh, int dw, int dpitch, const int* xi, const int* xa,
+                           const int* yi, const int* ya, hipStream_t s)
+{
+    hipLaunchKernelGGL(resize_cubic_u8_kernel, dim3(nblocks((long long)dh * dw)), dim3(256), 0, s, src, sw, dst, dh, dw, dpitch, xi, xa, yi, ya);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+int launch_fill_bgr(uint8_t* dst, long long npix, int b, int g, int r, hipStream_t s)
+{
+    hipLaunchKernelGGL(fill_bgr_kernel, dim3(nblocks(npix)), dim3(256), 0, s, dst, npix, b, g, r);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+int launch_scale_f32(float* p, long long n, float divisor, hipStream_t s)
+{
+    hipLaunchKernelGGL(scale_f32_kernel, dim3(nblocks(n)), dim3(256), 0, s, p, n, divisor);
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }

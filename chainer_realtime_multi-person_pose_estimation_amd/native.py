@@ -117,6 +117,9 @@ def load():
         'pmx_create': (ci, [C.POINTER(vp), ci, ci, ci, ci]),
         'pmx_create_net': (ci, [C.POINTER(vp), C.c_char_p, ci, ci, ci, ci]),
         'pmx_keypoints': (ci, [vp, ci, ci, ci, cd, vp]),
+        'pmx_precise_begin': (ci, [vp, ci, ci]),
+        'pmx_precise_add_scale': (ci, [vp, vp, ci, ci]),
+        'pmx_precise_finish': (ci, [vp]),
         'pmx_destroy': (None, [vp]),
         'pmx_set_stream': (ci, [vp, vp]),
         'pmx_synchronize': (ci, [vp]),
@@ -299,6 +302,19 @@ class Engine(object):
         self._check(self.lib.pmx_set_maps(self._ctx, None, _ptr(heat), B, fh, fw))
         self._B = B
         self._fhw = (fh, fw)
+
+    def precise_begin(self, orig_h, orig_w):
+        self._check(self.lib.pmx_precise_begin(self._ctx, int(orig_h), int(orig_w)))
+        self._precise_hw = (int(orig_h), int(orig_w))
+
+    def precise_add_scale(self, img_u8, scaled_h, scaled_w):
+        img = np.ascontiguousarray(img_u8, dtype=np.uint8)
+        self._check(self.lib.pmx_precise_add_scale(self._ctx, _ptr(img), int(scaled_h), int(scaled_w)))
+
+    def precise_finish(self):
+        self._check(self.lib.pmx_precise_finish(self._ctx))
+        self._B = 1
+        self._fhw = self._precise_hw
 
     def keypoints(self, out_h, out_w, thresh):
         """facenet / handnet: (B, maps - 1, 4) float64 rows (x, y, confidence, valid)."""

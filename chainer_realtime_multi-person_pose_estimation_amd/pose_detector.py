@@ -131,9 +131,12 @@ class PoseDetector(object):
         """reference pose_detector.py:433-482: average the network outputs over `inference_scales`, resized
         (cv2 INTER_CUBIC, restated in resize_cubic_*) to the ORIGINAL resolution, then the same post-process at that
         resolution with img_len = orig_img_w (:478) and no coordinate rescale.  The four forward passes and the
-        full-resolution post-process run on the GPU; the cubic resizes are host code as in the reference."""
+        full-resolution post-process run on the GPU.  With the native network the cubic resizes and the accumulation run on
+        the device too (pmx_precise_*); with a plugged-in `model=` callable they are host code as in the reference."""
         orig_img = np.ascontiguousarray(orig_img, dtype=np.uint8)
         orig_img_h, orig_img_w, _ = orig_img.shape
+        if self.model is None:
+            return self._detect_precise_device(orig_img)
         pafs_sum = 0
         heatmaps_sum = 0
         for scale in params['inference_scales']:
@@ -141,17 +144,9 @@ class PoseDetector(object):
             img = resize_cubic_u8(orig_img, math.ceil(orig_img_w * multiplier), math.ceil(orig_img_h * multiplier))
             padded_img, pad = self.pad_image(img, params['downscale'], (104, 117, 123))              # :445
             p_h, p_w = padded_img.shape[:2]
-            if self.model is None:
-                if self._weights is None:
-                    raise RuntimeError('PoseDetector has no weights: pass weights_file=, weights= or model=')
-                self._grow(1, p_h, p_w)
-                self.engine.forward_u8(padded_img[None])                                             # :451
-                paf, heat = self.engine.get_maps()
-                paf, heat = paf[0], heat[0]
-            else:
-                h1s, h2s = self.model(self.preprocess(padded_img))
-                paf = np.asarray(_data(h1s[-1]), dtype=np.float32)[0]
-                heat = np.asarray(_data(h2s[-1]), dtype=np.float32)[0]
+            h1s, h2s = self.model(self.preprocess(padded_img))
+            paf = np.asarray(_data(h1s[-1]), dtype=np.float32)[0]
+            heat = np.asarray(_data(h2s[-1]), dtype=np.float32)[0]
             tmp_paf = np.ascontiguousarray(paf.transpose(1, 2, 0))                                   # :453
             tmp_heatmap = np.ascontiguousarray(heat.transpose(1, 2, 0))                              # :454
             tmp_paf = resize_cubic_f32(tmp_paf, p_w, p_h)                                            # :461
@@ -167,6 +162,29 @@ class PoseDetector(object):
         # post-process at the original resolution on the device (resize to the same size is the identity)
         self._grow(1, 8, 8)
         self.engine.set_maps(np.ascontiguousarray(self.pafs)[None], np.ascontiguousarray(self.heatmaps)[None])
+        self.engine.postprocess(orig_img_h, orig_img_w, img_len=orig_img_w, scale_xy=None)           # :475-481
+        self.all_peaks = self.engine.peaks(0)
+        return unpack_results(self.engine.results())[0]
+
+    def _detect_precise_device(self, orig_img, fetch_maps=True):
+        """detect_precise with everything between the uint8 image and the result record on the device."""
+        if self._weights is None:
+            raise RuntimeError('PoseDetector has no weights: pass weights_file=, weights= or model=')
+        orig_img_h, orig_img_w, _ = orig_img.shape
+        sizes = []
+        for scale in params['inference_scales']:
+            multiplier = scale * params['inference_img_size'] / min(orig_img.shape[:2])            # :442
+            sizes.append((math.ceil(orig_img_h * multiplier), math.ceil(orig_img_w * multiplier)))
+        ds = params['downscale']
+        big = max(sizes)
+        self._grow(1, -(-big[0] // ds) * ds, -(-big[1] // ds) * ds)
+        self.engine.precise_begin(orig_img_h, orig_img_w)
+        for sh, sw in sizes:
+            self.engine.precise_add_scale(orig_img, sh, sw)                                          # :443-467
+        self.engine.precise_finish()                                                                 # :469-470
+        if fetch_maps:
+            pafs, heatmaps = self.engine.get_maps()
+            self.pafs, self.heatmaps = pafs[0], heatmaps[0]
         self.engine.postprocess(orig_img_h, orig_img_w, img_len=orig_img_w, scale_xy=None)           # :475-481
         self.all_peaks = self.engine.peaks(0)
         return unpack_results(self.engine.results())[0]

@@ -126,6 +126,14 @@ int pmx_set_maps(pmx_ctx* ctx, const float* paf_nchw, const float* heat_nchw, in
 int pmx_set_gaussian(pmx_ctx* ctx, const double* taps, int radius);
 int pmx_postprocess(pmx_ctx* ctx, int batch, int map_h, int map_w, double img_len, const double* scale_xy);
 
+/* ---- detect_precise (pose_detector.py:433-482) accumulated on the device ------------------------------------
+ * begin(orig size) -> add_scale(host uint8 orig image, scaled size = ceil(orig * multiplier), :442-443) per inference scale ->
+ * finish() (average, :469-470; installs the full-resolution maps as a batch of one) -> pmx_postprocess(ctx, 1, orig_h,
+ * orig_w, img_len = orig_w, NULL) (:475-481).  cv2.resize(INTER_CUBIC) is restated (uint8 fixed-point and float32 paths). */
+int pmx_precise_begin(pmx_ctx* ctx, int orig_h, int orig_w);
+int pmx_precise_add_scale(pmx_ctx* ctx, const uint8_t* bgr_hwc, int scaled_h, int scaled_w);
+int pmx_precise_finish(pmx_ctx* ctx);
+
 /* FaceDetector / HandDetector post-process (face_detector.py:37-38,58-68; hand_detector.py:41,68-78) for facenet / handnet
  * contexts: F.resize_images(hs[-1], (out_h, out_w)) + gaussian_filter + per-channel arg-max.  out: batch x (maps - 1) x 4
  * float64 rows (x, y, confidence, valid); valid = 0 where the reference appends None.  Synchronises. */

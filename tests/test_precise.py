@@ -110,6 +110,44 @@ def test_detect_precise_native_network(native):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(120, 152), (97, 141), (368, 368)])
+def test_device_cubic_path_equals_host_restatement(native, shape):
+    """pmx_precise_* (cubic uint8 / float32 resizes, crop, accumulation, average on the device) is bit-identical to the
+    host restatement of the same steps fed by the same network kernels (the `model=` seam wrapping the engine)."""
+    PD = pkg('pose_detector')
+    W_ = pkg('weights')
+    weights = W_.synthetic_weights(0)
+    rng = np.random.default_rng(shape[0])
+    img = rng.integers(0, 256, shape + (3,), dtype=np.uint8)
+    dev = PD.PoseDetector(weights=weights, device=0, precise=True, max_size=(368, 472))
+    res_dev = None
+    try:
+        res_dev = dev(img)
+    except (IndexError, RuntimeError):        # random-weight maps may overflow the peak capacity; maps are still compared
+        pass
+    eng = dev.engine
+
+    def model(x):
+        eng.forward_f32(x)
+        paf, heat = eng.get_maps()
+        return [paf], [heat]
+    host = PD.PoseDetector(model=model, device=0, precise=True)
+    res_host = None
+    try:
+        res_host = host(img)
+    except (IndexError, RuntimeError):        # random-weight maps may overflow the peak capacity; maps are still compared
+        pass
+    assert np.array_equal(dev.pafs, host.pafs)
+    assert np.array_equal(dev.heatmaps, host.heatmaps)
+    assert (res_dev is None) == (res_host is None)
+    if res_dev is not None:
+        assert np.array_equal(np.asarray(res_dev[0]), np.asarray(res_host[0]))
+        assert np.array_equal(np.asarray(res_dev[1]), np.asarray(res_host[1]))
+    host.engine.close()
+    dev.engine.close()
+
+
+@pytest.mark.gpu
 def test_detect_precise_crowd_config5(native):
     """BASELINE config 5: multi-scale (0.5/1.0/1.5/2.0) crowd image -- 22 synthetic people at 482 x 642 (dinner.png's
     size), full PAF grouping stress at the ORIGINAL resolution.  Maps enter through the `model=` seam at every scale;

@@ -1,0 +1,29 @@
+"""Wall time of PoseDetector(precise=True) on one image: device path vs host-resize path (model= seam around the same engine)."""
+import sys, os, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import importlib
+PD = importlib.import_module('chainer_realtime_multi-person_pose_estimation_amd.pose_detector')
+W_ = importlib.import_module('chainer_realtime_multi-person_pose_estimation_amd.weights')
+weights = W_.synthetic_weights(0)
+img = np.random.default_rng(0).integers(0, 256, (480, 640, 3), dtype=np.uint8)
+dev = PD.PoseDetector(weights=weights, device=0, precise=True, max_size=(736, 984))
+for i in range(3):
+    t = time.time()
+    try:
+        dev(img)
+    except (IndexError, RuntimeError) as e:
+        print('note:', type(e).__name__)
+    print('device path  %.3f s' % (time.time() - t))
+eng = dev.engine
+def model(x):
+    eng.forward_f32(x)
+    paf, heat = eng.get_maps()
+    return [paf], [heat]
+host = PD.PoseDetector(model=model, device=0, precise=True)
+t = time.time()
+try:
+    host(img)
+except (IndexError, RuntimeError) as e:
+    print('note:', type(e).__name__)
+print('host-resize path  %.3f s' % (time.time() - t))
