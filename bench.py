@@ -163,9 +163,12 @@ def main():
 
     def step():
         eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(B, S, S), map_h=map_s, map_w=map_s)
+        if world > 1 and a.backend == 'nccl':
+            # RCCL all_gather (the only collective) straight from the device-resident records, then one D2H copy
+            return dist_mod.gather_device_records(eng, B, native.RESULT_DTYPE)
         rec = eng.results()                           # stream sync + D2H of the fixed-size records
         if world > 1:
-            rec = dist_mod.gather_records(rec, device=coll_dev)     # RCCL all_gather (the only collective)
+            rec = dist_mod.gather_records(rec, device=coll_dev)     # smoke mode (gloo): gather through the host
         return rec
 
     for _ in range(a.warmup):

@@ -42,3 +42,29 @@ def gather_records(local_records, group=None, device=None):
         b = outs[r][:counts[r] * itemsize].cpu().numpy().tobytes()
         parts.append(np.frombuffer(b, dtype=local_records.dtype, count=counts[r]))
     return np.concatenate(parts) if parts else local_records[:0].copy()
+
+
+class _DeviceBytes(object):
+    """Zero-copy view of `nbytes` of device memory for torch (``__cuda_array_interface__`` version 2)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {'shape': (int(nbytes),), 'typestr': '|u1', 'data': (int(ptr), False),
+                                         'version': 2, 'strides': None}
+
+
+def gather_device_records(engine, n_local, record_dtype, group=None):
+    """RCCL all_gather straight out of the engine's device-resident result records (equal shard sizes on every rank):
+    no host round trip before the collective, one device-to-host copy of the gathered records after it.
+
+    The engine runs on its own stream, so it is synchronised first; the collective then runs on torch's RCCL stream."""
+    import torch
+    import torch.distributed as dist
+    ptr, rec_bytes = engine.results_device_ptr()
+    assert rec_bytes == np.dtype(record_dtype).itemsize
+    engine.synchronize()
+    dev = torch.device('cuda', engine.device)
+    view = torch.as_tensor(_DeviceBytes(ptr, n_local * rec_bytes), device=dev)
+    world = dist.get_world_size(group)
+    out = torch.empty(world * n_local * rec_bytes, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out, view, group=group)
+    return out.cpu().numpy().view(record_dtype)
