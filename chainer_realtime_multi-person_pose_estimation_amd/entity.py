@@ -2,12 +2,12 @@
 
 Mirrors the *inference* part of the reference's ``entity.py``:
   * ``JointType``  -- reference ``entity.py:9-45`` (18 COCO-style joints, same order/values)
-  * ``params``     -- reference ``entity.py:71-105`` (inference keys only; training keys,
-                      face/hand keys and the ``archs`` class map are out of the hot path)
+  * ``params``     -- reference ``entity.py:71-105,126-151`` (inference keys of the pose, face and hand detectors;
+                      training keys are out of the hot path; ``archs`` maps to native network names)
 
-The same numbers are compiled into the HIP library (``csrc/pmx_common.h``); the test
-``tests/test_entity.py`` checks both copies against each other and against the golden fixture
-generated from the reference module.
+The same numbers are compiled into the HIP library (``csrc/pmx_common.h``, ``include/pose_mi355x.h``);
+``tests/test_host.py`` checks both copies against each other and against the golden fixture generated from the
+reference module (``tests/golden/host_fns.json``).
 """
 from enum import IntEnum
 
