@@ -692,9 +692,44 @@ struct TapBody {
             }
         }
     }
+
+    // v5 form of the same tap: weights come through a buffer resource (SGPR descriptor of the group's packed weights) with
+    // a per-lane 32-bit byte offset (VGPR, loop invariant) and the next tap's panel offset in an SGPR (`wnext`), so the
+    // loop has no address VALU for them; the taps are fully unrolled by the caller, which makes tapoff / tapoff_next
+    // compile-time constants that fold into the ds_read immediate offsets.
+    static __device__ __forceinline__ void run_u(f32x16 (&acc)[C::MT][C::NT], f32x4 (&av0)[C::MT], f32x4 (&av1)[C::MT],
+                                                 const f32x4 (&bc)[C::NT][2], f32x4 (&bn)[C::NT][2], __amdgpu_buffer_rsrc_t wrsrc,
+                                                 unsigned wnext, const unsigned (&b_off)[C::NT], const float* cur,
+                                                 const int (&a_base)[C::MT], int tapoff, int tapoff_next)
+    {
+        constexpr int NM = 4 * C::MT * C::NT;
+        constexpr int NB = 2 * C::NT;
+        static_assert(NM >= NB + C::MT, "not enough MFMA gaps for the memory instructions of a k-step");
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            const int e = i / (C::MT * C::NT), t = (i / C::NT) % C::MT, u = i % C::NT;
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t][e], bc[u][0][e], acc[t][u], 0, 0, 0);
+            if (i < NB) {
+                bn[i >> 1][i & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[i >> 1] + (i & 1) * 32, wnext, 0));
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (i < NB + C::MT) {
+                av1[i - NB] = *reinterpret_cast<const f32x4*>(&cur[a_base[i - NB] + tapoff + 8]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            const int e = i / (C::MT * C::NT), t = (i / C::NT) % C::MT, u = i % C::NT;
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t][e], bc[u][1][e], acc[t][u], 0, 0, 0);
+            if (i < C::MT) {
+                av0[i] = *reinterpret_cast<const f32x4*>(&cur[a_base[i] + tapoff_next]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
 };
 
-template <int KS, int TH, int TW, int BN, int CK, int WM, int WN, int ABL = 0>
+template <int KS, int TH, int TW, int BN, int CK, int WM, int WN, int ABL = 0, int UNR = 0>
 __global__ __launch_bounds__(256, 2) void conv_mfma_v4_kernel(const ConvArgs a)
 {
     using C = ConvCfg<KS, TH, TW, BN, CK, WM, WN>;
@@ -749,6 +784,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v4_kernel(const ConvArgs a)
 #pragma unroll
     for (int u = 0; u < C::NT; ++u) b_ptr[u] = G.w + (size_t)(n0 + (wn * C::NT + u) * 32 + li) * CK + kh * 4;
     const size_t w_panel_stride = (size_t)a.cout_pad * CK;
+    // v5 (UNR): buffer resource over the group's packed weights (raw buffer, 32-bit byte offsets) + per-lane byte offsets
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G.w), 0, 0x7fffffff, 0x00020000);
+    unsigned b_off[C::NT];
+#pragma unroll
+    for (int u = 0; u < C::NT; ++u) b_off[u] = (unsigned)(((n0 + (wn * C::NT + u) * 32 + li) * CK + kh * 4) * 4);
 
     int h_lds[NHF], h_goff[NHF];
     bool h_ok[NHF];
@@ -807,31 +847,53 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v4_kernel(const ConvArgs a)
         }
         const size_t chunk_off = (size_t)ch * w_panel_stride;
         const size_t tap_stride = (size_t)a.nch * w_panel_stride;
-        // taps 0 .. T-2 in pairs (A -> B -> A), then the last tap (A -> B) and one copy B -> A per chunk.
-        // LDS tap offsets and weight panel offsets advance incrementally (no divisions / 64-bit multiplies in the loop).
-        size_t pnext = chunk_off + tap_stride;       // panel of tap 1
-        int toff = 0, kx = 0;                        // LDS offset of the current tap, its column
-        auto advance = [&](int off, int& col) {      // offset of the following tap
-            if (col + 1 == KS) { col = 0; return off + (C::HALO_W - KS + 1) * C::LDP; }
-            col += 1;
-            return off + C::LDP;
-        };
-#pragma unroll 1
-        for (int tap = 0; tap + 1 < C::T; tap += 2) {
-            const int toff1 = advance(toff, kx);
-            TapBody<C, KS, ABL>::run(acc, av0, av1, bA, bB, b_ptr, pnext, cur, a_base, toff, toff1);
-            pnext += tap_stride;
-            const int toff2 = advance(toff1, kx);
-            TapBody<C, KS, ABL>::run(acc, av0, av1, bB, bA, b_ptr, pnext, cur, a_base, toff1, toff2);
-            pnext += tap_stride;
-            toff = toff2;
-        }
-        {
-            // last tap: prefetch tap 0 of the next chunk (or re-read this panel on the very last chunk)
-            const size_t plast = more_ch ? chunk_off + w_panel_stride : (size_t)(C::T - 1) * tap_stride + chunk_off;
-            TapBody<C, KS, ABL>::run(acc, av0, av1, bA, bB, b_ptr, plast, cur, a_base, toff, toff);
+        if constexpr (UNR) {
+            // v5: all taps unrolled (LDS offsets become immediates), ping-pong register sets alternate at compile time
+            const unsigned chunk_b = (unsigned)(chunk_off * 4);
+            unsigned tap_b = (unsigned)(tap_stride * 4);
+            asm volatile("" : "+s"(tap_b));          // keep the 49 panel offsets from being hoisted out of the chunk loop
+            unsigned soff = chunk_b;                 // byte offset of the current tap's panel
 #pragma unroll
-            for (int u = 0; u < C::NT; ++u) { bA[u][0] = bB[u][0]; bA[u][1] = bB[u][1]; }
+            for (int tap = 0; tap < C::T; ++tap) {
+                const int toff = ((tap / KS) * C::HALO_W + tap % KS) * C::LDP;
+                const int tnx = tap + 1 < C::T ? tap + 1 : tap;
+                const int toff_n = ((tnx / KS) * C::HALO_W + tnx % KS) * C::LDP;
+                // next tap's panel; the last tap prefetches tap 0 of the next chunk (or re-reads its own panel at the very end)
+                unsigned wnext;
+                if (tap + 1 < C::T) { soff += tap_b; wnext = soff; }
+                else wnext = more_ch ? chunk_b + (unsigned)(w_panel_stride * 4) : soff;
+                if (tap & 1) TapBody<C, KS, ABL>::run_u(acc, av0, av1, bB, bA, wrsrc, wnext, b_off, cur, a_base, toff, toff_n);
+                else TapBody<C, KS, ABL>::run_u(acc, av0, av1, bA, bB, wrsrc, wnext, b_off, cur, a_base, toff, toff_n);
+            }
+#pragma unroll
+            for (int u = 0; u < C::NT; ++u) { bA[u][0] = bB[u][0]; bA[u][1] = bB[u][1]; }     // T is odd
+        } else {
+        // taps 0 .. T-2 in pairs (A -> B -> A), then the last tap (A -> B) and one copy B -> A per chunk.
+            // LDS tap offsets and weight panel offsets advance incrementally (no divisions / 64-bit multiplies in the loop).
+            size_t pnext = chunk_off + tap_stride;       // panel of tap 1
+            int toff = 0, kx = 0;                        // LDS offset of the current tap, its column
+            auto advance = [&](int off, int& col) {      // offset of the following tap
+                if (col + 1 == KS) { col = 0; return off + (C::HALO_W - KS + 1) * C::LDP; }
+                col += 1;
+                return off + C::LDP;
+            };
+    #pragma unroll 1
+            for (int tap = 0; tap + 1 < C::T; tap += 2) {
+                const int toff1 = advance(toff, kx);
+                TapBody<C, KS, ABL>::run(acc, av0, av1, bA, bB, b_ptr, pnext, cur, a_base, toff, toff1);
+                pnext += tap_stride;
+                const int toff2 = advance(toff1, kx);
+                TapBody<C, KS, ABL>::run(acc, av0, av1, bB, bA, b_ptr, pnext, cur, a_base, toff1, toff2);
+                pnext += tap_stride;
+                toff = toff2;
+            }
+            {
+                // last tap: prefetch tap 0 of the next chunk (or re-read this panel on the very last chunk)
+                const size_t plast = more_ch ? chunk_off + w_panel_stride : (size_t)(C::T - 1) * tap_stride + chunk_off;
+                TapBody<C, KS, ABL>::run(acc, av0, av1, bA, bB, b_ptr, plast, cur, a_base, toff, toff);
+    #pragma unroll
+                for (int u = 0; u < C::NT; ++u) { bA[u][0] = bB[u][0]; bA[u][1] = bB[u][1]; }
+            }
         }
         if (more_ch && !(ABL & 4)) {
 #pragma unroll
@@ -1082,6 +1144,14 @@ static const ConvVariant g_variants[] = {
     {3, 8, 16, 64, 16, "conv3x3_v4_t8x16_n64"},    // 29
     {7, 8, 8, 64, 16, "conv7x7_v4_t8x8_n64"},      // 30
     {3, 8, 8, 64, 16, "conv3x3_v4_t8x8_n64"},      // 31
+    // v5 kernels: v4 with the taps fully unrolled (immediate LDS offsets) and saddr weight loads (no address VALU in the loop)
+    {7, 2, 46, 128, 16, "conv7x7_v5_t2x46_n128"},  // 32
+    {3, 2, 46, 128, 16, "conv3x3_v5_t2x46_n128"},  // 33
+    {7, 8, 16, 128, 16, "conv7x7_v5_t8x16_n128"},  // 34
+    {3, 8, 16, 128, 16, "conv3x3_v5_t8x16_n128"},  // 35
+    {3, 8, 16, 64, 16, "conv3x3_v5_t8x16_n64"},    // 36
+    {7, 8, 8, 64, 16, "conv7x7_v5_t8x8_n64"},      // 37
+    {3, 8, 8, 64, 16, "conv3x3_v5_t8x8_n64"},      // 38
 };
 
 int conv_num_variants() { return (int)(sizeof(g_variants) / sizeof(g_variants[0])); }
@@ -1098,6 +1168,11 @@ int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen
     const bool small = tiles816 * ((cout + 127) / 128) < 512;
     // 2 x 46 row strips tile 46-wide maps exactly (8 x 16 tiles waste 8.9 %); on 92-wide maps they measured neutral
     const bool strip = (W == 46) && (cout % 128 == 0) && ((long)((H + 1) / 2) * B * (cout / 128) >= 512);
+    if (gen == 5) {      // v5 = v4 with unrolled taps / saddr weight loads where a variant exists
+        if (ks == 7) return strip ? 32 : (small ? 37 : 34);
+        if (ks == 3) return strip ? 33 : (small ? 38 : (cout <= 64 ? 36 : 35));
+        return small ? 7 : (cout <= 64 ? 4 : 3);
+    }
     if (gen == 4) {      // v4 kernels (interleaved memory instructions, 2 blocks per CU) for 3x3 / 7x7; launches that
                          // would not fill the chip with 8x16 tiles use the v4 8x8 / BN64 tiles (measured best for B = 1..16)
         if (ks == 7) return strip ? 25 : (small ? 30 : 27);
@@ -1182,7 +1257,8 @@ static int launch_v3(const ConvArgs& a0, int groups, hipStream_t stream)
     PMX_CHECK(a.cout_pad % BN == 0, PMX_ERR_INVALID, "conv: cout_pad %d not a multiple of BN %d", a.cout_pad, BN);
     PMX_CHECK(!a.pool || (a.H % 2 == 0 && a.W % 2 == 0), PMX_ERR_INVALID, "conv: pooled layer needs even H, W");
     PMX_CHECK((long long)a.H * a.W * a.lda < (1ll << 31), PMX_ERR_INVALID, "conv: image too large for 32-bit offsets");
-    auto kern = GEN == 4 ? conv_mfma_v4_kernel<KS, TH, TW, BN, CK, WM, WN> : conv_mfma_v3_kernel<KS, TH, TW, BN, CK, WM, WN>;
+    auto kern = GEN == 5 ? conv_mfma_v4_kernel<KS, TH, TW, BN, CK, WM, WN, 0, 1>
+                : (GEN == 4 ? conv_mfma_v4_kernel<KS, TH, TW, BN, CK, WM, WN> : conv_mfma_v3_kernel<KS, TH, TW, BN, CK, WM, WN>);
     int lds = 2 * C::IN_ELEMS * 4;
     if (lds < g_v3_lds) lds = g_v3_lds;
     if (lds < g_min_lds) lds = g_min_lds;
@@ -1292,6 +1368,13 @@ int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream)
         case 29: return launch_v3<3, 8, 16, 64, 16, 2, 2, 4>(a, groups, stream);
         case 30: return launch_v3<7, 8, 8, 64, 16, 2, 2, 4>(a, groups, stream);
         case 31: return launch_v3<3, 8, 8, 64, 16, 2, 2, 4>(a, groups, stream);
+        case 32: return launch_v3<7, 2, 46, 128, 16, 1, 4, 5>(a, groups, stream);
+        case 33: return launch_v3<3, 2, 46, 128, 16, 1, 4, 5>(a, groups, stream);
+        case 34: return launch_v3<7, 8, 16, 128, 16, 1, 4, 5>(a, groups, stream);
+        case 35: return launch_v3<3, 8, 16, 128, 16, 1, 4, 5>(a, groups, stream);
+        case 36: return launch_v3<3, 8, 16, 64, 16, 2, 2, 5>(a, groups, stream);
+        case 37: return launch_v3<7, 8, 8, 64, 16, 2, 2, 5>(a, groups, stream);
+        case 38: return launch_v3<3, 8, 8, 64, 16, 2, 2, 5>(a, groups, stream);
     }
     pmx_set_error("conv_launch: unknown variant %d", variant);
     return PMX_ERR_INVALID;

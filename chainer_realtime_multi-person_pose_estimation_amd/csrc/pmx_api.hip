@@ -195,7 +195,7 @@ struct pmx_ctx {
     // options
     int opt_force[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // by ksize
     int opt_gpu_branch_peaks = 0;    // reference GPU-branch peak extraction (non-golden variant)
-    int opt_keep_smoothed = 0, opt_stop_stage = 6, opt_kernel_gen = 4, opt_conv_dbg = 0;
+    int opt_keep_smoothed = 0, opt_stop_stage = 6, opt_kernel_gen = 5, opt_conv_dbg = 0;
     // timing / profiling
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool prof_on = false;

@@ -60,6 +60,19 @@ def test_v4_variants(engine, variant, k, cout, hw, cin):
     _case(engine, 3, cin, hw[0], hw[1], cout, k, True, False, seed=270 + variant, variant=variant)
 
 
+@pytest.mark.parametrize('variant,k,cout', [(32, 7, 128), (33, 3, 128), (34, 7, 128), (35, 3, 256), (36, 3, 64), (37, 7, 128),
+                                            (38, 3, 38)])
+@pytest.mark.parametrize('hw,cin', [((46, 46), 48), ((9, 21), 16), ((20, 50), 185)])
+def test_v5_variants(engine, variant, k, cout, hw, cin):
+    # v5: v4 with fully unrolled taps (immediate LDS offsets) and buffer-resource weight loads (no address VALU in the loop)
+    _case(engine, 3, cin, hw[0], hw[1], cout, k, True, False, seed=370 + variant, variant=variant)
+
+
+@pytest.mark.parametrize('variant', [35, 36])
+def test_v5_fused_relu_maxpool(engine, variant):
+    _case(engine, 2, 32, 24, 40, 64 if variant == 36 else 128, 3, True, True, seed=390 + variant, variant=variant)
+
+
 @pytest.mark.parametrize('variant', [28, 29])
 def test_v4_fused_relu_maxpool(engine, variant):
     _case(engine, 2, 32, 24, 40, 64 if variant == 29 else 128, 3, True, True, seed=290 + variant, variant=variant)
@@ -93,10 +106,13 @@ def test_v2_network_equals_v1_network_bitwise(engine):
     engine.set_option('kernel_gen', 4)
     engine.forward_u8(img)
     p4, h4 = engine.get_maps()
-    engine.set_option('kernel_gen', 4)      # library default
+    engine.set_option('kernel_gen', 5)      # library default
+    engine.forward_u8(img)
+    p5, h5 = engine.get_maps()
     assert np.array_equal(p1, p2) and np.array_equal(h1, h2)
     assert np.array_equal(p1, p3) and np.array_equal(h1, h3)
     assert np.array_equal(p1, p4) and np.array_equal(h1, h4)
+    assert np.array_equal(p1, p5) and np.array_equal(h1, h5)
 
 
 @pytest.mark.parametrize('variant,k', [(8, 7), (9, 3)])
