@@ -729,8 +729,8 @@ struct TapBody {
     }
 };
 
-template <int KS, int TH, int TW, int BN, int CK, int WM, int WN, int ABL = 0, int UNR = 0>
-__global__ __launch_bounds__(256, 2) void conv_mfma_v4_kernel(const ConvArgs a)
+template <int KS, int TH, int TW, int BN, int CK, int WM, int WN, int ABL, int UNR>
+__device__ __forceinline__ void conv_v45_body(const ConvArgs& a)
 {
     using C = ConvCfg<KS, TH, TW, BN, CK, WM, WN>;
     static_assert(CK == 16 && KS > 1 && (KS * KS) % 2 == 1, "v4: 16-channel chunks, odd number of taps");
@@ -910,6 +910,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v4_kernel(const ConvArgs a)
 
     // ---- epilogue (identical to v1) ----
 conv_epilogue<C, TW>(acc, biasv, a, G.out, G.cout, bimg, y0, x0, n0, wm, wn, li, kh);
+}
+
+template <int KS, int TH, int TW, int BN, int CK, int WM, int WN, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void conv_mfma_v4_kernel(const ConvArgs a)
+{
+    conv_v45_body<KS, TH, TW, BN, CK, WM, WN, ABL, 0>(a);
+}
+
+// v5 = the v4 schedule with the taps fully unrolled and buffer-resource weight loads (see TapBody::run_u)
+template <int KS, int TH, int TW, int BN, int CK, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_mfma_v5_kernel(const ConvArgs a)
+{
+    conv_v45_body<KS, TH, TW, BN, CK, WM, WN, 0, 1>(a);
 }
 
 // Ablation twin of v3 (timing experiments only, results are wrong when ABL != 0): ABL bit0 = weight fragments loaded
@@ -1257,7 +1270,7 @@ static int launch_v3(const ConvArgs& a0, int groups, hipStream_t stream)
     PMX_CHECK(a.cout_pad % BN == 0, PMX_ERR_INVALID, "conv: cout_pad %d not a multiple of BN %d", a.cout_pad, BN);
     PMX_CHECK(!a.pool || (a.H % 2 == 0 && a.W % 2 == 0), PMX_ERR_INVALID, "conv: pooled layer needs even H, W");
     PMX_CHECK((long long)a.H * a.W * a.lda < (1ll << 31), PMX_ERR_INVALID, "conv: image too large for 32-bit offsets");
-    auto kern = GEN == 5 ? conv_mfma_v4_kernel<KS, TH, TW, BN, CK, WM, WN, 0, 1>
+    auto kern = GEN == 5 ? conv_mfma_v5_kernel<KS, TH, TW, BN, CK, WM, WN>
                 : (GEN == 4 ? conv_mfma_v4_kernel<KS, TH, TW, BN, CK, WM, WN> : conv_mfma_v3_kernel<KS, TH, TW, BN, CK, WM, WN>);
     int lds = 2 * C::IN_ELEMS * 4;
     if (lds < g_v3_lds) lds = g_v3_lds;

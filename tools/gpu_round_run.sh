@@ -1,13 +1,18 @@
+# Round measurement on the GPU box: GPU tests, rocprofv3 kernel stats, PMC passes (one counter group per pass, as
+# MI355X_MICROARCH.md prescribes), their summary, then bench.py (whose roofline.traffic reads that summary).
+# Usage: gpurun -- 'bash tools/gpu_round_run.sh r01'; afterwards here: python tools/summarize_profiles.py r01
+ROUND=${1:-r01}
 R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=$R/gpurun_out; mkdir -p $O; cd $R
 (timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -60) > $O/pytest_gpu.log
-(timeout 300 python tools/profile_driver.py --batch 32 --steps 3 --k7 0 --k3 1 --profile-json $O/prof_old_tiles.json) > $O/drv_old.log 2>&1
+(timeout 300 python tools/profile_driver.py --batch 32 --steps 3 --gen 4 --profile-json $O/prof_gen4.json) > $O/drv_old.log 2>&1
 (timeout 300 python tools/profile_driver.py --batch 32 --steps 3 --profile-json $O/prof_strip_tiles.json) > $O/drv_new.log 2>&1
-(timeout 600 python bench.py --steps 5 --warmup 2 --dump-profile $O/prof_bench.json) > $O/bench.log 2>&1
 cd /tmp
 (timeout 300 rocprofv3 --kernel-trace --stats -d $O/rp_stats -o drv --output-format csv -- python $R/tools/profile_driver.py --batch 32 --steps 3) > $O/rp_stats.log 2>&1
-(rocprofv3 -L 2>&1 | grep -E "^\s*(Name|gpu|Counter)|FETCH_SIZE|WRITE_SIZE|MFMA|GRBM_GUI|SQ_WAVE_CYCLES|SQ_WAIT|SQ_ACTIVE_INST_ANY|SQ_BUSY|LDS_BANK|LDS_IDX" | head -80) > $O/counters.txt 2>&1
 for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   N=$(echo $P | cut -d" " -f1)
   (timeout 300 rocprofv3 --pmc $P --kernel-trace -d $O/pmc_$N -o drv --output-format csv -- python $R/tools/profile_driver.py --batch 32 --steps 1) > $O/pmc_$N.log 2>&1
 done
-cd $R; tail -3 $O/pytest_gpu.log; tail -2 $O/drv_old.log $O/drv_new.log; tail -1 $O/bench.log; ls -R $O | head -60; du -sh $O
+cd $R
+python tools/summarize_profiles.py $ROUND > $O/summary.log 2>&1
+(timeout 600 python bench.py --steps 5 --warmup 2 --dump-profile $O/prof_bench.json) > $O/bench.log 2>&1
+tail -3 $O/pytest_gpu.log; tail -2 $O/drv_old.log $O/drv_new.log; tail -1 $O/bench.log; du -sh $O
