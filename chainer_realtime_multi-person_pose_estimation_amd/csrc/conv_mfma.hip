@@ -925,6 +925,230 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v5_kernel(const ConvArgs a)
     conv_v45_body<KS, TH, TW, BN, CK, WM, WN, 0, 1>(a);
 }
 
+// ---- v6: one block per CU, 17 MFMA row tiles of consecutive pixels per wave -------------------------------------------
+// For W-wide maps whose launch would otherwise quantise badly (46x46 at batch 32: 1472 strip blocks on 512 slots = 2.875
+// rounds, 92 -> 96 padded rows): a block owns MT*32 CONSECUTIVE pixels of one image in row-major order (MT = 17: 544 px,
+// 4 blocks per 46x46 image = 2.8 % padding; batch 32 x 2 branch groups x 4 = 256 blocks = one per CU) and all 128 output
+// channels of the group (wave w = channels 32w..32w+31, all MT row tiles: 272 accumulator registers, 1 wave per SIMD).
+// Same 16-channel chunks, same tap / k8-step / k order as every other generation -> bit-identical results.
+//   LDS: the SPAN+KS-1 input rows the pixel run touches, full width + padding columns, 16 channels, double-buffered
+//        (7x7: 2 x 19 x 52 x 20 floats = 158 080 B -> exactly one block per CU).
+//   Inner loop (one kernel row = KS taps x 2 k8-steps x MT tiles, fully unrolled; rows are a run-time loop): per "unit"
+//        (tap, step, tile) 4 MFMAs + one ds_read_b128 that refills a RING-deep A-fragment ring DIST units ahead (immediate
+//        offsets, also across the row boundary); one buffer_load_dwordx4 of weights per step, one step ahead.
+template <int KS, int W, int MT>
+struct V6Cfg {
+    static constexpr int PADK = KS / 2, T = KS * KS, CK = 16, LDP = 20, M = MT * 32;
+    static constexpr int SPAN = (W - 1 + M - 1) / W + 1;          // image rows a run of M consecutive pixels can touch
+    static constexpr int HALO_H = SPAN + KS - 1, HALO_W = W + KS - 1;
+    static constexpr int IN_ELEMS = HALO_H * HALO_W * LDP;
+    static constexpr int LDS_BYTES = 2 * IN_ELEMS * 4;
+    static constexpr int NHF = (HALO_H * HALO_W * (CK / 4) + 255) / 256;
+    static constexpr int UNITS_ROW = KS * 2 * MT;
+    static constexpr int RING = KS == 7 ? 7 : 6, DIST = RING - 1;
+    static_assert(UNITS_ROW % RING == 0, "the A ring must close over one kernel row");
+    static_assert(LDS_BYTES <= 160 * 1024, "halo double buffer exceeds the LDS");
+    static_assert(NHF <= 32, "halo slot mask is 32 bits");
+};
+
+// One of the MT accumulator tiles must live in VGPRs: the compiler's MFMAs take C/D from AGPRs and 17 tiles need 272 > 256
+// of them (it would shuttle one tile through v_accvgpr moves around every use).  VGPR-form MFMA, same instruction.
+__device__ __forceinline__ void mfma_32x32x2_vgpr(f32x16& acc, float a, float b)
+{
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+
+template <int KS, int W, int MT>
+__global__ __launch_bounds__(256, 1) void conv_mfma_v6_kernel(const ConvArgs a)
+{
+    using C = V6Cfg<KS, W, MT>;
+    constexpr int CK = C::CK;
+    constexpr int MTA = MT > 16 ? 16 : MT;                  // tiles accumulated in AGPRs (compiler MFMAs); the rest in VGPRs
+    static_assert(MT <= 17, "at most one VGPR-resident accumulator tile");
+    extern __shared__ float4 smem4[];
+    float* const s_in = reinterpret_cast<float*>(smem4);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 31;
+    const int kh = lane >> 5;
+
+    const bool g1 = blockIdx.z != 0;
+    ConvGroupArgs G;
+    G.in = g1 ? a.g[1].in : a.g[0].in;
+    G.w = g1 ? a.g[1].w : a.g[0].w;
+    G.bias = g1 ? a.g[1].bias : a.g[0].bias;
+    G.out = g1 ? a.g[1].out : a.g[0].out;
+    G.cout = g1 ? a.g[1].cout : a.g[0].cout;
+    const int H = a.H, HW = a.H * W;
+
+    int tile;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int bimg = tile / a.tiles_x;
+    const int p0 = (tile - bimg * a.tiles_x) * C::M;      // first pixel (row-major index) of this block
+    const int y0 = p0 / W;                                  // first image row it touches
+    const int n0 = blockIdx.y * 128;
+    const int n = n0 + wave * 32 + li;                      // this lane's output channel
+    const float* in_b = G.in + (size_t)bimg * HW * a.lda;
+    float bias = G.bias[n];                                 // padded to cout_pad
+    asm volatile("" : "+v"(bias));
+
+    // LDS element offsets of this lane's pixel in each row tile (kernel row 0, tap column 0, buffer 0); advanced per
+    // kernel row and rewound / switched to the other buffer per chunk
+    int a_cur[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        int p = p0 + t * 32 + li;
+        if (p >= HW) p = HW - 1;                            // padded rows recompute the last pixel; never stored
+        const int y = p / W, x = p - y * W;
+        a_cur[t] = ((y - y0) * C::HALO_W + x) * C::LDP + kh * 4;
+    }
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G.w), 0, 0x7fffffff, 0x00020000);
+    const unsigned b_off = (unsigned)((n * CK + kh * 4) * 4);
+    const unsigned panel_b = (unsigned)((size_t)a.cout_pad * CK * 4);     // bytes between (tap, chunk) panels
+    const unsigned tap_b0 = panel_b * (unsigned)a.nch;                    // bytes between taps
+
+    // halo staging slots of this thread (same for every chunk): clamped global offset + in-bounds bit; the LDS offset is
+    // recomputed at the write (hp * LDP + c4 * 4) to save registers
+    int h_goff[C::NHF];
+    unsigned h_ok = 0;
+#pragma unroll
+    for (int r = 0; r < C::NHF; ++r) {
+        const int f = tid + r * 256;
+        const bool slot = f < C::HALO_H * C::HALO_W * (CK / 4);
+        const int hp = slot ? f / (CK / 4) : 0, c4 = f % (CK / 4);
+        const int hy = hp / C::HALO_W, hx = hp - hy * C::HALO_W;
+        const int gy = y0 + hy - C::PADK, gx = hx - C::PADK;
+        const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+        h_goff[r] = (cy * W + cx) * a.lda + c4 * 4;
+        h_ok |= (slot && inb) ? (1u << r) : 0u;
+    }
+    auto halo_store = [&](float* buf, const float4 (&hv)[C::NHF]) {
+#pragma unroll
+        for (int r = 0; r < C::NHF; ++r) {
+            const int f = tid + r * 256;
+            float4 v = hv[r];
+            if (!((h_ok >> r) & 1)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < C::HALO_H * C::HALO_W * (CK / 4)) *reinterpret_cast<float4*>(&buf[(f >> 2) * C::LDP + (f & 3) * 4]) = v;
+        }
+    };
+
+    f32x16 acc[MTA];
+    f32x16 accv;                                            // tile MT-1 when MT == 17
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accv[i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < MTA; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    // chunk 0 halo -> buffer 0; first weight fragment (tap 0, step 0)
+    f32x4 bw[2];
+    bw[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off, 0u, 0));
+    {
+        float4 hv[C::NHF];
+#pragma unroll
+        for (int r = 0; r < C::NHF; ++r) hv[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r]);
+        halo_store(s_in, hv);
+    }
+    __syncthreads();
+
+    f32x4 av[C::RING];
+    for (int ch = 0; ch < a.nch; ++ch) {
+        float* nxt = s_in + ((ch + 1) & 1) * C::IN_ELEMS;
+        const bool more_ch = ch + 1 < a.nch;
+        float4 hreg[C::NHF];
+        // prime the A ring: units 0 .. DIST-1 of kernel row 0 (tap 0, step 0, tiles 0 ..)
+#pragma unroll
+        for (int d = 0; d < C::DIST; ++d) {
+            const int kxn = d / (2 * MT), stepn = (d / MT) % 2, tn = d % MT;
+            av[d] = *reinterpret_cast<const f32x4*>(&s_in[a_cur[tn] + kxn * C::LDP + stepn * 8]);
+        }
+        const unsigned chunk_b = (unsigned)ch * panel_b;
+        unsigned tap_b = tap_b0;
+        asm volatile("" : "+s"(tap_b));          // keep the per-row panel offsets inside the chunk loop
+        unsigned soff_row = chunk_b;             // panel of the first tap of the current kernel row
+#pragma unroll 1
+        for (int ky = 0; ky < KS; ++ky) {
+            // weights that follow this row's last step: next row's first tap, or tap 0 of the next chunk, or (at the very
+            // end) this row's last panel again
+            const unsigned wnext_end = ky + 1 < KS ? soff_row + KS * tap_b
+                                                   : (more_ch ? chunk_b + panel_b : soff_row + (KS - 1) * tap_b);
+#pragma unroll
+            for (int q = 0; q < 2 * KS; ++q) {              // q = 2 * kx + step within the row
+                {                                           // start of a k8 step: fetch the next step's weight fragment
+                    const int qn = q + 1;
+                    const unsigned so = qn < 2 * KS ? soff_row + (unsigned)(qn / 2) * tap_b : wnext_end;
+                    bw[qn & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off + (qn & 1) * 32, so, 0));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const int u = q * MT + t;
+                    if (u == 1 && ky == 0) {
+                        // next chunk's halo: global -> registers now, registers -> LDS after the last row (issued behind
+                        // the weight load so that the in-order vmcnt wait of the next step covers them for free)
+                        const int cn = more_ch ? ch + 1 : ch;
+#pragma unroll
+                        for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + cn * CK);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (t < MTA) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[t < MTA ? t : 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u % C::RING][e], bw[q & 1][e], acc[t < MTA ? t : 0], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) mfma_32x32x2_vgpr(accv, av[u % C::RING][e], bw[q & 1][e]);
+                    }
+                    {
+                        int un = u + C::DIST, rowadd = 0;
+                        if (un >= C::UNITS_ROW) { un -= C::UNITS_ROW; rowadd = C::HALO_W * C::LDP; }
+                        const int kxn = un / (2 * MT), stepn = (un / MT) % 2, tn = un % MT;
+                        av[(u + C::DIST) % C::RING] = *reinterpret_cast<const f32x4*>(&s_in[a_cur[tn] + rowadd + kxn * C::LDP + stepn * 8]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < MT; ++t) a_cur[t] += C::HALO_W * C::LDP;
+            soff_row += KS * tap_b;
+        }
+        {
+            // rewind to kernel row 0 and switch to the other halo buffer
+            const int delta = ((ch & 1) ? -C::IN_ELEMS : C::IN_ELEMS) - KS * C::HALO_W * C::LDP;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) a_cur[t] += delta;
+        }
+        if (more_ch) {
+            halo_store(nxt, hreg);
+            __syncthreads();
+        }
+    }
+    // the VGPR-form MFMAs are opaque to the compiler's hazard recogniser: let the last one retire before VALU reads accv
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+
+    // ---- epilogue: bias + ReLU + masked NHWC store (C/D layout: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * kh)
+    const bool nok = n < G.cout;
+    float* out_b = G.out + (size_t)bimg * HW * a.ldc + n;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int p = p0 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+            float v = (t < MTA ? acc[t < MTA ? t : 0][reg] : accv[reg]) + bias;
+            if (a.relu) v = fmaxf(v, 0.f);
+            if (nok && p < HW) out_b[(size_t)p * a.ldc] = v;
+        }
+    }
+}
+
 // Ablation twin of v3 (timing experiments only, results are wrong when ABL != 0): ABL bit0 = weight fragments loaded
 // once (no per-tap global loads), bit1 = A fragments read once per chunk (no per-step ds_reads), bit2 = halo staged
 // once (no per-chunk global loads / LDS writes / barrier), bit3 = no B register copies (prefetch into bc directly).
@@ -1165,23 +1389,34 @@ static const ConvVariant g_variants[] = {
     {3, 8, 16, 64, 16, "conv3x3_v5_t8x16_n64"},    // 36
     {7, 8, 8, 64, 16, "conv7x7_v5_t8x8_n64"},      // 37
     {3, 8, 8, 64, 16, "conv3x3_v5_t8x8_n64"},      // 38
+    // v6 kernels: one block per CU, 17 x 32 consecutive pixels of a 46-wide map x 128 channels (see conv_mfma_v6_kernel)
+    {7, 17, 32, 128, 16, "conv7x7_v6_t17x32_n128"},  // 39
+    {3, 17, 32, 128, 16, "conv3x3_v6_t17x32_n128"},  // 40
+    {3, 17, 32, 128, 16, "conv3x3_v6w92_t17x32_n128"},  // 41: the same on 92-wide maps
 };
 
 int conv_num_variants() { return (int)(sizeof(g_variants) / sizeof(g_variants[0])); }
 const ConvVariant& conv_variant(int idx) { return g_variants[idx]; }
 
-int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen)
+int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen, int pool)
 {
     // `cout` is the padded channel count of the layer
     if (forced >= 100 && ks == 7) return forced;      // ablation kernels
-    if (forced >= 0 && forced < conv_num_variants() && g_variants[forced].ks == ks && cout % g_variants[forced].bn == 0)
+    if (forced >= 0 && forced < conv_num_variants() && g_variants[forced].ks == ks && cout % g_variants[forced].bn == 0 &&
+        !(forced >= 39 && forced <= 41 && (pool || W != (forced == 41 ? 92 : 46))))      // v6: fixed map width, no pooling
         return forced;
     // enough 8x16 tiles to fill 256 CUs a few times over?  otherwise use the small tiles
     const long tiles816 = (long)((H + 7) / 8) * ((W + 15) / 16) * B;
     const bool small = tiles816 * ((cout + 127) / 128) < 512;
     // 2 x 46 row strips tile 46-wide maps exactly (8 x 16 tiles waste 8.9 %); on 92-wide maps they measured neutral
     const bool strip = (W == 46) && (cout % 128 == 0) && ((long)((H + 1) / 2) * B * (cout / 128) >= 512);
-    if (gen == 5) {      // v5 = v4 with unrolled taps / saddr weight loads where a variant exists
+    if (gen == 6 && cout % 128 == 0 && !pool && ((W == 46 && (ks == 7 || ks == 3)) || (W == 92 && ks == 3))) {
+        // v6 (one 544-pixel block per CU) when its blocks fill whole rounds of the 256 CUs; otherwise as gen 5
+        const long nblk = (long)((H * W + 543) / 544) * B * (cout / 128);
+        const long rounds = (nblk + 255) / 256;
+        if (nblk >= 256 && nblk * 100 >= rounds * 256 * 93) return W == 92 ? 41 : (ks == 7 ? 39 : 40);
+    }
+    if (gen >= 5) {      // v5 = v4 with unrolled taps / saddr weight loads where a variant exists
         if (ks == 7) return strip ? 32 : (small ? 37 : 34);
         if (ks == 3) return strip ? 33 : (small ? 38 : (cout <= 64 ? 36 : 35));
         return small ? 7 : (cout <= 64 ? 4 : 3);
@@ -1282,6 +1517,28 @@ static int launch_v3(const ConvArgs& a0, int groups, hipStream_t stream)
     }
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / BN), (unsigned)groups);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+template <int KS, int W, int MT>
+static int launch_v6(const ConvArgs& a0, int groups, hipStream_t stream)
+{
+    using C = V6Cfg<KS, W, MT>;
+    ConvArgs a = a0;
+    PMX_CHECK(a.W == W && !a.pool, PMX_ERR_INVALID, "conv v6: needs a %d-wide map without pooling (W = %d, pool = %d)", W, a.W, a.pool);
+    PMX_CHECK(a.cout_pad % 128 == 0, PMX_ERR_INVALID, "conv v6: cout_pad %d not a multiple of 128", a.cout_pad);
+    PMX_CHECK((long long)a.H * a.W * a.lda < (1ll << 31), PMX_ERR_INVALID, "conv: image too large for 32-bit offsets");
+    a.tiles_x = (a.H * a.W + C::M - 1) / C::M;
+    a.tiles_y = 1;
+    auto kern = conv_mfma_v6_kernel<KS, W, MT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(a.tiles_x * a.B), (unsigned)(a.cout_pad / 128), (unsigned)groups);
+    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, a);
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
@@ -1388,6 +1645,9 @@ int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream)
         case 36: return launch_v3<3, 8, 16, 64, 16, 2, 2, 5>(a, groups, stream);
         case 37: return launch_v3<7, 8, 8, 64, 16, 2, 2, 5>(a, groups, stream);
         case 38: return launch_v3<3, 8, 8, 64, 16, 2, 2, 5>(a, groups, stream);
+        case 39: return launch_v6<7, 46, 17>(a, groups, stream);
+        case 40: return launch_v6<3, 46, 17>(a, groups, stream);
+        case 41: return launch_v6<3, 92, 17>(a, groups, stream);
     }
     pmx_set_error("conv_launch: unknown variant %d", variant);
     return PMX_ERR_INVALID;

@@ -77,7 +77,7 @@ struct ConvVariant {
     const char* name;
 };
 // picks a kernel variant for (ksize, cout, B*H*W); returns index into the variant table
-int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen);
+int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen, int pool);
 const ConvVariant& conv_variant(int idx);
 int conv_num_variants();
 // launches the variant; groups = 1 or 2 (blockIdx.z)

@@ -68,6 +68,19 @@ def test_v5_variants(engine, variant, k, cout, hw, cin):
     _case(engine, 3, cin, hw[0], hw[1], cout, k, True, False, seed=370 + variant, variant=variant)
 
 
+@pytest.mark.parametrize('variant,k', [(39, 7), (40, 3)])
+@pytest.mark.parametrize('h,cin,cout,B', [(46, 48, 128, 3), (46, 185, 256, 2), (9, 16, 128, 5), (47, 32, 100, 1)])
+def test_v6_variants(engine, variant, k, h, cin, cout, B):
+    # v6: one block per CU, 17 x 32 consecutive pixels of a 46-wide map x 128 channels (last tile partially filled,
+    # blocks that start mid-row, maps shorter / taller than 46 rows, cout below the 128-channel block)
+    _case(engine, B, cin, h, 46, cout, k, True, False, seed=470 + variant + h, variant=variant)
+
+
+@pytest.mark.parametrize('h,cin,cout,B', [(92, 48, 128, 2), (31, 128, 256, 1)])
+def test_v6_w92_variant(engine, h, cin, cout, B):
+    _case(engine, B, cin, h, 92, cout, 3, True, False, seed=520 + h, variant=41)
+
+
 @pytest.mark.parametrize('variant', [35, 36])
 def test_v5_fused_relu_maxpool(engine, variant):
     _case(engine, 2, 32, 24, 40, 64 if variant == 36 else 128, 3, True, True, seed=390 + variant, variant=variant)
@@ -106,13 +119,40 @@ def test_v2_network_equals_v1_network_bitwise(engine):
     engine.set_option('kernel_gen', 4)
     engine.forward_u8(img)
     p4, h4 = engine.get_maps()
-    engine.set_option('kernel_gen', 5)      # library default
+    engine.set_option('kernel_gen', 5)
     engine.forward_u8(img)
     p5, h5 = engine.get_maps()
+    engine.set_option('kernel_gen', 6)      # library default (v6 only engages on 46-wide maps: see the 368x368 test below)
     assert np.array_equal(p1, p2) and np.array_equal(h1, h2)
     assert np.array_equal(p1, p3) and np.array_equal(h1, h3)
     assert np.array_equal(p1, p4) and np.array_equal(h1, h4)
     assert np.array_equal(p1, p5) and np.array_equal(h1, h5)
+
+
+def test_v6_network_equals_v5_network_bitwise(engine):
+    """368x368 input (46x46 maps) at batch 32: the one-block-per-CU v6 kernels take the 7x7 / 3x3 layers whose blocks fill
+    whole rounds of the 256 CUs; same K order -> the same bits as v5, and as batch 1 (small tiles)."""
+    from conftest import pkg
+    native = pkg('native')
+    w = pkg('weights').synthetic_weights(0)
+    eng = native.Engine(0, max_batch=32, max_h=368, max_w=368)
+    eng.set_weights(w)
+    img = np.random.default_rng(7).integers(0, 256, (32, 368, 368, 3), dtype=np.uint8)
+    eng.set_option('kernel_gen', 5)
+    eng.forward_u8(img)
+    p5, h5 = eng.get_maps()
+    eng.set_option('kernel_gen', 6)
+    eng.profile_enable(True)
+    eng.forward_u8(img)
+    p6, h6 = eng.get_maps()
+    names = {e['kernel'] for e in eng.profile()}
+    eng.profile_enable(False)
+    assert any('_v6_' in k for k in names), names
+    assert np.array_equal(p5, p6) and np.array_equal(h5, h6)
+    eng.forward_u8(img[5:6])
+    p1, h1 = eng.get_maps()
+    assert np.array_equal(p1[0], p6[5]) and np.array_equal(h1[0], h6[5])
+    eng.close()
 
 
 @pytest.mark.parametrize('variant,k', [(8, 7), (9, 3)])
