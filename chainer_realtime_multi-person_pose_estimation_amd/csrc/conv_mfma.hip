@@ -1339,6 +1339,104 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v3abl_kernel(const ConvArgs 
 conv_epilogue<C, TW>(acc, biasv, a, G.out, G.cout, bimg, y0, x0, n0, wm, wn, li, kh);
 }
 
+// ---- conv1_1: 3 input channels ---------------------------------------------------------------------------------------
+// The generic kernels spend a whole 16-channel chunk (8 MFMA k-pairs per tap) on 3 real channels.  Here K = 27 is packed
+// tap-major / channel-minor into 14 k-pairs (the 28th k is zero) - the order in which the generic kernels meet the three
+// non-zero channels, so the fp32 FMA chain per output is the same.  Block = 16 x 16 pixels x 64 channels (wave w: rows
+// 4w .. 4w+3 as two 32-pixel row tiles x two 32-channel tiles); the 18 x 18 x 3 input patch goes through LDS (pitch 3 floats:
+// conflict-free ds_read_b32), weights and bias live in registers, blocks loop over tiles.  Memory-bound (writes 64 ch/pixel).
+__global__ __launch_bounds__(256) void conv3x3_c3_kernel(const ConvArgs a)
+{
+    constexpr int TH = 16, TW = 16, PH = TH + 2, PW = TW + 2;
+    __shared__ float s_patch[PH * PW * 3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
+    const float* wp = a.g[0].w;                     // packed [tap][1 chunk][cout_pad = 64][16]
+    float wv[14][2], biasv[2];
+#pragma unroll
+    for (int s = 0; s < 14; ++s) {
+        const int k = 2 * s + kh;
+        const int kk = k < 27 ? k : 26;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float w = wp[(size_t)((kk / 3) * 64 + u * 32 + li) * 16 + kk % 3];
+            wv[s][u] = k < 27 ? w : 0.f;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) biasv[u] = a.g[0].bias[u * 32 + li];
+    // A gather: row tile T = 2 * wave + t covers tile rows 2T, 2T+1; lane's pixel = (li >> 4, li & 15); k -> (ky, kx, c)
+    int aoff[14];
+#pragma unroll
+    for (int s = 0; s < 14; ++s) {
+        const int k = 2 * s + kh, kk = k < 27 ? k : 26;
+        const int tap = kk / 3, cc = kk % 3;
+        aoff[s] = ((4 * wave + (li >> 4) + tap / 3) * PW + (li & 15) + tap % 3) * 3 + cc;
+    }
+    const int H = a.H, W = a.W, cout = a.g[0].cout;
+    const int ntiles = a.tiles_x * a.tiles_y * a.B;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int bimg = tile / (a.tiles_x * a.tiles_y);
+        const int trem = tile - bimg * a.tiles_x * a.tiles_y;
+        const int y0 = (trem / a.tiles_x) * TH, x0 = (trem % a.tiles_x) * TW;
+        const float* in_b = a.g[0].in + (size_t)bimg * H * W * a.lda;
+        __syncthreads();
+        for (int f = tid; f < PH * PW; f += 256) {
+            const int hy = f / PW, hx = f - hy * PW;
+            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+                v = *reinterpret_cast<const float4*>(in_b + ((size_t)gy * W + gx) * a.lda);
+            s_patch[f * 3 + 0] = v.x; s_patch[f * 3 + 1] = v.y; s_patch[f * 3 + 2] = v.z;
+        }
+        __syncthreads();
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 14; ++s) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float av = s_patch[aoff[s] + t * 2 * PW * 3];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wv[s][u], acc[t][u], 0, 0, 0);
+            }
+        }
+        float* out_b = a.g[0].out + (size_t)bimg * H * W * a.ldc;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n = u * 32 + li;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int m = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                    const int gy = y0 + 4 * wave + 2 * t + (m >> 4), gx = x0 + (m & 15);
+                    float v = acc[t][u][reg] + biasv[u];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (n < cout && gy < H && gx < W) out_b[((size_t)gy * W + gx) * a.ldc + n] = v;
+                }
+            }
+    }
+}
+
+static int launch_c3(const ConvArgs& a0, int groups, hipStream_t stream)
+{
+    ConvArgs a = a0;
+    PMX_CHECK(groups == 1 && !a.pool && a.nch == 1 && a.cout_pad == 64, PMX_ERR_INVALID,
+              "conv c3: needs one group, no pooling, one 16-channel chunk and 64 padded output channels");
+    a.tiles_x = (a.W + 15) / 16;
+    a.tiles_y = (a.H + 15) / 16;
+    const long ntiles = (long)a.tiles_x * a.tiles_y * a.B;
+    const unsigned grid = (unsigned)(ntiles < 256 * 8 ? ntiles : 256 * 8);
+    hipLaunchKernelGGL(conv3x3_c3_kernel, dim3(grid), dim3(256), 0, stream, a);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
 // minimum dynamic LDS per block: caps the number of co-resident blocks per CU (the fp32 MFMA pipe
 // loses ~20% with 3+ waves per SIMD)
 static int g_min_lds = 0;
@@ -1393,18 +1491,21 @@ static const ConvVariant g_variants[] = {
     {7, 17, 32, 128, 16, "conv7x7_v6_t17x32_n128"},  // 39
     {3, 17, 32, 128, 16, "conv3x3_v6_t17x32_n128"},  // 40
     {3, 17, 32, 128, 16, "conv3x3_v6w92_t17x32_n128"},  // 41: the same on 92-wide maps
+    {3, 16, 16, 64, 16, "conv3x3_c3_t16x16_n64"},       // 42: conv1_1 (3 input channels, K packed to 28)
 };
 
 int conv_num_variants() { return (int)(sizeof(g_variants) / sizeof(g_variants[0])); }
 const ConvVariant& conv_variant(int idx) { return g_variants[idx]; }
 
-int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen, int pool)
+int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen, int pool, int cin)
 {
     // `cout` is the padded channel count of the layer
     if (forced >= 100 && ks == 7) return forced;      // ablation kernels
     if (forced >= 0 && forced < conv_num_variants() && g_variants[forced].ks == ks && cout % g_variants[forced].bn == 0 &&
-        !(forced >= 39 && forced <= 41 && (pool || W != (forced == 41 ? 92 : 46))))      // v6: fixed map width, no pooling
+        !(forced >= 39 && forced <= 41 && (pool || W != (forced == 41 ? 92 : 46))) &&     // v6: fixed map width, no pooling
+        !(forced == 42 && (cin > 3 || cout != 64 || pool)))                                // c3: conv1_1-shaped layers only
         return forced;
+    if (gen >= 6 && ks == 3 && cin <= 3 && cout == 64 && !pool) return 42;
     // enough 8x16 tiles to fill 256 CUs a few times over?  otherwise use the small tiles
     const long tiles816 = (long)((H + 7) / 8) * ((W + 15) / 16) * B;
     const bool small = tiles816 * ((cout + 127) / 128) < 512;
@@ -1648,6 +1749,7 @@ int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream)
         case 39: return launch_v6<7, 46, 17>(a, groups, stream);
         case 40: return launch_v6<3, 46, 17>(a, groups, stream);
         case 41: return launch_v6<3, 92, 17>(a, groups, stream);
+        case 42: return launch_c3(a, groups, stream);
     }
     pmx_set_error("conv_launch: unknown variant %d", variant);
     return PMX_ERR_INVALID;

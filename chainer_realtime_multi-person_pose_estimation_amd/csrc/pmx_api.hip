@@ -467,7 +467,7 @@ static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float
     }
     a.B = B; a.H = H; a.W = W; a.lda = lda; a.ldc = ldc; a.nch = L0.nch; a.cout_pad = L0.cout_pad;
     a.relu = relu; a.pool = pool;
-    const int v = conv_pick_variant(L0.ks, L0.cout_pad, H, W, B * groups, c->opt_force[L0.ks], c->opt_kernel_gen, pool);
+    const int v = conv_pick_variant(L0.ks, L0.cout_pad, H, W, B * groups, c->opt_force[L0.ks], c->opt_kernel_gen, pool, groups == 1 ? L0.cin : 9999);
     int rc;
     if (c->prof_on) {
         const double bytes = 4.0 * B * H * W * ((double)L0.cin * groups + (double)L0.cout * groups / (pool ? 4 : 1));
@@ -1294,7 +1294,7 @@ extern "C" int pmx_conv2d(pmx_ctx* c, const float* x, const float* w, const floa
     a.g[0].in = d_xn; a.g[0].w = d_w; a.g[0].bias = d_b; a.g[0].out = d_yn; a.g[0].cout = cout;
     a.B = B; a.H = H; a.W = W; a.lda = cin_pad; a.ldc = cout; a.nch = cin_pad / CK; a.cout_pad = cpad; a.relu = relu; a.pool = pool;
     a.dbg = c->opt_conv_dbg;
-    const int v = conv_pick_variant(ks, cpad, H, W, B, c->opt_force[ks], c->opt_kernel_gen, pool);
+    const int v = conv_pick_variant(ks, cpad, H, W, B, c->opt_force[ks], c->opt_kernel_gen, pool, cin);
     if (!rc) rc = conv_launch(v, a, 1, c->stream);
     if (!rc && iters > 0) {
         hipEvent_t e0, e1;

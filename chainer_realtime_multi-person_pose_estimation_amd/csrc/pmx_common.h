@@ -77,7 +77,7 @@ struct ConvVariant {
     const char* name;
 };
 // picks a kernel variant for (ksize, cout, B*H*W); returns index into the variant table
-int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen, int pool);
+int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen, int pool, int cin);
 const ConvVariant& conv_variant(int idx);
 int conv_num_variants();
 // launches the variant; groups = 1 or 2 (blockIdx.z)

@@ -81,6 +81,23 @@ def test_v6_w92_variant(engine, h, cin, cout, B):
     _case(engine, B, cin, h, 92, cout, 3, True, False, seed=520 + h, variant=41)
 
 
+@pytest.mark.parametrize('cin,h,w,B', [(3, 40, 56, 2), (3, 37, 21, 1), (2, 16, 16, 3), (3, 368, 368, 1)])
+def test_c3_packed_k_kernel(engine, cin, h, w, B):
+    """conv1_1-shaped layers (<= 3 input channels -> 64): K packed to 14 k-pairs; vs torch, and bit-identical to the generic
+    16-channel-chunk kernel (same fp32 FMA chain per output)."""
+    _case(engine, B, cin, h, w, 64, 3, True, False, seed=600 + h, variant=42)
+    rng = np.random.default_rng(h)
+    x = rng.standard_normal((B, cin, h, w)).astype('f')
+    wt = rng.standard_normal((64, cin, 3, 3)).astype('f')
+    b = rng.standard_normal(64).astype('f')
+    engine.set_option('force_variant_k3', 42)
+    y42 = engine.conv2d(x, wt, b, relu=False)
+    engine.set_option('force_variant_k3', 36)
+    y36 = engine.conv2d(x, wt, b, relu=False)
+    engine.set_option('force_variant_k3', -1)
+    assert np.array_equal(y42, y36)
+
+
 @pytest.mark.parametrize('variant', [35, 36])
 def test_v5_fused_relu_maxpool(engine, variant):
     _case(engine, 2, 32, 24, 40, 64 if variant == 36 else 128, 3, True, True, seed=390 + variant, variant=variant)
