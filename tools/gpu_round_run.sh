@@ -15,4 +15,9 @@ done
 cd $R
 python tools/summarize_profiles.py $ROUND > $O/summary.log 2>&1
 (timeout 600 python bench.py --steps 5 --warmup 2 --dump-profile $O/prof_bench.json) > $O/bench.log 2>&1
-tail -3 $O/pytest_gpu.log; tail -2 $O/drv_old.log $O/drv_new.log; tail -1 $O/bench.log; du -sh $O
+# the same command under rocprofv3 (kernel durations must agree with the HIP-event figures in the bench line)
+cd /tmp
+(timeout 600 rocprofv3 --kernel-trace --stats -d $O/rp_bench -o bench --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline) > $O/rp_bench.log 2>&1
+cd $R
+(timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')") > $O/smoke.log 2>&1
+tail -1 $O/smoke.log; tail -3 $O/pytest_gpu.log; tail -2 $O/drv_old.log $O/drv_new.log; tail -1 $O/bench.log; du -sh $O

@@ -26,6 +26,8 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else 'r01'
 os.makedirs(P, exist_ok=True)
 
 shutil.copy(os.path.join(G, 'rp_stats', 'drv_kernel_stats.csv'), os.path.join(P, rnd + '_kernel_stats.csv'))
+if os.path.exists(os.path.join(G, 'rp_bench', 'bench_kernel_stats.csv')):      # rocprofv3 --kernel-trace --stats -- python bench.py
+    shutil.copy(os.path.join(G, 'rp_bench', 'bench_kernel_stats.csv'), os.path.join(P, rnd + '_bench_kernel_stats.csv'))
 
 summary = {'source': 'rocprofv3 --pmc <counters> --kernel-trace -- python tools/profile_driver.py --batch 32 --steps 1 '
                      '(one pass per counter group); rocprofv3 --kernel-trace --stats for durations',
