@@ -48,8 +48,8 @@ def pmc_traffic(kernel_name):
     if not m or not files:
         return None, None
     sig = 'conv_mfma%s_kernel<%s, %s, %s, %s,' % (m.group(2) or '', m.group(1), m.group(3), m.group(4), m.group(5))
-    if m.group(2) == '_v6':          # conv_mfma_v6_kernel<KS, W, MT>: 17 x 32 consecutive pixels of a 46-wide map
-        sig = 'conv_mfma_v6_kernel<%s, 46, %s>' % (m.group(1), m.group(3))
+    if m.group(2) == '_v6':          # conv_mfma_v6_kernel<KS, MT, POOL>: 17 x 32 consecutive pixels of a 46-column slab
+        sig = 'conv_mfma_v6_kernel<%s, %s, 0>' % (m.group(1), m.group(3))
     try:
         d = json.load(open(files[-1]))
         for k, e in d['kernels'].items():

@@ -926,20 +926,25 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v5_kernel(const ConvArgs a)
 }
 
 // ---- v6: one block per CU, 17 MFMA row tiles of consecutive pixels per wave -------------------------------------------
-// For W-wide maps whose launch would otherwise quantise badly (46x46 at batch 32: 1472 strip blocks on 512 slots = 2.875
-// rounds, 92 -> 96 padded rows): a block owns MT*32 CONSECUTIVE pixels of one image in row-major order (MT = 17: 544 px,
-// 4 blocks per 46x46 image = 2.8 % padding; batch 32 x 2 branch groups x 4 = 256 blocks = one per CU) and all 128 output
-// channels of the group (wave w = channels 32w..32w+31, all MT row tiles: 272 accumulator registers, 1 wave per SIMD).
+// For maps whose launch would otherwise quantise badly (46x46 at batch 32: 1472 strip blocks on 512 slots = 2.875 rounds,
+// 92 -> 96 padded rows): the map is cut into vertical SLABS of 46 columns (46 / 92 / 184 / 368-wide maps = 1 / 2 / 4 / 8
+// slabs; the left / right halo columns come from the neighbouring slab or are zero at the image border) and a block owns
+// MT*32 CONSECUTIVE pixels of one slab (MT = 17: 544 px, 4 blocks per 46x46 map = 2.8 % padding; batch 32 x 2 branch
+// groups x 4 = 256 blocks = one per CU) and all 128 output channels of the group (wave w = channels 32w..32w+31, all MT
+// row tiles: 272 accumulator registers, 1 wave per SIMD).  Pixel order inside a slab: row-major, or (POOL) row pairs
+// interleaved - index = (y / 2) * 92 + 2 * x + (y & 1) - so that four consecutive MFMA rows are one 2x2 pooling window.
 // Same 16-channel chunks, same tap / k8-step / k order as every other generation -> bit-identical results.
 //   LDS: the SPAN+KS-1 input rows the pixel run touches, full width + padding columns, 16 channels, double-buffered
 //        (7x7: 2 x 19 x 52 x 20 floats = 158 080 B -> exactly one block per CU).
 //   Inner loop (one kernel row = KS taps x 2 k8-steps x MT tiles, fully unrolled; rows are a run-time loop): per "unit"
 //        (tap, step, tile) 4 MFMAs + one ds_read_b128 that refills a RING-deep A-fragment ring DIST units ahead (immediate
 //        offsets, also across the row boundary); one buffer_load_dwordx4 of weights per step, one step ahead.
-template <int KS, int W, int MT>
+template <int KS, int MT, int POOL>
 struct V6Cfg {
+    static constexpr int W = 46;                                  // slab width
     static constexpr int PADK = KS / 2, T = KS * KS, CK = 16, LDP = 20, M = MT * 32;
-    static constexpr int SPAN = (W - 1 + M - 1) / W + 1;          // image rows a run of M consecutive pixels can touch
+    // image rows a run of M consecutive slab pixels can touch (POOL: whole row pairs)
+    static constexpr int SPAN = POOL ? 2 * ((2 * W - 1 + M - 1) / (2 * W) + 1) : (W - 1 + M - 1) / W + 1;
     static constexpr int HALO_H = SPAN + KS - 1, HALO_W = W + KS - 1;
     static constexpr int IN_ELEMS = HALO_H * HALO_W * LDP;
     static constexpr int LDS_BYTES = 2 * IN_ELEMS * 4;
@@ -958,10 +963,11 @@ __device__ __forceinline__ void mfma_32x32x2_vgpr(f32x16& acc, float a, float b)
     asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 
-template <int KS, int W, int MT>
+template <int KS, int MT, int POOL>
 __global__ __launch_bounds__(256, 1) void conv_mfma_v6_kernel(const ConvArgs a)
 {
-    using C = V6Cfg<KS, W, MT>;
+    using C = V6Cfg<KS, MT, POOL>;
+    constexpr int SW = C::W;
     constexpr int CK = C::CK;
     constexpr int MTA = MT > 16 ? 16 : MT;                  // tiles accumulated in AGPRs (compiler MFMAs); the rest in VGPRs
     static_assert(MT <= 17, "at most one VGPR-resident accumulator tile");
@@ -981,7 +987,8 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_v6_kernel(const ConvArgs a)
     G.bias = g1 ? a.g[1].bias : a.g[0].bias;
     G.out = g1 ? a.g[1].out : a.g[0].out;
     G.cout = g1 ? a.g[1].cout : a.g[0].cout;
-    const int H = a.H, HW = a.H * W;
+    const int H = a.H, W = a.W;
+    const int SP = H * SW;                                  // pixels of one slab
 
     int tile;
     {
@@ -989,12 +996,16 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_v6_kernel(const ConvArgs a)
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    const int bimg = tile / a.tiles_x;
-    const int p0 = (tile - bimg * a.tiles_x) * C::M;      // first pixel (row-major index) of this block
-    const int y0 = p0 / W;                                  // first image row it touches
+    // tile -> (image, slab, block of the slab); a.tiles_x = blocks per slab, a.tiles_y = slabs per image
+    const int bimg = tile / (a.tiles_x * a.tiles_y);
+    const int trem = tile - bimg * a.tiles_x * a.tiles_y;
+    const int slab = trem / a.tiles_x;
+    const int sx0 = slab * SW;                              // first image column of the slab
+    const int p0 = (trem - slab * a.tiles_x) * C::M;        // first slab pixel (in slab order) of this block
+    const int y0 = POOL ? 2 * (p0 / (2 * SW)) : p0 / SW;    // first image row it touches
     const int n0 = blockIdx.y * 128;
     const int n = n0 + wave * 32 + li;                      // this lane's output channel
-    const float* in_b = G.in + (size_t)bimg * HW * a.lda;
+    const float* in_b = G.in + (size_t)bimg * H * W * a.lda;
     float bias = G.bias[n];                                 // padded to cout_pad
     asm volatile("" : "+v"(bias));
 
@@ -1004,8 +1015,10 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_v6_kernel(const ConvArgs a)
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         int p = p0 + t * 32 + li;
-        if (p >= HW) p = HW - 1;                            // padded rows recompute the last pixel; never stored
-        const int y = p / W, x = p - y * W;
+        if (p >= SP) p = SP - 1;                            // padded rows recompute the last pixel; never stored
+        int y, x;
+        if (POOL) { const int rp = p / (2 * SW), q = p - rp * 2 * SW; y = 2 * rp + (q & 1); x = q >> 1; }
+        else { y = p / SW; x = p - y * SW; }
         a_cur[t] = ((y - y0) * C::HALO_W + x) * C::LDP + kh * 4;
     }
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G.w), 0, 0x7fffffff, 0x00020000);
@@ -1023,7 +1036,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_v6_kernel(const ConvArgs a)
         const bool slot = f < C::HALO_H * C::HALO_W * (CK / 4);
         const int hp = slot ? f / (CK / 4) : 0, c4 = f % (CK / 4);
         const int hy = hp / C::HALO_W, hx = hp - hy * C::HALO_W;
-        const int gy = y0 + hy - C::PADK, gx = hx - C::PADK;
+        const int gy = y0 + hy - C::PADK, gx = sx0 + hx - C::PADK;
         const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
         const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
         h_goff[r] = (cy * W + cx) * a.lda + c4 * 4;
@@ -1134,17 +1147,43 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_v6_kernel(const ConvArgs a)
     // the VGPR-form MFMAs are opaque to the compiler's hazard recogniser: let the last one retire before VALU reads accv
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
 
-    // ---- epilogue: bias + ReLU + masked NHWC store (C/D layout: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * kh)
+    // ---- epilogue: bias + ReLU (+ 2x2 max-pool) + masked NHWC store
+    // (C/D layout: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * kh)
     const bool nok = n < G.cout;
-    float* out_b = G.out + (size_t)bimg * HW * a.ldc + n;
+    if (!POOL) {
+        float* out_b = G.out + (size_t)bimg * H * W * a.ldc + n;
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
+        for (int t = 0; t < MT; ++t) {
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int p = p0 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
-            float v = (t < MTA ? acc[t < MTA ? t : 0][reg] : accv[reg]) + bias;
-            if (a.relu) v = fmaxf(v, 0.f);
-            if (nok && p < HW) out_b[(size_t)p * a.ldc] = v;
+            for (int reg = 0; reg < 16; ++reg) {
+                const int p = p0 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                const int y = p / SW, x = p - y * SW;
+                float v = (t < MTA ? acc[t < MTA ? t : 0][reg] : accv[reg]) + bias;
+                if (a.relu) v = fmaxf(v, 0.f);
+                if (nok && p < SP) out_b[((size_t)y * W + sx0 + x) * a.ldc] = v;
+            }
+        }
+    } else {
+        // four consecutive slab pixels (index % 4 == 0) are one window: pooled pixel (p / (2 * SW), (p % (2 * SW)) / 4)
+        const int Hp = H >> 1, Wp = W >> 1;
+        float* out_b = G.out + (size_t)bimg * Hp * Wp * a.ldc + n;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float v;
+                if (t < MTA) {
+                    const f32x16& A = acc[t < MTA ? t : 0];
+                    v = fmaxf(fmaxf(A[4 * g4 + 0], A[4 * g4 + 1]), fmaxf(A[4 * g4 + 2], A[4 * g4 + 3]));
+                } else {
+                    v = fmaxf(fmaxf(accv[4 * g4 + 0], accv[4 * g4 + 1]), fmaxf(accv[4 * g4 + 2], accv[4 * g4 + 3]));
+                }
+                v += bias;
+                if (a.relu) v = fmaxf(v, 0.f);
+                const int p = p0 + t * 32 + 8 * g4 + 4 * kh;
+                const int rp = p / (2 * SW), ox = (p - rp * 2 * SW) >> 2;
+                if (nok && p < SP) out_b[((size_t)rp * Wp + (sx0 >> 1) + ox) * a.ldc] = v;
+            }
         }
     }
 }
@@ -1490,7 +1529,7 @@ static const ConvVariant g_variants[] = {
     // v6 kernels: one block per CU, 17 x 32 consecutive pixels of a 46-wide map x 128 channels (see conv_mfma_v6_kernel)
     {7, 17, 32, 128, 16, "conv7x7_v6_t17x32_n128"},  // 39
     {3, 17, 32, 128, 16, "conv3x3_v6_t17x32_n128"},  // 40
-    {3, 17, 32, 128, 16, "conv3x3_v6w92_t17x32_n128"},  // 41: the same on 92-wide maps
+    {3, 17, 32, 128, 16, "conv3x3_v6p_t17x32_n128"},    // 41: with the fused 2x2 max-pool (row-pair pixel order)
     {3, 16, 16, 64, 16, "conv3x3_c3_t16x16_n64"},       // 42: conv1_1 (3 input channels, K packed to 28)
 };
 
@@ -1502,7 +1541,7 @@ int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen
     // `cout` is the padded channel count of the layer
     if (forced >= 100 && ks == 7) return forced;      // ablation kernels
     if (forced >= 0 && forced < conv_num_variants() && g_variants[forced].ks == ks && cout % g_variants[forced].bn == 0 &&
-        !(forced >= 39 && forced <= 41 && (pool || W != (forced == 41 ? 92 : 46))) &&     // v6: fixed map width, no pooling
+        !(forced >= 39 && forced <= 41 && (W % 46 != 0 || !!pool != (forced == 41))) &&      // v6: 46-column slabs
         !(forced == 42 && (cin > 3 || cout != 64 || pool)))                                // c3: conv1_1-shaped layers only
         return forced;
     if (gen >= 6 && ks == 3 && cin <= 3 && cout == 64 && !pool) return 42;
@@ -1511,11 +1550,13 @@ int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen
     const bool small = tiles816 * ((cout + 127) / 128) < 512;
     // 2 x 46 row strips tile 46-wide maps exactly (8 x 16 tiles waste 8.9 %); on 92-wide maps they measured neutral
     const bool strip = (W == 46) && (cout % 128 == 0) && ((long)((H + 1) / 2) * B * (cout / 128) >= 512);
-    if (gen == 6 && cout % 128 == 0 && !pool && ((W == 46 && (ks == 7 || ks == 3)) || (W == 92 && ks == 3))) {
-        // v6 (one 544-pixel block per CU) when its blocks fill whole rounds of the 256 CUs; otherwise as gen 5
-        const long nblk = (long)((H * W + 543) / 544) * B * (cout / 128);
+    // (3x3 layers with fewer than 8 input chunks have too little work per chunk transition for one wave per SIMD: measured
+    //  slower than v5 on conv2_1)
+    if (gen == 6 && cout % 128 == 0 && W % 46 == 0 && ((ks == 3 && cin >= 128) || (ks == 7 && !pool)) && (!pool || H % 2 == 0)) {
+        // v6 (one 544-pixel block per CU, 46-column slabs) when its blocks fill whole rounds of the 256 CUs; otherwise as gen 5
+        const long nblk = (long)((H * 46 + 543) / 544) * (W / 46) * B * (cout / 128);
         const long rounds = (nblk + 255) / 256;
-        if (nblk >= 256 && nblk * 100 >= rounds * 256 * 93) return W == 92 ? 41 : (ks == 7 ? 39 : 40);
+        if (nblk >= 256 && nblk * 100 >= rounds * 256 * 93) return ks == 7 ? 39 : (pool ? 41 : 40);
     }
     if (gen >= 5) {      // v5 = v4 with unrolled taps / saddr weight loads where a variant exists
         if (ks == 7) return strip ? 32 : (small ? 37 : 34);
@@ -1622,23 +1663,25 @@ static int launch_v3(const ConvArgs& a0, int groups, hipStream_t stream)
     return PMX_OK;
 }
 
-template <int KS, int W, int MT>
+template <int KS, int MT, int POOL>
 static int launch_v6(const ConvArgs& a0, int groups, hipStream_t stream)
 {
-    using C = V6Cfg<KS, W, MT>;
+    using C = V6Cfg<KS, MT, POOL>;
     ConvArgs a = a0;
-    PMX_CHECK(a.W == W && !a.pool, PMX_ERR_INVALID, "conv v6: needs a %d-wide map without pooling (W = %d, pool = %d)", W, a.W, a.pool);
+    PMX_CHECK(a.W % C::W == 0 && !!a.pool == !!POOL, PMX_ERR_INVALID, "conv v6: needs a map width that is a multiple of %d (W = %d) and pool = %d",
+              C::W, a.W, POOL);
+    PMX_CHECK(!POOL || a.H % 2 == 0, PMX_ERR_INVALID, "conv: pooled layer needs even H, W");
     PMX_CHECK(a.cout_pad % 128 == 0, PMX_ERR_INVALID, "conv v6: cout_pad %d not a multiple of 128", a.cout_pad);
     PMX_CHECK((long long)a.H * a.W * a.lda < (1ll << 31), PMX_ERR_INVALID, "conv: image too large for 32-bit offsets");
-    a.tiles_x = (a.H * a.W + C::M - 1) / C::M;
-    a.tiles_y = 1;
-    auto kern = conv_mfma_v6_kernel<KS, W, MT>;
+    a.tiles_x = (a.H * C::W + C::M - 1) / C::M;       // blocks per slab
+    a.tiles_y = a.W / C::W;                            // slabs per image
+    auto kern = conv_mfma_v6_kernel<KS, MT, POOL>;
     static bool attr_set = false;
     if (!attr_set) {
         PMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    dim3 grid((unsigned)(a.tiles_x * a.B), (unsigned)(a.cout_pad / 128), (unsigned)groups);
+    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / 128), (unsigned)groups);
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, a);
     PMX_HIP(hipGetLastError());
     return PMX_OK;
@@ -1746,9 +1789,9 @@ int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream)
         case 36: return launch_v3<3, 8, 16, 64, 16, 2, 2, 5>(a, groups, stream);
         case 37: return launch_v3<7, 8, 8, 64, 16, 2, 2, 5>(a, groups, stream);
         case 38: return launch_v3<3, 8, 8, 64, 16, 2, 2, 5>(a, groups, stream);
-        case 39: return launch_v6<7, 46, 17>(a, groups, stream);
-        case 40: return launch_v6<3, 46, 17>(a, groups, stream);
-        case 41: return launch_v6<3, 92, 17>(a, groups, stream);
+        case 39: return launch_v6<7, 17, 0>(a, groups, stream);
+        case 40: return launch_v6<3, 17, 0>(a, groups, stream);
+        case 41: return launch_v6<3, 17, 1>(a, groups, stream);
         case 42: return launch_c3(a, groups, stream);
     }
     pmx_set_error("conv_launch: unknown variant %d", variant);

@@ -76,9 +76,19 @@ def test_v6_variants(engine, variant, k, h, cin, cout, B):
     _case(engine, B, cin, h, 46, cout, k, True, False, seed=470 + variant + h, variant=variant)
 
 
-@pytest.mark.parametrize('h,cin,cout,B', [(92, 48, 128, 2), (31, 128, 256, 1)])
-def test_v6_w92_variant(engine, h, cin, cout, B):
-    _case(engine, B, cin, h, 92, cout, 3, True, False, seed=520 + h, variant=41)
+@pytest.mark.parametrize('h,w,cin,cout,B', [(92, 92, 48, 128, 2), (31, 92, 128, 256, 1), (20, 184, 32, 128, 1), (7, 368, 16, 128, 1)])
+def test_v6_slabs(engine, h, w, cin, cout, B):
+    # maps wider than one 46-column slab: the left / right halo columns come from the neighbouring slab
+    _case(engine, B, cin, h, w, cout, 3, True, False, seed=520 + h, variant=40)
+    if h >= 20:
+        _case(engine, B, cin, h, w, cout, 7, False, False, seed=530 + h, variant=39)
+
+
+@pytest.mark.parametrize('h,w,cin,cout,B', [(46, 46, 48, 128, 3), (92, 92, 32, 256, 1), (24, 184, 64, 128, 2), (2, 46, 16, 128, 1),
+                                            (50, 92, 16, 100, 1)])
+def test_v6_fused_relu_maxpool(engine, h, w, cin, cout, B):
+    # row-pair pixel order: four consecutive MFMA rows = one 2x2 window, pooled in registers
+    _case(engine, B, cin, h, w, cout, 3, True, True, seed=540 + h, variant=41)
 
 
 @pytest.mark.parametrize('cin,h,w,B', [(3, 40, 56, 2), (3, 37, 21, 1), (2, 16, 16, 3), (3, 368, 368, 1)])
