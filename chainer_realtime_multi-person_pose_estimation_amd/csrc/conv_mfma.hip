@@ -1531,6 +1531,10 @@ static const ConvVariant g_variants[] = {
     {3, 17, 32, 128, 16, "conv3x3_v6_t17x32_n128"},  // 40
     {3, 17, 32, 128, 16, "conv3x3_v6p_t17x32_n128"},    // 41: with the fused 2x2 max-pool (row-pair pixel order)
     {3, 16, 16, 64, 16, "conv3x3_c3_t16x16_n64"},       // 42: conv1_1 (3 input channels, K packed to 28)
+    // v6 with 9 row tiles per block (288 px): fills the chip at batch 16 / 48 (8 blocks per 46x46 map)
+    {7, 9, 32, 128, 16, "conv7x7_v6_t9x32_n128"},       // 43
+    {3, 9, 32, 128, 16, "conv3x3_v6_t9x32_n128"},       // 44
+    {3, 9, 32, 128, 16, "conv3x3_v6p_t9x32_n128"},      // 45
 };
 
 int conv_num_variants() { return (int)(sizeof(g_variants) / sizeof(g_variants[0])); }
@@ -1541,7 +1545,8 @@ int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen
     // `cout` is the padded channel count of the layer
     if (forced >= 100 && ks == 7) return forced;      // ablation kernels
     if (forced >= 0 && forced < conv_num_variants() && g_variants[forced].ks == ks && cout % g_variants[forced].bn == 0 &&
-        !(forced >= 39 && forced <= 41 && (W % 46 != 0 || !!pool != (forced == 41))) &&      // v6: 46-column slabs
+        !(((forced >= 39 && forced <= 41) || (forced >= 43 && forced <= 45)) &&
+          (W % 46 != 0 || !!pool != (forced == 41 || forced == 45))) &&                       // v6: 46-column slabs
         !(forced == 42 && (cin > 3 || cout != 64 || pool)))                                // c3: conv1_1-shaped layers only
         return forced;
     if (gen >= 6 && ks == 3 && cin <= 3 && cout == 64 && !pool) return 42;
@@ -1553,10 +1558,21 @@ int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen
     // (3x3 layers with fewer than 8 input chunks have too little work per chunk transition for one wave per SIMD: measured
     //  slower than v5 on conv2_1)
     if (gen == 6 && cout % 128 == 0 && W % 46 == 0 && ((ks == 3 && cin >= 128) || (ks == 7 && !pool)) && (!pool || H % 2 == 0)) {
-        // v6 (one 544-pixel block per CU, 46-column slabs) when its blocks fill whole rounds of the 256 CUs; otherwise as gen 5
-        const long nblk = (long)((H * 46 + 543) / 544) * (W / 46) * B * (cout / 128);
-        const long rounds = (nblk + 255) / 256;
-        if (nblk >= 256 && nblk * 100 >= rounds * 256 * 93) return ks == 7 ? 39 : (pool ? 41 : 40);
+        // v6 (one block of 17 or 9 row tiles per CU, 46-column slabs) when its blocks fill whole rounds of the 256 CUs and
+        // the pixel padding is small: efficiency = useful pixels / (rounds * 256 CUs * block pixels) >= 0.88; else as gen 5
+        const long useful = (long)H * W * B * (cout / 128);
+        double best = 0.0;
+        int best_mt = 0;
+        for (int mt : {17, 9}) {
+            const long nblk = (long)((H * 46 + 32 * mt - 1) / (32 * mt)) * (W / 46) * B * (cout / 128);
+            const long rounds = (nblk + 255) / 256;
+            const double eff = (double)useful / ((double)rounds * 256 * 32 * mt);
+            if (eff > best + 1e-9) { best = eff; best_mt = mt; }
+        }
+        if (best >= 0.88) {
+            if (best_mt == 17) return ks == 7 ? 39 : (pool ? 41 : 40);
+            return ks == 7 ? 43 : (pool ? 45 : 44);
+        }
     }
     if (gen >= 5) {      // v5 = v4 with unrolled taps / saddr weight loads where a variant exists
         if (ks == 7) return strip ? 32 : (small ? 37 : 34);
@@ -1793,6 +1809,9 @@ int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream)
         case 40: return launch_v6<3, 17, 0>(a, groups, stream);
         case 41: return launch_v6<3, 17, 1>(a, groups, stream);
         case 42: return launch_c3(a, groups, stream);
+        case 43: return launch_v6<7, 9, 0>(a, groups, stream);
+        case 44: return launch_v6<3, 9, 0>(a, groups, stream);
+        case 45: return launch_v6<3, 9, 1>(a, groups, stream);
     }
     pmx_set_error("conv_launch: unknown variant %d", variant);
     return PMX_ERR_INVALID;

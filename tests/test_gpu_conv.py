@@ -76,6 +76,12 @@ def test_v6_variants(engine, variant, k, h, cin, cout, B):
     _case(engine, B, cin, h, 46, cout, k, True, False, seed=470 + variant + h, variant=variant)
 
 
+@pytest.mark.parametrize('variant,k,pool', [(43, 7, False), (44, 3, False), (45, 3, True)])
+@pytest.mark.parametrize('h,w,cin,cout,B', [(46, 46, 48, 128, 3), (20, 92, 185, 256, 1)])
+def test_v6_nine_tile_blocks(engine, variant, k, pool, h, w, cin, cout, B):
+    _case(engine, B, cin, h, w, cout, k, True, pool, seed=560 + variant + h, variant=variant)
+
+
 @pytest.mark.parametrize('h,w,cin,cout,B', [(92, 92, 48, 128, 2), (31, 92, 128, 256, 1), (20, 184, 32, 128, 1), (7, 368, 16, 128, 1)])
 def test_v6_slabs(engine, h, w, cin, cout, B):
     # maps wider than one 46-column slab: the left / right halo columns come from the neighbouring slab
