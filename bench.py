@@ -93,34 +93,63 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(weights, img, map_hw, budget_s=20.0, max_threads=32):
+def cpu_baseline(weights, imgs, map_hw, budget_s=20.0, max_threads=32):
     """Oracle timed on the host: one image per call, as the reference does (pose_detector.py:430,501).
-    Bounded sample: one warm-up frame, then as many frames as fit in ~budget_s (at least one)."""
+    Bounded sample: one warm-up frame, then as many frames of the batch as fit in ~budget_s (at least one).
+    Returns (cpu_baseline object, per-frame oracle results for the keypoint-match check)."""
     import torch
     from oracle import network_ref, postprocess_ref
     threads = min(usable_cores(), max_threads)     # oneDNN scales poorly beyond a few tens of threads at batch 1
     torch.set_num_threads(threads)
 
-    def one():
-        x = postprocess_ref.preprocess(img)
+    def one(i):
+        x = postprocess_ref.preprocess(imgs[i % len(imgs)])
         paf, heat = network_ref.forward(weights, x)
-        return postprocess_ref.postprocess_from_net_output(paf[0], heat[0], map_hw[0], map_hw[1])
+        o = postprocess_ref.postprocess_from_net_output(paf[0], heat[0], map_hw[0], map_hw[1])
+        return {k: o[k] for k in ('all_peaks', 'poses', 'scores')}
     t0 = time.perf_counter()
-    one()                      # warm-up (thread pool, oneDNN primitives)
+    one(0)                      # warm-up (thread pool, oneDNN primitives)
     warm = time.perf_counter() - t0
-    frames = 0
+    results = []
     t0 = time.perf_counter()
     while True:
-        one()
-        frames += 1
+        results.append(one(len(results)))
+        frames = len(results)
         dt = time.perf_counter() - t0
         if dt + dt / frames > budget_s or frames >= 30:
             break
-    return {'value': frames / dt, 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
-            'sample': '%d frames (after 1 warm-up frame of %.1f s) of the same 368x368 synthetic workload, batch 1 per '
-                      'call, torch-CPU fp32 (oneDNN) network restatement + NumPy restatement of the reference '
-                      'post-process, %d threads of %d visible cores; %.1f s'
-                      % (frames, warm, threads, os.cpu_count() or 1, dt)}
+    return ({'value': frames / dt, 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
+             'sample': '%d frames (after 1 warm-up frame of %.1f s) of the same 368x368 synthetic workload, batch 1 per '
+                       'call, torch-CPU fp32 (oneDNN) network restatement + NumPy restatement of the reference '
+                       'post-process, %d threads of %d visible cores; %.1f s'
+                       % (frames, warm, threads, os.cpu_count() or 1, dt)}, results)
+
+
+def keypoint_match(eng, rec, results):
+    """The second half of the metric: the GPU path's key points against the oracle's on the frames the CPU baseline
+    processed (same images, same weights).  Target (BASELINE.json): integer peak indices identical, scores within 1e-4.
+    The two networks differ by ~1e-6 (summation order), so a peak exactly at a tie / threshold could legitimately flip."""
+    n = len(results)
+    peaks_same = poses_same = 0
+    d_peak = d_person = 0.0
+    for i, o in enumerate(results):
+        gp, op = eng.peaks(i), np.asarray(o['all_peaks'], dtype=np.float64).reshape(-1, 5)
+        if gp.shape == op.shape and np.array_equal(gp[:, [0, 1, 2, 4]], op[:, [0, 1, 2, 4]]):
+            peaks_same += 1
+            if len(gp):
+                d_peak = max(d_peak, float(np.abs(gp[:, 3] - op[:, 3]).max()))
+        k = int(rec[i]['n_people'])
+        g_poses, g_scores = rec[i]['poses'][:k], rec[i]['scores'][:k]
+        o_poses = np.asarray(o['poses'], dtype=np.float64).reshape(-1, 18, 3)
+        o_scores = np.asarray(o['scores'], dtype=np.float64).reshape(-1)
+        if g_poses.shape == o_poses.shape and np.array_equal(g_poses, o_poses):
+            poses_same += 1
+            if k:
+                d_person = max(d_person, float(np.abs(g_scores - o_scores).max()))
+    return {'frames_compared': n, 'frames_with_identical_peak_indices': peaks_same, 'max_abs_peak_score_diff': d_peak,
+            'frames_with_identical_poses': poses_same, 'max_abs_person_score_diff': d_person,
+            'target': 'peak indices identical, scores within 1e-4 (oracle = torch-CPU fp32 network + NumPy restatement of '
+                      'the reference post-process)'}
 
 
 def main():
@@ -249,7 +278,8 @@ def main():
                     json.dump({'batch': B, 'steps': a.steps, 'entries': prof}, f, indent=1)
         out['roofline'] = roof
         if world == 1 and not a.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(weights, imgs[0], (map_s, map_s), a.cpu_budget)
+            out['cpu_baseline'], oracle_results = cpu_baseline(weights, imgs, (map_s, map_s), a.cpu_budget)
+            out['keypoint_match'] = keypoint_match(eng, rec, oracle_results)
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out))
