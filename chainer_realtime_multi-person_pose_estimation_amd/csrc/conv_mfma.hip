@@ -1476,6 +1476,20 @@ static int launch_c3(const ConvArgs& a0, int groups, hipStream_t stream)
     return PMX_OK;
 }
 
+// dynamic LDS above 64 KB must be allowed per kernel AND per device (a process may hold contexts on several GPUs)
+constexpr int PMX_MAX_DEVICES = 64;
+static int conv_allow_big_lds(const void* kern, bool (&done)[PMX_MAX_DEVICES])
+{
+    int dev = 0;
+    PMX_HIP(hipGetDevice(&dev));
+    PMX_CHECK(dev >= 0 && dev < PMX_MAX_DEVICES, PMX_ERR_INVALID, "device index %d out of range", dev);
+    if (!done[dev]) {
+        PMX_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        done[dev] = true;
+    }
+    return PMX_OK;
+}
+
 // minimum dynamic LDS per block: caps the number of co-resident blocks per CU (the fp32 MFMA pipe
 // loses ~20% with 3+ waves per SIMD)
 static int g_min_lds = 0;
@@ -1614,11 +1628,8 @@ static int launch_cfg(const ConvArgs& a0, int groups, hipStream_t stream)
     PMX_CHECK(a.cout_pad % BN == 0, PMX_ERR_INVALID, "conv: cout_pad %d not a multiple of BN %d", a.cout_pad, BN);
     PMX_CHECK(!a.pool || (a.H % 2 == 0 && a.W % 2 == 0), PMX_ERR_INVALID, "conv: pooled layer needs even H, W");
     auto kern = conv_mfma_kernel<KS, TH, TW, BN, CK, WM, WN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static bool attr_set[PMX_MAX_DEVICES] = {};
+    if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(kern), attr_set)) return rc;
     const int lds = C::LDS_BYTES > g_min_lds ? C::LDS_BYTES : g_min_lds;
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / BN), (unsigned)groups);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
@@ -1639,11 +1650,8 @@ static int launch_v2(const ConvArgs& a0, int groups, hipStream_t stream)
     auto kern = conv_mfma_v2_kernel<KS, TH, TW, BN, CK, WM, WN>;
     int lds = KS == 1 ? 0 : C::IN_ELEMS * 4;
     if (lds < g_min_lds) lds = g_min_lds;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static bool attr_set[PMX_MAX_DEVICES] = {};
+    if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(kern), attr_set)) return rc;
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / BN), (unsigned)groups);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
     PMX_HIP(hipGetLastError());
@@ -1668,11 +1676,8 @@ static int launch_v3(const ConvArgs& a0, int groups, hipStream_t stream)
     int lds = 2 * C::IN_ELEMS * 4;
     if (lds < g_v3_lds) lds = g_v3_lds;
     if (lds < g_min_lds) lds = g_min_lds;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static bool attr_set[PMX_MAX_DEVICES] = {};
+    if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(kern), attr_set)) return rc;
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / BN), (unsigned)groups);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
     PMX_HIP(hipGetLastError());
@@ -1692,11 +1697,8 @@ static int launch_v6(const ConvArgs& a0, int groups, hipStream_t stream)
     a.tiles_x = (a.H * C::W + C::M - 1) / C::M;       // blocks per slab
     a.tiles_y = a.W / C::W;                            // slabs per image
     auto kern = conv_mfma_v6_kernel<KS, MT, POOL>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static bool attr_set[PMX_MAX_DEVICES] = {};
+    if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(kern), attr_set)) return rc;
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / 128), (unsigned)groups);
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, a);
     PMX_HIP(hipGetLastError());
@@ -1714,11 +1716,8 @@ static int launch_v4abl(const ConvArgs& a0, int groups, hipStream_t stream)
     int lds = 2 * C::IN_ELEMS * 4;
     if (lds < g_v3_lds) lds = g_v3_lds;
     if (lds < g_min_lds) lds = g_min_lds;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static bool attr_set[PMX_MAX_DEVICES] = {};
+    if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(kern), attr_set)) return rc;
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / 128), (unsigned)groups);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
     PMX_HIP(hipGetLastError());
@@ -1736,11 +1735,8 @@ static int launch_v3abl(const ConvArgs& a0, int groups, hipStream_t stream)
     int lds = 2 * C::IN_ELEMS * 4;
     if (lds < g_v3_lds) lds = g_v3_lds;
     if (lds < g_min_lds) lds = g_min_lds;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static bool attr_set[PMX_MAX_DEVICES] = {};
+    if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(kern), attr_set)) return rc;
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / 128), (unsigned)groups);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
     PMX_HIP(hipGetLastError());
