@@ -236,3 +236,45 @@ def test_identity_kernel_detects_layout_errors(engine):
     ref = np.zeros_like(x)
     ref[:, :, :-1, 1:] = x[:, :, 1:, :-1]
     assert np.array_equal(y, ref)
+
+
+# ---- randomised shapes (deterministic example set by default; PMX_FUZZ=<n> draws n fresh random examples) -------------------
+import os as _os
+from hypothesis import given, settings, strategies as st, HealthCheck
+
+_FUZZ = int(_os.environ.get('PMX_FUZZ', '0'))
+
+
+@settings(max_examples=_FUZZ or 30, derandomize=not _FUZZ, deadline=None, database=None,
+          suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(seed=st.integers(0, 10 ** 6), k=st.sampled_from([1, 3, 7]), B=st.integers(1, 3), h=st.integers(1, 40), w=st.integers(1, 60),
+       cin=st.integers(1, 70), cout=st.integers(1, 260), relu=st.booleans(), pool=st.booleans(), gen=st.sampled_from([1, 5, 6]),
+       slab=st.sampled_from([0, 0, 46, 92]))
+def test_random_shapes_default_selection(engine, seed, k, B, h, w, cin, cout, relu, pool, gen, slab):
+    """Whatever conv_pick_variant chooses for a random layer shape must match the torch fp32 reference (odd sizes, single
+    rows / columns, partial channel chunks, pooled layers, maps that are / are not a multiple of the 46-column slab)."""
+    if slab:
+        w = slab
+    if pool:
+        h, w = max(2, h - h % 2), max(2, w - w % 2)
+        if k == 1:
+            pool = False
+    engine.set_option('kernel_gen', gen)
+    try:
+        _case(engine, B, cin, h, w, cout, k, relu, pool, seed=seed)
+    finally:
+        engine.set_option('kernel_gen', 6)
+
+
+@settings(max_examples=_FUZZ or 12, derandomize=not _FUZZ, deadline=None, database=None,
+          suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(seed=st.integers(0, 10 ** 6), variant=st.sampled_from([39, 40, 41, 43, 44, 45]), B=st.integers(1, 3), h=st.integers(1, 50),
+       slabs=st.integers(1, 3), cin=st.integers(1, 70), cout=st.integers(65, 300), relu=st.booleans())
+def test_random_shapes_v6(engine, seed, variant, B, h, slabs, cin, cout, relu):
+    """The one-block-per-CU kernels forced onto random map heights / slab counts / channel counts (blocks that start
+    mid-row, last block nearly empty, single-row maps, pooled row pairs)."""
+    pool = variant in (41, 45)
+    k = 7 if variant in (39, 43) else 3
+    if pool:
+        h = max(2, h - h % 2)
+    _case(engine, B, cin, h, 46 * slabs, cout, k, relu, pool, seed=seed, variant=variant)

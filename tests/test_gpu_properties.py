@@ -1,6 +1,8 @@
 """GPU: size-independent properties at BASELINE.json's full sizes (368 x 368 frames, batch 32), where the CPU oracle
 would take minutes -- determinism, batch independence, permutation equivariance, sharding == single rank -- plus
 hypothesis-driven post-process cases against the NumPy oracle (T4)."""
+import os
+
 import numpy as np
 import pytest
 from hypothesis import given, settings, strategies as st, HealthCheck
@@ -83,7 +85,12 @@ def test_maps_are_a_pure_function_of_the_image(big):
     assert np.array_equal(p1, p2[::-1]) and np.array_equal(h1, h2[::-1])
 
 
-@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+# deterministic example set by default (the round-end run must be reproducible); PMX_FUZZ=<n> draws n fresh random examples
+_FUZZ = int(os.environ.get('PMX_FUZZ', '0'))
+
+
+@settings(max_examples=_FUZZ or 25, derandomize=not _FUZZ, deadline=None, database=None,
+          suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(seed=st.integers(0, 10 ** 6), n=st.integers(0, 10), fh=st.integers(12, 48), fw=st.integers(12, 48),
        up=st.sampled_from([1, 3, 5, 7]), noise=st.sampled_from([0.0, 0.01, 0.04]))
 def test_hypothesis_postprocess_matches_oracle(engine, seed, n, fh, fw, up, noise):
