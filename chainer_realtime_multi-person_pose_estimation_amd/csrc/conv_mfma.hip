@@ -1554,8 +1554,12 @@ static const ConvVariant g_variants[] = {
 int conv_num_variants() { return (int)(sizeof(g_variants) / sizeof(g_variants[0])); }
 const ConvVariant& conv_variant(int idx) { return g_variants[idx]; }
 
+static int g_num_cus = 256;
+void conv_set_num_cus(int n) { if (n > 0) g_num_cus = n; }
+
 int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen, int pool, int cin)
 {
+    const int ncu = g_num_cus;      // compute units of the device (256 on an MI355X in SPX mode)
     // `cout` is the padded channel count of the layer
     if (forced >= 100 && ks == 7) return forced;      // ablation kernels
     if (forced >= 0 && forced < conv_num_variants() && g_variants[forced].ks == ks && cout % g_variants[forced].bn == 0 &&
@@ -1564,23 +1568,23 @@ int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen
         !(forced == 42 && (cin > 3 || cout != 64 || pool)))                                // c3: conv1_1-shaped layers only
         return forced;
     if (gen >= 6 && ks == 3 && cin <= 3 && cout == 64 && !pool) return 42;
-    // enough 8x16 tiles to fill 256 CUs a few times over?  otherwise use the small tiles
+    // enough 8x16 tiles to fill the CUs a few times over?  otherwise use the small tiles
     const long tiles816 = (long)((H + 7) / 8) * ((W + 15) / 16) * B;
-    const bool small = tiles816 * ((cout + 127) / 128) < 512;
+    const bool small = tiles816 * ((cout + 127) / 128) < 2 * ncu;
     // 2 x 46 row strips tile 46-wide maps exactly (8 x 16 tiles waste 8.9 %); on 92-wide maps they measured neutral
-    const bool strip = (W == 46) && (cout % 128 == 0) && ((long)((H + 1) / 2) * B * (cout / 128) >= 512);
+    const bool strip = (W == 46) && (cout % 128 == 0) && ((long)((H + 1) / 2) * B * (cout / 128) >= 2 * ncu);
     // (3x3 layers with fewer than 8 input chunks have too little work per chunk transition for one wave per SIMD: measured
     //  slower than v5 on conv2_1)
     if (gen == 6 && cout % 128 == 0 && W % 46 == 0 && ((ks == 3 && cin >= 128) || (ks == 7 && !pool)) && (!pool || H % 2 == 0)) {
-        // v6 (one block of 17 or 9 row tiles per CU, 46-column slabs) when its blocks fill whole rounds of the 256 CUs and
-        // the pixel padding is small: efficiency = useful pixels / (rounds * 256 CUs * block pixels) >= 0.88; else as gen 5
+        // v6 (one block of 17 or 9 row tiles per CU, 46-column slabs) when its blocks fill whole rounds of the CUs and
+        // the pixel padding is small: efficiency = useful pixels / (rounds * CUs * block pixels) >= 0.88; else as gen 5
         const long useful = (long)H * W * B * (cout / 128);
         double best = 0.0;
         int best_mt = 0;
         for (int mt : {17, 9}) {
             const long nblk = (long)((H * 46 + 32 * mt - 1) / (32 * mt)) * (W / 46) * B * (cout / 128);
-            const long rounds = (nblk + 255) / 256;
-            const double eff = (double)useful / ((double)rounds * 256 * 32 * mt);
+            const long rounds = (nblk + ncu - 1) / ncu;
+            const double eff = (double)useful / ((double)rounds * ncu * 32 * mt);
             if (eff > best + 1e-9) { best = eff; best_mt = mt; }
         }
         if (best >= 0.88) {
@@ -1608,7 +1612,7 @@ int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen
                          // small launches (few blocks, one wave per SIMD) use the software-pipelined v3 small tiles
         // (v3 small tiles only while there is at most ~1 block per CU; with more blocks the v1 small tiles win)
         const long blocks88 = (long)((H + 7) / 8) * ((W + 7) / 8) * B * ((cout + 63) / 64);
-        const bool tiny = blocks88 <= 320;
+        const bool tiny = blocks88 <= ncu + ncu / 4;
         if (ks == 7) return strip ? 10 : (small ? (tiny ? 23 : 5) : 12);
         if (ks == 3) return strip ? 11 : (small ? (tiny ? 24 : 6) : (cout <= 64 ? 2 : 13));
         return small ? 7 : (cout <= 64 ? 4 : 3);

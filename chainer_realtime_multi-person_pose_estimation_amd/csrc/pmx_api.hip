@@ -292,6 +292,7 @@ extern "C" int pmx_create_net(pmx_ctx** out, const char* arch, int device, int m
         pmx_set_error("pmx_create: device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
         return PMX_ERR_NO_DEVICE;
     }
+    conv_set_num_cus(prop.multiProcessorCount);      // kernel / tile selection counts blocks against the CUs of this device
     PMX_HIP(hipSetDevice(device));
     pmx_ctx* c = new pmx_ctx();
     c->device = device;

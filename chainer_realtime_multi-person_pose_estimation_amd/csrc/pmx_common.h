@@ -83,6 +83,7 @@ int conv_num_variants();
 // launches the variant; groups = 1 or 2 (blockIdx.z)
 int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream);
 void conv_set_min_lds(int bytes);
+void conv_set_num_cus(int n);     // compute units of the device the contexts run on (tile / kernel selection heuristics)
 // packed weight geometry helpers
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
