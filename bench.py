@@ -125,7 +125,7 @@ def cpu_baseline(weights, imgs, map_hw, budget_s=20.0, max_threads=32):
                        % (frames, warm, threads, os.cpu_count() or 1, dt)}, results)
 
 
-def keypoint_match(eng, rec, results):
+def keypoint_match(eng, rec, results, weights_for_match, imgs_for_match):
     """The second half of the metric: the GPU path's key points against the oracle's on the frames the CPU baseline
     processed (same images, same weights).  Target (BASELINE.json): integer peak indices identical, scores within 1e-4.
     The two networks differ by ~1e-6 (summation order), so a peak exactly at a tie / threshold could legitimately flip."""
@@ -146,7 +146,19 @@ def keypoint_match(eng, rec, results):
             poses_same += 1
             if k:
                 d_person = max(d_person, float(np.abs(g_scores - o_scores).max()))
+    # one full-size frame through the order-defined fp32 oracle (plain C, the kernels' summation order): bit-exact maps
+    exact = None
+    try:
+        from oracle import conv_fma_ref, postprocess_ref
+        t0 = time.perf_counter()
+        paf, heat = eng.get_maps()
+        epaf, eheat = conv_fma_ref.forward_fma(weights_for_match, postprocess_ref.preprocess(imgs_for_match[0]))
+        exact = {'frames': 1, 'paf_and_heat_maps_bit_identical': bool(np.array_equal(paf[0], epaf[0]) and np.array_equal(heat[0], eheat[0])),
+                 'oracle_seconds': time.perf_counter() - t0}
+    except Exception as e:          # the checker must never break the measurement
+        exact = {'error': repr(e)}
     return {'frames_compared': n, 'frames_with_identical_peak_indices': peaks_same, 'max_abs_peak_score_diff': d_peak,
+            'network_vs_order_defined_oracle': exact,
             'frames_with_identical_poses': poses_same, 'max_abs_person_score_diff': d_person,
             'target': 'peak indices identical, scores within 1e-4 (oracle = torch-CPU fp32 network + NumPy restatement of '
                       'the reference post-process)'}
@@ -279,7 +291,7 @@ def main():
         out['roofline'] = roof
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'], oracle_results = cpu_baseline(weights, imgs, (map_s, map_s), a.cpu_budget)
-            out['keypoint_match'] = keypoint_match(eng, rec, oracle_results)
+            out['keypoint_match'] = keypoint_match(eng, rec, oracle_results, weights, imgs)
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out))

@@ -1,0 +1,88 @@
+"""TEST INFRASTRUCTURE: ctypes binding of oracle/conv_fma_ref.c (order-defined fp32 conv, bit-exact twin of the HIP kernels).
+
+Built by `build()` below (gcc, -ffp-contract=off) into oracle/_build/ -- called from __graft_entry__.build() and lazily here."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, 'conv_fma_ref.c')
+OUT_DIR = os.path.join(HERE, '_build')
+LIB = os.path.join(OUT_DIR, 'libconv_fma_ref.so')
+
+
+def build(force=False):
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= os.path.getmtime(SRC):
+        return LIB
+    os.makedirs(OUT_DIR, exist_ok=True)
+    subprocess.check_call(['gcc', '-O2', '-mfma', '-fopenmp', '-ffp-contract=off', '-shared', '-fPIC', '-o', LIB, SRC, '-lm'])
+    return LIB
+
+
+_lib = None
+
+
+def conv_fma(x, w, b, relu=False, pool=False):
+    """x (B, cin, H, W), w (cout, cin, k, k), b (cout,) float32 -> y float32, in the HIP kernels' summation order."""
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.conv_fma_ref.restype = None
+        _lib.conv_fma_ref.argtypes = [C.c_void_p] * 4 + [C.c_int] * 8
+    x = np.ascontiguousarray(x, np.float32)
+    w = np.ascontiguousarray(w, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    B, cin, H, W = x.shape
+    cout, _, ks, _ = w.shape
+    y = np.empty((B, cout, H // 2 if pool else H, W // 2 if pool else W), np.float32)
+    _lib.conv_fma_ref(x.ctypes.data, w.ctypes.data, b.ctypes.data, y.ctypes.data, B, cin, H, W, cout, ks, int(relu), int(pool))
+    return y
+
+
+# ---- the whole network in the kernels' order ---------------------------------------------------------------------------
+# Stage inputs are the "cat" buffer of the HIP path: [feature 0..127 | PAF 128..165 | 0, 0 | heat 168..186 | 0 x 5]
+# (csrc/pmx_api.hip::concat_map); the reference concatenates (PAF, heat, feature) (models/CocoPoseNet.py:168).  K is walked
+# in buffer order, so the Mconv1 weights are permuted (and zero-padded) accordingly.
+CAT_C, CAT_PAF, CAT_HEAT = 192, 128, 168
+
+
+def _cat_weights(W):
+    Wp = np.zeros((W.shape[0], CAT_C) + W.shape[2:], np.float32)
+    Wp[:, 0:128] = W[:, 57:185]
+    Wp[:, CAT_PAF:CAT_PAF + 38] = W[:, 0:38]
+    Wp[:, CAT_HEAT:CAT_HEAT + 19] = W[:, 38:57]
+    return Wp
+
+
+def forward_fma(weights, x):
+    """CocoPoseNet forward (models/CocoPoseNet.py:132-262) with every convolution in the HIP kernels' summation order.
+    x: (B, 3, H, W) float32 as produced by preprocess; returns (paf (B,38,h,w), heat (B,19,h,w)) of the last stage."""
+    def conv(name, h, relu=True, pool=False, cat=False):
+        W, b = weights[name]
+        return conv_fma(h, _cat_weights(W) if cat else W, b, relu=relu, pool=pool)
+    h = conv('conv1_1', x); h = conv('conv1_2', h, pool=True)
+    h = conv('conv2_1', h); h = conv('conv2_2', h, pool=True)
+    h = conv('conv3_1', h); h = conv('conv3_2', h); h = conv('conv3_3', h); h = conv('conv3_4', h, pool=True)
+    h = conv('conv4_1', h); h = conv('conv4_2', h); h = conv('conv4_3_CPM', h); feat = conv('conv4_4_CPM', h)
+    h1, h2 = feat, feat
+    for i in range(1, 5):
+        h1 = conv('conv5_%d_CPM_L1' % i, h1)
+        h2 = conv('conv5_%d_CPM_L2' % i, h2)
+    h1 = conv('conv5_5_CPM_L1', h1, relu=False)
+    h2 = conv('conv5_5_CPM_L2', h2, relu=False)
+    B, _, fh, fw = feat.shape
+    for s in range(2, 7):
+        cat = np.zeros((B, CAT_C, fh, fw), np.float32)
+        cat[:, 0:128] = feat
+        cat[:, CAT_PAF:CAT_PAF + 38] = h1
+        cat[:, CAT_HEAT:CAT_HEAT + 19] = h2
+        h1 = conv('Mconv1_stage%d_L1' % s, cat, cat=True)
+        h2 = conv('Mconv1_stage%d_L2' % s, cat, cat=True)
+        for i in range(2, 7):
+            h1 = conv('Mconv%d_stage%d_L1' % (i, s), h1)
+            h2 = conv('Mconv%d_stage%d_L2' % (i, s), h2)
+        h1 = conv('Mconv7_stage%d_L1' % s, h1, relu=False)
+        h2 = conv('Mconv7_stage%d_L2' % s, h2, relu=False)
+    return h1, h2

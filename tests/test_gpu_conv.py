@@ -29,6 +29,35 @@ def _case(engine, B, cin, H, W, cout, k, relu, pool, seed, variant=None):
     assert err <= TOL * max(1.0, np.abs(ref).max()), (err, np.abs(ref).max())
 
 
+def _exact_case(engine, B, cin, H, W, cout, k, relu, pool, seed, variant=None):
+    """GPU conv == oracle/conv_fma_ref.c bit for bit (same K order, sequential fused multiply-add chain)."""
+    from oracle import conv_fma_ref as R
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, cin, H, W)).astype('f')
+    w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype('f')
+    b = rng.standard_normal(cout).astype('f')
+    for kk in (1, 3, 7):
+        engine.set_option('force_variant_k%d' % kk, -1)
+    if variant is not None:
+        engine.set_option('force_variant_k%d' % k, variant)
+    y = engine.conv2d(x, w, b, relu=relu, pool=pool)
+    engine.set_option('force_variant_k%d' % k, -1)
+    ref = R.conv_fma(x, w, b, relu=relu, pool=pool)
+    assert y.shape == ref.shape
+    assert np.array_equal(y, ref), (np.abs(y - ref).max(), int((y != ref).sum()))
+
+
+@pytest.mark.parametrize('variant,k,cin,h,w,cout,pool', [
+    (None, 7, 40, 12, 15, 128, False), (None, 3, 70, 14, 10, 64, True), (None, 1, 100, 9, 13, 38, False),
+    (3, 1, 128, 8, 16, 128, False), (2, 3, 16, 10, 12, 64, False),            # v1
+    (32, 7, 48, 6, 46, 128, False), (36, 3, 35, 16, 16, 64, True), (38, 3, 20, 9, 9, 19, False),    # v5
+    (39, 7, 33, 13, 46, 128, False), (40, 3, 140, 25, 92, 256, False), (41, 3, 128, 12, 46, 128, True),
+    (43, 7, 17, 7, 46, 200, False),                                                                    # v6
+    (42, 3, 3, 20, 24, 64, False)])                                                                    # conv1_1
+def test_conv_bit_exact_vs_order_defined_c_oracle(engine, variant, k, cin, h, w, cout, pool):
+    _exact_case(engine, 2, cin, h, w, cout, k, True, pool, seed=700 + k + cin, variant=variant)
+
+
 # variant indices: see conv_mfma.hip g_variants
 @pytest.mark.parametrize('variant,k,cout', [(0, 7, 128), (5, 7, 128), (1, 3, 128), (2, 3, 64), (6, 3, 64),
                                             (3, 1, 128), (4, 1, 64), (7, 1, 64)])

@@ -33,6 +33,50 @@ def test_network_forward_matches_torch_oracle(engine, weights):
     assert _rel_err(heat, rheat) < 1e-4, _rel_err(heat, rheat)
 
 
+@pytest.mark.parametrize('shape', [(1, 64, 64), (2, 96, 128), (1, 40, 184)])
+def test_network_bit_exact_vs_order_defined_oracle(engine, weights, shape):
+    """The whole 92-layer forward (fused preprocess, pooling, the concat layout of the stage inputs, both branches) equals
+    oracle/conv_fma_ref.py::forward_fma BIT FOR BIT: the kernels' summation order is defined (sequential fused multiply-add
+    chain over chunk -> tap -> half -> k) and the plain-C oracle walks K the same way."""
+    from oracle import conv_fma_ref as R
+    engine.set_weights(weights)
+    rng = np.random.default_rng(sum(shape))
+    imgs = rng.integers(0, 256, shape + (3,), dtype=np.uint8)
+    engine.forward_u8(imgs)
+    paf, heat = engine.get_maps()
+    x = np.concatenate([P.preprocess(im) for im in imgs])
+    rpaf, rheat = R.forward_fma(weights, x)
+    assert np.array_equal(paf, rpaf), np.abs(paf - rpaf).max()
+    assert np.array_equal(heat, rheat), np.abs(heat - rheat).max()
+
+
+def test_end_to_end_identical_to_order_defined_oracle(native, weights, monkeypatch):
+    """PoseDetector.__call__ on the GPU == (order-defined network oracle -> NumPy restatement of the reference post-process):
+    identical pose arrays and scores, no tolerance anywhere.  The image is not at the network size, so the device resize is
+    in the path; the network / map sizes are shrunk through entity.params to keep the scalar C oracle fast."""
+    from oracle import conv_fma_ref as R
+    from oracle import resize_ref
+    PD, W, ent = pkg('pose_detector'), pkg('weights'), pkg('entity')
+    monkeypatch.setitem(ent.params, 'inference_img_size', 64)
+    monkeypatch.setitem(ent.params, 'heatmap_size', 56)
+    det = PD.PoseDetector(weights=weights, device=0, max_size=(64, 96))
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (50, 70, 3), dtype=np.uint8)
+    in_w, in_h = det.compute_optimal_size(img, 64)
+    map_w, map_h = det.compute_optimal_size(img, 56)
+    small = resize_ref.resize_linear_u8(img, in_w, in_h)
+    paf, heat = R.forward_fma(weights, P.preprocess(small))
+    w2 = W.calibrate_head(weights, paf[0], heat[0])              # a head that produces people on this image
+    det.engine.set_weights({k: w2[k] for k in ('Mconv7_stage6_L1', 'Mconv7_stage6_L2')})
+    paf, heat = R.forward_fma(w2, P.preprocess(small))
+    ref = P.postprocess_from_net_output(paf[0], heat[0], map_h, map_w, orig_w=img.shape[1], orig_h=img.shape[0])
+    poses, scores = det(img)
+    assert len(ref['all_peaks']) > 0
+    assert np.array_equal(np.asarray(poses, dtype=np.float64).reshape(-1, 18, 3), np.asarray(ref['poses']).reshape(-1, 18, 3))
+    assert np.allclose(scores, ref['scores'], rtol=0, atol=1e-9)
+    det.engine.close()
+
+
 def test_forward_f32_seam_equals_u8_path(engine, weights):
     engine.set_weights(weights)
     rng = np.random.default_rng(1)

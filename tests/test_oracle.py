@@ -71,3 +71,19 @@ def test_fixture_renderer_shapes():
     assert heat.shape == (19, 46, 46) and paf.shape == (38, 46, 46) and poses.shape == (2, 18, 3)
     assert heat.dtype == np.float32 and paf.dtype == np.float32
     assert np.all(heat[:18] >= 0) and np.all(heat[:18] <= 1)
+
+
+def test_order_defined_conv_oracle_matches_torch_and_is_deterministic():
+    """oracle/conv_fma_ref.c (the bit-exact twin of the HIP kernels, checked on the GPU) agrees with the BLAS-order torch
+    restatement to fp32 summation noise, handles pooled / 1x1 / partial-chunk layers, and is thread-count independent."""
+    from oracle import conv_fma_ref as R, network_ref as N
+    rng = np.random.default_rng(3)
+    for (B, cin, H, W, cout, k, pool) in [(2, 20, 9, 11, 7, 3, False), (1, 5, 8, 10, 3, 3, True), (1, 33, 6, 7, 40, 7, False),
+                                          (2, 17, 5, 5, 9, 1, False)]:
+        x = rng.standard_normal((B, cin, H, W)).astype('f')
+        w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype('f')
+        b = rng.standard_normal(cout).astype('f')
+        y = R.conv_fma(x, w, b, relu=True, pool=pool)
+        ref = N.conv2d_ref(x, w, b, relu=True, pool=pool)
+        assert y.shape == ref.shape and np.abs(y - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+        assert np.array_equal(y, R.conv_fma(x, w, b, relu=True, pool=pool))
