@@ -259,441 +259,29 @@ conv_epilogue<C, TW>(acc, biasv, a, G.out, G.cout, bimg, y0, x0, n0, wm, wn, li,
 }
 
 // =============================================================================================================
-// v2: weights stream L2 -> registers (no weight panel in LDS, no barrier inside a channel chunk)
-//
-// With the waves of a block split along N (WN = 4: each wave owns 32 output channels x all pixels of the tile) the
-// B (weight) fragment of a wave is private to it, so staging it through LDS only adds a write, a read and a
-// block-wide barrier per tap.  Here every lane loads its own fragment -- 16 B = 4 channels of one output channel for
-// one tap -- directly from the packed weight array (the same global_load_dwordx4 count per lane as the LDS staging
-// needed), double-buffered in registers one tap ahead so the L2 latency hides under the current tap's MFMAs.  LDS
-// holds only the input halo tile (read-only during a chunk): barriers remain at chunk boundaries only (every KS*KS
-// taps), and the smaller LDS footprint admits 4 blocks per CU.  For KS == 1 the A operand has no tap reuse either, so
-// it is loaded straight from global memory too: no LDS and no barrier at all.
-// The block index is remapped so that consecutive tiles (neighbouring strips of one image, which share halo rows)
-// run on the same XCD and hit in its L2 (blocks are dispatched round-robin over the 8 XCDs).
-template <int KS, int TH, int TW, int BN, int CK, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_mfma_v2_kernel(const ConvArgs a)
-{
-    using C = ConvCfg<KS, TH, TW, BN, CK, WM, WN>;
-    static_assert(CK == 16, "v2 is written for 16-channel chunks (two k8 steps per tap)");
-    extern __shared__ float4 smem4[];
-    float* const s_in = reinterpret_cast<float*>(smem4);
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int li = lane & 31;
-    const int kh = lane >> 5;
-
-    const bool g1 = blockIdx.z != 0;
-    ConvGroupArgs G;
-    G.in = g1 ? a.g[1].in : a.g[0].in;
-    G.w = g1 ? a.g[1].w : a.g[0].w;
-    G.bias = g1 ? a.g[1].bias : a.g[0].bias;
-    G.out = g1 ? a.g[1].out : a.g[0].out;
-    G.cout = g1 ? a.g[1].cout : a.g[0].cout;
-    const int H = a.H, W = a.W;
-
-    // XCD-aware tile order (bijective for any grid size)
-    int tile;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
-    const int tiles_per_img = a.tiles_x * a.tiles_y;
-    const int bimg = tile / tiles_per_img;
-    const int trem = tile - bimg * tiles_per_img;
-    const int y0 = (trem / a.tiles_x) * TH;
-    const int x0 = (trem % a.tiles_x) * TW;
-    const int n0 = blockIdx.y * BN;
-    const float* in_b = G.in + (size_t)bimg * H * W * a.lda;
-    float biasv[C::NT];
-    conv_load_bias<C>(biasv, G.bias, n0, wn, li);
-
-    // A fragment addressing: LDS offsets (KS > 1) or global float offsets (KS == 1)
-    int a_base[C::MT];
-#pragma unroll
-    for (int t = 0; t < C::MT; ++t) {
-        int m = (wm * C::MT + t) * 32 + li;
-        if (C::MASK_M && m >= C::M) m = C::M - 1;
-        const int q = m >> 2, r = m & 3;
-        const int wy = q / (TW / 2), wx = q % (TW / 2);
-        const int py = 2 * wy + (r >> 1), px = 2 * wx + (r & 1);
-        if constexpr (KS == 1) {
-            const int gy = min(y0 + py, H - 1), gx = min(x0 + px, W - 1);   // clamped; masked at the store
-            a_base[t] = (gy * W + gx) * a.lda + kh * 4;
-        } else {
-            a_base[t] = (py * C::HALO_W + px) * C::LDP + kh * 4;
-        }
-    }
-    // B fragment pointers: packed weights [tap][chunk][cout_pad][16]
-    const float* b_ptr[C::NT];
-#pragma unroll
-    for (int u = 0; u < C::NT; ++u) b_ptr[u] = G.w + (size_t)(n0 + (wn * C::NT + u) * 32 + li) * CK + kh * 4;
-    const size_t w_panel_stride = (size_t)a.cout_pad * CK;
-
-    f32x16 acc[C::MT][C::NT];
-#pragma unroll
-    for (int t = 0; t < C::MT; ++t)
-#pragma unroll
-        for (int u = 0; u < C::NT; ++u)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
-
-    float4 bc[C::NT][2], bn[C::NT][2];       // current / next tap's B fragments (two k8 steps each)
-#pragma unroll
-    for (int u = 0; u < C::NT; ++u) {
-        bc[u][0] = *reinterpret_cast<const float4*>(b_ptr[u]);
-        bc[u][1] = *reinterpret_cast<const float4*>(b_ptr[u] + 8);
-    }
-
-    if constexpr (KS == 1) {
-        // ---- pointwise: A and B straight from global memory, one "tap" per 16-channel chunk, no LDS ----
-        float4 ac[C::MT][2], an[C::MT][2];
-#pragma unroll
-        for (int t = 0; t < C::MT; ++t) {
-            ac[t][0] = *reinterpret_cast<const float4*>(in_b + a_base[t]);
-            ac[t][1] = *reinterpret_cast<const float4*>(in_b + a_base[t] + 8);
-        }
-#pragma unroll 1
-        for (int ch = 0; ch < a.nch; ++ch) {
-            const int cn = (ch + 1 < a.nch) ? ch + 1 : ch;
-#pragma unroll
-            for (int u = 0; u < C::NT; ++u) {
-                bn[u][0] = *reinterpret_cast<const float4*>(b_ptr[u] + (size_t)cn * w_panel_stride);
-                bn[u][1] = *reinterpret_cast<const float4*>(b_ptr[u] + (size_t)cn * w_panel_stride + 8);
-            }
-#pragma unroll
-            for (int t = 0; t < C::MT; ++t) {
-                an[t][0] = *reinterpret_cast<const float4*>(in_b + a_base[t] + cn * CK);
-                an[t][1] = *reinterpret_cast<const float4*>(in_b + a_base[t] + cn * CK + 8);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int t = 0; t < C::MT; ++t)
-#pragma unroll
-                    for (int u = 0; u < C::NT; ++u) {
-                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][s].x, bc[u][s].x, acc[t][u], 0, 0, 0);
-                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][s].y, bc[u][s].y, acc[t][u], 0, 0, 0);
-                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][s].z, bc[u][s].z, acc[t][u], 0, 0, 0);
-                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][s].w, bc[u][s].w, acc[t][u], 0, 0, 0);
-                    }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < C::NT; ++u) { bc[u][0] = bn[u][0]; bc[u][1] = bn[u][1]; }
-#pragma unroll
-            for (int t = 0; t < C::MT; ++t) { ac[t][0] = an[t][0]; ac[t][1] = an[t][1]; }
-        }
-    } else {
-        for (int ch = 0; ch < a.nch; ++ch) {
-            __syncthreads();   // everyone is done reading the previous chunk's halo tile
-            if (!(a.dbg & 1) || ch == 0)
-            for (int f = tid; f < C::HALO_H * C::HALO_W * (CK / 4); f += 256) {
-                const int hp = f / (CK / 4), c4 = f % (CK / 4);
-                const int hy = hp / C::HALO_W, hx = hp - hy * C::HALO_W;
-                const int gy = y0 + hy - C::PADK, gx = x0 + hx - C::PADK;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
-                    v = *reinterpret_cast<const float4*>(in_b + ((size_t)gy * W + gx) * a.lda + ch * CK + c4 * 4);
-                *reinterpret_cast<float4*>(&s_in[hp * C::LDP + c4 * 4]) = v;
-            }
-            __syncthreads();
-#pragma unroll 1
-            for (int tap = 0; tap < C::T; ++tap) {
-                // prefetch the next (tap, chunk) weight fragments: next tap, or tap 0 of the next chunk
-                int tn = tap + 1, cn = ch;
-                if (tn == C::T) {
-                    if (ch + 1 < a.nch) { tn = 0; cn = ch + 1; }
-                    else tn = tap;
-                }
-                const size_t poff = (a.dbg & 2) ? 0 : ((size_t)tn * a.nch + cn) * w_panel_stride;
-#pragma unroll
-                for (int u = 0; u < C::NT; ++u) {
-                    bn[u][0] = *reinterpret_cast<const float4*>(b_ptr[u] + poff);
-                    bn[u][1] = *reinterpret_cast<const float4*>(b_ptr[u] + poff + 8);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const int ky = tap / KS, kx = tap - ky * KS;
-                const int tapoff = (a.dbg & 8) ? 0 : (ky * C::HALO_W + kx) * C::LDP;
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    float4 av[C::MT];
-#pragma unroll
-                    for (int t = 0; t < C::MT; ++t)
-                        av[t] = *reinterpret_cast<const float4*>(&s_in[a_base[t] + tapoff + s * 8]);
-#pragma unroll
-                    for (int t = 0; t < C::MT; ++t)
-#pragma unroll
-                        for (int u = 0; u < C::NT; ++u) {
-                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].x, bc[u][s].x, acc[t][u], 0, 0, 0);
-                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].y, bc[u][s].y, acc[t][u], 0, 0, 0);
-                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].z, bc[u][s].z, acc[t][u], 0, 0, 0);
-                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].w, bc[u][s].w, acc[t][u], 0, 0, 0);
-                        }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < C::NT; ++u) { bc[u][0] = bn[u][0]; bc[u][1] = bn[u][1]; }
-            }
-        }
-    }
-
-    if ((a.dbg & 4) && acc[0][0][0] != 12345.678f) return;   // ablation: drop the stores but keep the accumulators live
-    // ---- epilogue (identical to v1) ----
-conv_epilogue<C, TW>(acc, biasv, a, G.out, G.cout, bimg, y0, x0, n0, wm, wn, li, kh);
-}
-
 // =============================================================================================================
-// v3: software-pipelined for TWO waves per SIMD
+// v5: the general 3x3 / 7x7 kernel (two blocks per CU)
 //
-// Measured on MI355X (tools/mfma_peak2.hip, profiles/): a pure v_mfma_f32_32x32x2_f32 loop sustains 98 % of the
-// 157.3 TFLOP/s peak with 1 or 2 waves per SIMD but only 75-79 % with 3 or 4 -- co-resident waves lose a fifth of the
-// matrix pipe in arbitration.  v1/v2 hide LDS and L2 latency with 3-4 blocks per CU and therefore top out at ~80 %.
-// v3 keeps the v2 data flow (weights L2 -> registers one tap ahead, halo tile in LDS) but hides latency inside the
-// wave instead, and asks for enough LDS that at most 2 blocks (2 waves per SIMD) are resident:
-//   * A fragments are double-buffered in registers: the ds_read_b128s of k-step q+1 are issued before the MFMAs of
-//     k-step q (two register sets, the tap loop body handles the two k8 steps of a 16-channel chunk explicitly);
-//   * the next chunk's halo tile is fetched into registers at the start of a chunk and written to the SECOND LDS halo
-//     buffer at its end: one barrier per chunk (every KS*KS taps) and no exposed global-memory latency.
-template <int KS, int TH, int TW, int BN, int CK, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv_mfma_v3_kernel(const ConvArgs a)
-{
-    using C = ConvCfg<KS, TH, TW, BN, CK, WM, WN>;
-    static_assert(CK == 16 && KS > 1, "v3: 16-channel chunks, spatial kernels");
-    constexpr int NHF = (C::HALO_H * C::HALO_W * (CK / 4) + 255) / 256;   // halo float4 per thread
-    extern __shared__ float4 smem4[];
-    float* const s_in = reinterpret_cast<float*>(smem4);                  // two halo buffers of IN_ELEMS floats
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int li = lane & 31;
-    const int kh = lane >> 5;
-
-    const bool g1 = blockIdx.z != 0;
-    ConvGroupArgs G;
-    G.in = g1 ? a.g[1].in : a.g[0].in;
-    G.w = g1 ? a.g[1].w : a.g[0].w;
-    G.bias = g1 ? a.g[1].bias : a.g[0].bias;
-    G.out = g1 ? a.g[1].out : a.g[0].out;
-    G.cout = g1 ? a.g[1].cout : a.g[0].cout;
-    const int H = a.H, W = a.W;
-
-    int tile;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
-    const int tiles_per_img = a.tiles_x * a.tiles_y;
-    const int bimg = tile / tiles_per_img;
-    const int trem = tile - bimg * tiles_per_img;
-    const int y0 = (trem / a.tiles_x) * TH;
-    const int x0 = (trem % a.tiles_x) * TW;
-    const int n0 = blockIdx.y * BN;
-    const float* in_b = G.in + (size_t)bimg * H * W * a.lda;
-    float biasv[C::NT];
-    conv_load_bias<C>(biasv, G.bias, n0, wn, li);
-
-    int a_base[C::MT];
-#pragma unroll
-    for (int t = 0; t < C::MT; ++t) {
-        int m = (wm * C::MT + t) * 32 + li;
-        if (C::MASK_M && m >= C::M) m = C::M - 1;
-        const int q = m >> 2, r = m & 3;
-        const int wy = q / (TW / 2), wx = q % (TW / 2);
-        const int py = 2 * wy + (r >> 1), px = 2 * wx + (r & 1);
-        a_base[t] = (py * C::HALO_W + px) * C::LDP + kh * 4;
-    }
-    const float* b_ptr[C::NT];
-#pragma unroll
-    for (int u = 0; u < C::NT; ++u) b_ptr[u] = G.w + (size_t)(n0 + (wn * C::NT + u) * 32 + li) * CK + kh * 4;
-    const size_t w_panel_stride = (size_t)a.cout_pad * CK;
-
-    // halo staging slots of this thread: LDS offset, clamped global offset, in-bounds flag (same for every chunk)
-    int h_lds[NHF], h_goff[NHF];
-    bool h_ok[NHF];
-#pragma unroll
-    for (int r = 0; r < NHF; ++r) {
-        const int f = tid + r * 256;
-        const bool slot = f < C::HALO_H * C::HALO_W * (CK / 4);
-        const int hp = slot ? f / (CK / 4) : 0, c4 = f % (CK / 4);
-        const int hy = hp / C::HALO_W, hx = hp - hy * C::HALO_W;
-        const int gy = y0 + hy - C::PADK, gx = x0 + hx - C::PADK;
-        const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-        const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-        h_lds[r] = slot ? hp * C::LDP + c4 * 4 : -1;
-        h_goff[r] = (cy * W + cx) * a.lda + c4 * 4;
-        h_ok[r] = inb;
-    }
-
-    f32x16 acc[C::MT][C::NT];
-#pragma unroll
-    for (int t = 0; t < C::MT; ++t)
-#pragma unroll
-        for (int u = 0; u < C::NT; ++u)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
-
-    // ---- prologue: chunk 0 halo -> buffer 0, first weight fragments, first A fragments ----
-    float4 bc[C::NT][2], bn[C::NT][2];
-#pragma unroll
-    for (int u = 0; u < C::NT; ++u) {
-        bc[u][0] = *reinterpret_cast<const float4*>(b_ptr[u]);
-        bc[u][1] = *reinterpret_cast<const float4*>(b_ptr[u] + 8);
-    }
-#pragma unroll
-    for (int r = 0; r < NHF; ++r) {
-        float4 v = *reinterpret_cast<const float4*>(in_b + h_goff[r]);
-        if (!h_ok[r]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (h_lds[r] >= 0) *reinterpret_cast<float4*>(&s_in[h_lds[r]]) = v;
-    }
-    __syncthreads();
-    float4 av0[C::MT], av1[C::MT];
-#pragma unroll
-    for (int t = 0; t < C::MT; ++t) av0[t] = *reinterpret_cast<const float4*>(&s_in[a_base[t]]);
-
-    for (int ch = 0; ch < a.nch; ++ch) {
-        const float* cur = s_in + (ch & 1) * C::IN_ELEMS;
-        float* nxt = s_in + ((ch + 1) & 1) * C::IN_ELEMS;
-        const bool more_ch = ch + 1 < a.nch;
-        // next chunk's halo: global -> registers now, registers -> LDS after the last tap
-        float4 hreg[NHF];
-        {
-            const int cn = more_ch ? ch + 1 : ch;
-#pragma unroll
-            for (int r = 0; r < NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + cn * CK);
-        }
-#pragma unroll 1
-        for (int tap = 0; tap < C::T; ++tap) {
-            int tn = tap + 1, cn = ch;
-            if (tn == C::T) {
-                if (more_ch) { tn = 0; cn = ch + 1; }
-                else tn = tap;
-            }
-            const size_t poff = ((size_t)tn * a.nch + cn) * w_panel_stride;
-#pragma unroll
-            for (int u = 0; u < C::NT; ++u) {
-                bn[u][0] = *reinterpret_cast<const float4*>(b_ptr[u] + poff);
-                bn[u][1] = *reinterpret_cast<const float4*>(b_ptr[u] + poff + 8);
-            }
-            const int ky = tap / KS, kx = tap - ky * KS;
-            const int tapoff = (ky * C::HALO_W + kx) * C::LDP;
-            // k8 step 0: prefetch step 1's A fragments, then the MFMAs of step 0
-#pragma unroll
-            for (int t = 0; t < C::MT; ++t) av1[t] = *reinterpret_cast<const float4*>(&cur[a_base[t] + tapoff + 8]);
-            __builtin_amdgcn_sched_barrier(0);   // loads above are issued before the MFMAs below (pins the prefetch distance)
-#pragma unroll
-            for (int t = 0; t < C::MT; ++t)
-#pragma unroll
-                for (int u = 0; u < C::NT; ++u) {
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t].x, bc[u][0].x, acc[t][u], 0, 0, 0);
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t].y, bc[u][0].y, acc[t][u], 0, 0, 0);
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t].z, bc[u][0].z, acc[t][u], 0, 0, 0);
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t].w, bc[u][0].w, acc[t][u], 0, 0, 0);
-                }
-            // k8 step 1: prefetch the next tap's step-0 fragments (clamped to this tap on the chunk's last one)
-            {
-                const int t2 = (tap + 1 < C::T) ? tap + 1 : tap;
-                const int ky2 = t2 / KS, kx2 = t2 - ky2 * KS;
-                const int tapoff2 = (ky2 * C::HALO_W + kx2) * C::LDP;
-#pragma unroll
-                for (int t = 0; t < C::MT; ++t) av0[t] = *reinterpret_cast<const float4*>(&cur[a_base[t] + tapoff2]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < C::MT; ++t)
-#pragma unroll
-                for (int u = 0; u < C::NT; ++u) {
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t].x, bc[u][1].x, acc[t][u], 0, 0, 0);
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t].y, bc[u][1].y, acc[t][u], 0, 0, 0);
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t].z, bc[u][1].z, acc[t][u], 0, 0, 0);
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t].w, bc[u][1].w, acc[t][u], 0, 0, 0);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < C::NT; ++u) { bc[u][0] = bn[u][0]; bc[u][1] = bn[u][1]; }
-        }
-        if (more_ch) {
-#pragma unroll
-            for (int r = 0; r < NHF; ++r) {
-                float4 v = hreg[r];
-                if (!h_ok[r]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (h_lds[r] >= 0) *reinterpret_cast<float4*>(&nxt[h_lds[r]]) = v;
-            }
-            __syncthreads();   // next halo visible; nobody still reads the buffer that the chunk after next will overwrite
-#pragma unroll
-            for (int t = 0; t < C::MT; ++t) av0[t] = *reinterpret_cast<const float4*>(&nxt[a_base[t]]);
-        }
-    }
-
-    // ---- epilogue (identical to v1) ----
-conv_epilogue<C, TW>(acc, biasv, a, G.out, G.cout, bimg, y0, x0, n0, wm, wn, li, kh);
-}
-
-// =============================================================================================================
-// v4: v3 with the memory instructions interleaved into the MFMA stream
-//
-// Compile-time ablations of v3 (profiles/r01_conv_ablate3.txt) showed that the tap loop without any memory
-// instruction reaches the structural ceiling (~85 % of peak: row padding, block quantisation, DVFS), and that the two
-// weight loads (-9 %) and six LDS reads (-7 %) per tap cost far more than their latency: a wave issues in order, so
-// when the loads of a tap are issued in one clump only the first 64 cycles of that issue time are covered by the MFMA
-// in flight and the matrix pipe idles for the rest.  v4 therefore issues exactly one memory instruction in the gap
-// after each of the first MFMAs of a k-step (the 64-cycle MFMA hides a 1 KB load issue), keeps the prefetch distances
-// of v3 (weights one tap ahead, A fragments one k-step ahead, halo one chunk ahead) and ping-pongs two named weight
-// register sets across an unrolled-by-two tap loop so that no register copies are left in the loop.
+// History (profiles/r01_conv_*; the intermediate generations v2 - v4 are in the git history):
+//   * with the waves of a block split along N (WN = 4) a wave's weight fragment is private, so it streams L2 -> registers
+//     one tap ahead instead of going through LDS: no barrier inside a channel chunk, LDS holds only the halo tile (v2);
+//   * the fp32 MFMA pipe loses ~20 % with 3-4 waves per SIMD, so latency is hidden inside the wave (A fragments one k-step
+//     ahead in registers, next chunk's halo prefetched into registers and written to a second LDS buffer: one barrier per
+//     chunk) and an LDS floor keeps at most two blocks per CU (v3);
+//   * a wave issues in order: memory instructions issued in a clump leave the matrix pipe idle, so exactly one memory
+//     instruction goes into the gap after each of the first MFMAs of a k-step, and two weight register sets ping-pong (v4);
+//   * every VALU / SALU instruction between two MFMAs costs matrix-pipe time: all KS*KS taps of a chunk are unrolled so
+//     the LDS tap offsets are ds_read immediates, and the weights come through a buffer resource (descriptor and per-tap
+//     panel offset in SGPRs), leaving only MFMAs, ds_reads, buffer_loads and s_waitcnts in the loop (v5: +6 % over v4).
+// The block index is remapped so that consecutive tiles (which share halo rows) run on the same XCD and hit in its L2
+// (blocks are dispatched round-robin over the 8 XCDs).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <typename C, int KS, int ABL = 0>
+template <typename C, int KS>
 struct TapBody {
     // one tap = two k8 steps.  bc: this tap's weight fragments; bn: filled with the next tap's (prefetch).
     // av0: this tap's step-0 A fragments (prefetched); on return holds the next tap's step-0 fragments.
-    static __device__ __forceinline__ void run(f32x16 (&acc)[C::MT][C::NT], f32x4 (&av0)[C::MT], f32x4 (&av1)[C::MT],
-                                               const f32x4 (&bc)[C::NT][2], f32x4 (&bn)[C::NT][2],
-                                               const float* const (&b_ptr)[C::NT], size_t poff_next, const float* cur,
-                                               const int (&a_base)[C::MT], int tapoff, int tapoff_next)
-    {
-        constexpr int NM = 4 * C::MT * C::NT;     // MFMAs per k8 step
-        constexpr int NB = 2 * C::NT;             // weight loads per tap
-        static_assert(NM >= NB + C::MT, "not enough MFMA gaps for the memory instructions of a k-step");
-        // ---- k8 step 0: + weight prefetch (NB loads) + A fragments of step 1 (MT LDS reads) ----
-#pragma unroll
-        for (int i = 0; i < NM; ++i) {
-            const int e = i / (C::MT * C::NT), t = (i / C::NT) % C::MT, u = i % C::NT;
-            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t][e], bc[u][0][e], acc[t][u], 0, 0, 0);
-            if (i < NB) {
-                if constexpr (!(ABL & 1)) {
-                    bn[i >> 1][i & 1] = *reinterpret_cast<const f32x4*>(b_ptr[i >> 1] + poff_next + (i & 1) * 8);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else if (i < NB + C::MT) {
-                if constexpr (!(ABL & 2)) {
-                    av1[i - NB] = *reinterpret_cast<const f32x4*>(&cur[a_base[i - NB] + tapoff + 8]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        // ---- k8 step 1: + A fragments of the next tap's step 0 ----
-#pragma unroll
-        for (int i = 0; i < NM; ++i) {
-            const int e = i / (C::MT * C::NT), t = (i / C::NT) % C::MT, u = i % C::NT;
-            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t][e], bc[u][1][e], acc[t][u], 0, 0, 0);
-            if (i < C::MT) {
-                // (the read replaces av0[i], whose last use was in step 0)
-                if constexpr (!(ABL & 2)) {
-                    av0[i] = *reinterpret_cast<const f32x4*>(&cur[a_base[i] + tapoff_next]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-    }
-
-    // v5 form of the same tap: weights come through a buffer resource (SGPR descriptor of the group's packed weights) with
+    // Weights come through a buffer resource (SGPR descriptor of the group's packed weights) with
     // a per-lane 32-bit byte offset (VGPR, loop invariant) and the next tap's panel offset in an SGPR (`wnext`), so the
     // loop has no address VALU for them; the taps are fully unrolled by the caller, which makes tapoff / tapoff_next
     // compile-time constants that fold into the ds_read immediate offsets.
@@ -729,11 +317,11 @@ struct TapBody {
     }
 };
 
-template <int KS, int TH, int TW, int BN, int CK, int WM, int WN, int ABL, int UNR>
-__device__ __forceinline__ void conv_v45_body(const ConvArgs& a)
+template <int KS, int TH, int TW, int BN, int CK, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_mfma_v5_kernel(const ConvArgs a)
 {
     using C = ConvCfg<KS, TH, TW, BN, CK, WM, WN>;
-    static_assert(CK == 16 && KS > 1 && (KS * KS) % 2 == 1, "v4: 16-channel chunks, odd number of taps");
+    static_assert(CK == 16 && KS > 1 && (KS * KS) % 2 == 1, "v5: 16-channel chunks, odd number of taps");
     constexpr int NHF = (C::HALO_H * C::HALO_W * (CK / 4) + 255) / 256;
     extern __shared__ float4 smem4[];
     float* const s_in = reinterpret_cast<float*>(smem4);
@@ -780,11 +368,8 @@ __device__ __forceinline__ void conv_v45_body(const ConvArgs& a)
         const int py = 2 * wy + (r >> 1), px = 2 * wx + (r & 1);
         a_base[t] = (py * C::HALO_W + px) * C::LDP + kh * 4;
     }
-    const float* b_ptr[C::NT];
-#pragma unroll
-    for (int u = 0; u < C::NT; ++u) b_ptr[u] = G.w + (size_t)(n0 + (wn * C::NT + u) * 32 + li) * CK + kh * 4;
     const size_t w_panel_stride = (size_t)a.cout_pad * CK;
-    // v5 (UNR): buffer resource over the group's packed weights (raw buffer, 32-bit byte offsets) + per-lane byte offsets
+    // buffer resource over the group's packed weights (raw buffer, 32-bit byte offsets) + per-lane byte offsets
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G.w), 0, 0x7fffffff, 0x00020000);
     unsigned b_off[C::NT];
 #pragma unroll
@@ -817,9 +402,8 @@ __device__ __forceinline__ void conv_v45_body(const ConvArgs& a)
     f32x4 bA[C::NT][2], bB[C::NT][2];      // ping-pong weight fragment sets
 #pragma unroll
     for (int u = 0; u < C::NT; ++u) {
-        bA[u][0] = *reinterpret_cast<const f32x4*>(b_ptr[u]);
-        bA[u][1] = *reinterpret_cast<const f32x4*>(b_ptr[u] + 8);
-        if constexpr (ABL & 1) { bB[u][0] = bA[u][0]; bB[u][1] = bA[u][1]; }
+        bA[u][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[u], 0u, 0));
+        bA[u][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[u] + 32, 0u, 0));
     }
 #pragma unroll
     for (int r = 0; r < NHF; ++r) {
@@ -832,70 +416,39 @@ __device__ __forceinline__ void conv_v45_body(const ConvArgs& a)
 #pragma unroll
     for (int t = 0; t < C::MT; ++t) {
         av0[t] = *reinterpret_cast<const f32x4*>(&s_in[a_base[t]]);
-        if constexpr (ABL & 2) av1[t] = *reinterpret_cast<const f32x4*>(&s_in[a_base[t] + 8]);
     }
 
     for (int ch = 0; ch < a.nch; ++ch) {
-        const float* cur = s_in + ((ABL & 4) ? 0 : (ch & 1)) * C::IN_ELEMS;
+        const float* cur = s_in + (ch & 1) * C::IN_ELEMS;
         float* nxt = s_in + ((ch + 1) & 1) * C::IN_ELEMS;
         const bool more_ch = ch + 1 < a.nch;
         float4 hreg[NHF];
-        if constexpr (!(ABL & 4)) {
+        {
+            // next chunk's halo: global -> registers now, registers -> LDS after the last tap
             const int cn = more_ch ? ch + 1 : ch;
 #pragma unroll
             for (int r = 0; r < NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + cn * CK);
         }
-        const size_t chunk_off = (size_t)ch * w_panel_stride;
-        const size_t tap_stride = (size_t)a.nch * w_panel_stride;
-        if constexpr (UNR) {
-            // v5: all taps unrolled (LDS offsets become immediates), ping-pong register sets alternate at compile time
-            const unsigned chunk_b = (unsigned)(chunk_off * 4);
-            unsigned tap_b = (unsigned)(tap_stride * 4);
-            asm volatile("" : "+s"(tap_b));          // keep the 49 panel offsets from being hoisted out of the chunk loop
-            unsigned soff = chunk_b;                 // byte offset of the current tap's panel
+        // all taps unrolled (LDS offsets become immediates); the two weight register sets alternate at compile time
+        const unsigned chunk_b = (unsigned)((size_t)ch * w_panel_stride * 4);
+        unsigned tap_b = (unsigned)((size_t)a.nch * w_panel_stride * 4);
+        asm volatile("" : "+s"(tap_b));          // keep the KS*KS panel offsets from being hoisted out of the chunk loop
+        unsigned soff = chunk_b;                 // byte offset of the current tap's panel
 #pragma unroll
-            for (int tap = 0; tap < C::T; ++tap) {
-                const int toff = ((tap / KS) * C::HALO_W + tap % KS) * C::LDP;
-                const int tnx = tap + 1 < C::T ? tap + 1 : tap;
-                const int toff_n = ((tnx / KS) * C::HALO_W + tnx % KS) * C::LDP;
-                // next tap's panel; the last tap prefetches tap 0 of the next chunk (or re-reads its own panel at the very end)
-                unsigned wnext;
-                if (tap + 1 < C::T) { soff += tap_b; wnext = soff; }
-                else wnext = more_ch ? chunk_b + (unsigned)(w_panel_stride * 4) : soff;
-                if (tap & 1) TapBody<C, KS, ABL>::run_u(acc, av0, av1, bB, bA, wrsrc, wnext, b_off, cur, a_base, toff, toff_n);
-                else TapBody<C, KS, ABL>::run_u(acc, av0, av1, bA, bB, wrsrc, wnext, b_off, cur, a_base, toff, toff_n);
-            }
-#pragma unroll
-            for (int u = 0; u < C::NT; ++u) { bA[u][0] = bB[u][0]; bA[u][1] = bB[u][1]; }     // T is odd
-        } else {
-        // taps 0 .. T-2 in pairs (A -> B -> A), then the last tap (A -> B) and one copy B -> A per chunk.
-            // LDS tap offsets and weight panel offsets advance incrementally (no divisions / 64-bit multiplies in the loop).
-            size_t pnext = chunk_off + tap_stride;       // panel of tap 1
-            int toff = 0, kx = 0;                        // LDS offset of the current tap, its column
-            auto advance = [&](int off, int& col) {      // offset of the following tap
-                if (col + 1 == KS) { col = 0; return off + (C::HALO_W - KS + 1) * C::LDP; }
-                col += 1;
-                return off + C::LDP;
-            };
-    #pragma unroll 1
-            for (int tap = 0; tap + 1 < C::T; tap += 2) {
-                const int toff1 = advance(toff, kx);
-                TapBody<C, KS, ABL>::run(acc, av0, av1, bA, bB, b_ptr, pnext, cur, a_base, toff, toff1);
-                pnext += tap_stride;
-                const int toff2 = advance(toff1, kx);
-                TapBody<C, KS, ABL>::run(acc, av0, av1, bB, bA, b_ptr, pnext, cur, a_base, toff1, toff2);
-                pnext += tap_stride;
-                toff = toff2;
-            }
-            {
-                // last tap: prefetch tap 0 of the next chunk (or re-read this panel on the very last chunk)
-                const size_t plast = more_ch ? chunk_off + w_panel_stride : (size_t)(C::T - 1) * tap_stride + chunk_off;
-                TapBody<C, KS, ABL>::run(acc, av0, av1, bA, bB, b_ptr, plast, cur, a_base, toff, toff);
-    #pragma unroll
-                for (int u = 0; u < C::NT; ++u) { bA[u][0] = bB[u][0]; bA[u][1] = bB[u][1]; }
-            }
+        for (int tap = 0; tap < C::T; ++tap) {
+            const int toff = ((tap / KS) * C::HALO_W + tap % KS) * C::LDP;
+            const int tnx = tap + 1 < C::T ? tap + 1 : tap;
+            const int toff_n = ((tnx / KS) * C::HALO_W + tnx % KS) * C::LDP;
+            // next tap's panel; the last tap prefetches tap 0 of the next chunk (or re-reads its own panel at the very end)
+            unsigned wnext;
+            if (tap + 1 < C::T) { soff += tap_b; wnext = soff; }
+            else wnext = more_ch ? chunk_b + (unsigned)(w_panel_stride * 4) : soff;
+            if (tap & 1) TapBody<C, KS>::run_u(acc, av0, av1, bB, bA, wrsrc, wnext, b_off, cur, a_base, toff, toff_n);
+            else TapBody<C, KS>::run_u(acc, av0, av1, bA, bB, wrsrc, wnext, b_off, cur, a_base, toff, toff_n);
         }
-        if (more_ch && !(ABL & 4)) {
+#pragma unroll
+        for (int u = 0; u < C::NT; ++u) { bA[u][0] = bB[u][0]; bA[u][1] = bB[u][1]; }     // T is odd
+        if (more_ch) {
 #pragma unroll
             for (int r = 0; r < NHF; ++r) {
                 float4 v = hreg[r];
@@ -908,21 +461,8 @@ __device__ __forceinline__ void conv_v45_body(const ConvArgs& a)
         }
     }
 
-    // ---- epilogue (identical to v1) ----
-conv_epilogue<C, TW>(acc, biasv, a, G.out, G.cout, bimg, y0, x0, n0, wm, wn, li, kh);
-}
-
-template <int KS, int TH, int TW, int BN, int CK, int WM, int WN, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void conv_mfma_v4_kernel(const ConvArgs a)
-{
-    conv_v45_body<KS, TH, TW, BN, CK, WM, WN, ABL, 0>(a);
-}
-
-// v5 = the v4 schedule with the taps fully unrolled and buffer-resource weight loads (see TapBody::run_u)
-template <int KS, int TH, int TW, int BN, int CK, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv_mfma_v5_kernel(const ConvArgs a)
-{
-    conv_v45_body<KS, TH, TW, BN, CK, WM, WN, 0, 1>(a);
+    // ---- epilogue (shared with v1) ----
+    conv_epilogue<C, TW>(acc, biasv, a, G.out, G.cout, bimg, y0, x0, n0, wm, wn, li, kh);
 }
 
 // ---- v6: one block per CU, 17 MFMA row tiles of consecutive pixels per wave -------------------------------------------
@@ -1188,196 +728,6 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_v6_kernel(const ConvArgs a)
     }
 }
 
-// Ablation twin of v3 (timing experiments only, results are wrong when ABL != 0): ABL bit0 = weight fragments loaded
-// once (no per-tap global loads), bit1 = A fragments read once per chunk (no per-step ds_reads), bit2 = halo staged
-// once (no per-chunk global loads / LDS writes / barrier), bit3 = no B register copies (prefetch into bc directly).
-template <int KS, int TH, int TW, int BN, int CK, int WM, int WN, int ABL>
-__global__ __launch_bounds__(256, 2) void conv_mfma_v3abl_kernel(const ConvArgs a)
-{
-    using C = ConvCfg<KS, TH, TW, BN, CK, WM, WN>;
-    static_assert(CK == 16 && KS > 1, "v3: 16-channel chunks, spatial kernels");
-    constexpr int NHF = (C::HALO_H * C::HALO_W * (CK / 4) + 255) / 256;   // halo float4 per thread
-    extern __shared__ float4 smem4[];
-    float* const s_in = reinterpret_cast<float*>(smem4);                  // two halo buffers of IN_ELEMS floats
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int li = lane & 31;
-    const int kh = lane >> 5;
-
-    const bool g1 = blockIdx.z != 0;
-    ConvGroupArgs G;
-    G.in = g1 ? a.g[1].in : a.g[0].in;
-    G.w = g1 ? a.g[1].w : a.g[0].w;
-    G.bias = g1 ? a.g[1].bias : a.g[0].bias;
-    G.out = g1 ? a.g[1].out : a.g[0].out;
-    G.cout = g1 ? a.g[1].cout : a.g[0].cout;
-    const int H = a.H, W = a.W;
-
-    int tile;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
-    const int tiles_per_img = a.tiles_x * a.tiles_y;
-    const int bimg = tile / tiles_per_img;
-    const int trem = tile - bimg * tiles_per_img;
-    const int y0 = (trem / a.tiles_x) * TH;
-    const int x0 = (trem % a.tiles_x) * TW;
-    const int n0 = blockIdx.y * BN;
-    const float* in_b = G.in + (size_t)bimg * H * W * a.lda;
-    float biasv[C::NT];
-    conv_load_bias<C>(biasv, G.bias, n0, wn, li);
-
-    int a_base[C::MT];
-#pragma unroll
-    for (int t = 0; t < C::MT; ++t) {
-        int m = (wm * C::MT + t) * 32 + li;
-        if (C::MASK_M && m >= C::M) m = C::M - 1;
-        const int q = m >> 2, r = m & 3;
-        const int wy = q / (TW / 2), wx = q % (TW / 2);
-        const int py = 2 * wy + (r >> 1), px = 2 * wx + (r & 1);
-        a_base[t] = (py * C::HALO_W + px) * C::LDP + kh * 4;
-    }
-    const float* b_ptr[C::NT];
-#pragma unroll
-    for (int u = 0; u < C::NT; ++u) b_ptr[u] = G.w + (size_t)(n0 + (wn * C::NT + u) * 32 + li) * CK + kh * 4;
-    const size_t w_panel_stride = (size_t)a.cout_pad * CK;
-
-    // halo staging slots of this thread: LDS offset, clamped global offset, in-bounds flag (same for every chunk)
-    int h_lds[NHF], h_goff[NHF];
-    bool h_ok[NHF];
-#pragma unroll
-    for (int r = 0; r < NHF; ++r) {
-        const int f = tid + r * 256;
-        const bool slot = f < C::HALO_H * C::HALO_W * (CK / 4);
-        const int hp = slot ? f / (CK / 4) : 0, c4 = f % (CK / 4);
-        const int hy = hp / C::HALO_W, hx = hp - hy * C::HALO_W;
-        const int gy = y0 + hy - C::PADK, gx = x0 + hx - C::PADK;
-        const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-        const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-        h_lds[r] = slot ? hp * C::LDP + c4 * 4 : -1;
-        h_goff[r] = (cy * W + cx) * a.lda + c4 * 4;
-        h_ok[r] = inb;
-    }
-
-    f32x16 acc[C::MT][C::NT];
-#pragma unroll
-    for (int t = 0; t < C::MT; ++t)
-#pragma unroll
-        for (int u = 0; u < C::NT; ++u)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
-
-    // ---- prologue: chunk 0 halo -> buffer 0, first weight fragments, first A fragments ----
-    float4 bc[C::NT][2], bn[C::NT][2];
-#pragma unroll
-    for (int u = 0; u < C::NT; ++u) {
-        bc[u][0] = *reinterpret_cast<const float4*>(b_ptr[u]);
-        bc[u][1] = *reinterpret_cast<const float4*>(b_ptr[u] + 8);
-    }
-#pragma unroll
-    for (int r = 0; r < NHF; ++r) {
-        float4 v = *reinterpret_cast<const float4*>(in_b + h_goff[r]);
-        if (!h_ok[r]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (h_lds[r] >= 0) *reinterpret_cast<float4*>(&s_in[h_lds[r]]) = v;
-    }
-    __syncthreads();
-    float4 av0[C::MT], av1[C::MT];
-#pragma unroll
-    for (int t = 0; t < C::MT; ++t) { av0[t] = *reinterpret_cast<const float4*>(&s_in[a_base[t]]); av1[t] = *reinterpret_cast<const float4*>(&s_in[a_base[t] + 8]); }
-
-    for (int ch = 0; ch < a.nch; ++ch) {
-        const float* cur = s_in + ((ABL & 4) ? 0 : (ch & 1)) * C::IN_ELEMS;
-        float* nxt = s_in + ((ch + 1) & 1) * C::IN_ELEMS;
-        const bool more_ch = ch + 1 < a.nch;
-        // next chunk's halo: global -> registers now, registers -> LDS after the last tap
-        float4 hreg[NHF];
-        if constexpr (!(ABL & 4)) {
-            const int cn = more_ch ? ch + 1 : ch;
-#pragma unroll
-            for (int r = 0; r < NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + cn * CK);
-        }
-#pragma unroll 1
-        for (int tap = 0; tap < C::T; ++tap) {
-            int tn = tap + 1, cn = ch;
-            if (tn == C::T) {
-                if (more_ch) { tn = 0; cn = ch + 1; }
-                else tn = tap;
-            }
-            const size_t poff = ((size_t)tn * a.nch + cn) * w_panel_stride;
-            if constexpr (!(ABL & 1)) {
-#pragma unroll
-            for (int u = 0; u < C::NT; ++u) {
-                bn[u][0] = *reinterpret_cast<const float4*>(b_ptr[u] + poff);
-                bn[u][1] = *reinterpret_cast<const float4*>(b_ptr[u] + poff + 8);
-            }
-            }
-            const int ky = tap / KS, kx = tap - ky * KS;
-            const int tapoff = (ky * C::HALO_W + kx) * C::LDP;
-            // k8 step 0: prefetch step 1's A fragments, then the MFMAs of step 0
-            if constexpr (!(ABL & 2) )
-#pragma unroll
-            for (int t = 0; t < C::MT; ++t) av1[t] = *reinterpret_cast<const float4*>(&cur[a_base[t] + tapoff + 8]);
-            __builtin_amdgcn_sched_barrier(0);   // loads above are issued before the MFMAs below (pins the prefetch distance)
-#pragma unroll
-            for (int t = 0; t < C::MT; ++t)
-#pragma unroll
-                for (int u = 0; u < C::NT; ++u) {
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t].x, bc[u][0].x, acc[t][u], 0, 0, 0);
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t].y, bc[u][0].y, acc[t][u], 0, 0, 0);
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t].z, bc[u][0].z, acc[t][u], 0, 0, 0);
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t].w, bc[u][0].w, acc[t][u], 0, 0, 0);
-                }
-            // k8 step 1: prefetch the next tap's step-0 fragments (clamped to this tap on the chunk's last one)
-            {
-                const int t2 = (tap + 1 < C::T) ? tap + 1 : tap;
-                const int ky2 = t2 / KS, kx2 = t2 - ky2 * KS;
-                const int tapoff2 = (ky2 * C::HALO_W + kx2) * C::LDP;
-                if constexpr (!(ABL & 2))
-#pragma unroll
-                for (int t = 0; t < C::MT; ++t) av0[t] = *reinterpret_cast<const float4*>(&cur[a_base[t] + tapoff2]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < C::MT; ++t)
-#pragma unroll
-                for (int u = 0; u < C::NT; ++u) {
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t].x, bc[u][1].x, acc[t][u], 0, 0, 0);
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t].y, bc[u][1].y, acc[t][u], 0, 0, 0);
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t].z, bc[u][1].z, acc[t][u], 0, 0, 0);
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t].w, bc[u][1].w, acc[t][u], 0, 0, 0);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!(ABL & 1) && !(ABL & 8)) {
-#pragma unroll
-            for (int u = 0; u < C::NT; ++u) { bc[u][0] = bn[u][0]; bc[u][1] = bn[u][1]; }
-            }
-            if constexpr ((ABL & 8) && !(ABL & 1)) {      // keep the loads alive without the copies
-#pragma unroll
-                for (int u = 0; u < C::NT; ++u) asm volatile("" ::"v"(bn[u][0].x), "v"(bn[u][1].x));
-            }
-        }
-        if (more_ch && !(ABL & 4)) {
-#pragma unroll
-            for (int r = 0; r < NHF; ++r) {
-                float4 v = hreg[r];
-                if (!h_ok[r]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (h_lds[r] >= 0) *reinterpret_cast<float4*>(&nxt[h_lds[r]]) = v;
-            }
-            __syncthreads();   // next halo visible; nobody still reads the buffer that the chunk after next will overwrite
-#pragma unroll
-            for (int t = 0; t < C::MT; ++t) av0[t] = *reinterpret_cast<const float4*>(&nxt[a_base[t]]);
-        }
-    }
-
-    // ---- epilogue (identical to v1) ----
-conv_epilogue<C, TW>(acc, biasv, a, G.out, G.cout, bimg, y0, x0, n0, wm, wn, li, kh);
-}
-
 // ---- conv1_1: 3 input channels ---------------------------------------------------------------------------------------
 // The generic kernels spend a whole 16-channel chunk (8 MFMA k-pairs per tap) on 3 real channels.  Here K = 27 is packed
 // tap-major / channel-minor into 14 k-pairs (the 28th k is zero) - the order in which the generic kernels meet the three
@@ -1496,8 +846,10 @@ static int g_min_lds = 0;
 void conv_set_min_lds(int bytes) { g_min_lds = bytes; }
 
 // ---- variant table ---------------------------------------------------------------------------------------
+// {ksize, tile rows (v6: row tiles per block), tile cols (v6: 32), BN, CK, name}
 static const ConvVariant g_variants[] = {
-    {7, 8, 16, 128, 16, "conv7x7_t8x16_n128"},    // 0: stages 2-6, the dominant kernel
+    // v1 kernels: weight panel through LDS, one barrier per tap (1x1 layers; reference implementation of the others)
+    {7, 8, 16, 128, 16, "conv7x7_t8x16_n128"},    // 0
     {3, 8, 16, 128, 16, "conv3x3_t8x16_n128"},    // 1
     {3, 8, 16, 64, 16, "conv3x3_t8x16_n64"},      // 2
     {1, 8, 16, 128, 16, "conv1x1_t8x16_n128"},    // 3
@@ -1507,49 +859,26 @@ static const ConvVariant g_variants[] = {
     {1, 8, 8, 64, 16, "conv1x1_t8x8_n64"},        // 7
     {7, 2, 46, 128, 16, "conv7x7_t2x46_n128"},    // 8: zero-waste row strips for 46-wide maps (368x368 input)
     {3, 2, 46, 128, 16, "conv3x3_t2x46_n128"},    // 9
-    // v2 kernels: weights L2 -> registers, no per-tap barrier (see conv_mfma_v2_kernel)
-    {7, 2, 46, 128, 16, "conv7x7_v2_t2x46_n128"},  // 10
-    {3, 2, 46, 128, 16, "conv3x3_v2_t2x46_n128"},  // 11
-    {7, 8, 16, 128, 16, "conv7x7_v2_t8x16_n128"},  // 12
-    {3, 8, 16, 128, 16, "conv3x3_v2_t8x16_n128"},  // 13
-    {3, 8, 16, 64, 16, "conv3x3_v2_t8x16_n64"},    // 14
-    {1, 8, 16, 128, 16, "conv1x1_v2_t8x16_n128"},  // 15
-    {1, 8, 16, 64, 16, "conv1x1_v2_t8x16_n64"},    // 16
-    {1, 2, 46, 128, 16, "conv1x1_v2_t2x46_n128"},  // 17
-    // v3 kernels: software-pipelined, 2 blocks per CU (see conv_mfma_v3_kernel)
-    {7, 2, 46, 128, 16, "conv7x7_v3_t2x46_n128"},  // 18
-    {3, 2, 46, 128, 16, "conv3x3_v3_t2x46_n128"},  // 19
-    {7, 8, 16, 128, 16, "conv7x7_v3_t8x16_n128"},  // 20
-    {3, 8, 16, 128, 16, "conv3x3_v3_t8x16_n128"},  // 21
-    {3, 8, 16, 64, 16, "conv3x3_v3_t8x16_n64"},    // 22
-    {7, 8, 8, 64, 16, "conv7x7_v3_t8x8_n64"},      // 23: small launches (single images): one wave per SIMD, pipelined
-    {3, 8, 8, 64, 16, "conv3x3_v3_t8x8_n64"},      // 24
-    // v4 kernels: v3 + memory instructions interleaved into the MFMA stream (see conv_mfma_v4_kernel)
-    {7, 2, 46, 128, 16, "conv7x7_v4_t2x46_n128"},  // 25
-    {3, 2, 46, 128, 16, "conv3x3_v4_t2x46_n128"},  // 26
-    {7, 8, 16, 128, 16, "conv7x7_v4_t8x16_n128"},  // 27
-    {3, 8, 16, 128, 16, "conv3x3_v4_t8x16_n128"},  // 28
-    {3, 8, 16, 64, 16, "conv3x3_v4_t8x16_n64"},    // 29
-    {7, 8, 8, 64, 16, "conv7x7_v4_t8x8_n64"},      // 30
-    {3, 8, 8, 64, 16, "conv3x3_v4_t8x8_n64"},      // 31
-    // v5 kernels: v4 with the taps fully unrolled (immediate LDS offsets) and saddr weight loads (no address VALU in the loop)
-    {7, 2, 46, 128, 16, "conv7x7_v5_t2x46_n128"},  // 32
-    {3, 2, 46, 128, 16, "conv3x3_v5_t2x46_n128"},  // 33
-    {7, 8, 16, 128, 16, "conv7x7_v5_t8x16_n128"},  // 34
-    {3, 8, 16, 128, 16, "conv3x3_v5_t8x16_n128"},  // 35
-    {3, 8, 16, 64, 16, "conv3x3_v5_t8x16_n64"},    // 36
-    {7, 8, 8, 64, 16, "conv7x7_v5_t8x8_n64"},      // 37
-    {3, 8, 8, 64, 16, "conv3x3_v5_t8x8_n64"},      // 38
-    // v6 kernels: one block per CU, 17 x 32 consecutive pixels of a 46-wide map x 128 channels (see conv_mfma_v6_kernel)
-    {7, 17, 32, 128, 16, "conv7x7_v6_t17x32_n128"},  // 39
-    {3, 17, 32, 128, 16, "conv3x3_v6_t17x32_n128"},  // 40
-    {3, 17, 32, 128, 16, "conv3x3_v6p_t17x32_n128"},    // 41: with the fused 2x2 max-pool (row-pair pixel order)
-    {3, 16, 16, 64, 16, "conv3x3_c3_t16x16_n64"},       // 42: conv1_1 (3 input channels, K packed to 28)
+    // v5 kernels: weights L2 -> registers, software-pipelined, taps unrolled, two blocks per CU (see conv_mfma_v5_kernel)
+    {7, 2, 46, 128, 16, "conv7x7_v5_t2x46_n128"},  // 10
+    {3, 2, 46, 128, 16, "conv3x3_v5_t2x46_n128"},  // 11
+    {7, 8, 16, 128, 16, "conv7x7_v5_t8x16_n128"},  // 12
+    {3, 8, 16, 128, 16, "conv3x3_v5_t8x16_n128"},  // 13
+    {3, 8, 16, 64, 16, "conv3x3_v5_t8x16_n64"},    // 14
+    {7, 8, 8, 64, 16, "conv7x7_v5_t8x8_n64"},      // 15: small launches (single images)
+    {3, 8, 8, 64, 16, "conv3x3_v5_t8x8_n64"},      // 16
+    // v6 kernels: one block per CU, 17 x 32 consecutive pixels of a 46-column slab x 128 channels (see conv_mfma_v6_kernel)
+    {7, 17, 32, 128, 16, "conv7x7_v6_t17x32_n128"},     // 17
+    {3, 17, 32, 128, 16, "conv3x3_v6_t17x32_n128"},     // 18
+    {3, 17, 32, 128, 16, "conv3x3_v6p_t17x32_n128"},    // 19: with the fused 2x2 max-pool (row-pair pixel order)
+    {3, 16, 16, 64, 16, "conv3x3_c3_t16x16_n64"},       // 20: conv1_1 (3 input channels, K packed to 28)
     // v6 with 9 row tiles per block (288 px): fills the chip at batch 16 / 48 (8 blocks per 46x46 map)
-    {7, 9, 32, 128, 16, "conv7x7_v6_t9x32_n128"},       // 43
-    {3, 9, 32, 128, 16, "conv3x3_v6_t9x32_n128"},       // 44
-    {3, 9, 32, 128, 16, "conv3x3_v6p_t9x32_n128"},      // 45
+    {7, 9, 32, 128, 16, "conv7x7_v6_t9x32_n128"},       // 21
+    {3, 9, 32, 128, 16, "conv3x3_v6_t9x32_n128"},       // 22
+    {3, 9, 32, 128, 16, "conv3x3_v6p_t9x32_n128"},      // 23
 };
+enum { V5_K7_STRIP = 10, V5_K3_STRIP = 11, V5_K7 = 12, V5_K3 = 13, V5_K3_N64 = 14, V5_K7_SMALL = 15, V5_K3_SMALL = 16,
+       V6_K7 = 17, V6_K3 = 18, V6_K3_POOL = 19, C3 = 20, V6M9_K7 = 21, V6M9_K3 = 22, V6M9_K3_POOL = 23 };
 
 int conv_num_variants() { return (int)(sizeof(g_variants) / sizeof(g_variants[0])); }
 const ConvVariant& conv_variant(int idx) { return g_variants[idx]; }
@@ -1557,17 +886,17 @@ const ConvVariant& conv_variant(int idx) { return g_variants[idx]; }
 static int g_num_cus = 256;
 void conv_set_num_cus(int n) { if (n > 0) g_num_cus = n; }
 
+// gen: 1 = v1 kernels everywhere, 5 = v5 for 3x3 / 7x7, 6 (default) = v6 / c3 where they apply, else v5
 int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen, int pool, int cin)
 {
     const int ncu = g_num_cus;      // compute units of the device (256 on an MI355X in SPX mode)
     // `cout` is the padded channel count of the layer
-    if (forced >= 100 && ks == 7) return forced;      // ablation kernels
+    const bool forced_v6 = (forced >= V6_K7 && forced <= V6_K3_POOL) || (forced >= V6M9_K7 && forced <= V6M9_K3_POOL);
     if (forced >= 0 && forced < conv_num_variants() && g_variants[forced].ks == ks && cout % g_variants[forced].bn == 0 &&
-        !(((forced >= 39 && forced <= 41) || (forced >= 43 && forced <= 45)) &&
-          (W % 46 != 0 || !!pool != (forced == 41 || forced == 45))) &&                       // v6: 46-column slabs
-        !(forced == 42 && (cin > 3 || cout != 64 || pool)))                                // c3: conv1_1-shaped layers only
+        !(forced_v6 && (W % 46 != 0 || !!pool != (forced == V6_K3_POOL || forced == V6M9_K3_POOL))) &&      // v6: 46-column slabs
+        !(forced == C3 && (cin > 3 || cout != 64 || pool)))                                                  // c3: conv1_1-shaped layers only
         return forced;
-    if (gen >= 6 && ks == 3 && cin <= 3 && cout == 64 && !pool) return 42;
+    if (gen >= 6 && ks == 3 && cin <= 3 && cout == 64 && !pool) return C3;
     // enough 8x16 tiles to fill the CUs a few times over?  otherwise use the small tiles
     const long tiles816 = (long)((H + 7) / 8) * ((W + 15) / 16) * B;
     const bool small = tiles816 * ((cout + 127) / 128) < 2 * ncu;
@@ -1575,9 +904,9 @@ int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen
     const bool strip = (W == 46) && (cout % 128 == 0) && ((long)((H + 1) / 2) * B * (cout / 128) >= 2 * ncu);
     // (3x3 layers with fewer than 8 input chunks have too little work per chunk transition for one wave per SIMD: measured
     //  slower than v5 on conv2_1)
-    if (gen == 6 && cout % 128 == 0 && W % 46 == 0 && ((ks == 3 && cin >= 128) || (ks == 7 && !pool)) && (!pool || H % 2 == 0)) {
+    if (gen >= 6 && cout % 128 == 0 && W % 46 == 0 && ((ks == 3 && cin >= 128) || (ks == 7 && !pool)) && (!pool || H % 2 == 0)) {
         // v6 (one block of 17 or 9 row tiles per CU, 46-column slabs) when its blocks fill whole rounds of the CUs and
-        // the pixel padding is small: efficiency = useful pixels / (rounds * CUs * block pixels) >= 0.88; else as gen 5
+        // the pixel padding is small: efficiency = useful pixels / (rounds * CUs * block pixels) >= 0.88; else v5
         const long useful = (long)H * W * B * (cout / 128);
         double best = 0.0;
         int best_mt = 0;
@@ -1588,33 +917,13 @@ int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen
             if (eff > best + 1e-9) { best = eff; best_mt = mt; }
         }
         if (best >= 0.88) {
-            if (best_mt == 17) return ks == 7 ? 39 : (pool ? 41 : 40);
-            return ks == 7 ? 43 : (pool ? 45 : 44);
+            if (best_mt == 17) return ks == 7 ? V6_K7 : (pool ? V6_K3_POOL : V6_K3);
+            return ks == 7 ? V6M9_K7 : (pool ? V6M9_K3_POOL : V6M9_K3);
         }
     }
-    if (gen >= 5) {      // v5 = v4 with unrolled taps / saddr weight loads where a variant exists
-        if (ks == 7) return strip ? 32 : (small ? 37 : 34);
-        if (ks == 3) return strip ? 33 : (small ? 38 : (cout <= 64 ? 36 : 35));
-        return small ? 7 : (cout <= 64 ? 4 : 3);
-    }
-    if (gen == 4) {      // v4 kernels (interleaved memory instructions, 2 blocks per CU) for 3x3 / 7x7; launches that
-                         // would not fill the chip with 8x16 tiles use the v4 8x8 / BN64 tiles (measured best for B = 1..16)
-        if (ks == 7) return strip ? 25 : (small ? 30 : 27);
-        if (ks == 3) return strip ? 26 : (small ? 31 : (cout <= 64 ? 2 : 28));
-        return small ? 7 : (cout <= 64 ? 4 : 3);
-    }
-    if (gen == 3) {      // every layer on the v2 kernels (A/B measurements only)
-        if (ks == 7) return strip ? 10 : (small ? 5 : 12);
-        if (ks == 3) return strip ? 11 : (small ? 6 : (cout <= 64 ? 14 : 13));
-        return strip ? 17 : (small ? 7 : (cout <= 64 ? 16 : 15));
-    }
-    if (gen == 2) {      // default: v2 (weights L2 -> registers) where it measured faster: 3x3 / 7x7 with cout >= 128;
-                         // small launches (few blocks, one wave per SIMD) use the software-pipelined v3 small tiles
-        // (v3 small tiles only while there is at most ~1 block per CU; with more blocks the v1 small tiles win)
-        const long blocks88 = (long)((H + 7) / 8) * ((W + 7) / 8) * B * ((cout + 63) / 64);
-        const bool tiny = blocks88 <= ncu + ncu / 4;
-        if (ks == 7) return strip ? 10 : (small ? (tiny ? 23 : 5) : 12);
-        if (ks == 3) return strip ? 11 : (small ? (tiny ? 24 : 6) : (cout <= 64 ? 2 : 13));
+    if (gen >= 5) {      // v5 for 3x3 / 7x7; launches that would not fill the chip with 8x16 tiles use the 8x8 / BN64 tiles
+        if (ks == 7) return strip ? V5_K7_STRIP : (small ? V5_K7_SMALL : V5_K7);
+        if (ks == 3) return strip ? V5_K3_STRIP : (small ? V5_K3_SMALL : (cout <= 64 ? V5_K3_N64 : V5_K3));
         return small ? 7 : (cout <= 64 ? 4 : 3);
     }
     if (ks == 7) return strip ? 8 : (small ? 5 : 0);
@@ -1641,8 +950,10 @@ static int launch_cfg(const ConvArgs& a0, int groups, hipStream_t stream)
     return PMX_OK;
 }
 
+static int g_v5_lds = 56 * 1024;     // dynamic LDS floor of the v5 kernels: 3 x 56 KB > 160 KB -> at most 2 blocks per CU
+
 template <int KS, int TH, int TW, int BN, int CK, int WM, int WN>
-static int launch_v2(const ConvArgs& a0, int groups, hipStream_t stream)
+static int launch_v5(const ConvArgs& a0, int groups, hipStream_t stream)
 {
     using C = ConvCfg<KS, TH, TW, BN, CK, WM, WN>;
     ConvArgs a = a0;
@@ -1651,34 +962,9 @@ static int launch_v2(const ConvArgs& a0, int groups, hipStream_t stream)
     PMX_CHECK(a.cout_pad % BN == 0, PMX_ERR_INVALID, "conv: cout_pad %d not a multiple of BN %d", a.cout_pad, BN);
     PMX_CHECK(!a.pool || (a.H % 2 == 0 && a.W % 2 == 0), PMX_ERR_INVALID, "conv: pooled layer needs even H, W");
     PMX_CHECK((long long)a.H * a.W * a.lda < (1ll << 31), PMX_ERR_INVALID, "conv: image too large for 32-bit offsets");
-    auto kern = conv_mfma_v2_kernel<KS, TH, TW, BN, CK, WM, WN>;
-    int lds = KS == 1 ? 0 : C::IN_ELEMS * 4;
-    if (lds < g_min_lds) lds = g_min_lds;
-    static bool attr_set[PMX_MAX_DEVICES] = {};
-    if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(kern), attr_set)) return rc;
-    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / BN), (unsigned)groups);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
-    PMX_HIP(hipGetLastError());
-    return PMX_OK;
-}
-
-static int g_v3_lds = 56 * 1024;     // dynamic LDS floor of the v3 kernels: 3 x 56 KB > 160 KB -> at most 2 blocks per CU
-void conv_set_v3_lds(int bytes) { g_v3_lds = bytes; }
-
-template <int KS, int TH, int TW, int BN, int CK, int WM, int WN, int GEN = 3>
-static int launch_v3(const ConvArgs& a0, int groups, hipStream_t stream)
-{
-    using C = ConvCfg<KS, TH, TW, BN, CK, WM, WN>;
-    ConvArgs a = a0;
-    a.tiles_x = (a.W + TW - 1) / TW;
-    a.tiles_y = (a.H + TH - 1) / TH;
-    PMX_CHECK(a.cout_pad % BN == 0, PMX_ERR_INVALID, "conv: cout_pad %d not a multiple of BN %d", a.cout_pad, BN);
-    PMX_CHECK(!a.pool || (a.H % 2 == 0 && a.W % 2 == 0), PMX_ERR_INVALID, "conv: pooled layer needs even H, W");
-    PMX_CHECK((long long)a.H * a.W * a.lda < (1ll << 31), PMX_ERR_INVALID, "conv: image too large for 32-bit offsets");
-    auto kern = GEN == 5 ? conv_mfma_v5_kernel<KS, TH, TW, BN, CK, WM, WN>
-                : (GEN == 4 ? conv_mfma_v4_kernel<KS, TH, TW, BN, CK, WM, WN> : conv_mfma_v3_kernel<KS, TH, TW, BN, CK, WM, WN>);
+    auto kern = conv_mfma_v5_kernel<KS, TH, TW, BN, CK, WM, WN>;
     int lds = 2 * C::IN_ELEMS * 4;
-    if (lds < g_v3_lds) lds = g_v3_lds;
+    if (lds < g_v5_lds) lds = g_v5_lds;
     if (lds < g_min_lds) lds = g_min_lds;
     static bool attr_set[PMX_MAX_DEVICES] = {};
     if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(kern), attr_set)) return rc;
@@ -1709,62 +995,8 @@ static int launch_v6(const ConvArgs& a0, int groups, hipStream_t stream)
     return PMX_OK;
 }
 
-template <int ABL>
-static int launch_v4abl(const ConvArgs& a0, int groups, hipStream_t stream)
-{
-    using C = ConvCfg<7, 2, 46, 128, 16, 1, 4>;
-    ConvArgs a = a0;
-    a.tiles_x = (a.W + 46 - 1) / 46;
-    a.tiles_y = (a.H + 2 - 1) / 2;
-    auto kern = conv_mfma_v4_kernel<7, 2, 46, 128, 16, 1, 4, ABL>;
-    int lds = 2 * C::IN_ELEMS * 4;
-    if (lds < g_v3_lds) lds = g_v3_lds;
-    if (lds < g_min_lds) lds = g_min_lds;
-    static bool attr_set[PMX_MAX_DEVICES] = {};
-    if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(kern), attr_set)) return rc;
-    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / 128), (unsigned)groups);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
-    PMX_HIP(hipGetLastError());
-    return PMX_OK;
-}
-
-template <int ABL>
-static int launch_v3abl(const ConvArgs& a0, int groups, hipStream_t stream)
-{
-    using C = ConvCfg<7, 2, 46, 128, 16, 1, 4>;
-    ConvArgs a = a0;
-    a.tiles_x = (a.W + 46 - 1) / 46;
-    a.tiles_y = (a.H + 2 - 1) / 2;
-    auto kern = conv_mfma_v3abl_kernel<7, 2, 46, 128, 16, 1, 4, ABL>;
-    int lds = 2 * C::IN_ELEMS * 4;
-    if (lds < g_v3_lds) lds = g_v3_lds;
-    if (lds < g_min_lds) lds = g_min_lds;
-    static bool attr_set[PMX_MAX_DEVICES] = {};
-    if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(kern), attr_set)) return rc;
-    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / 128), (unsigned)groups);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
-    PMX_HIP(hipGetLastError());
-    return PMX_OK;
-}
-
 int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream)
 {
-    switch (variant) {     // ablation twins of the v3 / v4 7x7 strip kernels (tools/conv_ablate3.py)
-        case 120: return launch_v4abl<0>(a, groups, stream);
-        case 121: return launch_v4abl<1>(a, groups, stream);
-        case 122: return launch_v4abl<2>(a, groups, stream);
-        case 123: return launch_v4abl<3>(a, groups, stream);
-        case 124: return launch_v4abl<4>(a, groups, stream);
-        case 127: return launch_v4abl<7>(a, groups, stream);
-        case 100: return launch_v3abl<0>(a, groups, stream);
-        case 101: return launch_v3abl<1>(a, groups, stream);
-        case 102: return launch_v3abl<2>(a, groups, stream);
-        case 103: return launch_v3abl<3>(a, groups, stream);
-        case 104: return launch_v3abl<4>(a, groups, stream);
-        case 107: return launch_v3abl<7>(a, groups, stream);
-        case 108: return launch_v3abl<8>(a, groups, stream);
-        case 115: return launch_v3abl<15>(a, groups, stream);
-    }
     switch (variant) {
         case 0: return launch_cfg<7, 8, 16, 128, 16, 2, 2>(a, groups, stream);
         case 1: return launch_cfg<3, 8, 16, 128, 16, 2, 2>(a, groups, stream);
@@ -1776,42 +1008,20 @@ int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream)
         case 7: return launch_cfg<1, 8, 8, 64, 16, 2, 2>(a, groups, stream);
         case 8: return launch_cfg<7, 2, 46, 128, 16, 1, 4>(a, groups, stream);
         case 9: return launch_cfg<3, 2, 46, 128, 16, 1, 4>(a, groups, stream);
-        case 10: return launch_v2<7, 2, 46, 128, 16, 1, 4>(a, groups, stream);
-        case 11: return launch_v2<3, 2, 46, 128, 16, 1, 4>(a, groups, stream);
-        case 12: return launch_v2<7, 8, 16, 128, 16, 1, 4>(a, groups, stream);
-        case 13: return launch_v2<3, 8, 16, 128, 16, 1, 4>(a, groups, stream);
-        case 14: return launch_v2<3, 8, 16, 64, 16, 2, 2>(a, groups, stream);
-        case 15: return launch_v2<1, 8, 16, 128, 16, 1, 4>(a, groups, stream);
-        case 16: return launch_v2<1, 8, 16, 64, 16, 2, 2>(a, groups, stream);
-        case 17: return launch_v2<1, 2, 46, 128, 16, 1, 4>(a, groups, stream);
-        case 18: return launch_v3<7, 2, 46, 128, 16, 1, 4>(a, groups, stream);
-        case 19: return launch_v3<3, 2, 46, 128, 16, 1, 4>(a, groups, stream);
-        case 20: return launch_v3<7, 8, 16, 128, 16, 1, 4>(a, groups, stream);
-        case 21: return launch_v3<3, 8, 16, 128, 16, 1, 4>(a, groups, stream);
-        case 22: return launch_v3<3, 8, 16, 64, 16, 2, 2>(a, groups, stream);
-        case 23: return launch_v3<7, 8, 8, 64, 16, 2, 2>(a, groups, stream);
-        case 24: return launch_v3<3, 8, 8, 64, 16, 2, 2>(a, groups, stream);
-        case 25: return launch_v3<7, 2, 46, 128, 16, 1, 4, 4>(a, groups, stream);
-        case 26: return launch_v3<3, 2, 46, 128, 16, 1, 4, 4>(a, groups, stream);
-        case 27: return launch_v3<7, 8, 16, 128, 16, 1, 4, 4>(a, groups, stream);
-        case 28: return launch_v3<3, 8, 16, 128, 16, 1, 4, 4>(a, groups, stream);
-        case 29: return launch_v3<3, 8, 16, 64, 16, 2, 2, 4>(a, groups, stream);
-        case 30: return launch_v3<7, 8, 8, 64, 16, 2, 2, 4>(a, groups, stream);
-        case 31: return launch_v3<3, 8, 8, 64, 16, 2, 2, 4>(a, groups, stream);
-        case 32: return launch_v3<7, 2, 46, 128, 16, 1, 4, 5>(a, groups, stream);
-        case 33: return launch_v3<3, 2, 46, 128, 16, 1, 4, 5>(a, groups, stream);
-        case 34: return launch_v3<7, 8, 16, 128, 16, 1, 4, 5>(a, groups, stream);
-        case 35: return launch_v3<3, 8, 16, 128, 16, 1, 4, 5>(a, groups, stream);
-        case 36: return launch_v3<3, 8, 16, 64, 16, 2, 2, 5>(a, groups, stream);
-        case 37: return launch_v3<7, 8, 8, 64, 16, 2, 2, 5>(a, groups, stream);
-        case 38: return launch_v3<3, 8, 8, 64, 16, 2, 2, 5>(a, groups, stream);
-        case 39: return launch_v6<7, 17, 0>(a, groups, stream);
-        case 40: return launch_v6<3, 17, 0>(a, groups, stream);
-        case 41: return launch_v6<3, 17, 1>(a, groups, stream);
-        case 42: return launch_c3(a, groups, stream);
-        case 43: return launch_v6<7, 9, 0>(a, groups, stream);
-        case 44: return launch_v6<3, 9, 0>(a, groups, stream);
-        case 45: return launch_v6<3, 9, 1>(a, groups, stream);
+        case V5_K7_STRIP: return launch_v5<7, 2, 46, 128, 16, 1, 4>(a, groups, stream);
+        case V5_K3_STRIP: return launch_v5<3, 2, 46, 128, 16, 1, 4>(a, groups, stream);
+        case V5_K7: return launch_v5<7, 8, 16, 128, 16, 1, 4>(a, groups, stream);
+        case V5_K3: return launch_v5<3, 8, 16, 128, 16, 1, 4>(a, groups, stream);
+        case V5_K3_N64: return launch_v5<3, 8, 16, 64, 16, 2, 2>(a, groups, stream);
+        case V5_K7_SMALL: return launch_v5<7, 8, 8, 64, 16, 2, 2>(a, groups, stream);
+        case V5_K3_SMALL: return launch_v5<3, 8, 8, 64, 16, 2, 2>(a, groups, stream);
+        case V6_K7: return launch_v6<7, 17, 0>(a, groups, stream);
+        case V6_K3: return launch_v6<3, 17, 0>(a, groups, stream);
+        case V6_K3_POOL: return launch_v6<3, 17, 1>(a, groups, stream);
+        case C3: return launch_c3(a, groups, stream);
+        case V6M9_K7: return launch_v6<7, 9, 0>(a, groups, stream);
+        case V6M9_K3: return launch_v6<3, 9, 0>(a, groups, stream);
+        case V6M9_K3_POOL: return launch_v6<3, 9, 1>(a, groups, stream);
     }
     pmx_set_error("conv_launch: unknown variant %d", variant);
     return PMX_ERR_INVALID;

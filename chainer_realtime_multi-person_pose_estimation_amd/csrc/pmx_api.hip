@@ -195,7 +195,7 @@ struct pmx_ctx {
     // options
     int opt_force[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // by ksize
     int opt_gpu_branch_peaks = 0;    // reference GPU-branch peak extraction (non-golden variant)
-    int opt_keep_smoothed = 0, opt_stop_stage = 6, opt_kernel_gen = 6, opt_conv_dbg = 0;
+    int opt_keep_smoothed = 0, opt_stop_stage = 6, opt_kernel_gen = 6;
     // timing / profiling
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool prof_on = false;
@@ -405,7 +405,6 @@ extern "C" int pmx_set_option(pmx_ctx* c, const char* key, int value)
     else if (!strcmp(key, "keep_smoothed")) c->opt_keep_smoothed = value;
     else if (!strcmp(key, "stop_stage")) c->opt_stop_stage = value;
     else if (!strcmp(key, "kernel_gen")) c->opt_kernel_gen = value;
-    else if (!strcmp(key, "conv_dbg")) c->opt_conv_dbg = value;
     else if (!strcmp(key, "conv_min_lds")) conv_set_min_lds(value);
     else if (!strcmp(key, "pp_generic")) pp_set_generic(value);
     else if (!strcmp(key, "peaks_gpu_branch")) { c->opt_gpu_branch_peaks = value; c->tab_in_h = -1; }
@@ -1294,7 +1293,6 @@ extern "C" int pmx_conv2d(pmx_ctx* c, const float* x, const float* w, const floa
     memset(&a, 0, sizeof a);
     a.g[0].in = d_xn; a.g[0].w = d_w; a.g[0].bias = d_b; a.g[0].out = d_yn; a.g[0].cout = cout;
     a.B = B; a.H = H; a.W = W; a.lda = cin_pad; a.ldc = cout; a.nch = cin_pad / CK; a.cout_pad = cpad; a.relu = relu; a.pool = pool;
-    a.dbg = c->opt_conv_dbg;
     const int v = conv_pick_variant(ks, cpad, H, W, B, c->opt_force[ks], c->opt_kernel_gen, pool, cin);
     if (!rc) rc = conv_launch(v, a, 1, c->stream);
     if (!rc && iters > 0) {

@@ -69,7 +69,6 @@ struct ConvArgs {
     int cout_pad;       // multiple of the kernel's BN
     int tiles_x, tiles_y;
     int relu, pool;
-    int dbg;            // ablation flags (tools/conv_ablate.py): 1 skip re-staging, 2 no weight streaming, 4 no stores, 8 one A read
 };
 
 struct ConvVariant {

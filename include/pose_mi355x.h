@@ -91,12 +91,13 @@ void pmx_destroy(pmx_ctx* ctx);
 int pmx_set_stream(pmx_ctx* ctx, void* hip_stream);   /* NULL -> the context's own stream */
 int pmx_synchronize(pmx_ctx* ctx);                    /* cuda.get_device_from_id().synchronize(), :506 */
 /* Test / measurement knobs (defaults are the product configuration):
- *   "kernel_gen" 1..6          conv kernel generation (6 = default, all generations compute identical bits)
+ *   "kernel_gen" 1 | 5 | 6     conv kernel generation: 1 = LDS-staged weights (v1) everywhere, 5 = v5 for 3x3 / 7x7,
+ *                              6 = default (v6 / conv1_1 kernel where they apply, else v5); all compute identical bits
  *   "force_variant_k1|k3|k7"   force one entry of the conv variant table for that kernel size (-1 = automatic)
  *   "keep_smoothed"            keep the smoothed heat maps for pmx_get_smoothed
  *   "stop_stage" 1..6          stop the network after this stage (profiling)
  *   "peaks_gpu_branch"         the reference's GPU-branch peak extraction (17 x 17 un-normalised kernel, zero pad, >=)
- *   "conv_min_lds", "pp_generic", "conv_dbg"   ablation switches; the first two are PROCESS-wide, not per context */
+ *   "conv_min_lds", "pp_generic"   ablation switches, PROCESS-wide (not per context) */
 int pmx_set_option(pmx_ctx* ctx, const char* key, int value);
 
 /* ---- weights: serializers.load_npz (pose_detector.py:26) --------------------------------------

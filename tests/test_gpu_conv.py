@@ -50,10 +50,10 @@ def _exact_case(engine, B, cin, H, W, cout, k, relu, pool, seed, variant=None):
 @pytest.mark.parametrize('variant,k,cin,h,w,cout,pool', [
     (None, 7, 40, 12, 15, 128, False), (None, 3, 70, 14, 10, 64, True), (None, 1, 100, 9, 13, 38, False),
     (3, 1, 128, 8, 16, 128, False), (2, 3, 16, 10, 12, 64, False),            # v1
-    (32, 7, 48, 6, 46, 128, False), (36, 3, 35, 16, 16, 64, True), (38, 3, 20, 9, 9, 19, False),    # v5
-    (39, 7, 33, 13, 46, 128, False), (40, 3, 140, 25, 92, 256, False), (41, 3, 128, 12, 46, 128, True),
-    (43, 7, 17, 7, 46, 200, False),                                                                    # v6
-    (42, 3, 3, 20, 24, 64, False)])                                                                    # conv1_1
+    (10, 7, 48, 6, 46, 128, False), (14, 3, 35, 16, 16, 64, True), (16, 3, 20, 9, 9, 19, False),    # v5
+    (17, 7, 33, 13, 46, 128, False), (18, 3, 140, 25, 92, 256, False), (19, 3, 128, 12, 46, 128, True),
+    (21, 7, 17, 7, 46, 200, False),                                                                    # v6
+    (20, 3, 3, 20, 24, 64, False)])                                                                    # conv1_1
 def test_conv_bit_exact_vs_order_defined_c_oracle(engine, variant, k, cin, h, w, cout, pool):
     _exact_case(engine, 2, cin, h, w, cout, k, True, pool, seed=700 + k + cin, variant=variant)
 
@@ -65,39 +65,15 @@ def test_variants_basic(engine, variant, k, cout):
     _case(engine, 2, 32, 24, 40, cout, k, True, False, seed=variant, variant=variant)
 
 
-@pytest.mark.parametrize('variant,k,cout', [(10, 7, 128), (11, 3, 128), (12, 7, 128), (13, 3, 256), (14, 3, 64), (15, 1, 128),
-                                            (16, 1, 38), (17, 1, 128)])
-@pytest.mark.parametrize('hw', [(46, 46), (9, 21)])
-def test_v2_variants(engine, variant, k, cout, hw):
-    # v2 kernels: weights streamed L2 -> registers, XCD-aware tile order, no LDS for 1x1
-    _case(engine, 3, 48, hw[0], hw[1], cout, k, True, False, seed=70 + variant, variant=variant)
-
-
-@pytest.mark.parametrize('variant,k,cout', [(18, 7, 128), (19, 3, 128), (20, 7, 128), (21, 3, 256), (22, 3, 64), (23, 7, 128),
-                                            (24, 3, 38)])
-@pytest.mark.parametrize('hw,cin', [((46, 46), 48), ((9, 21), 16), ((20, 50), 185)])
-def test_v3_variants(engine, variant, k, cout, hw, cin):
-    # v3: software-pipelined (A fragments one k-step ahead, halo double-buffered), 1..12 channel chunks
-    _case(engine, 3, cin, hw[0], hw[1], cout, k, True, False, seed=170 + variant, variant=variant)
-
-
-@pytest.mark.parametrize('variant,k,cout', [(25, 7, 128), (26, 3, 128), (27, 7, 128), (28, 3, 256), (29, 3, 64), (30, 7, 128),
-                                            (31, 3, 38)])
-@pytest.mark.parametrize('hw,cin', [((46, 46), 48), ((9, 21), 16), ((20, 50), 185)])
-def test_v4_variants(engine, variant, k, cout, hw, cin):
-    # v4: memory instructions interleaved into the MFMA stream, ping-pong weight registers; 1..12 channel chunks
-    _case(engine, 3, cin, hw[0], hw[1], cout, k, True, False, seed=270 + variant, variant=variant)
-
-
-@pytest.mark.parametrize('variant,k,cout', [(32, 7, 128), (33, 3, 128), (34, 7, 128), (35, 3, 256), (36, 3, 64), (37, 7, 128),
-                                            (38, 3, 38)])
+@pytest.mark.parametrize('variant,k,cout', [(10, 7, 128), (11, 3, 128), (12, 7, 128), (13, 3, 256), (14, 3, 64), (15, 7, 128),
+                                            (16, 3, 38)])
 @pytest.mark.parametrize('hw,cin', [((46, 46), 48), ((9, 21), 16), ((20, 50), 185)])
 def test_v5_variants(engine, variant, k, cout, hw, cin):
     # v5: v4 with fully unrolled taps (immediate LDS offsets) and buffer-resource weight loads (no address VALU in the loop)
     _case(engine, 3, cin, hw[0], hw[1], cout, k, True, False, seed=370 + variant, variant=variant)
 
 
-@pytest.mark.parametrize('variant,k', [(39, 7), (40, 3)])
+@pytest.mark.parametrize('variant,k', [(17, 7), (18, 3)])
 @pytest.mark.parametrize('h,cin,cout,B', [(46, 48, 128, 3), (46, 185, 256, 2), (9, 16, 128, 5), (47, 32, 100, 1)])
 def test_v6_variants(engine, variant, k, h, cin, cout, B):
     # v6: one block per CU, 17 x 32 consecutive pixels of a 46-wide map x 128 channels (last tile partially filled,
@@ -105,7 +81,7 @@ def test_v6_variants(engine, variant, k, h, cin, cout, B):
     _case(engine, B, cin, h, 46, cout, k, True, False, seed=470 + variant + h, variant=variant)
 
 
-@pytest.mark.parametrize('variant,k,pool', [(43, 7, False), (44, 3, False), (45, 3, True)])
+@pytest.mark.parametrize('variant,k,pool', [(21, 7, False), (22, 3, False), (23, 3, True)])
 @pytest.mark.parametrize('h,w,cin,cout,B', [(46, 46, 48, 128, 3), (20, 92, 185, 256, 1)])
 def test_v6_nine_tile_blocks(engine, variant, k, pool, h, w, cin, cout, B):
     _case(engine, B, cin, h, w, cout, k, True, pool, seed=560 + variant + h, variant=variant)
@@ -114,81 +90,54 @@ def test_v6_nine_tile_blocks(engine, variant, k, pool, h, w, cin, cout, B):
 @pytest.mark.parametrize('h,w,cin,cout,B', [(92, 92, 48, 128, 2), (31, 92, 128, 256, 1), (20, 184, 32, 128, 1), (7, 368, 16, 128, 1)])
 def test_v6_slabs(engine, h, w, cin, cout, B):
     # maps wider than one 46-column slab: the left / right halo columns come from the neighbouring slab
-    _case(engine, B, cin, h, w, cout, 3, True, False, seed=520 + h, variant=40)
+    _case(engine, B, cin, h, w, cout, 3, True, False, seed=520 + h, variant=18)
     if h >= 20:
-        _case(engine, B, cin, h, w, cout, 7, False, False, seed=530 + h, variant=39)
+        _case(engine, B, cin, h, w, cout, 7, False, False, seed=530 + h, variant=17)
 
 
 @pytest.mark.parametrize('h,w,cin,cout,B', [(46, 46, 48, 128, 3), (92, 92, 32, 256, 1), (24, 184, 64, 128, 2), (2, 46, 16, 128, 1),
                                             (50, 92, 16, 100, 1)])
 def test_v6_fused_relu_maxpool(engine, h, w, cin, cout, B):
     # row-pair pixel order: four consecutive MFMA rows = one 2x2 window, pooled in registers
-    _case(engine, B, cin, h, w, cout, 3, True, True, seed=540 + h, variant=41)
+    _case(engine, B, cin, h, w, cout, 3, True, True, seed=540 + h, variant=19)
 
 
 @pytest.mark.parametrize('cin,h,w,B', [(3, 40, 56, 2), (3, 37, 21, 1), (2, 16, 16, 3), (3, 368, 368, 1)])
 def test_c3_packed_k_kernel(engine, cin, h, w, B):
     """conv1_1-shaped layers (<= 3 input channels -> 64): K packed to 14 k-pairs; vs torch, and bit-identical to the generic
     16-channel-chunk kernel (same fp32 FMA chain per output)."""
-    _case(engine, B, cin, h, w, 64, 3, True, False, seed=600 + h, variant=42)
+    _case(engine, B, cin, h, w, 64, 3, True, False, seed=600 + h, variant=20)
     rng = np.random.default_rng(h)
     x = rng.standard_normal((B, cin, h, w)).astype('f')
     wt = rng.standard_normal((64, cin, 3, 3)).astype('f')
     b = rng.standard_normal(64).astype('f')
-    engine.set_option('force_variant_k3', 42)
-    y42 = engine.conv2d(x, wt, b, relu=False)
-    engine.set_option('force_variant_k3', 36)
-    y36 = engine.conv2d(x, wt, b, relu=False)
+    engine.set_option('force_variant_k3', 20)
+    yc3 = engine.conv2d(x, wt, b, relu=False)
+    engine.set_option('force_variant_k3', 14)
+    yv5 = engine.conv2d(x, wt, b, relu=False)
     engine.set_option('force_variant_k3', -1)
-    assert np.array_equal(y42, y36)
-
-
-@pytest.mark.parametrize('variant', [35, 36])
-def test_v5_fused_relu_maxpool(engine, variant):
-    _case(engine, 2, 32, 24, 40, 64 if variant == 36 else 128, 3, True, True, seed=390 + variant, variant=variant)
-
-
-@pytest.mark.parametrize('variant', [28, 29])
-def test_v4_fused_relu_maxpool(engine, variant):
-    _case(engine, 2, 32, 24, 40, 64 if variant == 29 else 128, 3, True, True, seed=290 + variant, variant=variant)
-
-
-@pytest.mark.parametrize('variant', [21, 22])
-def test_v3_fused_relu_maxpool(engine, variant):
-    _case(engine, 2, 32, 24, 40, 64 if variant == 22 else 128, 3, True, True, seed=190 + variant, variant=variant)
+    assert np.array_equal(yc3, yv5)
 
 
 @pytest.mark.parametrize('variant', [13, 14])
-def test_v2_fused_relu_maxpool(engine, variant):
-    _case(engine, 2, 32, 24, 40, 64 if variant == 14 else 128, 3, True, True, seed=90 + variant, variant=variant)
+def test_v5_fused_relu_maxpool(engine, variant):
+    _case(engine, 2, 32, 24, 40, 64 if variant == 14 else 128, 3, True, True, seed=390 + variant, variant=variant)
 
 
-def test_v2_network_equals_v1_network_bitwise(engine):
-    """Both kernel generations compute the same fp32 FMA chains in the same K order -> identical bits."""
+def test_kernel_generations_compute_identical_bits(engine):
+    """v1 (weights through LDS), v5 and the default selection compute the same fp32 FMA chains in the same K order."""
     from conftest import pkg
     w = pkg('weights').synthetic_weights(0)
     engine.set_weights(w)
     img = np.random.default_rng(5).integers(0, 256, (2, 184, 184, 3), dtype=np.uint8)
-    engine.set_option('kernel_gen', 1)
-    engine.forward_u8(img)
-    p1, h1 = engine.get_maps()
-    engine.set_option('kernel_gen', 2)
-    engine.forward_u8(img)
-    p2, h2 = engine.get_maps()
-    engine.set_option('kernel_gen', 3)
-    engine.forward_u8(img)
-    p3, h3 = engine.get_maps()
-    engine.set_option('kernel_gen', 4)
-    engine.forward_u8(img)
-    p4, h4 = engine.get_maps()
-    engine.set_option('kernel_gen', 5)
-    engine.forward_u8(img)
-    p5, h5 = engine.get_maps()
-    engine.set_option('kernel_gen', 6)      # library default (v6 only engages on 46-wide maps: see the 368x368 test below)
-    assert np.array_equal(p1, p2) and np.array_equal(h1, h2)
-    assert np.array_equal(p1, p3) and np.array_equal(h1, h3)
-    assert np.array_equal(p1, p4) and np.array_equal(h1, h4)
-    assert np.array_equal(p1, p5) and np.array_equal(h1, h5)
+    maps = {}
+    for gen in (1, 5, 6):
+        engine.set_option('kernel_gen', gen)
+        engine.forward_u8(img)
+        maps[gen] = engine.get_maps()
+    engine.set_option('kernel_gen', 6)      # library default (v6 only engages on maps a multiple of 46 wide: see below)
+    for gen in (5, 6):
+        assert np.array_equal(maps[1][0], maps[gen][0]) and np.array_equal(maps[1][1], maps[gen][1])
 
 
 def test_v6_network_equals_v5_network_bitwise(engine):
@@ -297,13 +246,13 @@ def test_random_shapes_default_selection(engine, seed, k, B, h, w, cin, cout, re
 
 @settings(max_examples=_FUZZ or 12, derandomize=not _FUZZ, deadline=None, database=None,
           suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
-@given(seed=st.integers(0, 10 ** 6), variant=st.sampled_from([39, 40, 41, 43, 44, 45]), B=st.integers(1, 3), h=st.integers(1, 50),
+@given(seed=st.integers(0, 10 ** 6), variant=st.sampled_from([17, 18, 19, 21, 22, 23]), B=st.integers(1, 3), h=st.integers(1, 50),
        slabs=st.integers(1, 3), cin=st.integers(1, 70), cout=st.integers(65, 300), relu=st.booleans())
 def test_random_shapes_v6(engine, seed, variant, B, h, slabs, cin, cout, relu):
     """The one-block-per-CU kernels forced onto random map heights / slab counts / channel counts (blocks that start
     mid-row, last block nearly empty, single-row maps, pooled row pairs)."""
-    pool = variant in (41, 45)
-    k = 7 if variant in (39, 43) else 3
+    pool = variant in (19, 23)
+    k = 7 if variant in (17, 21) else 3
     if pool:
         h = max(2, h - h % 2)
     _case(engine, B, cin, h, 46 * slabs, cout, k, relu, pool, seed=seed, variant=variant)

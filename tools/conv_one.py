@@ -5,7 +5,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
-ap.add_argument('--variant', type=int, default=18); ap.add_argument('--B', type=int, default=64)
+ap.add_argument('--variant', type=int, default=17, help='index into conv_mfma.hip g_variants (17 = 7x7 v6)'); ap.add_argument('--B', type=int, default=64)
 ap.add_argument('--k', type=int, default=7); ap.add_argument('--hw', type=int, default=46)
 ap.add_argument('--cin', type=int, default=128); ap.add_argument('--cout', type=int, default=128)
 ap.add_argument('--min-lds', type=int, default=0); ap.add_argument('--iters', type=int, default=3)

@@ -4,7 +4,7 @@
 ROUND=${1:-r01}
 R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=$R/gpurun_out; mkdir -p $O; cd $R
 (timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -60) > $O/pytest_gpu.log
-(timeout 300 python tools/profile_driver.py --batch 32 --steps 3 --gen 4 --profile-json $O/prof_gen4.json) > $O/drv_old.log 2>&1
+(timeout 300 python tools/profile_driver.py --batch 32 --steps 3 --gen 5 --profile-json $O/prof_gen5.json) > $O/drv_old.log 2>&1
 (timeout 300 python tools/profile_driver.py --batch 32 --steps 3 --profile-json $O/prof_strip_tiles.json) > $O/drv_new.log 2>&1
 cd /tmp
 (timeout 300 rocprofv3 --kernel-trace --stats -d $O/rp_stats -o drv --output-format csv -- python $R/tools/profile_driver.py --batch 32 --steps 3) > $O/rp_stats.log 2>&1
