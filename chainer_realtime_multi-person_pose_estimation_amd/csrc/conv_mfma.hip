@@ -9,8 +9,16 @@
 //                    buffer, which is how F.concat (CocoPoseNet.py:168) is eliminated)
 //   input panel      (TH+ks-1) x (TW+ks-1) halo tile x CK channels staged once per channel chunk in LDS
 //                    (zero-filled outside the image = the conv's zero padding), re-used by all ks*ks taps
-//   weight panel     per (tap, chunk): BN x CK floats, pre-packed contiguous, double-buffered in LDS,
-//                    next tap's panel prefetched into registers under the current tap's MFMAs
+//   weight panel     per (tap, chunk): BN x CK floats, pre-packed contiguous [tap][chunk][cout_pad][CK]
+//   kernel families  v1  conv_mfma_kernel     weight panel double-buffered in LDS, one barrier per tap (1x1 layers; simple
+//                                             reference implementation of the 3x3 / 7x7 layers)
+//                    v5  conv_mfma_v5_kernel  weights L2 -> registers, software-pipelined, taps unrolled, <= 2 blocks per CU
+//                                             (general 3x3 / 7x7 kernel)
+//                    v6  conv_mfma_v6_kernel  one block per CU, 17 (or 9) row tiles of consecutive pixels per wave
+//                                             (maps a multiple of 46 wide whose blocks fill whole rounds of the CUs)
+//                    c3  conv3x3_c3_kernel    conv1_1 (3 input channels, K packed to 14 k-pairs)
+//                    all walk K in the same order (chunk -> tap -> half -> k) => bit-identical outputs, equal to
+//                    oracle/conv_fma_ref.c (a plain-C fmaf chain)
 //   K ordering       one ds_read_b128 gives a lane 4 consecutive channels; lanes 0-31 hold k-half 0 (channels
 //                    c..c+3), lanes 32-63 k-half 1 (c+4..c+7); MFMA step e pairs channel c+e with c+4+e.  The
 //                    same permutation is applied to A (pixels) and B (weights), so the sum over K is unchanged.
