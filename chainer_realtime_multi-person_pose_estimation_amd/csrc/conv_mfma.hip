@@ -884,9 +884,13 @@ static const ConvVariant g_variants[] = {
     {7, 9, 32, 128, 16, "conv7x7_v6_t9x32_n128"},       // 21
     {3, 9, 32, 128, 16, "conv3x3_v6_t9x32_n128"},       // 22
     {3, 9, 32, 128, 16, "conv3x3_v6p_t9x32_n128"},      // 23
+    // v5 with 16 x 8 tiles: less padding than 8 x 16 on maps like 46 x 82 (368 x 656 inputs)
+    {7, 16, 8, 128, 16, "conv7x7_v5_t16x8_n128"},       // 24
+    {3, 16, 8, 128, 16, "conv3x3_v5_t16x8_n128"},       // 25
+    {3, 16, 8, 64, 16, "conv3x3_v5_t16x8_n64"},         // 26
 };
 enum { V5_K7_STRIP = 10, V5_K3_STRIP = 11, V5_K7 = 12, V5_K3 = 13, V5_K3_N64 = 14, V5_K7_SMALL = 15, V5_K3_SMALL = 16,
-       V6_K7 = 17, V6_K3 = 18, V6_K3_POOL = 19, C3 = 20, V6M9_K7 = 21, V6M9_K3 = 22, V6M9_K3_POOL = 23 };
+       V6_K7 = 17, V6_K3 = 18, V6_K3_POOL = 19, C3 = 20, V6M9_K7 = 21, V6M9_K3 = 22, V6M9_K3_POOL = 23, V5T_K7 = 24, V5T_K3 = 25, V5T_K3_N64 = 26 };
 
 int conv_num_variants() { return (int)(sizeof(g_variants) / sizeof(g_variants[0])); }
 const ConvVariant& conv_variant(int idx) { return g_variants[idx]; }
@@ -930,8 +934,11 @@ int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen
         }
     }
     if (gen >= 5) {      // v5 for 3x3 / 7x7; launches that would not fill the chip with 8x16 tiles use the 8x8 / BN64 tiles
-        if (ks == 7) return strip ? V5_K7_STRIP : (small ? V5_K7_SMALL : V5_K7);
-        if (ks == 3) return strip ? V5_K3_STRIP : (small ? V5_K3_SMALL : (cout <= 64 ? V5_K3_N64 : V5_K3));
+        // 8 x 16 or 16 x 8 tiles, whichever pads the map less (46 x 82: 48 x 96 vs 48 x 88)
+        const long pad816 = (long)((H + 7) / 8 * 8) * ((W + 15) / 16 * 16), pad168 = (long)((H + 15) / 16 * 16) * ((W + 7) / 8 * 8);
+        const bool tall = pad168 < pad816;
+        if (ks == 7) return strip ? V5_K7_STRIP : (small ? V5_K7_SMALL : (tall ? V5T_K7 : V5_K7));
+        if (ks == 3) return strip ? V5_K3_STRIP : (small ? V5_K3_SMALL : (cout <= 64 ? (tall ? V5T_K3_N64 : V5_K3_N64) : (tall ? V5T_K3 : V5_K3)));
         return small ? 7 : (cout <= 64 ? 4 : 3);
     }
     if (ks == 7) return strip ? 8 : (small ? 5 : 0);
@@ -1030,6 +1037,9 @@ int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream)
         case V6M9_K7: return launch_v6<7, 9, 0>(a, groups, stream);
         case V6M9_K3: return launch_v6<3, 9, 0>(a, groups, stream);
         case V6M9_K3_POOL: return launch_v6<3, 9, 1>(a, groups, stream);
+        case V5T_K7: return launch_v5<7, 16, 8, 128, 16, 1, 4>(a, groups, stream);
+        case V5T_K3: return launch_v5<3, 16, 8, 128, 16, 1, 4>(a, groups, stream);
+        case V5T_K3_N64: return launch_v5<3, 16, 8, 64, 16, 2, 2>(a, groups, stream);
     }
     pmx_set_error("conv_launch: unknown variant %d", variant);
     return PMX_ERR_INVALID;

@@ -66,7 +66,7 @@ def test_variants_basic(engine, variant, k, cout):
 
 
 @pytest.mark.parametrize('variant,k,cout', [(10, 7, 128), (11, 3, 128), (12, 7, 128), (13, 3, 256), (14, 3, 64), (15, 7, 128),
-                                            (16, 3, 38)])
+                                            (16, 3, 38), (24, 7, 128), (25, 3, 256), (26, 3, 64)])
 @pytest.mark.parametrize('hw,cin', [((46, 46), 48), ((9, 21), 16), ((20, 50), 185)])
 def test_v5_variants(engine, variant, k, cout, hw, cin):
     # v5: v4 with fully unrolled taps (immediate LDS offsets) and buffer-resource weight loads (no address VALU in the loop)
@@ -119,9 +119,9 @@ def test_c3_packed_k_kernel(engine, cin, h, w, B):
     assert np.array_equal(yc3, yv5)
 
 
-@pytest.mark.parametrize('variant', [13, 14])
+@pytest.mark.parametrize('variant', [13, 14, 25, 26])
 def test_v5_fused_relu_maxpool(engine, variant):
-    _case(engine, 2, 32, 24, 40, 64 if variant == 14 else 128, 3, True, True, seed=390 + variant, variant=variant)
+    _case(engine, 2, 32, 24, 40, 64 if variant in (14, 26) else 128, 3, True, True, seed=390 + variant, variant=variant)
 
 
 def test_kernel_generations_compute_identical_bits(engine):
