@@ -189,6 +189,8 @@ struct pmx_ctx {
     std::vector<double> gauss;
     PPBuffers pp{};
     double* d_scale = nullptr;
+    pmx_result_record* h_results = nullptr;     // pinned staging for pmx_get_results (pageable D2H is slow and jittery)
+    int h_results_cap = 0;
     bool pp_valid = false;
     int pp_B = 0, pp_h = 0, pp_w = 0;
     size_t smoothed_cap = 0;
@@ -377,6 +379,7 @@ extern "C" void pmx_destroy(pmx_ctx* c)
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& p : c->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->h_results) (void)hipHostFree(c->h_results);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1097,8 +1100,15 @@ extern "C" int pmx_get_results(pmx_ctx* c, int B, pmx_result_record* out)
     PMX_CHECK(c && out, PMX_ERR_INVALID, "null arg");
     PMX_CHECK(c->pp_valid && B >= 1 && B <= c->pp_B, PMX_ERR_STATE, "pmx_get_results: no post-process results for batch %d", B);
     PMX_DEV(c);
-    PMX_HIP(hipMemcpyAsync(out, c->pp.results, sizeof(pmx_result_record) * B, hipMemcpyDeviceToHost, c->stream));
+    if (B > c->h_results_cap) {
+        if (c->h_results) (void)hipHostFree(c->h_results);
+        c->h_results = nullptr; c->h_results_cap = 0;
+        PMX_HIP(hipHostMalloc((void**)&c->h_results, sizeof(pmx_result_record) * (size_t)c->max_batch, hipHostMallocDefault));
+        c->h_results_cap = c->max_batch;
+    }
+    PMX_HIP(hipMemcpyAsync(c->h_results, c->pp.results, sizeof(pmx_result_record) * B, hipMemcpyDeviceToHost, c->stream));
     PMX_HIP(hipStreamSynchronize(c->stream));
+    memcpy(out, c->h_results, sizeof(pmx_result_record) * B);
     return PMX_OK;
 }
 

@@ -361,8 +361,7 @@ class Engine(object):
 
     def results(self):
         """Structured array (B,) of RESULT_DTYPE (synchronises)."""
-        out = np.zeros(self._B, dtype=RESULT_DTYPE)
-        assert out.itemsize == 16 + 8 * MAX_PEOPLE * (1 + N_JOINTS * 3)
+        out = np.empty(self._B, dtype=RESULT_DTYPE)
         self._check(self.lib.pmx_get_results(self._ctx, self._B, _ptr(out)))
         return out
 
