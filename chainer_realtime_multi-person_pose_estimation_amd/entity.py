@@ -12,83 +12,34 @@ reference module (``tests/golden/host_fns.json``).
 from enum import IntEnum
 
 
-class JointType(IntEnum):
-    Nose = 0
-    Neck = 1
-    RightShoulder = 2
-    RightElbow = 3
-    RightHand = 4
-    LeftShoulder = 5
-    LeftElbow = 6
-    LeftHand = 7
-    RightWaist = 8
-    RightKnee = 9
-    RightFoot = 10
-    LeftWaist = 11
-    LeftKnee = 12
-    LeftFoot = 13
-    RightEye = 14
-    LeftEye = 15
-    RightEar = 16
-    LeftEar = 17
+# joint order = reference entity.py:9-45 (value = index in this tuple)
+JOINT_NAMES = ('Nose Neck RightShoulder RightElbow RightHand LeftShoulder LeftElbow LeftHand RightWaist RightKnee '
+               'RightFoot LeftWaist LeftKnee LeftFoot RightEye LeftEye RightEar LeftEar').split()
+JointType = IntEnum('JointType', [(name, i) for i, name in enumerate(JOINT_NAMES)])
 
+# the 19 limbs as (from, to) joint names -- reference entity.py:85-105; PAF channels (2i, 2i+1) = (x, y) of limb i
+_LIMBS = ('Neck-RightWaist RightWaist-RightKnee RightKnee-RightFoot Neck-LeftWaist LeftWaist-LeftKnee LeftKnee-LeftFoot '
+          'Neck-RightShoulder RightShoulder-RightElbow RightElbow-RightHand RightShoulder-RightEar Neck-LeftShoulder '
+          'LeftShoulder-LeftElbow LeftElbow-LeftHand LeftShoulder-LeftEar Neck-Nose Nose-RightEye Nose-LeftEye '
+          'RightEye-RightEar LeftEye-LeftEar').split()
 
-_J = JointType
-
-params = {
-    # reference entity.py:59
-    'downscale': 8,
-    # reference entity.py:71-84
-    'inference_img_size': 368,
-    'inference_scales': [0.5, 1, 1.5, 2],
-    'heatmap_size': 320,
-    'gaussian_sigma': 2.5,
-    'ksize': 17,
-    'n_integ_points': 10,
-    'n_integ_points_thresh': 8,
-    'heatmap_peak_thresh': 0.05,
-    'inner_product_thresh': 0.05,
-    'limb_length_ratio': 1.0,
-    'length_penalty_value': 1,
-    'n_subset_limbs_thresh': 3,
-    'subset_score_thresh': 0.2,
-    # reference entity.py:85-105 -- 19 limbs, PAF channels (2i, 2i+1) = (x, y) of limb i
-    'limbs_point': [
-        [_J.Neck, _J.RightWaist],
-        [_J.RightWaist, _J.RightKnee],
-        [_J.RightKnee, _J.RightFoot],
-        [_J.Neck, _J.LeftWaist],
-        [_J.LeftWaist, _J.LeftKnee],
-        [_J.LeftKnee, _J.LeftFoot],
-        [_J.Neck, _J.RightShoulder],
-        [_J.RightShoulder, _J.RightElbow],
-        [_J.RightElbow, _J.RightHand],
-        [_J.RightShoulder, _J.RightEar],
-        [_J.Neck, _J.LeftShoulder],
-        [_J.LeftShoulder, _J.LeftElbow],
-        [_J.LeftElbow, _J.LeftHand],
-        [_J.LeftShoulder, _J.LeftEar],
-        [_J.Neck, _J.Nose],
-        [_J.Nose, _J.RightEye],
-        [_J.Nose, _J.LeftEye],
-        [_J.RightEye, _J.RightEar],
-        [_J.LeftEye, _J.LeftEar],
-    ],
+params = dict(
+    downscale=8,                                  # reference entity.py:59
+    # inference keys, reference entity.py:71-84
+    inference_img_size=368, inference_scales=[0.5, 1, 1.5, 2], heatmap_size=320,
+    gaussian_sigma=2.5, ksize=17,
+    n_integ_points=10, n_integ_points_thresh=8,
+    heatmap_peak_thresh=0.05, inner_product_thresh=0.05,
+    limb_length_ratio=1.0, length_penalty_value=1,
+    n_subset_limbs_thresh=3, subset_score_thresh=0.2,
+    limbs_point=[[JointType[a], JointType[b]] for a, b in (pair.split('-') for pair in _LIMBS)],
     # face / hand key-point detectors (reference entity.py:126-151)
-    'face_inference_img_size': 368,
-    'face_heatmap_peak_thresh': 0.1,
-    'hand_inference_img_size': 368,
-    'hand_heatmap_peak_thresh': 0.1,
-    'fingers_indices': [
-        [[0, 1], [1, 2], [2, 3], [3, 4]],
-        [[0, 5], [5, 6], [6, 7], [7, 8]],
-        [[0, 9], [9, 10], [10, 11], [11, 12]],
-        [[0, 13], [13, 14], [14, 15], [15, 16]],
-        [[0, 17], [17, 18], [18, 19], [19, 20]],
-    ],
+    face_inference_img_size=368, face_heatmap_peak_thresh=0.1,
+    hand_inference_img_size=368, hand_heatmap_peak_thresh=0.1,
+    fingers_indices=[[[0 if k == 0 else 4 * f + k, 4 * f + k + 1] for k in range(4)] for f in range(5)],
     # name -> network architecture handled by the native library (reference entity.py:50-54)
-    'archs': {'posenet': 'posenet', 'facenet': 'facenet', 'handnet': 'handnet'},
-}
+    archs={'posenet': 'posenet', 'facenet': 'facenet', 'handnet': 'handnet'},
+)
 
 N_JOINTS = len(JointType)          # 18
 N_LIMBS = len(params['limbs_point'])  # 19
