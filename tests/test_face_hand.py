@@ -94,3 +94,28 @@ def test_network_matches_torch_oracle(native, arch, cls, n_maps):
         if r is not None:
             assert g[0] == r[0] and g[1] == r[1] and g[2] == r[2]
     det.engine.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('arch', ['facenet', 'handnet'])
+def test_cpm_nets_batch64_kernel_generations_identical(native, arch):
+    """At batch 64 x 368 x 368 the single-branch CPM nets take the one-block-per-CU v6 kernels (17- and 9-tile blocks, the
+    pooled variant, 13 / 10 input chunks); the maps must equal the v5 path's and a single image's bit for bit."""
+    W = pkg('weights')
+    eng = native.Engine(0, max_batch=64, max_h=368, max_w=368, arch=arch)
+    eng.set_weights(W.synthetic_weights(0, arch))
+    imgs = np.random.default_rng(3).integers(0, 256, (64, 368, 368, 3), dtype=np.uint8)
+    outs = {}
+    for gen in (5, 6):
+        eng.set_option('kernel_gen', gen)
+        eng.profile_reset()
+        eng.profile_enable(True)
+        eng.forward_u8(imgs)
+        outs[gen] = eng.get_maps()
+        names = {e['kernel'] for e in eng.profile()}
+        eng.profile_enable(False)
+        assert any('_v6' in k for k in names) == (gen == 6), names
+    assert np.array_equal(outs[5], outs[6])
+    eng.forward_u8(imgs[7:8])
+    assert np.array_equal(eng.get_maps()[0], outs[6][7])
+    eng.close()
