@@ -3,11 +3,15 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, 1 rank/GPU)
 
+With --gpus N > 1 and no WORLD_SIZE in the environment bench.py launches its N ranks itself (re-exec under
+torch.distributed.run on 127.0.0.1, one rank per GPU; it refuses when fewer than N GPUs are visible).
+
 A "step" is one pass of the hot path -- PoseDetector.__call__ semantics for every image of one batch:
 uint8 BGR NHWC images already resident in HBM -> fused preprocess -> 92-layer CocoPoseNet (47 fp32-MFMA conv
 launches) -> upsample + Gaussian + NMS peaks -> PAF scoring + greedy matching -> grouping -> result records
-copied to the host (+ for N > 1 the RCCL all_gather of the records).  Weak scaling: every rank processes its
-own batch of `--batch` images (BASELINE.json config "Batch 256 sharded 8 x 32"); value = all images / max-rank time.
+copied to the host (for N > 1: RCCL gather of the device-resident records to rank 0, the only collective, then one copy
+to the host there).  Weak scaling: every rank processes its own shard of `--batch` images of the global batch
+(BASELINE.json config "Batch 256 sharded 8 x 32"); value = all images / max-rank time.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline      the dominant kernel (7x7 128->128 conv, two branch groups per launch): algorithmic FLOP per launch
@@ -73,7 +77,30 @@ def parse():
     ap.add_argument('--dump-profile', default=None, help='write the per-layer table to this JSON file')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N > 1 ('nccl' = RCCL; 'gloo' only "
                     "for the single-GPU multi-rank smoke test, where all ranks share device 0)")
+    ap.add_argument('--dump-records', default=None, help='rank 0 writes the gathered result records of the last step (.npy)')
+    ap.add_argument('--no-extras', action='store_true', help='skip the single-image and upload-inclusive measurements')
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (same command line the driver uses)."""
+    import socket
+    import subprocess
+    import torch
+    n_dev = torch.cuda.device_count()
+    if a.backend == 'nccl' and n_dev < a.gpus:
+        raise SystemExit('bench.py: --gpus %d requested but only %d GPU(s) visible (one rank per GPU over RCCL; '
+                         '--backend gloo runs the ranks on the visible GPU(s) as a smoke test)' % (a.gpus, n_dev))
+    if n_dev < 1:
+        raise SystemExit('bench.py: no GPU visible (there is no CPU path)')
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % a.gpus,
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def usable_cores():
@@ -164,8 +191,20 @@ def keypoint_match(eng, rec, results, weights_for_match, imgs_for_match):
                       'the reference post-process)'}
 
 
+def dominant_kernel(prof):
+    """(name, total_ms, launches, total_flop) of the kernel with the largest total time (by name, as rocprofv3 groups them)."""
+    by_kernel = {}
+    for p_ in prof:
+        e = by_kernel.setdefault(p_['kernel'], [0.0, 0, 0.0])
+        e[0] += p_['total_ms']; e[1] += p_['launches']; e[2] += p_['flop_per_launch'] * p_['launches']
+    name = max(by_kernel, key=lambda k: by_kernel[k][0])
+    return (name,) + tuple(by_kernel[name])
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(a)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -178,6 +217,8 @@ def main():
         native.build()          # serialised across ranks by a lock file
     if a.backend != 'nccl':
         local_rank = local_rank % max(1, torch.cuda.device_count())    # smoke mode: ranks may share a GPU
+    elif torch.cuda.device_count() <= local_rank:
+        raise SystemExit('bench.py: rank %d has no GPU (%d visible)' % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if world > 1:
         if a.backend == 'nccl':
@@ -200,18 +241,32 @@ def main():
     weights = weights_mod.calibrate_head(weights, paf[0], heat[0])
     eng.set_weights({k: weights[k] for k in ('Mconv7_stage6_L1', 'Mconv7_stage6_L2')})
 
-    imgs = np.random.default_rng(1 + rank).integers(0, 256, (B, S, S, 3), dtype=np.uint8)
+    # the global batch (B * world images, one seeded stream) is sharded contiguously: rank r owns images [r*B, (r+1)*B),
+    # so a 2-rank run of --batch 4 sees exactly the images of a 1-rank run of --batch 8
+    lo, hi = dist_mod.shard_range(B * world, rank, world)
+    rng = np.random.default_rng(1)
+    if lo:
+        rng.integers(0, 256, (lo, S, S, 3), dtype=np.uint8)      # skip the images of the lower ranks (same stream position)
+    imgs = rng.integers(0, 256, (hi - lo, S, S, 3), dtype=np.uint8)
     d_imgs = torch.from_numpy(imgs).to(dev)          # inputs resident in HBM before the timed region
     torch.cuda.synchronize()
+    gather_ms = [0.0]
 
-    def step():
-        eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(B, S, S), map_h=map_s, map_w=map_s)
+    def step(ptr=None):
+        eng.detect_batch(device_ptr=d_imgs.data_ptr() if ptr is None else ptr, shape=(B, S, S), map_h=map_s, map_w=map_s)
         if world > 1 and a.backend == 'nccl':
-            # RCCL all_gather (the only collective) straight from the device-resident records, then one D2H copy
-            return dist_mod.gather_device_records(eng, B, native.RESULT_DTYPE)
-        rec = eng.results()                           # stream sync + D2H of the fixed-size records
+            # RCCL gather (the only collective) straight from the device-resident records, then one D2H copy on rank 0
+            t = time.perf_counter()
+            eng.results_layout()                      # stream sync: the records are final
+            t1 = time.perf_counter()
+            rec = dist_mod.gather_device_records(eng, B, dst=0)
+            gather_ms[0] += (time.perf_counter() - t1) * 1e3
+            return rec
+        rec = eng.results()                           # stream sync + D2H of the records
         if world > 1:
-            rec = dist_mod.gather_records(rec, device=coll_dev)     # smoke mode (gloo): gather through the host
+            t1 = time.perf_counter()
+            rec = dist_mod.gather_records(rec, dst=0, device=coll_dev)     # smoke mode (gloo): gather through the host
+            gather_ms[0] += (time.perf_counter() - t1) * 1e3
         return rec
 
     for _ in range(a.warmup):
@@ -220,6 +275,7 @@ def main():
     if profile:
         eng.profile_reset()
         eng.profile_enable(True)
+    gather_ms[0] = 0.0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -229,13 +285,18 @@ def main():
         rec = step()
     eng.synchronize()
     torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    per_rank = [B * a.steps / dt_local]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        pr = [torch.zeros(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
+        dist.all_gather(pr, torch.tensor([per_rank[0]], dtype=torch.float64, device=coll_dev))
+        per_rank = [float(v.item()) for v in pr]
 
     prof = eng.profile() if profile else []
     if profile:
@@ -244,6 +305,8 @@ def main():
         frames = B * world * a.steps
         ms_per_step = dt / a.steps * 1e3
         status_bits = int(np.bitwise_or.reduce(rec['status'])) if len(rec) else 0
+        if a.dump_records:
+            np.save(a.dump_records, rec)
         out = {
             'metric': 'frames/sec at 368x368 batch (1/2/4/8 GPU) + keypoint-match vs reference',
             'value': frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
@@ -251,22 +314,22 @@ def main():
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'batch%d_%dx%d_synthetic_uint8_per_gpu' % (B, S, S), 'per_gpu_batch': B,
                        'global_batch': B * world, 'map': '%dx%d' % (map_s, map_s), 'weights': 'seeded He + calibrated head',
-                       'parallelism': 'dp%d (independent images, RCCL gather of result records)' % world,
+                       'parallelism': 'dp%d (independent images, %s gather of the result records to rank 0)'
+                                      % (world, 'RCCL' if a.backend == 'nccl' else a.backend),
+                       'records_gathered': int(len(rec)),
                        'people_per_frame_mean': float(np.mean(rec['n_people'])) if len(rec) else 0.0,
                        'peaks_per_frame_mean': float(np.mean(rec['n_peaks'])) if len(rec) else 0.0,
                        'status_bits': status_bits},
             'achieved_tflops_whole_net': FLOP_PER_FRAME * (S * S / (368.0 * 368.0)) * frames / dt / 1e12,
         }
+        if world > 1:
+            out['per_rank_frames_per_s'] = per_rank
+            out['gather_ms_per_step_rank0'] = gather_ms[0] / a.steps
         roof = None
         if prof:
             # dominant kernel = the kernel (by name, as rocprofv3 groups them) with the largest total time in the
             # timed region: the 7x7 conv, 25 launches per step (5 x Mconv1 with 185 input channels + 20 x Mconv2-5)
-            by_kernel = {}
-            for p_ in prof:
-                e = by_kernel.setdefault(p_['kernel'], [0.0, 0, 0.0])
-                e[0] += p_['total_ms']; e[1] += p_['launches']; e[2] += p_['flop_per_launch'] * p_['launches']
-            dom_name = max(by_kernel, key=lambda k: by_kernel[k][0])
-            total_ms, launches, total_flop = by_kernel[dom_name]
+            dom_name, total_ms, launches, total_flop = dominant_kernel(prof)
             if launches:
                 avg_ms = total_ms / launches
                 flop = total_flop / launches
@@ -289,19 +352,12 @@ def main():
                 with open(a.dump_profile, 'w') as f:
                     json.dump({'batch': B, 'steps': a.steps, 'entries': prof}, f, indent=1)
         out['roofline'] = roof
-        # BASELINE config 2 (single 368x368 image per call, the reference's own usage): latency with the input resident in HBM
         eng.profile_enable(False)
-        for _ in range(3):
-            eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(1, S, S), map_h=map_s, map_w=map_s)
-            eng.results()
-        t1 = time.perf_counter()
-        for _ in range(20):
-            eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(1, S, S), map_h=map_s, map_w=map_s)
-            eng.results()
-        one_ms = (time.perf_counter() - t1) / 20 * 1e3
-        out['single_image'] = {'ms_per_call': one_ms, 'frames_per_s': 1e3 / one_ms, 'calls_timed': 20}
-        eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(B, S, S), map_h=map_s, map_w=map_s)     # restore the batch state
-        rec = eng.results()                                                                             # for keypoint_match
+        if world == 1 and not a.no_extras:
+            out['value_incl_h2d'] = upload_inclusive(eng, torch, dev, imgs, a.steps, map_s)
+            out['single_image'] = single_image(eng, d_imgs, S, map_s)
+            eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(B, S, S), map_h=map_s, map_w=map_s)     # restore the batch state
+            rec = eng.results()                                                                             # for keypoint_match
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'], oracle_results = cpu_baseline(weights, imgs, (map_s, map_s), a.cpu_budget)
             out['keypoint_match'] = keypoint_match(eng, rec, oracle_results, weights, imgs)
@@ -312,6 +368,77 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def upload_inclusive(eng, torch, dev, imgs, steps, map_s):
+    """The same K steps with the host->device upload of every batch INSIDE the timed region: pinned staging buffer, the
+    upload of batch k+1 on a second stream under the compute of batch k (double-buffered device input).  The first upload
+    is not hidden and is counted."""
+    B, S = imgs.shape[0], imgs.shape[1]
+    pinned = torch.from_numpy(imgs).pin_memory()
+    bufs = [torch.empty_like(pinned, device=dev) for _ in range(2)]
+    copy_stream = torch.cuda.Stream(device=dev)
+    ready = [torch.cuda.Event(), torch.cuda.Event()]
+
+    def upload(k):
+        with torch.cuda.stream(copy_stream):
+            bufs[k & 1].copy_(pinned, non_blocking=True)
+            ready[k & 1].record(copy_stream)
+
+    def run(n):
+        upload(0)
+        for k in range(n):
+            ready[k & 1].synchronize()                # batch k is in HBM
+            if k + 1 < n:
+                upload(k + 1)                         # overlaps the network of batch k (engine stream)
+            eng.detect_batch(device_ptr=bufs[k & 1].data_ptr(), shape=(B, S, S), map_h=map_s, map_w=map_s)
+            eng.results()
+    run(2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {'value': B * steps / dt, 'unit': 'frames/s', 'ms_per_step': dt / steps * 1e3, 'steps': steps,
+            'upload_bytes_per_step': int(imgs.nbytes),
+            'how': 'pinned host batch -> HBM on a copy stream, upload of batch k+1 overlapped with the compute of batch k; '
+                   'first upload exposed and counted'}
+
+
+def single_image(eng, d_imgs, S, map_s):
+    """BASELINE config 2 (one 368x368 image per call, the reference's own usage): latency with the input resident in HBM,
+    and its own roofline -- whole-network algorithmic FLOP / call time, and the dominant kernel at batch 1 (HIP events)."""
+    for _ in range(3):
+        eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(1, S, S), map_h=map_s, map_w=map_s)
+        eng.results()
+    n = 30
+    t1 = time.perf_counter()
+    for _ in range(n):
+        eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(1, S, S), map_h=map_s, map_w=map_s)
+        eng.results()
+    one_ms = (time.perf_counter() - t1) / n * 1e3
+    flop = FLOP_PER_FRAME * (S * S / (368.0 * 368.0))
+    out = {'ms_per_call': one_ms, 'frames_per_s': 1e3 / one_ms, 'calls_timed': n,
+           'roofline': {'bound': 'mfma', 'achieved': flop / (one_ms * 1e-3) / 1e12, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': flop / (one_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                        'note': 'whole call (network + post-process + result copy) against the fp32-MFMA peak'}}
+    eng.profile_reset()
+    eng.profile_enable(True)
+    for _ in range(10):
+        eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(1, S, S), map_h=map_s, map_w=map_s)
+        eng.results()
+    prof = eng.profile()
+    eng.profile_enable(False)
+    eng.profile_reset()
+    if prof:
+        name, total_ms, launches, total_flop = dominant_kernel(prof)
+        if launches and total_ms > 0:
+            ach = total_flop / (total_ms * 1e-3) / 1e12
+            out['roofline_dominant_kernel'] = {'kernel': name, 'bound': 'mfma', 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS,
+                                               'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS,
+                                               'avg_launch_ms': total_ms / launches, 'launches_timed': launches}
+        out['kernel_ms_per_call'] = sum(p['total_ms'] for p in prof) / 10
+    return out
 
 
 if __name__ == '__main__':

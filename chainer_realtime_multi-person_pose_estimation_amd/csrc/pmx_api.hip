@@ -189,10 +189,16 @@ struct pmx_ctx {
     std::vector<double> gauss;
     PPBuffers pp{};
     double* d_scale = nullptr;
-    pmx_result_record* h_results = nullptr;     // pinned staging for pmx_get_results (pageable D2H is slow and jittery)
-    int h_results_cap = 0;
+    unsigned char* h_results = nullptr;         // pinned staging for pmx_get_results (pageable D2H is slow and jittery)
+    size_t h_results_bytes = 0;
     bool pp_valid = false;
+    bool pp_final = false;                      // statuses checked: no image of the last post-process overflowed a capacity
     int pp_B = 0, pp_h = 0, pp_w = 0;
+    // arguments of the last post-process, kept for the grow-and-re-run
+    PPMaps pp_maps{};
+    double pp_img_len = 0;
+    bool pp_has_scale = false;
+    int pp_regrown = 0;                         // number of capacity growths so far (diagnostics)
     size_t smoothed_cap = 0;
     // options
     int opt_force[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // by ksize
@@ -267,6 +273,49 @@ static int dev_alloc(T** p, size_t count)
     return PMX_OK;
 }
 
+// (re)allocates every post-process buffer whose size depends on the capacities in c->pp (cap_pk, cap_sub, cap_cand)
+static void pp_free(pmx_ctx* c)
+{
+    PPBuffers& p = c->pp;
+    void* ptrs[] = {p.pk_raw_key, p.pk_raw_score, p.pk_count, p.pk_x, p.pk_y, p.pk_score, p.pk_start, p.cn_a, p.cn_b, p.cn_score,
+                    p.cn_count, p.cn_need, p.cand_score, p.cand_idx, p.cand_used, p.sub_work, p.subsets, p.status, p.results};
+    for (void* q : ptrs) if (q) (void)hipFree(q);
+    p.pk_raw_key = nullptr; p.pk_raw_score = nullptr; p.pk_count = nullptr; p.pk_x = p.pk_y = nullptr; p.pk_score = nullptr;
+    p.pk_start = nullptr; p.cn_a = p.cn_b = nullptr; p.cn_score = nullptr; p.cn_count = p.cn_need = nullptr;
+    p.cand_score = nullptr; p.cand_idx = nullptr; p.cand_used = nullptr; p.sub_work = p.subsets = nullptr; p.status = nullptr;
+    p.results = nullptr;
+}
+
+static int pp_alloc(pmx_ctx* c)
+{
+    PPBuffers& p = c->pp;
+    const size_t B = c->max_batch, npk = (size_t)PMX_N_JOINTS * p.cap_pk;
+    int rc;
+    p.rec_bytes = PMX_RECORD_BYTES(p.cap_ppl);
+    if ((rc = dev_alloc(&p.pk_raw_key, B * npk))) return rc;
+    if ((rc = dev_alloc(&p.pk_raw_score, B * npk))) return rc;
+    if ((rc = dev_alloc(&p.pk_count, B * PMX_N_JOINTS))) return rc;
+    if ((rc = dev_alloc(&p.pk_x, B * npk))) return rc;
+    if ((rc = dev_alloc(&p.pk_y, B * npk))) return rc;
+    if ((rc = dev_alloc(&p.pk_score, B * npk))) return rc;
+    if ((rc = dev_alloc(&p.pk_start, B * (PMX_N_JOINTS + 1)))) return rc;
+    if ((rc = dev_alloc(&p.cn_a, B * PMX_N_LIMBS * p.cap_pk))) return rc;
+    if ((rc = dev_alloc(&p.cn_b, B * PMX_N_LIMBS * p.cap_pk))) return rc;
+    if ((rc = dev_alloc(&p.cn_score, B * PMX_N_LIMBS * p.cap_pk))) return rc;
+    if ((rc = dev_alloc(&p.cn_count, B * PMX_N_LIMBS))) return rc;
+    if ((rc = dev_alloc(&p.cn_need, B * PMX_N_LIMBS))) return rc;
+    if (p.cap_cand > 0) {
+        if ((rc = dev_alloc(&p.cand_score, B * PMX_N_LIMBS * p.cap_cand))) return rc;
+        if ((rc = dev_alloc(&p.cand_idx, B * PMX_N_LIMBS * p.cap_cand))) return rc;
+        if ((rc = dev_alloc(&p.cand_used, B * PMX_N_LIMBS * 2 * p.cap_pk))) return rc;
+    }
+    if (p.cap_sub > PMX_LDS_SUBSETS && (rc = dev_alloc(&p.sub_work, B * p.cap_sub * 20))) return rc;
+    if ((rc = dev_alloc(&p.subsets, B * p.cap_sub * 20))) return rc;
+    if ((rc = dev_alloc(&p.status, B))) return rc;
+    if ((rc = dev_alloc(&p.results, B * p.rec_bytes))) return rc;
+    return PMX_OK;
+}
+
 extern "C" int pmx_create_net(pmx_ctx** out, const char* arch, int device, int max_batch, int max_h, int max_w);
 extern "C" int pmx_create(pmx_ctx** out, int device, int max_batch, int max_h, int max_w)
 {
@@ -308,44 +357,35 @@ extern "C" int pmx_create_net(pmx_ctx** out, const char* arch, int device, int m
     c->table = kind == NET_POSE ? make_layer_table() : make_cpm_table(c->n_heat);
     c->layers.resize(c->table.size());
     for (size_t i = 0; i < c->table.size(); ++i) c->index[c->table[i].name] = (int)i;
-    PMX_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    c->stream = c->own_stream;
-    PMX_HIP(hipEventCreate(&c->t0));
-    PMX_HIP(hipEventCreate(&c->t1));
 
     const size_t B = max_batch, HW = (size_t)max_h * max_w, hw8 = HW / 64;
-    int rc;
-    if ((rc = dev_alloc(&c->in16, B * HW * PMX_IN_C))) return rc;
-    if ((rc = dev_alloc(&c->act0, B * HW * 64))) return rc;      // conv1_1 out is the largest activation
-    if ((rc = dev_alloc(&c->act1, B * HW * 16))) return rc;      // (H/2)(W/2) x 64 = (H/4)(W/4) x 256
-    if ((rc = dev_alloc(&c->cat, B * hw8 * c->cat_c))) return rc;
-    if ((rc = dev_alloc(&c->brA, B * hw8 * 256))) return rc;
-    if ((rc = dev_alloc(&c->brB, B * hw8 * 256))) return rc;
-    if ((rc = dev_alloc(&c->brT, B * hw8 * 1024))) return rc;
-    PMX_HIP(hipMemset(c->cat, 0, B * hw8 * c->cat_c * sizeof(float)));   // pad channels stay zero forever
-    c->nchw_tmp_bytes = B * HW * 3 * sizeof(float);
-    if (c->nchw_tmp_bytes < B * hw8 * 80 * sizeof(float)) c->nchw_tmp_bytes = B * hw8 * 80 * sizeof(float);
-    PMX_HIP(hipMalloc((void**)&c->nchw_tmp, c->nchw_tmp_bytes));
-    PMX_HIP(hipMalloc((void**)&c->u8_tmp, B * HW * 3));
-
-    // post-process buffers
-    PPBuffers& p = c->pp;
-    if ((rc = dev_alloc(&p.pk_raw_key, B * PMX_MAX_PEAKS))) return rc;
-    if ((rc = dev_alloc(&p.pk_raw_score, B * PMX_MAX_PEAKS))) return rc;
-    if ((rc = dev_alloc(&p.pk_count, B * PMX_N_JOINTS))) return rc;
-    if ((rc = dev_alloc(&p.pk_x, B * PMX_MAX_PEAKS))) return rc;
-    if ((rc = dev_alloc(&p.pk_y, B * PMX_MAX_PEAKS))) return rc;
-    if ((rc = dev_alloc(&p.pk_score, B * PMX_MAX_PEAKS))) return rc;
-    if ((rc = dev_alloc(&p.pk_start, B * (PMX_N_JOINTS + 1)))) return rc;
-    if ((rc = dev_alloc(&p.cn_a, B * PMX_N_LIMBS * PMX_MAX_PEAKS_PER_JOINT))) return rc;
-    if ((rc = dev_alloc(&p.cn_b, B * PMX_N_LIMBS * PMX_MAX_PEAKS_PER_JOINT))) return rc;
-    if ((rc = dev_alloc(&p.cn_score, B * PMX_N_LIMBS * PMX_MAX_PEAKS_PER_JOINT))) return rc;
-    if ((rc = dev_alloc(&p.cn_count, B * PMX_N_LIMBS))) return rc;
-    if ((rc = dev_alloc(&p.subsets, B * PMX_MAX_SUBSETS * 20))) return rc;
-    if ((rc = dev_alloc(&p.status, B))) return rc;
-    if ((rc = dev_alloc(&p.results, B))) return rc;
-    if ((rc = dev_alloc(&c->d_scale, B * 2))) return rc;
-    p.smoothed = nullptr;
+    // any failure below frees what was created so far (the caller only ever sees a complete context or NULL)
+    auto build = [&]() -> int {
+        int rc;
+        PMX_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+        c->stream = c->own_stream;
+        PMX_HIP(hipEventCreate(&c->t0));
+        PMX_HIP(hipEventCreate(&c->t1));
+        if ((rc = dev_alloc(&c->in16, B * HW * PMX_IN_C))) return rc;
+        if ((rc = dev_alloc(&c->act0, B * HW * 64))) return rc;      // conv1_1 out is the largest activation
+        if ((rc = dev_alloc(&c->act1, B * HW * 16))) return rc;      // (H/2)(W/2) x 64 = (H/4)(W/4) x 256
+        if ((rc = dev_alloc(&c->cat, B * hw8 * c->cat_c))) return rc;
+        if ((rc = dev_alloc(&c->brA, B * hw8 * 256))) return rc;
+        if ((rc = dev_alloc(&c->brB, B * hw8 * 256))) return rc;
+        if ((rc = dev_alloc(&c->brT, B * hw8 * 1024))) return rc;
+        PMX_HIP(hipMemset(c->cat, 0, B * hw8 * c->cat_c * sizeof(float)));   // pad channels stay zero forever
+        c->nchw_tmp_bytes = B * HW * 3 * sizeof(float);
+        if (c->nchw_tmp_bytes < B * hw8 * 80 * sizeof(float)) c->nchw_tmp_bytes = B * hw8 * 80 * sizeof(float);
+        PMX_HIP(hipMalloc((void**)&c->nchw_tmp, c->nchw_tmp_bytes));
+        PMX_HIP(hipMalloc((void**)&c->u8_tmp, B * HW * 3));
+        // post-process buffers at the initial capacities
+        c->pp.cap_pk = PMX_INIT_PEAKS_PER_JOINT; c->pp.cap_sub = PMX_INIT_SUBSETS; c->pp.cap_ppl = PMX_INIT_PEOPLE; c->pp.cap_cand = 0;
+        if ((rc = pp_alloc(c))) return rc;
+        if ((rc = dev_alloc(&c->d_scale, B * 2))) return rc;
+        c->pp.smoothed = nullptr;
+        return PMX_OK;
+    };
+    if (int rc = build()) { pmx_destroy(c); return rc; }
 
     // default Gaussian taps (sigma 2.5 -> radius 10); the Python binding overrides them with NumPy's values
     {
@@ -371,9 +411,8 @@ extern "C" void pmx_destroy(pmx_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (auto& l : c->layers) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); }
+    pp_free(c);
     void* ptrs[] = {c->pr_tmp, c->pr_tab, c->d_kp, c->u8_src, c->rs_tab, c->in16, c->act0, c->act1, c->cat, c->brA, c->brB, c->brT, c->nchw_tmp, c->u8_tmp, c->ext_paf, c->ext_heat,
-                    c->pp.pk_raw_key, c->pp.pk_raw_score, c->pp.pk_count, c->pp.pk_x, c->pp.pk_y, c->pp.pk_score, c->pp.pk_start,
-                    c->pp.cn_a, c->pp.cn_b, c->pp.cn_score, c->pp.cn_count, c->pp.subsets, c->pp.status, c->pp.results,
                     c->pp.smoothed, c->d_scale, c->tab.xi0, c->tab.xi1, c->tab.xlo, c->tab.xhi, c->tab.yi0, c->tab.yi1,
                     c->tab.ylo, c->tab.yhi, c->tab.gauss};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -871,7 +910,97 @@ extern "C" int pmx_postprocess(pmx_ctx* c, int B, int map_h, int map_w, double i
     rc = pp_launch(m, c->tab, c->pp, B, map_h, map_w, img_len, dscale, c->opt_keep_smoothed && c->pp.smoothed, c->stream,
                    c->prof_on ? pp_prof_cb : nullptr, c);
     if (rc) return rc;
-    c->pp_valid = true; c->pp_B = B; c->pp_h = map_h; c->pp_w = map_w;
+    c->pp_valid = true; c->pp_final = false; c->pp_B = B; c->pp_h = map_h; c->pp_w = map_w;
+    c->pp_maps = m; c->pp_img_len = img_len; c->pp_has_scale = scale_xy != nullptr;
+    return PMX_OK;
+}
+
+// ---- capacities: the reference has none (np.vstack / lists); ours grow on demand ------------------------------------------
+static const int PMX_IMG_CAPACITY_BITS = PMX_IMG_PEAK_OVERFLOW | PMX_IMG_CAND_OVERFLOW | PMX_IMG_SUBSET_OVERFLOW | PMX_IMG_PEOPLE_OVERFLOW;
+static int next_pow2(long long v)
+{
+    long long p = 1;
+    while (p < v) p <<= 1;
+    return (int)(p > (1ll << 30) ? (1ll << 30) : p);
+}
+
+// Synchronise and look at the per-image status words of the last post-process.  If an image overflowed a capacity, grow it
+// (peaks: to the largest per-joint count seen; candidates: device-memory store sized to the largest accepted count; subsets:
+// doubled), reallocate the post-process buffers and run the post-process of the batch again on the same network output --
+// until every image fits.  After this the records on the device are final.
+static int pp_finalize(pmx_ctx* c)
+{
+    if (!c->pp_valid || c->pp_final) return PMX_OK;
+    for (int round = 0; round < 64; ++round) {
+        const int B = c->pp_B;
+        std::vector<int> status(B);
+        PMX_HIP(hipMemcpyAsync(status.data(), c->pp.status, sizeof(int) * B, hipMemcpyDeviceToHost, c->stream));
+        PMX_HIP(hipStreamSynchronize(c->stream));
+        int bits = 0;
+        for (int v : status) bits |= v;
+        if (!(bits & PMX_IMG_CAPACITY_BITS)) { c->pp_final = true; return PMX_OK; }
+        int cap_pk = c->pp.cap_pk, cap_sub = c->pp.cap_sub, cap_cand = c->pp.cap_cand, cap_ppl = c->pp.cap_ppl;
+        if (bits & PMX_IMG_PEAK_OVERFLOW) {
+            std::vector<int> cnt((size_t)B * PMX_N_JOINTS);
+            PMX_HIP(hipMemcpy(cnt.data(), c->pp.pk_count, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
+            int need = 0;
+            for (int v : cnt) need = v > need ? v : need;
+            cap_pk = next_pow2(need);
+        }
+        if (bits & PMX_IMG_CAND_OVERFLOW) {
+            std::vector<int> need_v((size_t)B * PMX_N_LIMBS);
+            PMX_HIP(hipMemcpy(need_v.data(), c->pp.cn_need, need_v.size() * sizeof(int), hipMemcpyDeviceToHost));
+            int need = PMX_LDS_CANDIDATES;
+            for (int v : need_v) need = v > need ? v : need;
+            cap_cand = next_pow2(need);
+        }
+        if (bits & PMX_IMG_SUBSET_OVERFLOW) cap_sub *= 2;
+        if (bits & PMX_IMG_PEOPLE_OVERFLOW) {
+            int need = 0;
+            for (int b = 0; b < B; ++b) {
+                pmx_image_info info;
+                PMX_HIP(hipMemcpy(&info, c->pp.results + (size_t)b * c->pp.rec_bytes, sizeof info, hipMemcpyDeviceToHost));
+                need = info.n_people > need ? info.n_people : need;
+            }
+            cap_ppl = next_pow2(need);
+        }
+        PMX_CHECK(cap_pk != c->pp.cap_pk || cap_sub != c->pp.cap_sub || cap_cand != c->pp.cap_cand || cap_ppl != c->pp.cap_ppl,
+                  PMX_ERR_STATE, "post-process reports a capacity overflow (0x%x) that growing does not resolve", bits);
+        pp_free(c);
+        c->pp.cap_pk = cap_pk; c->pp.cap_sub = cap_sub; c->pp.cap_cand = cap_cand; c->pp.cap_ppl = cap_ppl;
+        int rc = pp_alloc(c);
+        if (rc) { c->pp_valid = false; return rc; }
+        c->pp_regrown += 1;
+        rc = pp_launch(c->pp_maps, c->tab, c->pp, B, c->pp_h, c->pp_w, c->pp_img_len, c->pp_has_scale ? c->d_scale : nullptr,
+                       c->opt_keep_smoothed && c->pp.smoothed, c->stream, nullptr, nullptr);
+        if (rc) { c->pp_valid = false; return rc; }
+    }
+    pmx_set_error("post-process capacities did not converge");
+    return PMX_ERR_STATE;
+}
+
+extern "C" int pmx_set_capacities(pmx_ctx* c, int peaks_per_joint, int subsets, int people, int candidates)
+{
+    PMX_CHECK(c, PMX_ERR_INVALID, "null ctx");
+    PMX_CHECK(peaks_per_joint >= 0 && subsets >= 0 && people >= 0 && candidates >= 0, PMX_ERR_INVALID, "pmx_set_capacities: negative capacity");
+    PMX_DEV(c);
+    PMX_HIP(hipStreamSynchronize(c->stream));
+    pp_free(c);
+    if (peaks_per_joint) c->pp.cap_pk = peaks_per_joint;
+    if (subsets) c->pp.cap_sub = subsets;
+    if (people) c->pp.cap_ppl = people;
+    c->pp.cap_cand = candidates;
+    c->pp_valid = false;
+    return pp_alloc(c);
+}
+
+extern "C" int pmx_get_capacities(pmx_ctx* c, int* peaks_per_joint, int* subsets, int* people, int* candidates)
+{
+    PMX_CHECK(c, PMX_ERR_INVALID, "null ctx");
+    if (peaks_per_joint) *peaks_per_joint = c->pp.cap_pk;
+    if (subsets) *subsets = c->pp.cap_sub;
+    if (people) *people = c->pp.cap_ppl;
+    if (candidates) *candidates = c->pp.cap_cand;
     return PMX_OK;
 }
 
@@ -1083,7 +1212,7 @@ extern "C" int pmx_keypoints(pmx_ctx* c, int B, int out_h, int out_w, double thr
     if ((rc = pp_keypoints_launch(m, c->tab, c->pp, B, n_ch, out_h, out_w, thresh, c->d_kp, c->stream))) return rc;
     PMX_HIP(hipMemcpyAsync(out, c->d_kp, nkp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     PMX_HIP(hipStreamSynchronize(c->stream));
-    c->pp_valid = true; c->pp_B = B; c->pp_h = out_h; c->pp_w = out_w;
+    c->pp_valid = true; c->pp_final = true; c->pp_B = B; c->pp_h = out_h; c->pp_w = out_w;
     return PMX_OK;
 }
 
@@ -1095,28 +1224,57 @@ extern "C" int pmx_detect_batch(pmx_ctx* c, const uint8_t* img, int B, int H, in
     return pmx_postprocess(c, B, map_h, map_w, img_len, scale_xy);
 }
 
-extern "C" int pmx_get_results(pmx_ctx* c, int B, pmx_result_record* out)
+extern "C" int pmx_results_layout(pmx_ctx* c, int* people_cap, size_t* bytes_per_record)
+{
+    PMX_CHECK(c, PMX_ERR_INVALID, "null ctx");
+    PMX_CHECK(c->pp_valid, PMX_ERR_STATE, "pmx_results_layout: no post-process results yet");
+    PMX_DEV(c);
+    int rc = pp_finalize(c);
+    if (rc) return rc;
+    if (people_cap) *people_cap = c->pp.cap_ppl;
+    if (bytes_per_record) *bytes_per_record = c->pp.rec_bytes;
+    return PMX_OK;
+}
+
+extern "C" int pmx_get_results(pmx_ctx* c, int B, void* out, size_t out_bytes)
 {
     PMX_CHECK(c && out, PMX_ERR_INVALID, "null arg");
     PMX_CHECK(c->pp_valid && B >= 1 && B <= c->pp_B, PMX_ERR_STATE, "pmx_get_results: no post-process results for batch %d", B);
     PMX_DEV(c);
-    if (B > c->h_results_cap) {
-        if (c->h_results) (void)hipHostFree(c->h_results);
-        c->h_results = nullptr; c->h_results_cap = 0;
-        PMX_HIP(hipHostMalloc((void**)&c->h_results, sizeof(pmx_result_record) * (size_t)c->max_batch, hipHostMallocDefault));
-        c->h_results_cap = c->max_batch;
+    for (;;) {
+        const size_t rec = c->pp.rec_bytes, need = rec * (size_t)B;
+        PMX_CHECK(out_bytes >= need, PMX_ERR_CAPACITY, "pmx_get_results: %zu bytes for %d records of %zu bytes (see pmx_results_layout)",
+                  out_bytes, B, rec);
+        if (need > c->h_results_bytes) {
+            if (c->h_results) (void)hipHostFree(c->h_results);
+            c->h_results = nullptr; c->h_results_bytes = 0;
+            const size_t want = rec * (size_t)c->max_batch;
+            PMX_HIP(hipHostMalloc((void**)&c->h_results, want, hipHostMallocDefault));
+            c->h_results_bytes = want;
+        }
+        PMX_HIP(hipMemcpyAsync(c->h_results, c->pp.results, need, hipMemcpyDeviceToHost, c->stream));
+        PMX_HIP(hipStreamSynchronize(c->stream));
+        if (!c->pp_final) {
+            // common case: the records just copied carry the status words -- no extra round trip
+            int bits = 0;
+            for (int b = 0; b < B; ++b) bits |= reinterpret_cast<const pmx_image_info*>(c->h_results + (size_t)b * rec)->status;
+            if (B == c->pp_B && !(bits & PMX_IMG_CAPACITY_BITS)) c->pp_final = true;
+            else {
+                int rc = pp_finalize(c);        // grows + re-runs if needed; the record layout may have changed
+                if (rc) return rc;
+                continue;
+            }
+        }
+        memcpy(out, c->h_results, need);
+        return PMX_OK;
     }
-    PMX_HIP(hipMemcpyAsync(c->h_results, c->pp.results, sizeof(pmx_result_record) * B, hipMemcpyDeviceToHost, c->stream));
-    PMX_HIP(hipStreamSynchronize(c->stream));
-    memcpy(out, c->h_results, sizeof(pmx_result_record) * B);
-    return PMX_OK;
 }
 
 extern "C" int pmx_results_device_ptr(pmx_ctx* c, void** p, size_t* bytes)
 {
     PMX_CHECK(c && p && bytes, PMX_ERR_INVALID, "null arg");
     *p = c->pp.results;
-    *bytes = sizeof(pmx_result_record);
+    *bytes = c->pp.rec_bytes;
     return PMX_OK;
 }
 
@@ -1125,7 +1283,8 @@ static int check_pp_image(pmx_ctx* c, int image)
     PMX_CHECK(c, PMX_ERR_INVALID, "null ctx");
     PMX_CHECK(c->pp_valid, PMX_ERR_STATE, "no post-process results yet");
     PMX_CHECK(image >= 0 && image < c->pp_B, PMX_ERR_INVALID, "image %d outside 0..%d", image, c->pp_B - 1);
-    return PMX_OK;
+    if (hipSetDevice(c->device) != hipSuccess) { pmx_set_error("hipSetDevice failed"); return PMX_ERR_HIP; }
+    return pp_finalize(c);
 }
 
 extern "C" int pmx_get_peaks(pmx_ctx* c, int image, double* peaks5, int cap, int* n_rows)
@@ -1143,9 +1302,10 @@ extern "C" int pmx_get_peaks(pmx_ctx* c, int image, double* peaks5, int cap, int
     std::vector<int> x(n), y(n);
     std::vector<float> s(n);
     if (n) {
-        PMX_HIP(hipMemcpy(x.data(), c->pp.pk_x + (size_t)image * PMX_MAX_PEAKS, n * sizeof(int), hipMemcpyDeviceToHost));
-        PMX_HIP(hipMemcpy(y.data(), c->pp.pk_y + (size_t)image * PMX_MAX_PEAKS, n * sizeof(int), hipMemcpyDeviceToHost));
-        PMX_HIP(hipMemcpy(s.data(), c->pp.pk_score + (size_t)image * PMX_MAX_PEAKS, n * sizeof(float), hipMemcpyDeviceToHost));
+        const size_t pbase = (size_t)image * PMX_N_JOINTS * c->pp.cap_pk;
+        PMX_HIP(hipMemcpy(x.data(), c->pp.pk_x + pbase, n * sizeof(int), hipMemcpyDeviceToHost));
+        PMX_HIP(hipMemcpy(y.data(), c->pp.pk_y + pbase, n * sizeof(int), hipMemcpyDeviceToHost));
+        PMX_HIP(hipMemcpy(s.data(), c->pp.pk_score + pbase, n * sizeof(float), hipMemcpyDeviceToHost));
     }
     int j = 0;
     for (int i = 0; i < n; ++i) {
@@ -1169,12 +1329,13 @@ extern "C" int pmx_get_connections(pmx_ctx* c, int image, double* conns4, int ca
     *n_rows = total;
     PMX_CHECK(total <= cap, PMX_ERR_CAPACITY, "pmx_get_connections: %d rows > capacity %d", total, cap);
     int o = 0;
-    std::vector<int> a(PMX_MAX_PEAKS_PER_JOINT), b(PMX_MAX_PEAKS_PER_JOINT);
-    std::vector<double> s(PMX_MAX_PEAKS_PER_JOINT);
+    const int cap_pk = c->pp.cap_pk;
+    std::vector<int> a(cap_pk), b(cap_pk);
+    std::vector<double> s(cap_pk);
     for (int l = 0; l < PMX_N_LIMBS; ++l) {
         const int n = cnt[l];
         if (!n) continue;
-        const size_t base = ((size_t)image * PMX_N_LIMBS + l) * PMX_MAX_PEAKS_PER_JOINT;
+        const size_t base = ((size_t)image * PMX_N_LIMBS + l) * cap_pk;
         PMX_HIP(hipMemcpy(a.data(), c->pp.cn_a + base, n * sizeof(int), hipMemcpyDeviceToHost));
         PMX_HIP(hipMemcpy(b.data(), c->pp.cn_b + base, n * sizeof(int), hipMemcpyDeviceToHost));
         PMX_HIP(hipMemcpy(s.data(), c->pp.cn_score + base, n * sizeof(double), hipMemcpyDeviceToHost));
@@ -1193,12 +1354,11 @@ extern "C" int pmx_get_subsets(pmx_ctx* c, int image, double* subsets20, int cap
     PMX_DEV(c);
     PMX_HIP(hipStreamSynchronize(c->stream));
     pmx_image_info info;
-    PMX_HIP(hipMemcpy(&info, &c->pp.results[image].info, sizeof info, hipMemcpyDeviceToHost));
-    // rows kept by the final filter; n_people is clamped to PMX_MAX_PEOPLE, the subsets buffer is not
-    int n = info.n_people;
+    PMX_HIP(hipMemcpy(&info, c->pp.results + (size_t)image * c->pp.rec_bytes, sizeof info, hipMemcpyDeviceToHost));
+    int n = info.n_people;      // rows kept by the final filter
     *n_rows = n;
     PMX_CHECK(n <= cap, PMX_ERR_CAPACITY, "pmx_get_subsets: %d rows > capacity %d", n, cap);
-    if (n) PMX_HIP(hipMemcpy(subsets20, c->pp.subsets + (size_t)image * PMX_MAX_SUBSETS * 20, (size_t)n * 20 * sizeof(double),
+    if (n) PMX_HIP(hipMemcpy(subsets20, c->pp.subsets + (size_t)image * c->pp.cap_sub * 20, (size_t)n * 20 * sizeof(double),
                              hipMemcpyDeviceToHost));
     return PMX_OK;
 }

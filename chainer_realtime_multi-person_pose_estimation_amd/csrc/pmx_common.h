@@ -116,21 +116,34 @@ struct PPMaps {              // where the low-resolution network outputs live
     int fh, fw;
 };
 struct PPBuffers {
+    // capacities (runtime, per context; grown and the post-process re-run when an image needs more: the reference has none)
+    int cap_pk;              // peaks per joint type
+    int cap_sub;             // live subsets during grouping
+    int cap_ppl;             // persons per result record (<= cap_sub)
+    int cap_cand;            // 0: accepted candidates of a limb live in LDS (PMX_LDS_CANDIDATES); else slots per limb in `cand_*`
     // peaks
-    unsigned* pk_raw_key;    // [B][18][MAXPK]   y*W+x, unsorted
-    float* pk_raw_score;     // [B][18][MAXPK]
-    int* pk_count;           // [B][18] (raw, may exceed cap)
-    int* pk_x; int* pk_y; float* pk_score;   // [B][PMX_MAX_PEAKS] sorted, global ids
+    unsigned* pk_raw_key;    // [B][18][cap_pk]   y*W+x, unsorted
+    float* pk_raw_score;     // [B][18][cap_pk]
+    int* pk_count;           // [B][18] (raw, may exceed cap_pk)
+    int* pk_x; int* pk_y; float* pk_score;   // [B][18 * cap_pk] sorted, global ids
     int* pk_start;           // [B][19] first id of each joint type; [18] = total
     // connections
-    int* cn_a; int* cn_b; double* cn_score;  // [B][19][MAXPK]
+    int* cn_a; int* cn_b; double* cn_score;  // [B][19][cap_pk]
     int* cn_count;           // [B][19]
+    int* cn_need;            // [B][19] accepted candidates before greedy matching (may exceed the candidate capacity)
+    double* cand_score; unsigned* cand_idx;  // [B][19][cap_cand] (large mode only)
+    unsigned char* cand_used;                // [B][19][2][cap_pk] (large mode only)
     // grouping
-    double* subsets;         // [B][MAX_SUBSETS][20] (filtered, for parity accessors)
+    double* sub_work;        // [B][cap_sub][20] live subsets when they do not fit the LDS table (cap_sub > PMX_LDS_SUBSETS)
+    double* subsets;         // [B][cap_sub][20] (filtered, for parity accessors)
     int* status;             // [B]
-    pmx_result_record* results;   // [B]
+    unsigned char* results;  // [B] records of rec_bytes: pmx_image_info | double scores[cap_ppl] | double poses[cap_ppl][18][3]
+    size_t rec_bytes;
     float* smoothed;         // optional [B][18][map_h][map_w]
 };
+#define PMX_LDS_CANDIDATES 4096     // candidate slots per limb in the LDS fast path
+#define PMX_LDS_SUBSETS 128         // subset rows in the LDS fast path
+#define PMX_LDS_USED 4096           // peaks per joint type whose "used" flags fit the LDS fast path
 void pp_set_generic(int on);
 int pp_keypoints_launch(const PPMaps& maps, const PPTables& tab, const PPBuffers& buf, int B, int n_ch, int map_h, int map_w,
                         double thresh, double* d_out, hipStream_t stream);

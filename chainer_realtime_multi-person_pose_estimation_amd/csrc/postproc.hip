@@ -127,8 +127,9 @@ __global__ __launch_bounds__(256) void pp_peaks_kernel(PPMaps maps, PPTables tab
 
     if (!do_nms) return;      // smoothing-only mode (face / hand key points)
     // NMS + compaction
-    unsigned* keys = buf.pk_raw_key + ((long long)b * PMX_N_JOINTS + ch) * PMX_MAX_PEAKS_PER_JOINT;
-    float* scores = buf.pk_raw_score + ((long long)b * PMX_N_JOINTS + ch) * PMX_MAX_PEAKS_PER_JOINT;
+    const int cap_pk = buf.cap_pk;
+    unsigned* keys = buf.pk_raw_key + ((long long)b * PMX_N_JOINTS + ch) * cap_pk;
+    float* scores = buf.pk_raw_score + ((long long)b * PMX_N_JOINTS + ch) * cap_pk;
     int* counter = buf.pk_count + b * PMX_N_JOINTS + ch;
     const int lane = tid & 63;
     for (int i = tid; i < PK_TS * PK_TS; i += 256) {
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void pp_peaks_kernel(PPMaps maps, PPTables tab
             basei = __shfl(basei, 0);
             if (peak) {
                 const int slot = basei + __popcll(m & ((1ull << lane) - 1ull));
-                if (slot < PMX_MAX_PEAKS_PER_JOINT) {
+                if (slot < cap_pk) {
                     keys[slot] = (unsigned)(y * map_w + x);
                     scores[slot] = p;
                 }
@@ -293,8 +294,9 @@ __global__ __launch_bounds__(256) void pp_peaks_fast_kernel(PPMaps maps, PPTable
     __syncthreads();
 
     if (!do_nms) return;      // smoothing-only mode (face / hand key points)
-    unsigned* keys = buf.pk_raw_key + ((long long)b * PMX_N_JOINTS + ch) * PMX_MAX_PEAKS_PER_JOINT;
-    float* scores = buf.pk_raw_score + ((long long)b * PMX_N_JOINTS + ch) * PMX_MAX_PEAKS_PER_JOINT;
+    const int cap_pk = buf.cap_pk;
+    unsigned* keys = buf.pk_raw_key + ((long long)b * PMX_N_JOINTS + ch) * cap_pk;
+    float* scores = buf.pk_raw_score + ((long long)b * PMX_N_JOINTS + ch) * cap_pk;
     int* counter = buf.pk_count + b * PMX_N_JOINTS + ch;
     const int lane = tid & 63;
     for (int i = tid; i < PK_TS * PK_TS; i += 256) {
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(256) void pp_peaks_fast_kernel(PPMaps maps, PPTable
             basei = __shfl(basei, 0);
             if (peak) {
                 const int slot = basei + __popcll(m & ((1ull << lane) - 1ull));
-                if (slot < PMX_MAX_PEAKS_PER_JOINT) {
+                if (slot < cap_pk) {
                     keys[slot] = (unsigned)(y * map_w + x);
                     scores[slot] = p;
                 }
@@ -324,18 +326,19 @@ __global__ __launch_bounds__(256) void pp_peaks_fast_kernel(PPMaps maps, PPTable
 }
 
 // ============================================================================================== sort
-__global__ __launch_bounds__(256) void pp_sort_kernel(PPBuffers buf, int map_w)
+__global__ __launch_bounds__(256) void pp_sort_kernel(PPBuffers buf, int map_w, int keys_in_lds)
 {
-    __shared__ unsigned sKey[4][PMX_MAX_PEAKS_PER_JOINT];
+    extern __shared__ unsigned sKeyDyn[];             // [4 waves][cap_pk] when keys_in_lds (else the keys are read from L2)
     __shared__ int sStart[PMX_N_JOINTS + 1];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cap_pk = buf.cap_pk;
     const int* cnt = buf.pk_count + b * PMX_N_JOINTS;
     if (tid == 0) {
         int s = 0, ovf = 0;
         for (int j = 0; j < PMX_N_JOINTS; ++j) {
             sStart[j] = s;
             int n = cnt[j];
-            if (n > PMX_MAX_PEAKS_PER_JOINT) { n = PMX_MAX_PEAKS_PER_JOINT; ovf = 1; }
+            if (n > cap_pk) { n = cap_pk; ovf = 1; }
             s += n;
         }
         sStart[PMX_N_JOINTS] = s;
@@ -343,22 +346,28 @@ __global__ __launch_bounds__(256) void pp_sort_kernel(PPBuffers buf, int map_w)
     }
     __syncthreads();
     if (tid <= PMX_N_JOINTS) buf.pk_start[b * (PMX_N_JOINTS + 1) + tid] = sStart[tid];
+    const long long pbase = (long long)b * PMX_N_JOINTS * cap_pk;
     for (int j = wave; j < PMX_N_JOINTS; j += 4) {     // trip count is wave-uniform
-        const int n = min(cnt[j], PMX_MAX_PEAKS_PER_JOINT);
-        const unsigned* keys = buf.pk_raw_key + ((long long)b * PMX_N_JOINTS + j) * PMX_MAX_PEAKS_PER_JOINT;
-        const float* scores = buf.pk_raw_score + ((long long)b * PMX_N_JOINTS + j) * PMX_MAX_PEAKS_PER_JOINT;
-        for (int e = lane; e < n; e += 64) sKey[wave][e] = keys[e];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int n = min(cnt[j], cap_pk);
+        const unsigned* keys = buf.pk_raw_key + ((long long)b * PMX_N_JOINTS + j) * cap_pk;
+        const float* scores = buf.pk_raw_score + ((long long)b * PMX_N_JOINTS + j) * cap_pk;
+        const unsigned* kk = keys;
+        if (keys_in_lds) {
+            unsigned* mine = sKeyDyn + wave * cap_pk;
+            for (int e = lane; e < n; e += 64) mine[e] = keys[e];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            kk = mine;
+        }
         for (int e = lane; e < n; e += 64) {
-            const unsigned k = sKey[wave][e];
+            const unsigned k = kk[e];
             int rank = 0;
-            for (int o = 0; o < n; ++o) rank += (sKey[wave][o] < k) ? 1 : 0;   // keys are unique pixels
+            for (int o = 0; o < n; ++o) rank += (kk[o] < k) ? 1 : 0;   // keys are unique pixels
             const int id = sStart[j] + rank;
-            buf.pk_x[b * PMX_MAX_PEAKS + id] = (int)(k % (unsigned)map_w);
-            buf.pk_y[b * PMX_MAX_PEAKS + id] = (int)(k / (unsigned)map_w);
-            buf.pk_score[b * PMX_MAX_PEAKS + id] = scores[e];
+            buf.pk_x[pbase + id] = (int)(k % (unsigned)map_w);
+            buf.pk_y[pbase + id] = (int)(k / (unsigned)map_w);
+            buf.pk_score[pbase + id] = scores[e];
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -372,9 +381,11 @@ __device__ __forceinline__ bool cand_better(double s1, unsigned i1, double s2, u
 
 __global__ __launch_bounds__(256) void pp_limbs_kernel(PPMaps maps, PPTables tab, PPBuffers buf, double img_len)
 {
-    __shared__ double sScore[PMX_MAX_CANDIDATES];
-    __shared__ unsigned sIdx[PMX_MAX_CANDIDATES];
-    __shared__ unsigned char sUsedA[PMX_MAX_PEAKS_PER_JOINT], sUsedB[PMX_MAX_PEAKS_PER_JOINT];
+    // fast path: accepted candidates and the endpoint "used" flags of one limb live in LDS; large mode (buf.cap_cand > 0,
+    // entered by the host after an overflow): both live in device memory, same algorithm
+    __shared__ double sScore[PMX_LDS_CANDIDATES];
+    __shared__ unsigned sIdx[PMX_LDS_CANDIDATES];
+    __shared__ unsigned char sUsed[2][PMX_LDS_USED];
     __shared__ double sRedS[4];
     __shared__ unsigned sRedI[4];
     __shared__ int sRedE[4];
@@ -382,29 +393,39 @@ __global__ __launch_bounds__(256) void pp_limbs_kernel(PPMaps maps, PPTables tab
 
     const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ja = c_limbs[l][0], jb = c_limbs[l][1];
+    const int cap_pk = buf.cap_pk;
     const int* start = buf.pk_start + b * (PMX_N_JOINTS + 1);
     const int sA = start[ja], nA = start[ja + 1] - sA;
     const int sB = start[jb], nB = start[jb + 1] - sB;
     int* out_cnt = buf.cn_count + b * PMX_N_LIMBS + l;
     if (nA == 0 || nB == 0) {        // pose_detector.py:170,179-180
-        if (tid == 0) *out_cnt = 0;
+        if (tid == 0) { *out_cnt = 0; buf.cn_need[b * PMX_N_LIMBS + l] = 0; }
         return;
     }
+    const bool large = buf.cap_cand > 0;
+    const long long lb = (long long)b * PMX_N_LIMBS + l;
+    double* const cScore = large ? buf.cand_score + lb * buf.cap_cand : sScore;
+    unsigned* const cIdx = large ? buf.cand_idx + lb * buf.cap_cand : sIdx;
+    unsigned char* const usedA = large ? buf.cand_used + lb * 2 * cap_pk : sUsed[0];
+    unsigned char* const usedB = large ? usedA + cap_pk : sUsed[1];
+    const int ccap = large ? buf.cap_cand : PMX_LDS_CANDIDATES;
     if (tid == 0) sNC = 0;
-    if (tid < PMX_MAX_PEAKS_PER_JOINT) { sUsedA[tid] = 0; sUsedB[tid] = 0; }
+    for (int i = tid; i < nA; i += 256) usedA[i] = 0;
+    for (int i = tid; i < nB; i += 256) usedB[i] = 0;
     __syncthreads();
 
-    const int* px = buf.pk_x + b * PMX_MAX_PEAKS;
-    const int* py = buf.pk_y + b * PMX_MAX_PEAKS;
+    const long long pbase = (long long)b * PMX_N_JOINTS * cap_pk;
+    const int* px = buf.pk_x + pbase;
+    const int* py = buf.pk_y + pbase;
     const float* pafx = maps.paf + (long long)b * maps.sbp + (long long)(2 * l) * maps.sc;
     const float* pafy = pafx + maps.sc;
-    const int P = nA * nB;
+    const long long P = (long long)nA * nB;
     const int g = tid >> 4, k = tid & 15;        // 16 pair slots per block iteration, 16 lanes per pair
     const int gl = lane & ~15;                   // first lane of my group inside the wave
-    for (int base = 0; base < P; base += 16) {   // uniform trip count
-        const int p = base + g;
+    for (long long base = 0; base < P; base += 16) {   // uniform trip count
+        const long long p = base + g;
         const bool pv = p < P;
-        const int ia = pv ? p / nB : 0, ib = pv ? p - ia * nB : 0;
+        const int ia = pv ? (int)(p / nB) : 0, ib = pv ? (int)(p - (long long)ia * nB) : 0;
         const double ax = (double)px[sA + ia], ay = (double)py[sA + ia];
         const double bx = (double)px[sB + ib], by = (double)py[sB + ib];
         const double vx = bx - ax, vy = by - ay;                 // :139
@@ -439,35 +460,37 @@ __global__ __launch_bounds__(256) void pp_limbs_kernel(PPMaps maps, PPTables tab
             const double score = integ + prior;
             if (n_valid > PMX_N_INTEG_POINTS_THRESH && score > 0.0) {              // :156
                 const int slot = atomicAdd(&sNC, 1);
-                if (slot < PMX_MAX_CANDIDATES) {
-                    sScore[slot] = score;
-                    sIdx[slot] = (unsigned)p;
+                if (slot < ccap) {
+                    cScore[slot] = score;
+                    cIdx[slot] = (unsigned)p;
                 }
             }
         }
     }
     __syncthreads();
     int nc = sNC;
-    if (nc > PMX_MAX_CANDIDATES) {
-        if (tid == 0) atomicOr(buf.status + b, PMX_IMG_CAND_OVERFLOW);
-        nc = PMX_MAX_CANDIDATES;
+    if (tid == 0) buf.cn_need[b * PMX_N_LIMBS + l] = nc;
+    if (nc > ccap || (!large && max(nA, nB) > PMX_LDS_USED)) {
+        // does not fit: the host grows the candidate store (large mode) and re-runs the post-process of this batch
+        if (tid == 0) { atomicOr(buf.status + b, PMX_IMG_CAND_OVERFLOW); *out_cnt = 0; }
+        return;
     }
 
     // greedy matching (:172-177): repeatedly take the best remaining candidate whose endpoints are both free
     const int K = min(nA, nB);
-    int* oa = buf.cn_a + ((long long)b * PMX_N_LIMBS + l) * PMX_MAX_PEAKS_PER_JOINT;
-    int* ob = buf.cn_b + ((long long)b * PMX_N_LIMBS + l) * PMX_MAX_PEAKS_PER_JOINT;
-    double* os = buf.cn_score + ((long long)b * PMX_N_LIMBS + l) * PMX_MAX_PEAKS_PER_JOINT;
+    int* oa = buf.cn_a + lb * cap_pk;
+    int* ob = buf.cn_b + lb * cap_pk;
+    double* os = buf.cn_score + lb * cap_pk;
     int count = 0;
     while (count < K) {
         double bs = -1.0;
         unsigned bi = 0xFFFFFFFFu;
         int be = -1;
         for (int e = tid; e < nc; e += 256) {
-            const unsigned idx = sIdx[e];
+            const unsigned idx = cIdx[e];
             const int ia = idx / nB, ib = idx - ia * nB;
-            if (!sUsedA[ia] && !sUsedB[ib]) {
-                const double s = sScore[e];
+            if (!usedA[ia] && !usedB[ib]) {
+                const double s = cScore[e];
                 if (cand_better(s, idx, bs, bi)) { bs = s; bi = idx; be = e; }
             }
         }
@@ -487,8 +510,8 @@ __global__ __launch_bounds__(256) void pp_limbs_kernel(PPMaps maps, PPTables tab
             sBestE = e;
             if (e >= 0) {
                 const int ia = i / nB, ib = i - ia * nB;
-                sUsedA[ia] = 1;
-                sUsedB[ib] = 1;
+                usedA[ia] = 1;
+                usedB[ib] = 1;
                 oa[count] = sA + ia;        // global peak ids (:157)
                 ob[count] = sB + ib;
                 os[count] = s;
@@ -503,14 +526,23 @@ __global__ __launch_bounds__(256) void pp_limbs_kernel(PPMaps maps, PPTables tab
 }
 
 // ============================================================================================= group
+// LDS_TABLE: the live subset rows sit in LDS (cap_sub <= PMX_LDS_SUBSETS, the normal case); otherwise in device memory
+// (buf.sub_work) -- same code, entered by the host after a subset overflow.
+template <bool LDS_TABLE>
 __global__ __launch_bounds__(64) void pp_group_kernel(PPBuffers buf, const double* __restrict__ scale_xy)
 {
-    __shared__ double S[PMX_MAX_SUBSETS][20];
+    __shared__ double sS[LDS_TABLE ? PMX_LDS_SUBSETS * 20 : 20];
     const int b = blockIdx.x, lane = threadIdx.x;
+    const int cap_pk = buf.cap_pk, cap_sub = buf.cap_sub;
+    double* const S = LDS_TABLE ? sS : buf.sub_work + (long long)b * cap_sub * 20;      // row r at S + 20 * r
     const int* start = buf.pk_start + b * (PMX_N_JOINTS + 1);
     const int n_peaks = start[PMX_N_JOINTS];
-    const float* pscore = buf.pk_score + b * PMX_MAX_PEAKS;
-    pmx_result_record* res = buf.results + b;
+    const long long pbase = (long long)b * PMX_N_JOINTS * cap_pk;
+    const float* pscore = buf.pk_score + pbase;
+    pmx_image_info* info = reinterpret_cast<pmx_image_info*>(buf.results + (size_t)b * buf.rec_bytes);
+    const int cap_ppl = buf.cap_ppl;
+    double* res_scores = reinterpret_cast<double*>(info + 1);
+    double* res_poses = res_scores + cap_ppl;
     int n = 0;            // number of live subsets (wave-uniform)
     int status = 0;
     bool aborted = false;
@@ -518,55 +550,52 @@ __global__ __launch_bounds__(64) void pp_group_kernel(PPBuffers buf, const doubl
     for (int l = 0; l < PMX_N_LIMBS && !aborted; ++l) {
         const int ja = c_limbs[l][0], jb = c_limbs[l][1];
         const int cnt = buf.cn_count[b * PMX_N_LIMBS + l];
-        const long long cbase = ((long long)b * PMX_N_LIMBS + l) * PMX_MAX_PEAKS_PER_JOINT;
+        const long long cbase = ((long long)b * PMX_N_LIMBS + l) * cap_pk;
         for (int c = 0; c < cnt; ++c) {
             const int ind_a = buf.cn_a[cbase + c], ind_b = buf.cn_b[cbase + c];
             const double score = buf.cn_score[cbase + c];
             const double da = (double)ind_a, db = (double)ind_b;
-            // :194-198 which subsets hold either endpoint
-            const bool m0 = lane < n && (S[lane][ja] == da || S[lane][jb] == db);
-            const bool m1 = lane + 64 < n && (S[lane + 64][ja] == da || S[lane + 64][jb] == db);
-            unsigned long long k0 = __ballot(m0), k1 = __ballot(m1);
-            const int found = __popcll(k0) + __popcll(k1);
+            // :194-198 which subsets hold either endpoint (rows in ascending order; the third match aborts like the reference)
+            int found = 0, idx1 = -1, idx2 = -1;
+            for (int base = 0; base < n && found < 3; base += 64) {
+                const int r = base + lane;
+                const bool m = r < n && (S[r * 20 + ja] == da || S[r * 20 + jb] == db);
+                unsigned long long km = __ballot(m);
+                while (km && found < 3) {
+                    const int i = base + __ffsll((long long)km) - 1;
+                    km &= km - 1;
+                    if (found == 0) idx1 = i; else if (found == 1) idx2 = i;
+                    ++found;
+                }
+            }
             if (found >= 3) {                       // reference: IndexError at :197
                 status |= PMX_IMG_TRIPLE_MATCH;
                 aborted = true;
                 break;
             }
             if (found == 1) {                       // :200-206
-                const int idx = k0 ? (__ffsll((long long)k0) - 1) : (64 + __ffsll((long long)k1) - 1);
-                if (lane == 0 && S[idx][jb] != db) {
-                    S[idx][jb] = db;
-                    S[idx][19] += 1.0;
-                    S[idx][18] += (double)pscore[ind_b] + score;
+                if (lane == 0 && S[idx1 * 20 + jb] != db) {
+                    S[idx1 * 20 + jb] = db;
+                    S[idx1 * 20 + 19] += 1.0;
+                    S[idx1 * 20 + 18] += (double)pscore[ind_b] + score;
                 }
             } else if (found == 2) {                // :208-235
-                int idx1, idx2;
-                if (k0) {
-                    idx1 = __ffsll((long long)k0) - 1;
-                    k0 &= k0 - 1;
-                    idx2 = k0 ? (__ffsll((long long)k0) - 1) : (64 + __ffsll((long long)k1) - 1);
-                } else {
-                    idx1 = 64 + __ffsll((long long)k1) - 1;
-                    k1 &= k1 - 1;
-                    idx2 = 64 + __ffsll((long long)k1) - 1;
-                }
-                const bool both = lane < 18 && S[idx1][lane] >= 0.0 && S[idx2][lane] >= 0.0;   // :213
+                const bool both = lane < 18 && S[idx1 * 20 + lane] >= 0.0 && S[idx2 * 20 + lane] >= 0.0;   // :213
                 if (__ballot(both) == 0ull) {       // merge (:214-218)
                     __syncthreads();
                     if (lane < 18) {
-                        S[idx1][lane] += S[idx2][lane] + 1.0;
+                        S[idx1 * 20 + lane] += S[idx2 * 20 + lane] + 1.0;
                     } else if (lane < 20) {
-                        S[idx1][lane] += S[idx2][lane];
-                        S[idx1][lane] += score;     // (sic) score AND count, :217
+                        S[idx1 * 20 + lane] += S[idx2 * 20 + lane];
+                        S[idx1 * 20 + lane] += score;     // (sic) score AND count, :217
                     }
                     __syncthreads();
                     if (lane < 20)
-                        for (int r = idx2; r < n - 1; ++r) S[r][lane] = S[r + 1][lane];   // np.delete (:218)
+                        for (int r = idx2; r < n - 1; ++r) S[r * 20 + lane] = S[(r + 1) * 20 + lane];   // np.delete (:218)
                     n -= 1;
                 } else if (lane == 0) {             // :219-235
-                    double* s1 = S[idx1];
-                    double* s2 = S[idx2];
+                    double* s1 = S + idx1 * 20;
+                    double* s2 = S + idx2 * 20;
                     if (s1[ja] == -1.0) {
                         s1[ja] = da; s1[19] += 1.0; s1[18] += (double)pscore[ind_a] + score;
                     } else if (s1[jb] == -1.0) {
@@ -579,19 +608,20 @@ __global__ __launch_bounds__(64) void pp_group_kernel(PPBuffers buf, const doubl
                     }
                 }
             } else if (found == 0 && l != 9 && l != 13) {   // :237-243
-                if (n >= PMX_MAX_SUBSETS) {
-                    status |= PMX_IMG_SUBSET_OVERFLOW;
-                } else {
-                    if (lane < 20) {
-                        double v = -1.0;
-                        if (lane == ja) v = da;
-                        if (lane == jb) v = db;
-                        if (lane == 19) v = 2.0;
-                        if (lane == 18) v = ((0.0 + (double)pscore[ind_a]) + (double)pscore[ind_b]) + score;
-                        S[n][lane] = v;
-                    }
-                    n += 1;
+                if (n >= cap_sub) {
+                    status |= PMX_IMG_SUBSET_OVERFLOW;      // host doubles the capacity and re-runs
+                    aborted = true;
+                    break;
                 }
+                if (lane < 20) {
+                    double v = -1.0;
+                    if (lane == ja) v = da;
+                    if (lane == jb) v = db;
+                    if (lane == 19) v = 2.0;
+                    if (lane == 18) v = ((0.0 + (double)pscore[ind_a]) + (double)pscore[ind_b]) + score;
+                    S[n * 20 + lane] = v;
+                }
+                n += 1;
             }
             __syncthreads();
         }
@@ -601,32 +631,31 @@ __global__ __launch_bounds__(64) void pp_group_kernel(PPBuffers buf, const doubl
     // final filter (:248-249), rescale (:513-514), pose array (:252-265)
     const double sx = scale_xy ? scale_xy[2 * b] : 1.0;
     const double sy = scale_xy ? scale_xy[2 * b + 1] : 1.0;
-    const int* pkx = buf.pk_x + b * PMX_MAX_PEAKS;
-    const int* pky = buf.pk_y + b * PMX_MAX_PEAKS;
-    double* subs_out = buf.subsets + (long long)b * PMX_MAX_SUBSETS * 20;
+    const int* pkx = buf.pk_x + pbase;
+    const int* pky = buf.pk_y + pbase;
+    double* subs_out = buf.subsets + (long long)b * cap_sub * 20;
     int n_keep = 0;
     if (!aborted) {
-        for (int half = 0; half < 2; ++half) {
-            const int r = lane + 64 * half;
-            const bool keep = r < n && S[r][19] >= PMX_N_SUBSET_LIMBS_THRESH &&
-                              S[r][18] / S[r][19] >= PMX_SUBSET_SCORE_THRESH;
+        for (int base = 0; base < n; base += 64) {
+            const int r = base + lane;
+            const bool keep = r < n && S[r * 20 + 19] >= PMX_N_SUBSET_LIMBS_THRESH &&
+                              S[r * 20 + 18] / S[r * 20 + 19] >= PMX_SUBSET_SCORE_THRESH;
             const unsigned long long km = __ballot(keep);
             if (keep) {
-                const int o = n_keep + __popcll(km & ((1ull << lane) - 1ull));
-                for (int j = 0; j < 20; ++j) subs_out[o * 20 + j] = S[r][j];
-                if (o < PMX_MAX_PEOPLE) {
-                    res->scores[o] = S[r][18];
-                    for (int j = 0; j < PMX_N_JOINTS; ++j) {
-                        const int idx = (int)S[r][j];
-                        if (idx >= 0) {
-                            res->poses[o][j][0] = (double)pkx[idx] * sx;
-                            res->poses[o][j][1] = (double)pky[idx] * sy;
-                            res->poses[o][j][2] = 2.0;
-                        } else {
-                            res->poses[o][j][0] = 0.0;
-                            res->poses[o][j][1] = 0.0;
-                            res->poses[o][j][2] = 0.0;
-                        }
+                const int o = n_keep + __popcll(km & ((1ull << lane) - 1ull));     // o <= r < cap_sub
+                for (int j = 0; j < 20; ++j) subs_out[o * 20 + j] = S[r * 20 + j];
+                if (o < cap_ppl) res_scores[o] = S[r * 20 + 18];
+                double* pose = res_poses + (long long)o * PMX_N_JOINTS * 3;
+                for (int j = 0; j < PMX_N_JOINTS && o < cap_ppl; ++j) {
+                    const int idx = (int)S[r * 20 + j];
+                    if (idx >= 0) {
+                        pose[j * 3 + 0] = (double)pkx[idx] * sx;
+                        pose[j * 3 + 1] = (double)pky[idx] * sy;
+                        pose[j * 3 + 2] = 2.0;
+                    } else {
+                        pose[j * 3 + 0] = 0.0;
+                        pose[j * 3 + 1] = 0.0;
+                        pose[j * 3 + 2] = 0.0;
                     }
                 }
             }
@@ -634,12 +663,12 @@ __global__ __launch_bounds__(64) void pp_group_kernel(PPBuffers buf, const doubl
         }
     }
     if (lane == 0) {
-        if (n_keep > PMX_MAX_PEOPLE) status |= PMX_IMG_PEOPLE_OVERFLOW;
+        if (n_keep > cap_ppl) status |= PMX_IMG_PEOPLE_OVERFLOW;      // host grows the record and re-runs
         const int prev = atomicOr(buf.status + b, status);
-        res->info.n_people = min(n_keep, PMX_MAX_PEOPLE);
-        res->info.n_peaks = n_peaks;
-        res->info.status = prev | status;
-        res->info.n_subsets_raw = n;
+        info->n_people = n_keep;
+        info->n_peaks = n_peaks;
+        info->status = prev | status;
+        info->n_subsets_raw = n;
     }
 }
 
@@ -653,7 +682,7 @@ int pp_launch(const PPMaps& maps, const PPTables& tab, const PPBuffers& buf, int
 {
     PMX_HIP(hipMemsetAsync(buf.pk_count, 0, sizeof(int) * B * PMX_N_JOINTS, stream));
     PMX_HIP(hipMemsetAsync(buf.status, 0, sizeof(int) * B, stream));
-    PMX_HIP(hipMemsetAsync(buf.results, 0, sizeof(pmx_result_record) * B, stream));   // unused rows of a record are zero
+    PMX_HIP(hipMemsetAsync(buf.results, 0, buf.rec_bytes * B, stream));   // unused rows of a record are zero
     const int tiles_x = (map_w + PK_TS - 1) / PK_TS, tiles_y = (map_h + PK_TS - 1) / PK_TS;
 
     if (prof) prof(prof_ctx, "pp_peaks", 1);
@@ -667,7 +696,11 @@ int pp_launch(const PPMaps& maps, const PPTables& tab, const PPBuffers& buf, int
     if (prof) prof(prof_ctx, "pp_peaks", 0);
 
     if (prof) prof(prof_ctx, "pp_sort", 1);
-    hipLaunchKernelGGL(pp_sort_kernel, dim3(B), dim3(256), 0, stream, buf, map_w);
+    {
+        // rank sort of the keys of one joint type per wave: keys staged in LDS while 4 waves x cap_pk keys fit 32 KB
+        const int in_lds = buf.cap_pk <= 2048;
+        hipLaunchKernelGGL(pp_sort_kernel, dim3(B), dim3(256), in_lds ? sizeof(unsigned) * 4 * buf.cap_pk : 0, stream, buf, map_w, in_lds);
+    }
     PMX_HIP(hipGetLastError());
     if (prof) prof(prof_ctx, "pp_sort", 0);
 
@@ -677,7 +710,10 @@ int pp_launch(const PPMaps& maps, const PPTables& tab, const PPBuffers& buf, int
     if (prof) prof(prof_ctx, "pp_limbs", 0);
 
     if (prof) prof(prof_ctx, "pp_group", 1);
-    hipLaunchKernelGGL(pp_group_kernel, dim3(B), dim3(64), 0, stream, buf, d_scale_xy);
+    if (buf.cap_sub <= PMX_LDS_SUBSETS)
+        hipLaunchKernelGGL(pp_group_kernel<true>, dim3(B), dim3(64), 0, stream, buf, d_scale_xy);
+    else
+        hipLaunchKernelGGL(pp_group_kernel<false>, dim3(B), dim3(64), 0, stream, buf, d_scale_xy);
     PMX_HIP(hipGetLastError());
     if (prof) prof(prof_ctx, "pp_group", 0);
     return PMX_OK;

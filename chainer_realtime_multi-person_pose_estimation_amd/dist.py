@@ -1,8 +1,12 @@
 """Multi-GPU sharding of the hot path: one process per GPU, images are independent (the reference handles one
 image per call, pose_detector.py:430,501), so a batch is split contiguously over ranks with NO data-path
-collective; the only exchange is the final gather of the fixed-size result records (RCCL all_gather over xGMI
-when the backend is "nccl"; gloo on CPU in the tests).  Nothing in the reference to mirror: it has no
-distributed code at all."""
+collective; the only exchange is the final GATHER of the result records to rank 0 (RCCL over xGMI when the
+backend is "nccl": implemented by RCCL as grouped send/recv into the root; gloo on CPU in the tests).  Nothing in the
+reference to mirror: it has no distributed code at all.
+
+Records are moved as raw bytes.  Their size depends on the rank's current person capacity (native.result_dtype), which grows
+on demand, and shards may be uneven, so (count, people_cap) of every rank travels first (one small all_gather) and the root
+re-packs everything at the largest capacity."""
 import numpy as np
 
 
@@ -14,34 +18,69 @@ def shard_range(n_items, rank, world_size):
     return lo, hi
 
 
-def gather_records(local_records, group=None, device=None):
-    """all_gather of per-image result records (NumPy structured array, possibly of different length per rank).
+def _people_cap(dtype):
+    return int(dtype['scores'].shape[0])
 
-    Returns the concatenation in rank order on every rank.  Records are moved as raw bytes; lengths are
-    exchanged first so that uneven shards work.  `device`: torch device for the collective (cuda:N for nccl)."""
+
+def _repack(records, people_cap):
+    """Records at one person capacity -> the same records at a larger one (unused rows zero, as on the device)."""
+    from . import native
+    if _people_cap(records.dtype) == people_cap:
+        return records
+    out = np.zeros(len(records), dtype=native.result_dtype(people_cap))
+    k = _people_cap(records.dtype)
+    for f in ('n_people', 'n_peaks', 'status', 'n_subsets_raw'):
+        out[f] = records[f]
+    out['scores'][:, :k] = records['scores']
+    out['poses'][:, :k] = records['poses']
+    return out
+
+
+def _exchange_meta(n_local, people_cap, group, dev):
     import torch
     import torch.distributed as dist
+    world = dist.get_world_size(group)
+    mine = torch.tensor([n_local, people_cap], dtype=torch.int64, device=dev)
+    metas = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(metas, mine, group=group)
+    metas = [[int(v) for v in m.cpu()] for m in metas]
+    return [m[0] for m in metas], [m[1] for m in metas]
+
+
+def _assemble(chunks, counts, caps):
+    from . import native
+    cap = max(caps)
+    parts = []
+    for raw, n, c in zip(chunks, counts, caps):
+        dt = native.result_dtype(c)
+        parts.append(_repack(np.frombuffer(raw, dtype=dt, count=n), cap))
+    return np.concatenate(parts) if parts else np.zeros(0, dtype=native.result_dtype(cap))
+
+
+def gather_records(local_records, dst=0, group=None, device=None):
+    """Final gather of per-image result records (host NumPy structured arrays) to rank `dst`.
+
+    Returns the concatenation in rank order on `dst` and None on the other ranks (world size 1: a copy).
+    `device`: torch device the collective runs on (cuda:N for nccl, cpu for gloo)."""
+    import torch
+    import torch.distributed as dist
+    from . import native
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local_records.copy()
-    world = dist.get_world_size(group)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = torch.device('cpu') if device is None else torch.device(device)
-    n_local = torch.tensor([len(local_records)], dtype=torch.int64, device=dev)
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, n_local, group=group)
-    counts = [int(c.item()) for c in counts]
-    itemsize = local_records.dtype.itemsize
-    cap = max(counts) if counts else 0
-    buf = torch.zeros(max(cap, 1) * itemsize, dtype=torch.uint8, device=dev)
+    counts, caps = _exchange_meta(len(local_records), _people_cap(local_records.dtype), group, dev)
+    sizes = [n * native.result_dtype(c).itemsize for n, c in zip(counts, caps)]
+    nmax = max(max(sizes), 1)
+    buf = torch.zeros(nmax, dtype=torch.uint8, device=dev)
     raw = np.frombuffer(np.ascontiguousarray(local_records).tobytes(), dtype=np.uint8)
     if len(raw):
         buf[:len(raw)] = torch.from_numpy(raw.copy()).to(dev)
-    outs = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(outs, buf, group=group)
-    parts = []
-    for r in range(world):
-        b = outs[r][:counts[r] * itemsize].cpu().numpy().tobytes()
-        parts.append(np.frombuffer(b, dtype=local_records.dtype, count=counts[r]))
-    return np.concatenate(parts) if parts else local_records[:0].copy()
+    outs = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, outs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return _assemble([outs[r][:sizes[r]].cpu().numpy().tobytes() for r in range(world)], counts, caps)
 
 
 class _DeviceBytes(object):
@@ -52,19 +91,32 @@ class _DeviceBytes(object):
                                          'version': 2, 'strides': None}
 
 
-def gather_device_records(engine, n_local, record_dtype, group=None):
-    """RCCL all_gather straight out of the engine's device-resident result records (equal shard sizes on every rank):
-    no host round trip before the collective, one device-to-host copy of the gathered records after it.
+def gather_device_records(engine, n_local, dst=0, group=None):
+    """RCCL gather to rank `dst` straight out of the engine's device-resident result records: no host round trip before the
+    collective, one device-to-host copy of the gathered records on the root after it.
 
-    The engine runs on its own stream, so it is synchronised first; the collective then runs on torch's RCCL stream."""
+    `engine.results_layout()` first makes the records final (stream sync; capacity growth + re-run if an image needed it).
+    The collective runs on torch's RCCL stream.  Returns the records of all ranks on `dst`, None elsewhere."""
     import torch
     import torch.distributed as dist
-    ptr, rec_bytes = engine.results_device_ptr()
-    assert rec_bytes == np.dtype(record_dtype).itemsize
-    engine.synchronize()
+    from . import native
+    people_cap, rec_bytes = engine.results_layout()
+    ptr, rec_bytes2 = engine.results_device_ptr()
+    assert rec_bytes == rec_bytes2
     dev = torch.device('cuda', engine.device)
-    view = torch.as_tensor(_DeviceBytes(ptr, n_local * rec_bytes), device=dev)
-    world = dist.get_world_size(group)
-    out = torch.empty(world * n_local * rec_bytes, dtype=torch.uint8, device=dev)
-    dist.all_gather_into_tensor(out, view, group=group)
-    return out.cpu().numpy().view(record_dtype)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    counts, caps = _exchange_meta(n_local, people_cap, group, dev)
+    sizes = [n * native.result_dtype(c).itemsize for n, c in zip(counts, caps)]
+    nmax = max(max(sizes), 1)
+    if sizes[rank] == nmax:
+        view = torch.as_tensor(_DeviceBytes(ptr, nmax), device=dev)        # the common case: equal shards, equal capacities
+    else:
+        view = torch.zeros(nmax, dtype=torch.uint8, device=dev)
+        if sizes[rank]:
+            view[:sizes[rank]] = torch.as_tensor(_DeviceBytes(ptr, sizes[rank]), device=dev)
+    big = torch.empty(world * nmax, dtype=torch.uint8, device=dev) if rank == dst else None
+    dist.gather(view, list(big.split(nmax)) if rank == dst else None, dst=dst, group=group)
+    if rank != dst:
+        return None
+    host = big.cpu().numpy()
+    return _assemble([host[r * nmax:r * nmax + sizes[r]].tobytes() for r in range(world)], counts, caps)

@@ -20,16 +20,20 @@ SOURCES = [('pmx_api.hip', []), ('conv_mfma.hip', []), ('prep.hip', ['-ffp-contr
 HEADERS = ['pmx_common.h', HEADER]
 
 N_JOINTS, N_LIMBS, N_PAF, N_HEAT = 18, 19, 38, 19
-MAX_PEAKS_PER_JOINT = 128
-MAX_PEAKS = N_JOINTS * MAX_PEAKS_PER_JOINT
-MAX_SUBSETS = 128
-MAX_PEOPLE = 64
+# initial capacities of a context (PMX_INIT_* in the header); they grow on demand, results are never truncated
+INIT_PEAKS_PER_JOINT, INIT_SUBSETS, INIT_PEOPLE = 128, 128, 64
 
 IMG_PEAK_OVERFLOW, IMG_CAND_OVERFLOW, IMG_SUBSET_OVERFLOW, IMG_TRIPLE_MATCH, IMG_PEOPLE_OVERFLOW = 1, 2, 4, 8, 16
 
-RESULT_DTYPE = np.dtype([
-    ('n_people', np.int32), ('n_peaks', np.int32), ('status', np.int32), ('n_subsets_raw', np.int32),
-    ('scores', np.float64, (MAX_PEOPLE,)), ('poses', np.float64, (MAX_PEOPLE, N_JOINTS, 3))])
+
+def result_dtype(people_cap):
+    """NumPy view of one result record (include/pose_mi355x.h): pmx_image_info | scores[people_cap] | poses[people_cap][18][3]."""
+    return np.dtype([
+        ('n_people', np.int32), ('n_peaks', np.int32), ('status', np.int32), ('n_subsets_raw', np.int32),
+        ('scores', np.float64, (int(people_cap),)), ('poses', np.float64, (int(people_cap), N_JOINTS, 3))])
+
+
+RESULT_DTYPE = result_dtype(INIT_PEOPLE)       # layout at the initial person capacity
 
 
 class PmxError(RuntimeError):
@@ -135,8 +139,11 @@ def load():
         'pmx_set_gaussian': (ci, [vp, vp, ci]),
         'pmx_postprocess': (ci, [vp, ci, ci, ci, cd, vp]),
         'pmx_detect_batch': (ci, [vp, vp, ci, ci, ci, ci, ci, ci, cd, vp]),
-        'pmx_get_results': (ci, [vp, ci, vp]),
+        'pmx_results_layout': (ci, [vp, ip, C.POINTER(C.c_size_t)]),
+        'pmx_get_results': (ci, [vp, ci, vp, C.c_size_t]),
         'pmx_results_device_ptr': (ci, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+        'pmx_set_capacities': (ci, [vp, ci, ci, ci, ci]),
+        'pmx_get_capacities': (ci, [vp, ip, ip, ip, ip]),
         'pmx_get_peaks': (ci, [vp, ci, vp, ci, ip]),
         'pmx_get_connections': (ci, [vp, ci, vp, ci, ip]),
         'pmx_get_subsets': (ci, [vp, ci, vp, ci, ip]),
@@ -359,36 +366,59 @@ class Engine(object):
         self._fhw = (H // 8, W // 8)
         self._map = (int(map_h), int(map_w))
 
+    def set_capacities(self, peaks_per_joint=0, subsets=0, people=0, candidates=0):
+        """Pre-size the post-process buffers (0 keeps a value; candidates 0 = LDS store).  Tests shrink them to exercise the
+        growth path; crowds can pre-size to avoid the one-off re-run."""
+        self._check(self.lib.pmx_set_capacities(self._ctx, int(peaks_per_joint), int(subsets), int(people), int(candidates)))
+
+    def capacities(self):
+        v = [C.c_int(0) for _ in range(4)]
+        self._check(self.lib.pmx_get_capacities(self._ctx, *[C.byref(x) for x in v]))
+        return dict(zip(('peaks_per_joint', 'subsets', 'people', 'candidates'), [x.value for x in v]))
+
+    def results_layout(self):
+        """(people_cap, bytes_per_record) of the final records of the last post-process (synchronises; grows the capacities
+        and re-runs the post-process first if an image overflowed them)."""
+        cap, nbytes = C.c_int(0), C.c_size_t(0)
+        self._check(self.lib.pmx_results_layout(self._ctx, C.byref(cap), C.byref(nbytes)))
+        assert result_dtype(cap.value).itemsize == nbytes.value
+        return cap.value, nbytes.value
+
     def results(self):
-        """Structured array (B,) of RESULT_DTYPE (synchronises)."""
-        out = np.empty(self._B, dtype=RESULT_DTYPE)
-        self._check(self.lib.pmx_get_results(self._ctx, self._B, _ptr(out)))
+        """Structured array (B,) of result_dtype(people_cap) (synchronises)."""
+        cap, _ = self.results_layout()
+        out = np.empty(self._B, dtype=result_dtype(cap))
+        self._check(self.lib.pmx_get_results(self._ctx, self._B, _ptr(out), out.nbytes))
         return out
 
     def results_device_ptr(self):
+        """(device pointer, bytes per record) of the final records (call after results_layout())."""
         p = C.c_void_p()
         n = C.c_size_t()
         self._check(self.lib.pmx_results_device_ptr(self._ctx, C.byref(p), C.byref(n)))
         return p.value, n.value
 
-    def peaks(self, image=0):
-        buf = np.empty((MAX_PEAKS, 5), np.float64)
+    def _rows(self, fn, image, width, guess):
         n = C.c_int(0)
-        self._check(self.lib.pmx_get_peaks(self._ctx, image, _ptr(buf), MAX_PEAKS, C.byref(n)))
-        return buf[:n.value].copy()
+        cap = max(int(guess), 1)
+        for _ in range(2):
+            buf = np.empty((cap, width), np.float64)
+            rc = fn(self._ctx, image, _ptr(buf), cap, C.byref(n))
+            if rc == 5 and n.value > cap:        # PMX_ERR_CAPACITY: n_rows tells the size needed
+                cap = n.value
+                continue
+            self._check(rc)
+            return buf[:n.value].copy()
+        self._check(rc)
+
+    def peaks(self, image=0):
+        return self._rows(self.lib.pmx_get_peaks, image, 5, N_JOINTS * INIT_PEAKS_PER_JOINT)
 
     def connections(self, image=0):
-        cap = N_LIMBS * MAX_PEAKS_PER_JOINT
-        buf = np.empty((cap, 4), np.float64)
-        n = C.c_int(0)
-        self._check(self.lib.pmx_get_connections(self._ctx, image, _ptr(buf), cap, C.byref(n)))
-        return buf[:n.value].copy()
+        return self._rows(self.lib.pmx_get_connections, image, 4, N_LIMBS * INIT_PEAKS_PER_JOINT)
 
     def subsets(self, image=0):
-        buf = np.empty((MAX_SUBSETS, 20), np.float64)
-        n = C.c_int(0)
-        self._check(self.lib.pmx_get_subsets(self._ctx, image, _ptr(buf), MAX_SUBSETS, C.byref(n)))
-        return buf[:n.value].copy()
+        return self._rows(self.lib.pmx_get_subsets, image, 20, INIT_SUBSETS)
 
     def smoothed(self, image, joint):
         h, w = self._map

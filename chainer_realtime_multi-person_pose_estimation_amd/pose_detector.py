@@ -311,9 +311,8 @@ def unpack_results(records):
         if st & native.IMG_TRIPLE_MATCH:
             # the reference fails with IndexError at pose_detector.py:197 when a third subset matches
             raise IndexError('list assignment index out of range')
-        if st & (native.IMG_PEAK_OVERFLOW | native.IMG_CAND_OVERFLOW | native.IMG_SUBSET_OVERFLOW | native.IMG_PEOPLE_OVERFLOW):
-            raise RuntimeError('pose post-process capacity exceeded (status bits 0x%x: peaks>%d/joint, candidates, '
-                               'subsets>%d or people>%d)' % (st, native.MAX_PEAKS_PER_JOINT, native.MAX_SUBSETS, native.MAX_PEOPLE))
+        # (capacity bits never reach this point: the library grows its buffers and re-runs the post-process, the reference
+        #  has no limits on peaks / candidates / subsets / people)
         n = int(r['n_people'])
         if int(r['n_peaks']) == 0:
             out.append((np.empty((0, len(JointType), 3)), np.empty(0)))      # :509-510

@@ -24,19 +24,19 @@
 extern "C" {
 #endif
 
-#define PMX_ABI_VERSION 1
+#define PMX_ABI_VERSION 2
 
-/* fixed capacities of the device-side result records (a capacity overflow is reported per image in
- * pmx_image_info.status, never silently truncated) */
+/* The reference has no limits on peaks, candidate connections, person hypotheses or persons (np.vstack / Python lists,
+ * pose_detector.py:104-110,157,243).  The device-side buffers have CAPACITIES instead, owned by the context: they start at
+ * the values below and, when an image needs more, are grown and the post-process of that batch is re-run before any result
+ * is handed out (pmx_get_results / pmx_results_layout / the parity accessors) -- callers never see a truncated result. */
 #define PMX_N_JOINTS 18          /* entity.py:9-45 */
 #define PMX_N_LIMBS 19           /* entity.py:85-105 */
 #define PMX_N_PAF 38
 #define PMX_N_HEAT 19
-#define PMX_MAX_PEAKS_PER_JOINT 128
-#define PMX_MAX_PEAKS (PMX_N_JOINTS * PMX_MAX_PEAKS_PER_JOINT)
-#define PMX_MAX_CANDIDATES 4096  /* accepted candidate connections per limb before greedy matching */
-#define PMX_MAX_SUBSETS 128      /* live person hypotheses during grouping */
-#define PMX_MAX_PEOPLE 64        /* persons returned per image */
+#define PMX_INIT_PEAKS_PER_JOINT 128   /* initial capacity: peaks of one joint type per image */
+#define PMX_INIT_SUBSETS 128           /* initial capacity: live person hypotheses during grouping */
+#define PMX_INIT_PEOPLE 64             /* initial capacity: persons per result record */
 
 enum pmx_status {
     PMX_OK = 0,
@@ -48,15 +48,16 @@ enum pmx_status {
     PMX_ERR_STATE = 6        /* call sequence error (e.g. postprocess before forward) */
 };
 
-/* per-image status bits (pmx_image_info.status) */
+/* per-image status bits (pmx_image_info.status).  The capacity bits are internal: they trigger the grow-and-re-run and are
+ * never set in a record that is handed out. */
 enum pmx_image_status {
     PMX_IMG_OK = 0,
-    PMX_IMG_PEAK_OVERFLOW = 1,      /* > PMX_MAX_PEAKS_PER_JOINT peaks of one joint type */
-    PMX_IMG_CAND_OVERFLOW = 2,      /* > PMX_MAX_CANDIDATES accepted candidates for one limb */
-    PMX_IMG_SUBSET_OVERFLOW = 4,    /* > PMX_MAX_SUBSETS live subsets */
+    PMX_IMG_PEAK_OVERFLOW = 1,      /* more peaks of one joint type than the current capacity */
+    PMX_IMG_CAND_OVERFLOW = 2,      /* more accepted candidates for one limb than the current capacity */
+    PMX_IMG_SUBSET_OVERFLOW = 4,    /* more live subsets than the current capacity */
     PMX_IMG_TRIPLE_MATCH = 8,       /* third subset matches a connection: the reference raises IndexError
                                        (pose_detector.py:193,197); the binding re-raises it */
-    PMX_IMG_PEOPLE_OVERFLOW = 16    /* > PMX_MAX_PEOPLE persons after filtering */
+    PMX_IMG_PEOPLE_OVERFLOW = 16    /* more persons after the final filter than the record capacity */
 };
 
 typedef struct pmx_ctx pmx_ctx;
@@ -68,12 +69,13 @@ typedef struct pmx_image_info {
     int32_t n_subsets_raw; /* subsets alive before the final filter (pose_detector.py:248) */
 } pmx_image_info;
 
-/* device-resident result record, one per image, contiguous: what multi-GPU runs gather with RCCL */
-typedef struct pmx_result_record {
-    pmx_image_info info;
-    double scores[PMX_MAX_PEOPLE];                       /* subsets[:, -2]   (pose_detector.py:516) */
-    double poses[PMX_MAX_PEOPLE][PMX_N_JOINTS][3];       /* [x, y, 2] | [0,0,0] (pose_detector.py:252-265) */
-} pmx_result_record;
+/* Result record, one per image, contiguous on the device (what multi-GPU runs gather with RCCL) and in pmx_get_results:
+ *     pmx_image_info info;
+ *     double scores[people_cap];                  subsets[:, -2]        (pose_detector.py:516)
+ *     double poses[people_cap][PMX_N_JOINTS][3];  [x, y, 2] | [0, 0, 0] (pose_detector.py:252-265)
+ * people_cap is the context's current person capacity; query it (and the record size) with pmx_results_layout AFTER the
+ * post-process and BEFORE sizing the output buffer: it grows when an image needs it. */
+#define PMX_RECORD_BYTES(people_cap) (sizeof(pmx_image_info) + (size_t)(people_cap) * (1 + PMX_N_JOINTS * 3) * sizeof(double))
 
 /* ---- library / device ------------------------------------------------------------------------ */
 const char* pmx_version(void);
@@ -152,15 +154,23 @@ int pmx_keypoints(pmx_ctx* ctx, int batch, int out_h, int out_w, double thresh, 
 int pmx_detect_batch(pmx_ctx* ctx, const uint8_t* bgr_nhwc, int batch, int h, int w, int on_device,
                      int map_h, int map_w, double img_len, const double* scale_xy);
 
-/* results: copies `batch` records to host (synchronises). */
-int pmx_get_results(pmx_ctx* ctx, int batch, pmx_result_record* out);
-/* device pointer of the record array (for RCCL gathers); valid until the context is destroyed */
-int pmx_results_device_ptr(pmx_ctx* ctx, void** dev_ptr, size_t* bytes_per_image);
+/* results.  pmx_results_layout synchronises, grows the capacities and re-runs the post-process if an image overflowed them,
+ * and returns the layout of the (now final) records; pmx_get_results does the same and copies `batch` records to `out`
+ * (out_bytes >= batch * bytes_per_record, else PMX_ERR_CAPACITY). */
+int pmx_results_layout(pmx_ctx* ctx, int* people_cap, size_t* bytes_per_record);
+int pmx_get_results(pmx_ctx* ctx, int batch, void* out, size_t out_bytes);
+/* device pointer of the record array (for RCCL gathers): call pmx_results_layout first; valid until the next post-process */
+int pmx_results_device_ptr(pmx_ctx* ctx, void** dev_ptr, size_t* bytes_per_record);
+/* capacities: pre-size a context for crowds (or shrink them in tests to exercise the growth path); 0 keeps a value.
+ * candidates: 0 = accepted candidates of a limb are kept in LDS (4096 slots), > 0 = that many slots in device memory. */
+int pmx_set_capacities(pmx_ctx* ctx, int peaks_per_joint, int subsets, int people, int candidates);
+int pmx_get_capacities(pmx_ctx* ctx, int* peaks_per_joint, int* subsets, int* people, int* candidates);
 
 /* parity accessors for one image of the last post-process (host copies; synchronise).
  * peaks: rows (type, x, y, score, id) float64 = all_peaks (pose_detector.py:76,110), BEFORE the rescale;
  * conns: rows (limb, id_a, id_b, score) = all_connections (:161-181) flattened in limb order;
- * subsets: rows of 20 float64 after the final filter (:248-249). */
+ * subsets: rows of 20 float64 after the final filter (:248-249).
+ * n_rows is always set; PMX_ERR_CAPACITY if it exceeds cap_rows (call again with a larger buffer). */
 int pmx_get_peaks(pmx_ctx* ctx, int image, double* peaks5, int cap_rows, int* n_rows);
 int pmx_get_connections(pmx_ctx* ctx, int image, double* conns4, int cap_rows, int* n_rows);
 int pmx_get_subsets(pmx_ctx* ctx, int image, double* subsets20, int cap_rows, int* n_rows);

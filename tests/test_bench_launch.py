@@ -1,0 +1,56 @@
+"""bench.py's own multi-rank launcher (`--gpus N` without torch.distributed.run around it).
+
+CPU: it refuses loudly when fewer GPUs than ranks are visible.  GPU (`-m gpu`): two ranks on the one GPU of the box
+(`--backend gloo`, the single-GPU smoke mode) produce `n_gpus: 2` and exactly the records a single rank computes for the
+same global batch (images are sharded contiguously; the gather to rank 0 keeps rank order)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+BENCH = os.path.join(ROOT, 'bench.py')
+
+
+def _run(args, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    return subprocess.run([sys.executable, BENCH] + args, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+
+
+def test_launcher_refuses_without_enough_gpus():
+    import torch
+    if torch.cuda.device_count() >= 4:
+        pytest.skip('4+ GPUs present')
+    r = _run(['--gpus', '4', '--steps', '1', '--warmup', '0'], timeout=300)
+    assert r.returncode != 0
+    assert 'GPU' in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_two_ranks_equal_one_rank(tmp_path):
+    common = ['--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--no-profile', '--no-extras']
+    f2, f1 = str(tmp_path / 'r2.npy'), str(tmp_path / 'r1.npy')
+    r2 = _run(['--gpus', '2', '--backend', 'gloo', '--batch', '4', '--dump-records', f2] + common)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
+    line2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith('{')][-1])
+    assert line2['n_gpus'] == 2 and line2['config']['global_batch'] == 8 and line2['config']['records_gathered'] == 8
+    assert len(line2['per_rank_frames_per_s']) == 2 and line2['gather_ms_per_step_rank0'] >= 0
+    r1 = _run(['--gpus', '1', '--batch', '8', '--dump-records', f1] + common)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-4000:]
+    line1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith('{')][-1])
+    assert line1['n_gpus'] == 1 and line1['config']['global_batch'] == 8
+    a, b = np.load(f2), np.load(f1)
+    assert len(a) == len(b) == 8
+    assert np.array_equal(a['n_people'], b['n_people']) and np.array_equal(a['n_peaks'], b['n_peaks'])
+    assert int(a['n_peaks'].sum()) > 0
+    n = a['n_people']
+    for i in range(8):
+        # batch 4 and batch 8 may pick different conv kernels (split-K at small launches): poses exact, scores to 1e-6
+        assert np.array_equal(a['poses'][i, :n[i]], b['poses'][i, :n[i]])
+        assert np.allclose(a['scores'][i, :n[i]], b['scores'][i, :n[i]], rtol=0, atol=1e-6)

@@ -39,16 +39,20 @@ def _worker(rank, world, port, n_items, q):
     d = importlib.import_module(PKG + '.dist')
     native = importlib.import_module(PKG + '.native')
     lo, hi = d.shard_range(n_items, rank, world)
-    rec = np.zeros(hi - lo, dtype=native.RESULT_DTYPE)
+    # rank 1's context has grown its person capacity (crowd image): the root re-packs everything at the largest capacity
+    rec = np.zeros(hi - lo, dtype=native.result_dtype(64 if rank == 0 else 256))
     for i in range(lo, hi):     # deterministic fake "results" keyed by the global image index
         rec[i - lo]['n_people'] = i % 5
         rec[i - lo]['n_peaks'] = 10 * i
         rec[i - lo]['scores'][:3] = [i, i + 0.5, -i]
         rec[i - lo]['poses'][0, 0] = [i, 2 * i, 2]
-    allrec = d.gather_records(rec)
-    ok = len(allrec) == n_items and all(
-        allrec[i]['n_peaks'] == 10 * i and allrec[i]['poses'][0, 0, 1] == 2 * i and allrec[i]['scores'][2] == -i
-        for i in range(n_items))
+    allrec = d.gather_records(rec, dst=0)
+    if rank == 0:
+        ok = len(allrec) == n_items and allrec.dtype == native.result_dtype(256) and all(
+            allrec[i]['n_peaks'] == 10 * i and allrec[i]['poses'][0, 0, 1] == 2 * i and allrec[i]['scores'][2] == -i
+            for i in range(n_items))
+    else:
+        ok = allrec is None          # a root gather: only rank 0 holds the result
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

@@ -30,7 +30,7 @@ paf, heat = eng.get_maps()
 w = W.calibrate_head(W.synthetic_weights(0), paf[0], heat[0])
 eng.set_weights({k: w[k] for k in ("Mconv7_stage6_L1", "Mconv7_stage6_L2")})
 eng.detect_batch(imgs, 96, 128)
-gathered = D.gather_device_records(eng, B, native.RESULT_DTYPE)
+gathered = D.gather_device_records(eng, B, dst=0)
 local = eng.results()
 assert gathered.shape == local.shape, (gathered.shape, local.shape)
 assert gathered.tobytes() == local.tobytes()

@@ -60,7 +60,9 @@ def test_state_errors(native, small):
 def test_null_arguments_do_not_crash(native):
     lib = native.load()
     assert lib.pmx_forward_u8(None, None, 1, 64, 64, 0) != 0
-    assert lib.pmx_get_results(None, 1, None) != 0
+    assert lib.pmx_get_results(None, 1, None, 0) != 0
+    assert lib.pmx_results_layout(None, None, None) != 0
+    assert lib.pmx_set_capacities(None, 0, 0, 0, 0) != 0
     assert lib.pmx_create(None, 0, 1, 64, 64) != 0
     assert lib.pmx_create_net(None, b'posenet', 0, 1, 64, 64) != 0
     lib.pmx_destroy(None)                                                # no-op

@@ -28,9 +28,9 @@ def test_c_constants_match_python_constants():
         return re.search(r'#define\s+%s\s+([^\s/]+)' % name, txt).group(1)
     assert int(define(hdr, 'PMX_N_JOINTS')) == len(ent.JointType) == native.N_JOINTS
     assert int(define(hdr, 'PMX_N_LIMBS')) == len(ent.params['limbs_point']) == native.N_LIMBS
-    assert int(define(hdr, 'PMX_MAX_PEAKS_PER_JOINT')) == native.MAX_PEAKS_PER_JOINT
-    assert int(define(hdr, 'PMX_MAX_SUBSETS')) == native.MAX_SUBSETS
-    assert int(define(hdr, 'PMX_MAX_PEOPLE')) == native.MAX_PEOPLE
+    assert int(define(hdr, 'PMX_INIT_PEAKS_PER_JOINT')) == native.INIT_PEAKS_PER_JOINT
+    assert int(define(hdr, 'PMX_INIT_SUBSETS')) == native.INIT_SUBSETS
+    assert int(define(hdr, 'PMX_INIT_PEOPLE')) == native.INIT_PEOPLE
     assert float(define(common, 'PMX_HEATMAP_PEAK_THRESH').rstrip('f')) == ent.params['heatmap_peak_thresh']
     assert int(define(common, 'PMX_N_INTEG_POINTS')) == ent.params['n_integ_points']
     assert int(define(common, 'PMX_N_INTEG_POINTS_THRESH')) == ent.params['n_integ_points_thresh']
@@ -104,6 +104,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol(native):
     assert set(syms) == set(lib._pmx_sig), set(syms) ^ set(lib._pmx_sig)
     assert b'gfx950' in lib.pmx_version()
     assert native.RESULT_DTYPE.itemsize == 16 + 8 * 64 * (1 + 18 * 3)
+    assert native.result_dtype(200).itemsize == 16 + 8 * 200 * (1 + 18 * 3)       # PMX_RECORD_BYTES(people_cap)
 
 
 def test_product_never_imports_oracle():
