@@ -341,14 +341,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v5_kernel(const ConvArgs a)
     const int li = lane & 31;
     const int kh = lane >> 5;
 
-    const bool g1 = blockIdx.z != 0;
+    // blockIdx.z = group * ksplit + K slice (ksplit == 1: the group index)
+    const int zgrp = a.ksplit > 1 ? (int)blockIdx.z / a.ksplit : (int)blockIdx.z;
+    const int kslice = (int)blockIdx.z - zgrp * a.ksplit;
+    const bool g1 = zgrp != 0;
     ConvGroupArgs G;
     G.in = g1 ? a.g[1].in : a.g[0].in;
     G.w = g1 ? a.g[1].w : a.g[0].w;
     G.bias = g1 ? a.g[1].bias : a.g[0].bias;
-    G.out = g1 ? a.g[1].out : a.g[0].out;
+    G.out = (g1 ? a.g[1].out : a.g[0].out) + (size_t)kslice * a.slab_stride;
     G.cout = g1 ? a.g[1].cout : a.g[0].cout;
     const int H = a.H, W = a.W;
+    const int c0 = a.ksplit > 1 ? kslice * a.nch / a.ksplit : 0;               // this slice's chunk range [c0, c1)
+    const int c1 = a.ksplit > 1 ? (kslice + 1) * a.nch / a.ksplit : a.nch;
 
     int tile;
     {
@@ -362,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v5_kernel(const ConvArgs a)
     const int y0 = (trem / a.tiles_x) * TH;
     const int x0 = (trem % a.tiles_x) * TW;
     const int n0 = blockIdx.y * BN;
-    const float* in_b = G.in + (size_t)bimg * H * W * a.lda;
+    const float* in_b = G.in + (size_t)bimg * H * W * a.lda + c0 * CK;
     float biasv[C::NT];
     conv_load_bias<C>(biasv, G.bias, n0, wn, li);
 
@@ -408,10 +413,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v5_kernel(const ConvArgs a)
             for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
 
     f32x4 bA[C::NT][2], bB[C::NT][2];      // ping-pong weight fragment sets
+    const unsigned first_b = (unsigned)((size_t)c0 * w_panel_stride * 4);      // tap 0 of the slice's first chunk
 #pragma unroll
     for (int u = 0; u < C::NT; ++u) {
-        bA[u][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[u], 0u, 0));
-        bA[u][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[u] + 32, 0u, 0));
+        bA[u][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[u], first_b, 0));
+        bA[u][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[u] + 32, first_b, 0));
     }
 #pragma unroll
     for (int r = 0; r < NHF; ++r) {
@@ -426,14 +432,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v5_kernel(const ConvArgs a)
         av0[t] = *reinterpret_cast<const f32x4*>(&s_in[a_base[t]]);
     }
 
-    for (int ch = 0; ch < a.nch; ++ch) {
-        const float* cur = s_in + (ch & 1) * C::IN_ELEMS;
-        float* nxt = s_in + ((ch + 1) & 1) * C::IN_ELEMS;
-        const bool more_ch = ch + 1 < a.nch;
+    for (int ch = c0; ch < c1; ++ch) {
+        const float* cur = s_in + ((ch - c0) & 1) * C::IN_ELEMS;
+        float* nxt = s_in + ((ch - c0 + 1) & 1) * C::IN_ELEMS;
+        const bool more_ch = ch + 1 < c1;
         float4 hreg[NHF];
         {
-            // next chunk's halo: global -> registers now, registers -> LDS after the last tap
-            const int cn = more_ch ? ch + 1 : ch;
+            // next chunk's halo: global -> registers now, registers -> LDS after the last tap (in_b points at chunk c0)
+            const int cn = (more_ch ? ch + 1 : ch) - c0;
 #pragma unroll
             for (int r = 0; r < NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + cn * CK);
         }
@@ -946,6 +952,40 @@ int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen
     return small ? 7 : (cout <= 64 ? 4 : 3);
 }
 
+static bool is_v5_variant(int v) { return (v >= V5_K7_STRIP && v <= V5_K3_SMALL) || (v >= V5T_K7 && v <= V5T_K3_N64); }
+
+// Split-K for launches that cannot fill the chip (single images): nblk blocks over ncu CUs leave CUs idle or quantise badly
+// (144 blocks of a 7x7 layer at batch 1: 112 CUs idle; 288 blocks of conv4_2: a second round on 32 CUs).  With S K-slices
+// there are nblk * S smaller blocks; a CU works through ceil(nblk * S / ncu) of them (two co-resident share the matrix
+// pipe), each costing its share of the K loop plus a fixed part; the combine kernel costs about one launch boundary plus
+// S slab reads.  Picks the S (a divisor-free range split: slice s = chunks [s*nch/S, (s+1)*nch/S)) with the least
+// estimated time; 1 when the launch already fills the chip twice over.
+int conv_pick_ksplit(int variant, int H, int W, int B, int groups, int cout_pad, int nch, int pool, int forced)
+{
+    if (!is_v5_variant(variant) || nch < 2) return 1;
+    if (forced > 0) return forced < nch ? forced : nch;
+    const ConvVariant& v = g_variants[variant];
+    const long nblk = (long)((H + v.th - 1) / v.th) * ((W + v.tw - 1) / v.tw) * B * (cout_pad / v.bn) * groups;
+    const int ncu = g_num_cus;
+    if (nblk >= 2 * ncu) return 1;
+    // per-wave MFMAs of one chunk in this block shape (32x32x2 MFMA = 64 cycles), microseconds at 2.4 GHz
+    const int mt_nt = ((v.th * v.tw + 31) / 32) * (v.bn / 32) / 4;
+    const double t_chunk = (double)v.ks * v.ks * 8 * mt_nt * 64 / 2400.0;
+    const double t_fixed = 3.0;                         // prologue + epilogue + dispatch of one block, us
+    const double out_mb = (double)H * W * B * cout_pad * groups * 4 / 1e6;
+    double best = 1e30;
+    int best_s = 1;
+    for (int S = 1; S <= 8 && S <= nch; ++S) {
+        const long per_cu = (nblk * S + ncu - 1) / ncu;
+        const int chunks = (nch + S - 1) / S;
+        double t = per_cu * (chunks * t_chunk + t_fixed);
+        if (S > 1) t += 2.5 + (S + 1) * out_mb / 3.0;       // launch boundary + slab reads / output write at ~3 TB/s (L2 / MALL)
+        if (t < best - 1e-9) { best = t; best_s = S; }
+    }
+    (void)pool;
+    return best_s;
+}
+
 template <int KS, int TH, int TW, int BN, int CK, int WM, int WN>
 static int launch_cfg(const ConvArgs& a0, int groups, hipStream_t stream)
 {
@@ -983,8 +1023,62 @@ static int launch_v5(const ConvArgs& a0, int groups, hipStream_t stream)
     if (lds < g_min_lds) lds = g_min_lds;
     static bool attr_set[PMX_MAX_DEVICES] = {};
     if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(kern), attr_set)) return rc;
-    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / BN), (unsigned)groups);
+    if (a.ksplit < 1) a.ksplit = 1;
+    PMX_CHECK(a.ksplit <= a.nch, PMX_ERR_INVALID, "conv: %d K slices for %d chunks", a.ksplit, a.nch);
+    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / BN), (unsigned)(groups * a.ksplit));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+// ---- split-K: combine the partial-sum slabs ------------------------------------------------------------------------------
+// out = [pool2x2]( slab_0 + slab_1 + ... + slab_{S-1} ) + bias, ReLU -- slabs added in slice order (left to right), so the
+// result is a defined function of (ksplit, chunk order): oracle/conv_fma_ref.c reproduces it bit for bit.  One thread per
+// 4 output channels of one output pixel; the kernel boundary in front of it is the release / acquire between the slice
+// blocks (any XCD) and the combiner.
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const SplitKReduceArgs r)
+{
+    const int g = blockIdx.z;
+    const float* slabs = g ? r.slabs[1] : r.slabs[0];
+    const float* bias = g ? r.bias[1] : r.bias[0];
+    float* out = g ? r.out[1] : r.out[0];
+    const int cout = g ? r.cout[1] : r.cout[0];
+    const int c4n = cout >> 2;
+    const int Ho = r.pool ? r.H >> 1 : r.H, Wo = r.pool ? r.W >> 1 : r.W;
+    const long long total = (long long)r.B * Ho * Wo * c4n;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % c4n) * 4;
+    const long long p = i / c4n;                        // output pixel (b, oy, ox)
+    const int ox = (int)(p % Wo);
+    const long long q = p / Wo;
+    const int oy = (int)(q % Ho), b = (int)(q / Ho);
+    float4 best;
+    const int nwin = r.pool ? 4 : 1;
+    for (int wi = 0; wi < nwin; ++wi) {
+        const int y = r.pool ? 2 * oy + (wi >> 1) : oy, x = r.pool ? 2 * ox + (wi & 1) : ox;
+        const float* src = slabs + (((long long)b * r.H + y) * r.W + x) * r.ld_slab + c;
+        float4 acc = *reinterpret_cast<const float4*>(src);
+        for (int s = 1; s < r.ksplit; ++s) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (long long)s * r.slab_stride);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        if (wi == 0) best = acc;
+        else { best.x = fmaxf(best.x, acc.x); best.y = fmaxf(best.y, acc.y); best.z = fmaxf(best.z, acc.z); best.w = fmaxf(best.w, acc.w); }
+    }
+    const float4 bv = *reinterpret_cast<const float4*>(bias + c);
+    best.x += bv.x; best.y += bv.y; best.z += bv.z; best.w += bv.w;
+    if (r.relu) { best.x = fmaxf(best.x, 0.f); best.y = fmaxf(best.y, 0.f); best.z = fmaxf(best.z, 0.f); best.w = fmaxf(best.w, 0.f); }
+    *reinterpret_cast<float4*>(out + p * r.ldc + c) = best;
+}
+
+int conv_splitk_reduce(const SplitKReduceArgs& r, int groups, hipStream_t stream)
+{
+    PMX_CHECK(r.cout[0] % 4 == 0 && (groups < 2 || r.cout[1] == r.cout[0]) && r.ldc % 4 == 0 && r.ld_slab % 4 == 0, PMX_ERR_INVALID,
+              "split-K reduce: channel counts / strides must be multiples of 4");
+    const int Ho = r.pool ? r.H / 2 : r.H, Wo = r.pool ? r.W / 2 : r.W;
+    const long long total = (long long)r.B * Ho * Wo * (r.cout[0] / 4);
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256), 1, (unsigned)groups), dim3(256), 0, stream, r);
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }

@@ -204,6 +204,10 @@ struct pmx_ctx {
     int opt_force[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // by ksize
     int opt_gpu_branch_peaks = 0;    // reference GPU-branch peak extraction (non-golden variant)
     int opt_keep_smoothed = 0, opt_stop_stage = 6, opt_kernel_gen = 6;
+    int opt_ksplit = 0;              // 0: automatic split-K for small launches; n > 0: force n K slices where split-K applies
+    // split-K scratch: partial-sum slabs of the current launch + a zero bias vector for the slice blocks
+    float* sk_scratch = nullptr; size_t sk_floats = 0;
+    float* sk_zero_bias = nullptr;
     // timing / profiling
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool prof_on = false;
@@ -412,7 +416,7 @@ extern "C" void pmx_destroy(pmx_ctx* c)
     (void)hipDeviceSynchronize();
     for (auto& l : c->layers) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); }
     pp_free(c);
-    void* ptrs[] = {c->pr_tmp, c->pr_tab, c->d_kp, c->u8_src, c->rs_tab, c->in16, c->act0, c->act1, c->cat, c->brA, c->brB, c->brT, c->nchw_tmp, c->u8_tmp, c->ext_paf, c->ext_heat,
+    void* ptrs[] = {c->sk_scratch, c->sk_zero_bias, c->pr_tmp, c->pr_tab, c->d_kp, c->u8_src, c->rs_tab, c->in16, c->act0, c->act1, c->cat, c->brA, c->brB, c->brT, c->nchw_tmp, c->u8_tmp, c->ext_paf, c->ext_heat,
                     c->pp.smoothed, c->d_scale, c->tab.xi0, c->tab.xi1, c->tab.xlo, c->tab.xhi, c->tab.yi0, c->tab.yi1,
                     c->tab.ylo, c->tab.yhi, c->tab.gauss};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -451,6 +455,7 @@ extern "C" int pmx_set_option(pmx_ctx* c, const char* key, int value)
     else if (!strcmp(key, "keep_smoothed")) c->opt_keep_smoothed = value;
     else if (!strcmp(key, "stop_stage")) c->opt_stop_stage = value;
     else if (!strcmp(key, "kernel_gen")) c->opt_kernel_gen = value;
+    else if (!strcmp(key, "ksplit")) c->opt_ksplit = value;
     else if (!strcmp(key, "conv_min_lds")) conv_set_min_lds(value);
     else if (!strcmp(key, "pp_generic")) pp_set_generic(value);
     else if (!strcmp(key, "peaks_gpu_branch")) { c->opt_gpu_branch_peaks = value; c->tab_in_h = -1; }
@@ -496,6 +501,47 @@ extern "C" int pmx_weights_missing(pmx_ctx* c, int* n)
 // ------------------------------------------------------------------------------------------ forward
 struct ConvIO { const float* in; int lda; float* out; int ldc; };
 
+// Launches one convolution (1 or 2 groups) whose ConvArgs describe the FINAL result (real bias, ReLU, pool, output slices).
+// With S > 1 K slices the slice blocks write raw partial sums into the context's slab scratch and conv_splitk_reduce
+// produces the final result (slabs added in slice order, then bias, ReLU, pool).
+static const int SK_ZERO_BIAS = 1024;
+static int launch_conv(pmx_ctx* c, const ConvArgs& a0, int groups, int v, int S)
+{
+    if (S <= 1) {
+        ConvArgs a = a0;
+        a.ksplit = 1; a.slab_stride = 0;
+        return conv_launch(v, a, groups, c->stream);
+    }
+    PMX_CHECK(a0.cout_pad <= SK_ZERO_BIAS, PMX_ERR_INVALID, "split-K: cout_pad %d too large", a0.cout_pad);
+    const size_t slab = (size_t)a0.B * a0.H * a0.W * a0.cout_pad;
+    const size_t need = slab * S * groups;
+    if (need > c->sk_floats) {
+        PMX_HIP(hipStreamSynchronize(c->stream));
+        if (c->sk_scratch) (void)hipFree(c->sk_scratch);
+        c->sk_scratch = nullptr; c->sk_floats = 0;
+        PMX_HIP(hipMalloc((void**)&c->sk_scratch, need * sizeof(float)));
+        c->sk_floats = need;
+    }
+    if (!c->sk_zero_bias) {
+        PMX_HIP(hipMalloc((void**)&c->sk_zero_bias, SK_ZERO_BIAS * sizeof(float)));
+        PMX_HIP(hipMemset(c->sk_zero_bias, 0, SK_ZERO_BIAS * sizeof(float)));
+    }
+    ConvArgs a = a0;
+    SplitKReduceArgs r;
+    memset(&r, 0, sizeof r);
+    for (int g = 0; g < groups; ++g) {
+        float* base = c->sk_scratch + (size_t)g * S * slab;
+        r.slabs[g] = base; r.bias[g] = a0.g[g].bias; r.out[g] = a0.g[g].out; r.cout[g] = a0.g[g].cout;
+        a.g[g].out = base; a.g[g].bias = c->sk_zero_bias; a.g[g].cout = a0.cout_pad;
+    }
+    a.ldc = a0.cout_pad; a.relu = 0; a.pool = 0; a.ksplit = S; a.slab_stride = (long long)slab;
+    r.slab_stride = (long long)slab; r.ksplit = S; r.B = a0.B; r.H = a0.H; r.W = a0.W; r.ld_slab = a0.cout_pad; r.ldc = a0.ldc;
+    r.relu = a0.relu; r.pool = a0.pool;
+    int rc = conv_launch(v, a, groups, c->stream);
+    if (rc) return rc;
+    return conv_splitk_reduce(r, groups, c->stream);
+}
+
 // one launch of 1 or 2 groups (same geometry); in/out pointers are already offset to the group's channels
 static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float* in0, const float* in1, int lda,
                     float* out0, float* out1, int ldc, int B, int H, int W, int relu, int pool)
@@ -514,12 +560,16 @@ static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float
     a.B = B; a.H = H; a.W = W; a.lda = lda; a.ldc = ldc; a.nch = L0.nch; a.cout_pad = L0.cout_pad;
     a.relu = relu; a.pool = pool;
     const int v = conv_pick_variant(L0.ks, L0.cout_pad, H, W, B * groups, c->opt_force[L0.ks], c->opt_kernel_gen, pool, groups == 1 ? L0.cin : 9999);
+    int S = conv_pick_ksplit(v, H, W, B, groups, L0.cout_pad, L0.nch, pool, c->opt_ksplit);
+    if (L0.cout % 4 != 0 || ldc % 4 != 0 || (groups == 2 && c->layers[li1].cout != L0.cout)) S = 1;
     int rc;
     if (c->prof_on) {
         const double bytes = 4.0 * B * H * W * ((double)L0.cin * groups + (double)L0.cout * groups / (pool ? 4 : 1));
-        if ((rc = prof_begin(c, std::string(label) + "|" + conv_variant(v).name, flops, bytes))) return rc;
+        std::string kn = conv_variant(v).name;
+        if (S > 1) kn += "/k" + std::to_string(S);        // K slices (+ the combine kernel) are part of the launch's time
+        if ((rc = prof_begin(c, std::string(label) + "|" + kn, flops, bytes))) return rc;
     }
-    if ((rc = conv_launch(v, a, groups, c->stream))) return rc;
+    if ((rc = launch_conv(c, a, groups, v, S))) return rc;
     return prof_end(c);
 }
 
@@ -1468,12 +1518,14 @@ extern "C" int pmx_conv2d(pmx_ctx* c, const float* x, const float* w, const floa
     a.g[0].in = d_xn; a.g[0].w = d_w; a.g[0].bias = d_b; a.g[0].out = d_yn; a.g[0].cout = cout;
     a.B = B; a.H = H; a.W = W; a.lda = cin_pad; a.ldc = cout; a.nch = cin_pad / CK; a.cout_pad = cpad; a.relu = relu; a.pool = pool;
     const int v = conv_pick_variant(ks, cpad, H, W, B, c->opt_force[ks], c->opt_kernel_gen, pool, cin);
-    if (!rc) rc = conv_launch(v, a, 1, c->stream);
+    int S = conv_pick_ksplit(v, H, W, B, 1, cpad, cin_pad / CK, pool, c->opt_ksplit);
+    if (cout % 4 != 0) S = 1;
+    if (!rc) rc = launch_conv(c, a, 1, v, S);
     if (!rc && iters > 0) {
         hipEvent_t e0, e1;
         PMX_HIP(hipEventCreate(&e0)); PMX_HIP(hipEventCreate(&e1));
         PMX_HIP(hipEventRecord(e0, c->stream));
-        for (int i = 0; i < iters && !rc; ++i) rc = conv_launch(v, a, 1, c->stream);
+        for (int i = 0; i < iters && !rc; ++i) rc = launch_conv(c, a, 1, v, S);
         PMX_HIP(hipEventRecord(e1, c->stream));
         PMX_HIP(hipEventSynchronize(e1));
         float ms = 0.f;

@@ -69,7 +69,24 @@ struct ConvArgs {
     int cout_pad;       // multiple of the kernel's BN
     int tiles_x, tiles_y;
     int relu, pool;
+    // split-K (v5 kernels, small launches): blockIdx.z = group * ksplit + slice; slice s accumulates the 16-channel chunks
+    // [s * nch / ksplit, (s + 1) * nch / ksplit) and stores its raw partial sums (the host passes zero bias, relu = pool = 0)
+    // to g[].out + s * slab_stride; conv_splitk_reduce then adds the slabs in slice order, the bias, ReLU and the pool
+    int ksplit;              // >= 1
+    int pad2_;
+    long long slab_stride;   // floats between the partial-sum slabs of one group (0 when ksplit == 1)
 };
+struct SplitKReduceArgs {
+    const float* slabs[2];   // per group: ksplit slabs of B x H x W x ld_slab floats
+    const float* bias[2];
+    float* out[2];           // NHWC, channel stride ldc, already offset to the group's first output channel
+    int cout[2];
+    long long slab_stride;
+    int ksplit, B, H, W, ld_slab, ldc, relu, pool;
+};
+int conv_splitk_reduce(const SplitKReduceArgs& r, int groups, hipStream_t stream);
+// number of K slices for a launch of `variant` (1 = no split); forced > 0 overrides the heuristic
+int conv_pick_ksplit(int variant, int H, int W, int B, int groups, int cout_pad, int nch, int pool, int forced);
 
 struct ConvVariant {
     int ks, th, tw, bn, ck;

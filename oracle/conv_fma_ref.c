@@ -7,6 +7,8 @@
  * generation walks K as
  *     for 16-channel chunk: for tap (ky, kx) row-major: for half (channels +0..7, +8..15): for e in 0..3: k = e, then e + 4
  * so this plain-C loop reproduces their outputs bit for bit.  Bias is added after the chain; ReLU / 2x2 max-pool follow.
+ * Split-K (small launches, csrc/conv_mfma.hip::conv_pick_ksplit): with `splitk` = S > 1 slice s runs its own chain (from 0)
+ * over the chunks [s * nch / S, (s + 1) * nch / S) and the slices are added left to right (conv_splitk_reduce_kernel).
  * Compile with -ffp-contract=off (the fmaf calls are explicit); -mfma makes fmaf one instruction, -fopenmp spreads the
  * independent outputs over the host cores. */
 #include <math.h>
@@ -14,8 +16,9 @@
 
 /* x: [B][cin][H][W], w: [cout][cin][ks][ks], bias: [cout], y: [B][cout][Ho][Wo] (Ho = H or H/2), zero padding ks/2 */
 void conv_fma_ref(const float* x, const float* w, const float* bias, float* y, int B, int cin, int H, int W, int cout, int ks,
-                  int relu, int pool)
+                  int relu, int pool, int splitk)
 {
+    if (splitk < 1) splitk = 1;
     const int pad = ks / 2, nch = (cin + 15) / 16;
     const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
 #pragma omp parallel for collapse(2) schedule(static)
@@ -27,8 +30,10 @@ void conv_fma_ref(const float* x, const float* w, const float* bias, float* y, i
                     const int nwin = pool ? 4 : 1;
                     for (int wi = 0; wi < nwin; ++wi) {
                         const int py = pool ? 2 * oy + (wi >> 1) : oy, px = pool ? 2 * ox + (wi & 1) : ox;
+                        float total = 0.f;
+                        for (int sl = 0; sl < splitk; ++sl) {
                         float acc = 0.f;
-                        for (int c16 = 0; c16 < nch; ++c16)
+                        for (int c16 = sl * nch / splitk; c16 < (sl + 1) * nch / splitk; ++c16)
                             for (int ky = 0; ky < ks; ++ky)
                                 for (int kx = 0; kx < ks; ++kx) {
                                     const int iy = py + ky - pad, ix = px + kx - pad;
@@ -42,6 +47,9 @@ void conv_fma_ref(const float* x, const float* w, const float* bias, float* y, i
                                                 acc = fmaf(xv, w[(((size_t)n * cin + c) * ks + ky) * ks + kx], acc);
                                             }
                                 }
+                        total = sl == 0 ? acc : total + acc;
+                        }
+                        const float acc = total;
                         if (wi == 0 || acc > best) best = acc;
                     }
                     float v = best + bias[n];

@@ -24,20 +24,21 @@ def build(force=False):
 _lib = None
 
 
-def conv_fma(x, w, b, relu=False, pool=False):
-    """x (B, cin, H, W), w (cout, cin, k, k), b (cout,) float32 -> y float32, in the HIP kernels' summation order."""
+def conv_fma(x, w, b, relu=False, pool=False, splitk=1):
+    """x (B, cin, H, W), w (cout, cin, k, k), b (cout,) float32 -> y float32, in the HIP kernels' summation order
+    (`splitk` K slices over the 16-channel chunks, added left to right: what the kernels do for small launches)."""
     global _lib
     if _lib is None:
         _lib = C.CDLL(build())
         _lib.conv_fma_ref.restype = None
-        _lib.conv_fma_ref.argtypes = [C.c_void_p] * 4 + [C.c_int] * 8
+        _lib.conv_fma_ref.argtypes = [C.c_void_p] * 4 + [C.c_int] * 9
     x = np.ascontiguousarray(x, np.float32)
     w = np.ascontiguousarray(w, np.float32)
     b = np.ascontiguousarray(b, np.float32)
     B, cin, H, W = x.shape
     cout, _, ks, _ = w.shape
     y = np.empty((B, cout, H // 2 if pool else H, W // 2 if pool else W), np.float32)
-    _lib.conv_fma_ref(x.ctypes.data, w.ctypes.data, b.ctypes.data, y.ctypes.data, B, cin, H, W, cout, ks, int(relu), int(pool))
+    _lib.conv_fma_ref(x.ctypes.data, w.ctypes.data, b.ctypes.data, y.ctypes.data, B, cin, H, W, cout, ks, int(relu), int(pool), int(splitk))
     return y
 
 
@@ -56,12 +57,28 @@ def _cat_weights(W):
     return Wp
 
 
-def forward_fma(weights, x):
+def splitk_plan(profile):
+    """{layer label: K slices} from an engine profile of the SAME forward (native.Engine.profile(); the kernel label carries
+    "/k<S>" where the launch was split).  Labels are the layer names without the _L1 / _L2 branch suffix."""
+    plan = {}
+    for e in profile:
+        k = e['kernel']
+        if '/k' in k:
+            plan[e['layer']] = int(k.rsplit('/k', 1)[1])
+    return plan
+
+
+def forward_fma(weights, x, splitk=None):
     """CocoPoseNet forward (models/CocoPoseNet.py:132-262) with every convolution in the HIP kernels' summation order.
-    x: (B, 3, H, W) float32 as produced by preprocess; returns (paf (B,38,h,w), heat (B,19,h,w)) of the last stage."""
+    x: (B, 3, H, W) float32 as produced by preprocess; returns (paf (B,38,h,w), heat (B,19,h,w)) of the last stage.
+    splitk: {layer label: K slices} of the launch plan the kernels used (splitk_plan); None = no launch was split (large
+    batches)."""
+    splitk = splitk or {}
+
     def conv(name, h, relu=True, pool=False, cat=False):
         W, b = weights[name]
-        return conv_fma(h, _cat_weights(W) if cat else W, b, relu=relu, pool=pool)
+        label = name[:-3] if name.endswith(('_L1', '_L2')) else name
+        return conv_fma(h, _cat_weights(W) if cat else W, b, relu=relu, pool=pool, splitk=splitk.get(label, 1))
     h = conv('conv1_1', x); h = conv('conv1_2', h, pool=True)
     h = conv('conv2_1', h); h = conv('conv2_2', h, pool=True)
     h = conv('conv3_1', h); h = conv('conv3_2', h); h = conv('conv3_3', h); h = conv('conv3_4', h, pool=True)

@@ -54,3 +54,19 @@ def engine(native):
     e = native.Engine(0, max_batch=4, max_h=368, max_w=368)
     yield e
     e.close()
+
+
+def forward_plan(engine, run):
+    """Run `run()` (one forward through `engine`) with the per-launch profiler on and return the split-K plan the kernels used
+    ({layer label: K slices}, oracle/conv_fma_ref.py::splitk_plan) -- what the order-defined oracle needs to reproduce a
+    small-launch forward bit for bit."""
+    from oracle import conv_fma_ref
+    engine.profile_reset()
+    engine.profile_enable(True)
+    try:
+        out = run()
+        plan = conv_fma_ref.splitk_plan(engine.profile())
+    finally:
+        engine.profile_enable(False)
+        engine.profile_reset()
+    return plan, out

@@ -51,6 +51,6 @@ def test_two_ranks_equal_one_rank(tmp_path):
     assert int(a['n_peaks'].sum()) > 0
     n = a['n_people']
     for i in range(8):
-        # batch 4 and batch 8 may pick different conv kernels (split-K at small launches): poses exact, scores to 1e-6
+        # batch 4 and batch 8 may pick different conv kernels (split-K at small launches): poses exact, scores to 1e-5
         assert np.array_equal(a['poses'][i, :n[i]], b['poses'][i, :n[i]])
-        assert np.allclose(a['scores'][i, :n[i]], b['scores'][i, :n[i]], rtol=0, atol=1e-6)
+        assert np.allclose(a['scores'][i, :n[i]], b['scores'][i, :n[i]], rtol=0, atol=1e-5)

@@ -116,6 +116,7 @@ def test_cpm_nets_batch64_kernel_generations_identical(native, arch):
         eng.profile_enable(False)
         assert any('_v6' in k for k in names) == (gen == 6), names
     assert np.array_equal(outs[5], outs[6])
+    eng.set_option('ksplit', 1)          # unsplit single-image kernels: same K order as the batch kernels
     eng.forward_u8(imgs[7:8])
     assert np.array_equal(eng.get_maps()[0], outs[6][7])
     eng.close()

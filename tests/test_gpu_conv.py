@@ -29,8 +29,9 @@ def _case(engine, B, cin, H, W, cout, k, relu, pool, seed, variant=None):
     assert err <= TOL * max(1.0, np.abs(ref).max()), (err, np.abs(ref).max())
 
 
-def _exact_case(engine, B, cin, H, W, cout, k, relu, pool, seed, variant=None):
-    """GPU conv == oracle/conv_fma_ref.c bit for bit (same K order, sequential fused multiply-add chain)."""
+def _exact_case(engine, B, cin, H, W, cout, k, relu, pool, seed, variant=None, ksplit=1):
+    """GPU conv == oracle/conv_fma_ref.c bit for bit (same K order, sequential fused multiply-add chain; `ksplit` K slices
+    combined left to right on both sides)."""
     from oracle import conv_fma_ref as R
     rng = np.random.default_rng(seed)
     x = rng.standard_normal((B, cin, H, W)).astype('f')
@@ -40,11 +41,16 @@ def _exact_case(engine, B, cin, H, W, cout, k, relu, pool, seed, variant=None):
         engine.set_option('force_variant_k%d' % kk, -1)
     if variant is not None:
         engine.set_option('force_variant_k%d' % k, variant)
+    engine.set_option('ksplit', ksplit)
     y = engine.conv2d(x, w, b, relu=relu, pool=pool)
+    engine.set_option('ksplit', 0)
     engine.set_option('force_variant_k%d' % k, -1)
-    ref = R.conv_fma(x, w, b, relu=relu, pool=pool)
+    ref = R.conv_fma(x, w, b, relu=relu, pool=pool, splitk=ksplit)
     assert y.shape == ref.shape
     assert np.array_equal(y, ref), (np.abs(y - ref).max(), int((y != ref).sum()))
+    if ksplit > 1:      # and the split result is the same convolution (vs torch, tolerance)
+        t = N.conv2d_ref(x, w, b, relu=relu, pool=pool)
+        assert np.abs(y - t).max() <= TOL * max(1.0, np.abs(t).max())
 
 
 @pytest.mark.parametrize('variant,k,cin,h,w,cout,pool', [
@@ -56,6 +62,17 @@ def _exact_case(engine, B, cin, H, W, cout, k, relu, pool, seed, variant=None):
     (20, 3, 3, 20, 24, 64, False)])                                                                    # conv1_1
 def test_conv_bit_exact_vs_order_defined_c_oracle(engine, variant, k, cin, h, w, cout, pool):
     _exact_case(engine, 2, cin, h, w, cout, k, True, pool, seed=700 + k + cin, variant=variant)
+
+
+@pytest.mark.parametrize('variant,k,cin,h,w,cout,pool,S', [
+    (15, 7, 128, 46, 46, 128, False, 4), (15, 7, 128, 20, 23, 128, False, 8), (15, 7, 185, 16, 16, 64, False, 5),   # 12 chunks in 5 slices
+    (16, 3, 512, 23, 23, 256, False, 4), (16, 3, 256, 24, 40, 128, True, 2), (13, 3, 100, 24, 32, 128, True, 3),
+    (12, 7, 48, 16, 32, 128, False, 3), (14, 3, 64, 16, 32, 64, False, 4), (10, 7, 64, 6, 46, 128, False, 2)])
+def test_split_k_bit_exact_vs_order_defined_c_oracle(engine, variant, k, cin, h, w, cout, pool, S):
+    """Split-K of the v5 kernels (single-image launches): S slices over the 16-channel chunks, slabs combined left to right,
+    then bias / ReLU / pool -- bit-identical to the plain-C oracle with the same S, for even and uneven chunk splits.
+    (The automatic choice is covered at network level: the launch plan is read from the profile labels.)"""
+    _exact_case(engine, 1, cin, h, w, cout, k, True, pool, seed=900 + k + cin + S, variant=variant, ksplit=S)
 
 
 # variant indices: see conv_mfma.hip g_variants
@@ -131,11 +148,13 @@ def test_kernel_generations_compute_identical_bits(engine):
     engine.set_weights(w)
     img = np.random.default_rng(5).integers(0, 256, (2, 184, 184, 3), dtype=np.uint8)
     maps = {}
+    engine.set_option('ksplit', 1)          # (split-K changes the summation tree of small launches: compared separately)
     for gen in (1, 5, 6):
         engine.set_option('kernel_gen', gen)
         engine.forward_u8(img)
         maps[gen] = engine.get_maps()
     engine.set_option('kernel_gen', 6)      # library default (v6 only engages on maps a multiple of 46 wide: see below)
+    engine.set_option('ksplit', 0)
     for gen in (5, 6):
         assert np.array_equal(maps[1][0], maps[gen][0]) and np.array_equal(maps[1][1], maps[gen][1])
 
@@ -160,9 +179,15 @@ def test_v6_network_equals_v5_network_bitwise(engine):
     eng.profile_enable(False)
     assert any('_v6_' in k for k in names), names
     assert np.array_equal(p5, p6) and np.array_equal(h5, h6)
+    eng.set_option('ksplit', 1)             # unsplit small tiles: the same K order as the batch kernels
     eng.forward_u8(img[5:6])
     p1, h1 = eng.get_maps()
     assert np.array_equal(p1[0], p6[5]) and np.array_equal(h1[0], h6[5])
+    eng.set_option('ksplit', 0)             # default: split-K for the single image -- same maps to summation-order noise
+    eng.forward_u8(img[5:6])
+    q1, g1 = eng.get_maps()
+    assert np.abs(q1[0] - p6[5]).max() <= 2e-5 * max(1.0, np.abs(p6[5]).max())
+    assert np.abs(g1[0] - h6[5]).max() <= 2e-5 * max(1.0, np.abs(h6[5]).max())
     eng.close()
 
 

@@ -3,7 +3,7 @@ PoseDetector on top of it."""
 import numpy as np
 import pytest
 
-from conftest import pkg
+from conftest import forward_plan, pkg
 from oracle import network_ref as N
 from oracle import postprocess_ref as P
 
@@ -42,10 +42,10 @@ def test_network_bit_exact_vs_order_defined_oracle(engine, weights, shape):
     engine.set_weights(weights)
     rng = np.random.default_rng(sum(shape))
     imgs = rng.integers(0, 256, shape + (3,), dtype=np.uint8)
-    engine.forward_u8(imgs)
+    plan, _ = forward_plan(engine, lambda: engine.forward_u8(imgs))      # small launches are split over K: same plan on both sides
     paf, heat = engine.get_maps()
     x = np.concatenate([P.preprocess(im) for im in imgs])
-    rpaf, rheat = R.forward_fma(weights, x)
+    rpaf, rheat = R.forward_fma(weights, x, splitk=plan)
     assert np.array_equal(paf, rpaf), np.abs(paf - rpaf).max()
     assert np.array_equal(heat, rheat), np.abs(heat - rheat).max()
 
@@ -65,10 +65,11 @@ def test_end_to_end_identical_to_order_defined_oracle(native, weights, monkeypat
     in_w, in_h = det.compute_optimal_size(img, 64)
     map_w, map_h = det.compute_optimal_size(img, 56)
     small = resize_ref.resize_linear_u8(img, in_w, in_h)
-    paf, heat = R.forward_fma(weights, P.preprocess(small))
+    plan, _ = forward_plan(det.engine, lambda: det.engine.forward_u8(small[None]))      # the launch plan depends on shapes only
+    paf, heat = R.forward_fma(weights, P.preprocess(small), splitk=plan)
     w2 = W.calibrate_head(weights, paf[0], heat[0])              # a head that produces people on this image
     det.engine.set_weights({k: w2[k] for k in ('Mconv7_stage6_L1', 'Mconv7_stage6_L2')})
-    paf, heat = R.forward_fma(w2, P.preprocess(small))
+    paf, heat = R.forward_fma(w2, P.preprocess(small), splitk=plan)
     ref = P.postprocess_from_net_output(paf[0], heat[0], map_h, map_w, orig_w=img.shape[1], orig_h=img.shape[0])
     poses, scores = det(img)
     assert len(ref['all_peaks']) > 0
