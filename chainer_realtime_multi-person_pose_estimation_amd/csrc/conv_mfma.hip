@@ -31,6 +31,9 @@
 //                    run as the two groups of one launch).
 #include "pmx_common.h"
 
+#include <map>
+#include <string.h>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int KS, int TH, int TW, int BN, int CK, int WM, int WN>
@@ -341,9 +344,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v5_kernel(const ConvArgs a)
     const int li = lane & 31;
     const int kh = lane >> 5;
 
-    // blockIdx.z = group * ksplit + K slice (ksplit == 1: the group index)
-    const int zgrp = a.ksplit > 1 ? (int)blockIdx.z / a.ksplit : (int)blockIdx.z;
-    const int kslice = (int)blockIdx.z - zgrp * a.ksplit;
+    // blockIdx.z = K slice * ngroups + group (ksplit == 1: the group index)
+    const int kslice = a.ksplit > 1 ? (a.ngroups > 1 ? (int)blockIdx.z >> 1 : (int)blockIdx.z) : 0;
+    const int zgrp = a.ksplit > 1 ? (a.ngroups > 1 ? (int)blockIdx.z & 1 : 0) : (int)blockIdx.z;
     const bool g1 = zgrp != 0;
     ConvGroupArgs G;
     G.in = g1 ? a.g[1].in : a.g[0].in;
@@ -352,8 +355,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v5_kernel(const ConvArgs a)
     G.out = (g1 ? a.g[1].out : a.g[0].out) + (size_t)kslice * a.slab_stride;
     G.cout = g1 ? a.g[1].cout : a.g[0].cout;
     const int H = a.H, W = a.W;
-    const int c0 = a.ksplit > 1 ? kslice * a.nch / a.ksplit : 0;               // this slice's chunk range [c0, c1)
-    const int c1 = a.ksplit > 1 ? (kslice + 1) * a.nch / a.ksplit : a.nch;
+    // this slice's chunk range [c0, c1): packed boundaries (a dynamic index into a kernarg array would go through scratch)
+    const int c0 = a.ksplit > 1 ? (int)((a.kbounds >> (8 * kslice)) & 0xffull) : 0;
+    const int c1 = (a.ksplit > 1 && kslice + 1 < a.ksplit) ? (int)((a.kbounds >> (8 * (kslice + 1))) & 0xffull) : a.nch;
 
     int tile;
     {
@@ -956,34 +960,150 @@ static bool is_v5_variant(int v) { return (v >= V5_K7_STRIP && v <= V5_K3_SMALL)
 
 // Split-K for launches that cannot fill the chip (single images): nblk blocks over ncu CUs leave CUs idle or quantise badly
 // (144 blocks of a 7x7 layer at batch 1: 112 CUs idle; 288 blocks of conv4_2: a second round on 32 CUs).  With S K-slices
-// there are nblk * S smaller blocks; a CU works through ceil(nblk * S / ncu) of them (two co-resident share the matrix
-// pipe), each costing its share of the K loop plus a fixed part; the combine kernel costs about one launch boundary plus
-// S slab reads.  Picks the S (a divisor-free range split: slice s = chunks [s*nch/S, (s+1)*nch/S)) with the least
-// estimated time; 1 when the launch already fills the chip twice over.
-int conv_pick_ksplit(int variant, int H, int W, int B, int groups, int cout_pad, int nch, int pool, int forced)
+// there are nblk * S smaller blocks.  Which split is best depends on how the blocks land on the CUs, so the candidates are
+// SIMULATED: blocks are dispatched in grid order (all blocks of slice 0, then slice 1, ...: z is the slowest grid dimension),
+// two resident per CU (the LDS floor of the v5 kernels), round-robin at launch and then to whichever CU frees a slot; two
+// co-resident blocks share the matrix pipe.  Uneven slices, largest first, let the late small blocks fill the gaps (7x7 at
+// batch 1: slices of 3 + 2 + 2 + 1 chunks finish in 5 chunk times where 2 + 3 + 3 or 2 + 2 + 2 + 2 need 6).  The combine
+// kernel costs about one launch boundary plus S slab reads.  The schedule is a speed guess only -- any split computes the
+// same defined sum (slices added left to right).
+static double sk_simulate(const int* sizes, int S, long nblk, int ncu, double t_chunk, double t_fixed)
 {
-    if (!is_v5_variant(variant) || nch < 2) return 1;
-    if (forced > 0) return forced < nch ? forced : nch;
+    // per CU: up to two active blocks (remaining pipe work), local clock
+    struct CU { double rem[2]; int n; double t; };
+    std::vector<CU> cu((size_t)ncu);
+    for (auto& c : cu) { c.rem[0] = c.rem[1] = 0; c.n = 0; c.t = 0; }
+    const long total = nblk * S;
+    long next = 0;
+    auto work = [&](long i) { return sizes[i / nblk] * t_chunk + t_fixed; };
+    for (int slot = 0; slot < 2 && next < total; ++slot)
+        for (int c = 0; c < ncu && next < total; ++c) { cu[c].rem[cu[c].n++] = work(next++); }
+    double makespan = 0;
+    for (;;) {
+        // CU whose next block completion comes first
+        int best = -1;
+        double bt = 1e300;
+        for (int c = 0; c < ncu; ++c) {
+            if (!cu[c].n) continue;
+            const double m = cu[c].n == 2 ? (cu[c].rem[0] < cu[c].rem[1] ? cu[c].rem[0] : cu[c].rem[1]) : cu[c].rem[0];
+            const double tc = cu[c].t + m * cu[c].n;
+            if (tc < bt) { bt = tc; best = c; }
+        }
+        if (best < 0) break;
+        CU& c = cu[best];
+        const double m = c.n == 2 ? (c.rem[0] < c.rem[1] ? c.rem[0] : c.rem[1]) : c.rem[0];
+        c.t = bt;
+        if (c.n == 2) {
+            c.rem[0] -= m; c.rem[1] -= m;
+            if (c.rem[0] <= 1e-12) { c.rem[0] = c.rem[1]; }
+            c.n = 1;
+            if (c.rem[0] <= 1e-12) c.n = 0;
+        } else c.n = 0;
+        if (bt > makespan) makespan = bt;
+        while (c.n < 2 && next < total) c.rem[c.n++] = work(next++);
+    }
+    return makespan;
+}
+
+static void sk_partitions(int n, int parts, int maxpart, int* cur, int depth, std::vector<std::vector<int>>& out)
+{
+    if (parts == 0) { if (n == 0) out.emplace_back(cur, cur + depth); return; }
+    for (int v = (n - (parts - 1) < maxpart ? n - (parts - 1) : maxpart); v >= 1 && v * parts >= n; --v) {
+        cur[depth] = v;
+        sk_partitions(n - v, parts - 1, v, cur, depth + 1, out);
+    }
+}
+
+SplitPlan conv_pick_ksplit(int variant, int H, int W, int B, int groups, int cout_pad, int nch, int pool, int forced)
+{
+    (void)pool;
+    SplitPlan none;
+    memset(&none, 0, sizeof none);
+    none.S = 1; none.sizes[0] = nch;
+    auto make = [&](const std::vector<int>& sizes) {
+        SplitPlan p;
+        memset(&p, 0, sizeof p);
+        p.S = (int)sizes.size();
+        int c = 0;
+        for (int s = 0; s < p.S; ++s) { p.bounds |= (unsigned long long)c << (8 * s); p.sizes[s] = sizes[s]; c += sizes[s]; }
+        return p;
+    };
+    if (!is_v5_variant(variant) || nch < 2 || nch > 255) return none;
+    if (forced == 1) return none;
+    if (forced < 0) {      // tuning: explicit plan, decimal digits = chunks per slice (must sum to nch, else ignored)
+        std::vector<int> sizes;
+        for (long d = -(long)forced; d > 0; d /= 10) sizes.insert(sizes.begin(), (int)(d % 10));
+        int sum = 0;
+        for (int v : sizes) sum += v;
+        if (sum != nch || sizes.size() > 8) return none;
+        for (int v : sizes) if (v < 1) return none;
+        return make(sizes);
+    }
+    if (forced > 1) {      // (near-)even slices, the larger ones first
+        const int S = forced < nch ? (forced < 8 ? forced : 8) : (nch < 8 ? nch : 8);
+        std::vector<int> sizes(S);
+        for (int s = 0; s < S; ++s) sizes[s] = nch / S + (s < nch % S ? 1 : 0);
+        return make(sizes);
+    }
     const ConvVariant& v = g_variants[variant];
     const long nblk = (long)((H + v.th - 1) / v.th) * ((W + v.tw - 1) / v.tw) * B * (cout_pad / v.bn) * groups;
     const int ncu = g_num_cus;
-    if (nblk >= 2 * ncu) return 1;
-    // per-wave MFMAs of one chunk in this block shape (32x32x2 MFMA = 64 cycles), microseconds at 2.4 GHz
-    const int mt_nt = ((v.th * v.tw + 31) / 32) * (v.bn / 32) / 4;
-    const double t_chunk = (double)v.ks * v.ks * 8 * mt_nt * 64 / 2400.0;
-    const double t_fixed = 3.0;                         // prologue + epilogue + dispatch of one block, us
-    const double out_mb = (double)H * W * B * cout_pad * groups * 4 / 1e6;
-    double best = 1e30;
-    int best_s = 1;
-    for (int S = 1; S <= 8 && S <= nch; ++S) {
-        const long per_cu = (nblk * S + ncu - 1) / ncu;
-        const int chunks = (nch + S - 1) / S;
-        double t = per_cu * (chunks * t_chunk + t_fixed);
-        if (S > 1) t += 2.5 + (S + 1) * out_mb / 3.0;       // launch boundary + slab reads / output write at ~3 TB/s (L2 / MALL)
-        if (t < best - 1e-9) { best = t; best_s = S; }
+    if (nblk >= 8 * ncu) return none;
+    // measured plans (tools/splitk_tune.py, in-network HIP-event times on an MI355X, profiles/r02_splitk_tune.txt) for the
+    // launch shapes of 368 x 368 inputs at batch 1-6; {ksize, chunks, blocks before the split, slices...}.  How the
+    // dispatcher really places late blocks is not modelled well enough by the simulation below (it is right about
+    // 3-2-2-1 at batch 1 and wrong about the 12-chunk layers), so shapes that were measured use the measurement.
+    static const int tuned[][12] = {
+        {7, 8, 144, 3, 2, 2, 1}, {7, 12, 144, 5, 3, 3, 1},                                  // batch 1: 106.6 -> 70.2 us, 168.7 -> 103.2
+        {3, 16, 576, 8, 8}, {3, 16, 288, 6, 5, 5}, {3, 32, 288, 7, 7, 6, 6, 6}, {3, 32, 144, 11, 11, 10}, {3, 16, 72, 3, 3, 3, 3, 2, 2},
+        {7, 8, 288, 5, 1, 1, 1}, {7, 12, 288, 6, 2, 2, 2},                                  // batch 2: 182.5 -> 124.4, 270.4 -> 176.2
+        {3, 32, 576, 11, 11, 10}, {3, 16, 144, 6, 5, 5},
+        {7, 8, 432, 4, 3, 1}, {7, 12, 432, 7, 3, 1, 1}, {3, 32, 864, 16, 16}, {3, 16, 216, 8, 8},      // batch 3
+        {7, 8, 576, 5, 2, 1}, {7, 12, 576, 7, 4, 1}, {3, 32, 1152, 16, 16},                 // batch 4: 273.5 -> 231.2, 406.8 -> 332.7
+        {7, 8, 864, 6, 2}, {7, 12, 864, 5, 5, 2}, {3, 32, 1728, 11, 11, 10}, {3, 16, 1728, 8, 8},      // batch 6
+    };
+    // 3x3 layers that measured no better split than unsplit at these block counts
+    static const int tuned_unsplit[][3] = {{3, 8, 1058}, {3, 8, 576}, {3, 8, 144}, {3, 16, 1152}, {3, 8, 2116}, {3, 8, 1152}, {3, 16, 2304}};
+    if (ncu == 256) {
+        for (const auto& u : tuned_unsplit)
+            if (u[0] == v.ks && u[1] == nch && u[2] == nblk) return none;
+        for (const auto& t : tuned)
+            if (t[0] == v.ks && t[1] == nch && t[2] == nblk) {
+                std::vector<int> sizes;
+                for (int i = 3; i < 12 && t[i] > 0; ++i) sizes.push_back(t[i]);
+                return make(sizes);
+            }
     }
-    (void)pool;
-    return best_s;
+    // one answer per launch shape
+    static std::map<std::vector<long>, SplitPlan> cache;
+    const std::vector<long> key = {variant, H, W, B, groups, cout_pad, nch, ncu};
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    // per-wave MFMAs of one chunk in this block shape (32x32x2 MFMA = 64 cycles), microseconds at 2.4 GHz, ~91 % pipe rate
+    const int mt_nt = ((v.th * v.tw + 31) / 32) * (v.bn / 32) / 4;
+    const double t_chunk = (double)v.ks * v.ks * 8 * mt_nt * 64 / 2400.0 / 0.91;
+    const double t_fixed = 1.5;                         // prologue + epilogue of one block that the co-resident block cannot hide, us
+    const double out_mb = (double)H * W * B * cout_pad * groups * 4 / 1e6;
+    int one[1] = {nch};
+    double best = sk_simulate(one, 1, nblk, ncu, t_chunk, t_fixed);
+    SplitPlan best_p = none;
+    for (int S = 2; S <= 8 && S <= nch; ++S) {
+        std::vector<std::vector<int>> cands;
+        if (nch <= 12) {
+            int cur[8];
+            sk_partitions(nch, S, nch, cur, 0, cands);          // all splits into S parts, parts in descending order
+        } else {
+            std::vector<int> sizes(S);
+            for (int s = 0; s < S; ++s) sizes[s] = nch / S + (s < nch % S ? 1 : 0);
+            cands.push_back(sizes);
+        }
+        for (const auto& sizes : cands) {
+            const double t = sk_simulate(sizes.data(), S, nblk, ncu, t_chunk, t_fixed) + 2.5 + (S + 1) * out_mb / 3.0;
+            if (t < best * 0.97 - 1e-9 && (best_p.S == 1 || t < best - 1e-9)) { best = t; best_p = make(sizes); }
+        }
+    }
+    cache[key] = best_p;
+    return best_p;
 }
 
 template <int KS, int TH, int TW, int BN, int CK, int WM, int WN>
@@ -1024,7 +1144,8 @@ static int launch_v5(const ConvArgs& a0, int groups, hipStream_t stream)
     static bool attr_set[PMX_MAX_DEVICES] = {};
     if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(kern), attr_set)) return rc;
     if (a.ksplit < 1) a.ksplit = 1;
-    PMX_CHECK(a.ksplit <= a.nch, PMX_ERR_INVALID, "conv: %d K slices for %d chunks", a.ksplit, a.nch);
+    a.ngroups = groups;
+    PMX_CHECK(a.ksplit <= a.nch && a.ksplit <= 8, PMX_ERR_INVALID, "conv: %d K slices for %d chunks", a.ksplit, a.nch);
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / BN), (unsigned)(groups * a.ksplit));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
     PMX_HIP(hipGetLastError());

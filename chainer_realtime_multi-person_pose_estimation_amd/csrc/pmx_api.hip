@@ -377,7 +377,7 @@ extern "C" int pmx_create_net(pmx_ctx** out, const char* arch, int device, int m
         if ((rc = dev_alloc(&c->brA, B * hw8 * 256))) return rc;
         if ((rc = dev_alloc(&c->brB, B * hw8 * 256))) return rc;
         if ((rc = dev_alloc(&c->brT, B * hw8 * 1024))) return rc;
-        PMX_HIP(hipMemset(c->cat, 0, B * hw8 * c->cat_c * sizeof(float)));   // pad channels stay zero forever
+        PMX_HIP(hipMemsetAsync(c->cat, 0, B * hw8 * c->cat_c * sizeof(float), c->stream));   // pad channels stay zero forever (stream-ordered)
         c->nchw_tmp_bytes = B * HW * 3 * sizeof(float);
         if (c->nchw_tmp_bytes < B * hw8 * 80 * sizeof(float)) c->nchw_tmp_bytes = B * hw8 * 80 * sizeof(float);
         PMX_HIP(hipMalloc((void**)&c->nchw_tmp, c->nchw_tmp_bytes));
@@ -456,6 +456,7 @@ extern "C" int pmx_set_option(pmx_ctx* c, const char* key, int value)
     else if (!strcmp(key, "stop_stage")) c->opt_stop_stage = value;
     else if (!strcmp(key, "kernel_gen")) c->opt_kernel_gen = value;
     else if (!strcmp(key, "ksplit")) c->opt_ksplit = value;
+    else if (!strcmp(key, "ksplit_plan")) c->opt_ksplit = value > 0 ? -value : 0;     // decimal digits = chunks per slice, e.g. 3221
     else if (!strcmp(key, "conv_min_lds")) conv_set_min_lds(value);
     else if (!strcmp(key, "pp_generic")) pp_set_generic(value);
     else if (!strcmp(key, "peaks_gpu_branch")) { c->opt_gpu_branch_peaks = value; c->tab_in_h = -1; }
@@ -505,8 +506,9 @@ struct ConvIO { const float* in; int lda; float* out; int ldc; };
 // With S > 1 K slices the slice blocks write raw partial sums into the context's slab scratch and conv_splitk_reduce
 // produces the final result (slabs added in slice order, then bias, ReLU, pool).
 static const int SK_ZERO_BIAS = 1024;
-static int launch_conv(pmx_ctx* c, const ConvArgs& a0, int groups, int v, int S)
+static int launch_conv(pmx_ctx* c, const ConvArgs& a0, int groups, int v, const SplitPlan& plan)
 {
+    const int S = plan.S;
     if (S <= 1) {
         ConvArgs a = a0;
         a.ksplit = 1; a.slab_stride = 0;
@@ -524,7 +526,9 @@ static int launch_conv(pmx_ctx* c, const ConvArgs& a0, int groups, int v, int S)
     }
     if (!c->sk_zero_bias) {
         PMX_HIP(hipMalloc((void**)&c->sk_zero_bias, SK_ZERO_BIAS * sizeof(float)));
-        PMX_HIP(hipMemset(c->sk_zero_bias, 0, SK_ZERO_BIAS * sizeof(float)));
+        // stream-ordered: a null-stream hipMemset is not ordered against this (non-blocking) stream and may still be in flight
+        // when the first slice kernel reads the vector
+        PMX_HIP(hipMemsetAsync(c->sk_zero_bias, 0, SK_ZERO_BIAS * sizeof(float), c->stream));
     }
     ConvArgs a = a0;
     SplitKReduceArgs r;
@@ -534,7 +538,7 @@ static int launch_conv(pmx_ctx* c, const ConvArgs& a0, int groups, int v, int S)
         r.slabs[g] = base; r.bias[g] = a0.g[g].bias; r.out[g] = a0.g[g].out; r.cout[g] = a0.g[g].cout;
         a.g[g].out = base; a.g[g].bias = c->sk_zero_bias; a.g[g].cout = a0.cout_pad;
     }
-    a.ldc = a0.cout_pad; a.relu = 0; a.pool = 0; a.ksplit = S; a.slab_stride = (long long)slab;
+    a.ldc = a0.cout_pad; a.relu = 0; a.pool = 0; a.ksplit = S; a.slab_stride = (long long)slab; a.kbounds = plan.bounds;
     r.slab_stride = (long long)slab; r.ksplit = S; r.B = a0.B; r.H = a0.H; r.W = a0.W; r.ld_slab = a0.cout_pad; r.ldc = a0.ldc;
     r.relu = a0.relu; r.pool = a0.pool;
     int rc = conv_launch(v, a, groups, c->stream);
@@ -560,16 +564,19 @@ static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float
     a.B = B; a.H = H; a.W = W; a.lda = lda; a.ldc = ldc; a.nch = L0.nch; a.cout_pad = L0.cout_pad;
     a.relu = relu; a.pool = pool;
     const int v = conv_pick_variant(L0.ks, L0.cout_pad, H, W, B * groups, c->opt_force[L0.ks], c->opt_kernel_gen, pool, groups == 1 ? L0.cin : 9999);
-    int S = conv_pick_ksplit(v, H, W, B, groups, L0.cout_pad, L0.nch, pool, c->opt_ksplit);
-    if (L0.cout % 4 != 0 || ldc % 4 != 0 || (groups == 2 && c->layers[li1].cout != L0.cout)) S = 1;
+    SplitPlan plan = conv_pick_ksplit(v, H, W, B, groups, L0.cout_pad, L0.nch, pool, c->opt_ksplit);
+    if (L0.cout % 4 != 0 || ldc % 4 != 0 || (groups == 2 && c->layers[li1].cout != L0.cout)) plan.S = 1;
     int rc;
     if (c->prof_on) {
         const double bytes = 4.0 * B * H * W * ((double)L0.cin * groups + (double)L0.cout * groups / (pool ? 4 : 1));
         std::string kn = conv_variant(v).name;
-        if (S > 1) kn += "/k" + std::to_string(S);        // K slices (+ the combine kernel) are part of the launch's time
+        if (plan.S > 1) {       // "/k<chunks of slice 0>-<slice 1>-...": the K slices (+ the combine kernel) are part of the launch
+            kn += "/k";
+            for (int i = 0; i < plan.S; ++i) kn += (i ? "-" : "") + std::to_string(plan.sizes[i]);
+        }
         if ((rc = prof_begin(c, std::string(label) + "|" + kn, flops, bytes))) return rc;
     }
-    if ((rc = launch_conv(c, a, groups, v, S))) return rc;
+    if ((rc = launch_conv(c, a, groups, v, plan))) return rc;
     return prof_end(c);
 }
 
@@ -1507,25 +1514,25 @@ extern "C" int pmx_conv2d(pmx_ctx* c, const float* x, const float* w, const floa
     PMX_HIP(hipMalloc((void**)&d_y, ny * 4));
     PMX_HIP(hipMalloc((void**)&d_yn, ny * 4));
     PMX_HIP(hipMemcpy(d_x, x, nx * 4, hipMemcpyHostToDevice));
-    PMX_HIP(hipMemset(d_xn, 0, nxn * 4));
+    PMX_HIP(hipMemsetAsync(d_xn, 0, nxn * 4, c->stream));
     PMX_HIP(hipMemcpy(d_w, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
     PMX_HIP(hipMemcpy(d_b, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
     // poison the output so that unwritten elements are caught by the test
-    PMX_HIP(hipMemset(d_yn, 0xFF, ny * 4));
+    PMX_HIP(hipMemsetAsync(d_yn, 0xFF, ny * 4, c->stream));
     int rc = launch_nchw_to_nhwc(d_x, d_xn, B, cin, H, W, cin_pad, 0, c->stream);
     ConvArgs a;
     memset(&a, 0, sizeof a);
     a.g[0].in = d_xn; a.g[0].w = d_w; a.g[0].bias = d_b; a.g[0].out = d_yn; a.g[0].cout = cout;
     a.B = B; a.H = H; a.W = W; a.lda = cin_pad; a.ldc = cout; a.nch = cin_pad / CK; a.cout_pad = cpad; a.relu = relu; a.pool = pool;
     const int v = conv_pick_variant(ks, cpad, H, W, B, c->opt_force[ks], c->opt_kernel_gen, pool, cin);
-    int S = conv_pick_ksplit(v, H, W, B, 1, cpad, cin_pad / CK, pool, c->opt_ksplit);
-    if (cout % 4 != 0) S = 1;
-    if (!rc) rc = launch_conv(c, a, 1, v, S);
+    SplitPlan plan = conv_pick_ksplit(v, H, W, B, 1, cpad, cin_pad / CK, pool, c->opt_ksplit);
+    if (cout % 4 != 0) plan.S = 1;
+    if (!rc) rc = launch_conv(c, a, 1, v, plan);
     if (!rc && iters > 0) {
         hipEvent_t e0, e1;
         PMX_HIP(hipEventCreate(&e0)); PMX_HIP(hipEventCreate(&e1));
         PMX_HIP(hipEventRecord(e0, c->stream));
-        for (int i = 0; i < iters && !rc; ++i) rc = launch_conv(c, a, 1, v, S);
+        for (int i = 0; i < iters && !rc; ++i) rc = launch_conv(c, a, 1, v, plan);
         PMX_HIP(hipEventRecord(e1, c->stream));
         PMX_HIP(hipEventSynchronize(e1));
         float ms = 0.f;

@@ -69,13 +69,16 @@ struct ConvArgs {
     int cout_pad;       // multiple of the kernel's BN
     int tiles_x, tiles_y;
     int relu, pool;
-    // split-K (v5 kernels, small launches): blockIdx.z = group * ksplit + slice; slice s accumulates the 16-channel chunks
-    // [s * nch / ksplit, (s + 1) * nch / ksplit) and stores its raw partial sums (the host passes zero bias, relu = pool = 0)
+    // split-K (v5 kernels, small launches): blockIdx.z = slice * ngroups + group (slice-major, so the blocks of the first --
+    // largest -- slice are dispatched first whatever the group); slice s accumulates the 16-channel chunks
+    // [kbounds byte s, kbounds byte s+1) and stores its raw partial sums (the host passes zero bias, relu = pool = 0)
     // to g[].out + s * slab_stride; conv_splitk_reduce then adds the slabs in slice order, the bias, ReLU and the pool
-    int ksplit;              // >= 1
-    int pad2_;
+    int ksplit;              // >= 1 (<= 8)
+    int ngroups;             // 1 | 2 (split-K launches only)
     long long slab_stride;   // floats between the partial-sum slabs of one group (0 when ksplit == 1)
+    unsigned long long kbounds;   // byte s = first chunk of slice s (s = 0 .. ksplit - 1); slice s ends where s + 1 starts / at nch
 };
+struct SplitPlan { int S; unsigned long long bounds; int sizes[8]; };
 struct SplitKReduceArgs {
     const float* slabs[2];   // per group: ksplit slabs of B x H x W x ld_slab floats
     const float* bias[2];
@@ -85,8 +88,8 @@ struct SplitKReduceArgs {
     int ksplit, B, H, W, ld_slab, ldc, relu, pool;
 };
 int conv_splitk_reduce(const SplitKReduceArgs& r, int groups, hipStream_t stream);
-// number of K slices for a launch of `variant` (1 = no split); forced > 0 overrides the heuristic
-int conv_pick_ksplit(int variant, int H, int W, int B, int groups, int cout_pad, int nch, int pool, int forced);
+// K slices for a launch of `variant` (S = 1: no split); forced > 0 asks for that many (near-)even slices
+SplitPlan conv_pick_ksplit(int variant, int H, int W, int B, int groups, int cout_pad, int nch, int pool, int forced);
 
 struct ConvVariant {
     int ks, th, tw, bn, ck;

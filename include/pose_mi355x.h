@@ -99,6 +99,8 @@ int pmx_synchronize(pmx_ctx* ctx);                    /* cuda.get_device_from_id
  *   "ksplit" 0 | 1 | n         split-K of the 3x3 / 7x7 launches that cannot fill the chip (single images): 0 = automatic,
  *                              1 = never, n = n K slices wherever split-K applies.  The slices are combined in a fixed
  *                              order, so results stay deterministic; they differ in the last bits from the unsplit sum
+ *   "ksplit_plan" digits       tuning: explicit slices, decimal digits = 16-channel chunks per slice (3221 = 3 + 2 + 2 + 1);
+ *                              applied to launches whose chunk count equals the digit sum
  *   "keep_smoothed"            keep the smoothed heat maps for pmx_get_smoothed
  *   "stop_stage" 1..6          stop the network after this stage (profiling)
  *   "peaks_gpu_branch"         the reference's GPU-branch peak extraction (17 x 17 un-normalised kernel, zero pad, >=)

@@ -8,7 +8,7 @@
  *     for 16-channel chunk: for tap (ky, kx) row-major: for half (channels +0..7, +8..15): for e in 0..3: k = e, then e + 4
  * so this plain-C loop reproduces their outputs bit for bit.  Bias is added after the chain; ReLU / 2x2 max-pool follow.
  * Split-K (small launches, csrc/conv_mfma.hip::conv_pick_ksplit): with `splitk` = S > 1 slice s runs its own chain (from 0)
- * over the chunks [s * nch / S, (s + 1) * nch / S) and the slices are added left to right (conv_splitk_reduce_kernel).
+ * over `slice_chunks[s]` consecutive 16-channel chunks and the slices are added left to right (conv_splitk_reduce_kernel).
  * Compile with -ffp-contract=off (the fmaf calls are explicit); -mfma makes fmaf one instruction, -fopenmp spreads the
  * independent outputs over the host cores. */
 #include <math.h>
@@ -16,9 +16,12 @@
 
 /* x: [B][cin][H][W], w: [cout][cin][ks][ks], bias: [cout], y: [B][cout][Ho][Wo] (Ho = H or H/2), zero padding ks/2 */
 void conv_fma_ref(const float* x, const float* w, const float* bias, float* y, int B, int cin, int H, int W, int cout, int ks,
-                  int relu, int pool, int splitk)
+                  int relu, int pool, int splitk, const int* slice_chunks)
 {
-    if (splitk < 1) splitk = 1;
+    int start[9];
+    if (splitk < 1 || !slice_chunks) splitk = 1;
+    start[0] = 0;
+    for (int s = 0; s < splitk; ++s) start[s + 1] = splitk == 1 ? (cin + 15) / 16 : start[s] + slice_chunks[s];
     const int pad = ks / 2, nch = (cin + 15) / 16;
     const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
 #pragma omp parallel for collapse(2) schedule(static)
@@ -33,7 +36,7 @@ void conv_fma_ref(const float* x, const float* w, const float* bias, float* y, i
                         float total = 0.f;
                         for (int sl = 0; sl < splitk; ++sl) {
                         float acc = 0.f;
-                        for (int c16 = sl * nch / splitk; c16 < (sl + 1) * nch / splitk; ++c16)
+                        for (int c16 = start[sl]; c16 < start[sl + 1]; ++c16)
                             for (int ky = 0; ky < ks; ++ky)
                                 for (int kx = 0; kx < ks; ++kx) {
                                     const int iy = py + ky - pad, ix = px + kx - pad;

@@ -26,19 +26,29 @@ _lib = None
 
 def conv_fma(x, w, b, relu=False, pool=False, splitk=1):
     """x (B, cin, H, W), w (cout, cin, k, k), b (cout,) float32 -> y float32, in the HIP kernels' summation order
-    (`splitk` K slices over the 16-channel chunks, added left to right: what the kernels do for small launches)."""
+    (`splitk`: K slices over the 16-channel chunks, added left to right -- what the kernels do for small launches; an int S
+    means S near-even slices, larger first (the kernels' forced split), a sequence gives the chunks of every slice)."""
     global _lib
     if _lib is None:
         _lib = C.CDLL(build())
         _lib.conv_fma_ref.restype = None
-        _lib.conv_fma_ref.argtypes = [C.c_void_p] * 4 + [C.c_int] * 9
+        _lib.conv_fma_ref.argtypes = [C.c_void_p] * 4 + [C.c_int] * 9 + [C.c_void_p]
     x = np.ascontiguousarray(x, np.float32)
     w = np.ascontiguousarray(w, np.float32)
     b = np.ascontiguousarray(b, np.float32)
     B, cin, H, W = x.shape
     cout, _, ks, _ = w.shape
     y = np.empty((B, cout, H // 2 if pool else H, W // 2 if pool else W), np.float32)
-    _lib.conv_fma_ref(x.ctypes.data, w.ctypes.data, b.ctypes.data, y.ctypes.data, B, cin, H, W, cout, ks, int(relu), int(pool), int(splitk))
+    nch = (cin + 15) // 16
+    if isinstance(splitk, (int, np.integer)):
+        S = max(1, min(int(splitk), nch, 8))
+        sizes = [nch // S + (1 if s < nch % S else 0) for s in range(S)]
+    else:
+        sizes = [int(v) for v in splitk]
+    assert sum(sizes) == nch and len(sizes) <= 8, (sizes, nch)
+    arr = np.asarray(sizes, dtype=np.int32)
+    _lib.conv_fma_ref(x.ctypes.data, w.ctypes.data, b.ctypes.data, y.ctypes.data, B, cin, H, W, cout, ks, int(relu), int(pool),
+                      len(sizes), arr.ctypes.data)
     return y
 
 
@@ -58,13 +68,13 @@ def _cat_weights(W):
 
 
 def splitk_plan(profile):
-    """{layer label: K slices} from an engine profile of the SAME forward (native.Engine.profile(); the kernel label carries
-    "/k<S>" where the launch was split).  Labels are the layer names without the _L1 / _L2 branch suffix."""
+    """{layer label: chunks of every K slice} from an engine profile of the SAME forward (native.Engine.profile(); the kernel
+    label carries "/k3-2-2-1" where the launch was split).  Labels are the layer names without the _L1 / _L2 branch suffix."""
     plan = {}
     for e in profile:
         k = e['kernel']
         if '/k' in k:
-            plan[e['layer']] = int(k.rsplit('/k', 1)[1])
+            plan[e['layer']] = [int(v) for v in k.rsplit('/k', 1)[1].split('-')]
     return plan
 
 

@@ -186,8 +186,8 @@ def test_v6_network_equals_v5_network_bitwise(engine):
     eng.set_option('ksplit', 0)             # default: split-K for the single image -- same maps to summation-order noise
     eng.forward_u8(img[5:6])
     q1, g1 = eng.get_maps()
-    assert np.abs(q1[0] - p6[5]).max() <= 2e-5 * max(1.0, np.abs(p6[5]).max())
-    assert np.abs(g1[0] - h6[5]).max() <= 2e-5 * max(1.0, np.abs(h6[5]).max())
+    assert np.abs(q1[0] - p6[5]).max() <= 1e-4 * max(1.0, np.abs(p6[5]).max())
+    assert np.abs(g1[0] - h6[5]).max() <= 1e-4 * max(1.0, np.abs(h6[5]).max())
     eng.close()
 
 
