@@ -1204,6 +1204,142 @@ int conv_splitk_reduce(const SplitKReduceArgs& r, int groups, hipStream_t stream
     return PMX_OK;
 }
 
+// ---- pair: two chained 1x1 convolutions in one launch ------------------------------------------------------------------------
+// The last two layers of every stage (CocoPoseNet.py: conv5_4 -> conv5_5, Mconv6 -> Mconv7; FaceNet / HandNet: conv6_1 -> conv6_2,
+// Mconv6 -> Mconv7) are 1x1 convolutions: 128 -> CMID (+ReLU) -> cout.  As separate launches they are short, latency-bound
+// kernels (24-120 us at batch 32, 13 us each at batch 1) that write and re-read the hidden map.  Here a block owns 32 pixels
+// (1x1 has no spatial structure: the whole batch is one pixel list): X tile -> LDS, wave w computes hidden channels
+// [w * CMID / 4, (w + 1) * CMID / 4) (weights L2 -> registers), bias + ReLU, hidden tile -> LDS, then waves 0 .. N2T - 1 each
+// compute one 32-channel tile of the second layer over all CMID hidden channels.  Every output walks K in the same order
+// as the single-layer kernels (chunk -> half -> k, one sequential FMA chain) -> bit-identical to running the two layers apart.
+template <int CMID, int N2T>
+__global__ __launch_bounds__(256) void conv1x1_pair_kernel(const PairArgs a)
+{
+    constexpr int CIN = 128, LDX = CIN + 4, LDH = CMID + 4, NT1 = CMID / 128;     // col tiles of the hidden layer per wave
+    extern __shared__ float4 smem4[];
+    float* const sX = reinterpret_cast<float*>(smem4);          // [32][LDX]
+    float* const sH = sX + 32 * LDX;                            // [32][LDH]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
+    const bool g1 = blockIdx.z != 0;
+    const float* in = g1 ? a.g[1].in : a.g[0].in;
+    const float* w1 = g1 ? a.g[1].w1 : a.g[0].w1;
+    const float* b1 = g1 ? a.g[1].b1 : a.g[0].b1;
+    const float* w2 = g1 ? a.g[1].w2 : a.g[0].w2;
+    const float* b2 = g1 ? a.g[1].b2 : a.g[0].b2;
+    float* out = g1 ? a.g[1].out : a.g[0].out;
+    const int cout = g1 ? a.g[1].cout : a.g[0].cout;
+    const long long p0 = (long long)blockIdx.x * 32;
+
+    // X tile: 32 pixels x 128 channels (zero rows past the end)
+    for (int f = tid; f < 32 * (CIN / 4); f += 256) {
+        const int r = f / (CIN / 4), c4 = f % (CIN / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p0 + r < a.npix) v = *reinterpret_cast<const float4*>(in + (p0 + r) * a.lda + c4 * 4);
+        *reinterpret_cast<float4*>(&sX[r * LDX + c4 * 4]) = v;
+    }
+    // hidden layer: wave -> NT1 column tiles
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w1), 0, 0x7fffffff, 0x00020000);
+    f32x16 acc[NT1];
+    float bias1[NT1];
+#pragma unroll
+    for (int u = 0; u < NT1; ++u) {
+        bias1[u] = b1[(wave * NT1 + u) * 32 + li];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[u][i] = 0.f;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int ch = 0; ch < CIN / 16; ++ch) {
+        f32x4 bw[NT1][2];
+#pragma unroll
+        for (int u = 0; u < NT1; ++u) {
+            const unsigned off = (unsigned)(((ch * CMID + (wave * NT1 + u) * 32 + li) * 16 + kh * 4) * 4);
+            bw[u][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, off, 0u, 0));
+            bw[u][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, off + 32, 0u, 0));
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(&sX[li * LDX + ch * 16 + s * 8 + kh * 4]);
+#pragma unroll
+            for (int u = 0; u < NT1; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bw[u][s][e], acc[u], 0, 0, 0);
+        }
+    }
+    // bias + ReLU -> hidden tile in LDS (C layout: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * kh)
+#pragma unroll
+    for (int u = 0; u < NT1; ++u)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+            sH[row * LDH + (wave * NT1 + u) * 32 + li] = fmaxf(acc[u][reg] + bias1[u], 0.f);
+        }
+    __syncthreads();
+    if (wave >= N2T) return;
+    // second layer: wave -> one 32-channel tile over all CMID hidden channels
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w2), 0, 0x7fffffff, 0x00020000);
+    const int n = wave * 32 + li;
+    const float bias2 = b2[n];
+    f32x16 y;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) y[i] = 0.f;
+    f32x4 bq[2][2];
+    {
+        const unsigned off = (unsigned)(((0 * a.cout_pad + n) * 16 + kh * 4) * 4);
+        bq[0][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2, off, 0u, 0));
+        bq[0][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2, off + 32, 0u, 0));
+    }
+#pragma unroll 2
+    for (int ch = 0; ch < CMID / 16; ++ch) {
+        const int cn = ch + 1 < CMID / 16 ? ch + 1 : ch;          // next chunk's weights under this chunk's MFMAs
+        const unsigned off = (unsigned)(((cn * a.cout_pad + n) * 16 + kh * 4) * 4);
+        bq[(ch + 1) & 1][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2, off, 0u, 0));
+        bq[(ch + 1) & 1][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2, off + 32, 0u, 0));
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(&sH[li * LDH + ch * 16 + s * 8 + kh * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bq[ch & 1][s][e], y, 0, 0, 0);
+        }
+    }
+    if (n < cout) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+            float v = y[reg] + bias2;
+            if (a.relu2) v = fmaxf(v, 0.f);
+            if (p0 + row < a.npix) out[(p0 + row) * a.ldc + n] = v;
+        }
+    }
+}
+
+bool conv_pair_supported(int cin, int cmid, int cout_pad)
+{
+    return cin == 128 && (cmid == 128 || cmid == 512) && (cout_pad == 64 || cout_pad == 128);
+}
+
+template <int CMID, int N2T>
+static int launch_pair(const PairArgs& a, int groups, hipStream_t stream)
+{
+    constexpr int LDS = (32 * (128 + 4) + 32 * (CMID + 4)) * 4;
+    auto kern = conv1x1_pair_kernel<CMID, N2T>;
+    static bool attr_set[PMX_MAX_DEVICES] = {};
+    if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(kern), attr_set)) return rc;
+    const long long nblk = (a.npix + 31) / 32;
+    PMX_CHECK(nblk < (1ll << 31), PMX_ERR_INVALID, "conv pair: too many pixels");
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, 1, (unsigned)groups), dim3(256), LDS, stream, a);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+int conv_pair_launch(const PairArgs& a, int groups, hipStream_t stream)
+{
+    PMX_CHECK(conv_pair_supported(128, a.cmid, a.cout_pad), PMX_ERR_INVALID, "conv pair: unsupported shape (cmid %d, cout_pad %d)", a.cmid, a.cout_pad);
+    PMX_CHECK(a.npix * (long long)(a.lda > a.ldc ? a.lda : a.ldc) < (1ll << 40), PMX_ERR_INVALID, "conv pair: map too large");
+    if (a.cmid == 128) return a.cout_pad == 64 ? launch_pair<128, 2>(a, groups, stream) : launch_pair<128, 4>(a, groups, stream);
+    return a.cout_pad == 64 ? launch_pair<512, 2>(a, groups, stream) : launch_pair<512, 4>(a, groups, stream);
+}
+
 template <int KS, int MT, int POOL>
 static int launch_v6(const ConvArgs& a0, int groups, hipStream_t stream)
 {

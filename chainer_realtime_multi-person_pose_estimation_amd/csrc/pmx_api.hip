@@ -204,6 +204,7 @@ struct pmx_ctx {
     int opt_force[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // by ksize
     int opt_gpu_branch_peaks = 0;    // reference GPU-branch peak extraction (non-golden variant)
     int opt_keep_smoothed = 0, opt_stop_stage = 6, opt_kernel_gen = 6;
+    int opt_fuse_pairs = 1;          // the two 1x1 layers that end every stage run as one launch (conv1x1_pair_kernel)
     int opt_ksplit = 0;              // 0: automatic split-K for small launches; n > 0: force n K slices where split-K applies
     // split-K scratch: partial-sum slabs of the current launch + a zero bias vector for the slice blocks
     float* sk_scratch = nullptr; size_t sk_floats = 0;
@@ -455,6 +456,7 @@ extern "C" int pmx_set_option(pmx_ctx* c, const char* key, int value)
     else if (!strcmp(key, "keep_smoothed")) c->opt_keep_smoothed = value;
     else if (!strcmp(key, "stop_stage")) c->opt_stop_stage = value;
     else if (!strcmp(key, "kernel_gen")) c->opt_kernel_gen = value;
+    else if (!strcmp(key, "fuse_pairs")) c->opt_fuse_pairs = value;
     else if (!strcmp(key, "ksplit")) c->opt_ksplit = value;
     else if (!strcmp(key, "ksplit_plan")) c->opt_ksplit = value > 0 ? -value : 0;     // decimal digits = chunks per slice, e.g. 3221
     else if (!strcmp(key, "conv_min_lds")) conv_set_min_lds(value);
@@ -580,6 +582,41 @@ static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float
     return prof_end(c);
 }
 
+// the two 1x1 layers that end a stage (A: 128 -> cmid + ReLU, B: cmid -> cout [+ ReLU]) as ONE launch when the shapes allow
+// (else, or with option fuse_pairs = 0, as two run_conv launches through `mid`): bit-identical either way
+static int run_pair(pmx_ctx* c, const char* labelA, const char* labelB, int a0, int a1, int b0, int b1, const float* in0,
+                    const float* in1, int lda, float* mid0, float* mid1, int ldm, float* out0, float* out1, int ldc, int B, int H,
+                    int W, int reluB)
+{
+    const PackedLayer& LA = c->layers[a0];
+    const PackedLayer& LB = c->layers[b0];
+    const int groups = a1 >= 0 ? 2 : 1;
+    const bool ok = c->opt_fuse_pairs && c->opt_kernel_gen >= 6 && LA.ks == 1 && LB.ks == 1 && LA.cin_pad == 128 && LB.cin == LA.cout &&
+                    conv_pair_supported(LA.cin, LA.cout, LB.cout_pad) && (groups == 1 || c->layers[b1].cout_pad == LB.cout_pad);
+    int rc;
+    if (!ok) {
+        if ((rc = run_conv(c, labelA, a0, a1, in0, in1, lda, mid0, mid1, ldm, B, H, W, 1, 0))) return rc;
+        return run_conv(c, labelB, b0, b1, mid0, mid1, ldm, out0, out1, ldc, B, H, W, reluB, 0);
+    }
+    PairArgs p;
+    memset(&p, 0, sizeof p);
+    double flops = 0;
+    for (int g = 0; g < groups; ++g) {
+        const PackedLayer& A = c->layers[g ? a1 : a0];
+        const PackedLayer& Bl = c->layers[g ? b1 : b0];
+        p.g[g].in = g ? in1 : in0; p.g[g].w1 = A.d_w; p.g[g].b1 = A.d_b; p.g[g].w2 = Bl.d_w; p.g[g].b2 = Bl.d_b;
+        p.g[g].out = g ? out1 : out0; p.g[g].cout = Bl.cout;
+        flops += 2.0 * B * H * W * ((double)A.cout * A.cin + (double)Bl.cout * Bl.cin);
+    }
+    p.npix = (long long)B * H * W; p.lda = lda; p.ldc = ldc; p.cmid = LA.cout; p.cout_pad = LB.cout_pad; p.relu2 = reluB;
+    if (c->prof_on) {
+        const std::string kn = "conv1x1_pair_c" + std::to_string(LA.cout) + "_n" + std::to_string(LB.cout_pad);
+        if ((rc = prof_begin(c, std::string(labelA) + "+" + labelB + "|" + kn, flops, 4.0 * B * H * W * groups * (LA.cin + LB.cout)))) return rc;
+    }
+    if ((rc = conv_pair_launch(p, groups, c->stream))) return rc;
+    return prof_end(c);
+}
+
 // FaceNet / HandNet forward (models/FaceNet.py:78-160): one branch, groups = 1 everywhere
 static int forward_cpm(pmx_ctx* c, int B, int H, int W)
 {
@@ -606,21 +643,24 @@ static int forward_cpm(pmx_ctx* c, int B, int H, int W)
     RUN1("conv5_1", c->act1, 512, c->act0, 512, H8, W8, 1, 0);
     RUN1("conv5_2", c->act0, 512, c->act1, 512, H8, W8, 1, 0);
     RUN1("conv5_3_CPM", c->act1, 512, cat, CC, H8, W8, 1, 0);               // feature_map -> cat[:, 0:128]
-    RUN1("conv6_1_CPM", cat, CC, c->brT, 512, H8, W8, 1, 0);                  // reads the 128 feature channels
-    RUN1("conv6_2_CPM", c->brT, 512, heat, CC, H8, W8, 0, 0);                 // stage-1 heat maps -> cat[:, 128:128+C]
-    char nm[48];
+    // conv6_1_CPM (reads the 128 feature channels) -> conv6_2_CPM (stage-1 heat maps -> cat[:, 128:128+C])
+    if ((rc = run_pair(c, "conv6_1_CPM", "conv6_2_CPM", id("conv6_1_CPM"), -1, id("conv6_2_CPM"), -1, cat, nullptr, CC, c->brT, nullptr, 512,
+                       heat, nullptr, CC, B, H8, W8, 0))) return rc;
+    char nm[48], nm2[48];
     for (int s = 2; s <= 6 && s <= c->opt_stop_stage; ++s) {
-        for (int i = 1; i <= 7; ++i) {
+        for (int i = 1; i <= 5; ++i) {
             snprintf(nm, sizeof nm, "Mconv%d_stage%d", i, s);
-            const float* in; float* out; int lda, ldc;
+            const float* in; float* out; int lda;
             if (i == 1) { in = cat; lda = CC; }
             else if (i % 2 == 0) { in = c->brA; lda = 128; }
             else { in = c->brB; lda = 128; }
-            if (i == 7) { out = heat; ldc = CC; }
-            else if (i % 2 == 1) { out = c->brA; ldc = 128; }
-            else { out = c->brB; ldc = 128; }
-            RUN1(nm, in, lda, out, ldc, H8, W8, i == 7 ? 0 : 1, 0);
+            out = i % 2 == 1 ? c->brA : c->brB;
+            RUN1(nm, in, lda, out, 128, H8, W8, 1, 0);
         }
+        snprintf(nm, sizeof nm, "Mconv6_stage%d", s);
+        snprintf(nm2, sizeof nm2, "Mconv7_stage%d", s);
+        if ((rc = run_pair(c, nm, nm2, id(nm), -1, id(nm2), -1, c->brA, nullptr, 128, c->brB, nullptr, 128, heat, nullptr, CC, B, H8, W8, 0)))
+            return rc;
     }
 #undef RUN1
     c->maps_valid = true; c->maps_external = false;
@@ -654,25 +694,31 @@ static int forward_from_in16(pmx_ctx* c, int B, int H, int W)
     RUN("conv5_1_CPM", id("conv5_1_CPM_L1"), id("conv5_1_CPM_L2"), cat, cat, PMX_CAT_C, c->brA, c->brA + 128, 256, B, H8, W8, 1, 0);
     RUN("conv5_2_CPM", id("conv5_2_CPM_L1"), id("conv5_2_CPM_L2"), c->brA, c->brA + 128, 256, c->brB, c->brB + 128, 256, B, H8, W8, 1, 0);
     RUN("conv5_3_CPM", id("conv5_3_CPM_L1"), id("conv5_3_CPM_L2"), c->brB, c->brB + 128, 256, c->brA, c->brA + 128, 256, B, H8, W8, 1, 0);
-    RUN("conv5_4_CPM", id("conv5_4_CPM_L1"), id("conv5_4_CPM_L2"), c->brA, c->brA + 128, 256, c->brT, c->brT + 512, 1024, B, H8, W8, 1, 0);
-    RUN("conv5_5_CPM", id("conv5_5_CPM_L1"), id("conv5_5_CPM_L2"), c->brT, c->brT + 512, 1024, cat + PMX_CAT_PAF, cat + PMX_CAT_HEAT,
-        PMX_CAT_C, B, H8, W8, 0, 0);
+    // conv5_4 (128 -> 512, ReLU) -> conv5_5 (512 -> 38 | 19): one launch
+    if ((rc = run_pair(c, "conv5_4_CPM", "conv5_5_CPM", id("conv5_4_CPM_L1"), id("conv5_4_CPM_L2"), id("conv5_5_CPM_L1"), id("conv5_5_CPM_L2"),
+                       c->brA, c->brA + 128, 256, c->brT, c->brT + 512, 1024, cat + PMX_CAT_PAF, cat + PMX_CAT_HEAT, PMX_CAT_C, B, H8, W8, 0)))
+        return rc;
     // stages 2-6 (CocoPoseNet.py:168-260)
-    char n1[48], n2[48], lab[48];
+    char n1[48], n2[48], m1[48], m2[48], lab[48], lab2[48];
     for (int s = 2; s <= 6 && s <= c->opt_stop_stage; ++s) {
-        for (int i = 1; i <= 7; ++i) {
+        for (int i = 1; i <= 5; ++i) {
             snprintf(n1, sizeof n1, "Mconv%d_stage%d_L1", i, s);
             snprintf(n2, sizeof n2, "Mconv%d_stage%d_L2", i, s);
             snprintf(lab, sizeof lab, "Mconv%d_stage%d", i, s);
-            const float *in0, *in1; float *o0, *o1; int lda, ldc;
+            const float *in0, *in1; float *o0, *o1; int lda;
             if (i == 1) { in0 = cat; in1 = cat; lda = PMX_CAT_C; }
             else if (i % 2 == 0) { in0 = c->brA; in1 = c->brA + 128; lda = 256; }
             else { in0 = c->brB; in1 = c->brB + 128; lda = 256; }
-            if (i == 7) { o0 = cat + PMX_CAT_PAF; o1 = cat + PMX_CAT_HEAT; ldc = PMX_CAT_C; }
-            else if (i % 2 == 1) { o0 = c->brA; o1 = c->brA + 128; ldc = 256; }
-            else { o0 = c->brB; o1 = c->brB + 128; ldc = 256; }
-            RUN(lab, id(n1), id(n2), in0, in1, lda, o0, o1, ldc, B, H8, W8, i == 7 ? 0 : 1, 0);
+            if (i % 2 == 1) { o0 = c->brA; o1 = c->brA + 128; }
+            else { o0 = c->brB; o1 = c->brB + 128; }
+            RUN(lab, id(n1), id(n2), in0, in1, lda, o0, o1, 256, B, H8, W8, 1, 0);
         }
+        // Mconv6 (1x1 128 -> 128, ReLU; reads Mconv5's output in brA) -> Mconv7 (1x1 128 -> 38 | 19, into the cat slices): one launch
+        snprintf(n1, sizeof n1, "Mconv6_stage%d_L1", s); snprintf(n2, sizeof n2, "Mconv6_stage%d_L2", s);
+        snprintf(m1, sizeof m1, "Mconv7_stage%d_L1", s); snprintf(m2, sizeof m2, "Mconv7_stage%d_L2", s);
+        snprintf(lab, sizeof lab, "Mconv6_stage%d", s); snprintf(lab2, sizeof lab2, "Mconv7_stage%d", s);
+        if ((rc = run_pair(c, lab, lab2, id(n1), id(n2), id(m1), id(m2), c->brA, c->brA + 128, 256, c->brB, c->brB + 128, 256,
+                           cat + PMX_CAT_PAF, cat + PMX_CAT_HEAT, PMX_CAT_C, B, H8, W8, 0))) return rc;
     }
 #undef RUN
     c->maps_valid = true; c->maps_external = false;

@@ -88,6 +88,26 @@ struct SplitKReduceArgs {
     int ksplit, B, H, W, ld_slab, ldc, relu, pool;
 };
 int conv_splitk_reduce(const SplitKReduceArgs& r, int groups, hipStream_t stream);
+// two chained 1x1 convolutions (x -> relu(W1 x + b1) -> W2 . + b2 [relu2]) in one launch: the last two layers of every stage
+struct PairGroupArgs {
+    const float* in;     // NHWC, channel stride lda, already offset to the group's first input channel (128 channels read)
+    const float* w1; const float* b1;   // packed [chunk][cmid][16], [cmid]
+    const float* w2; const float* b2;   // packed [chunk][cout_pad][16], [cout_pad]
+    float* out;          // NHWC, channel stride ldc, already offset
+    int cout;            // real output channels of the second layer
+    int pad_;
+};
+struct PairArgs {
+    PairGroupArgs g[2];
+    long long npix;      // B * H * W
+    int lda, ldc;
+    int cmid;            // hidden channels (128 | 512)
+    int cout_pad;        // padded output channels of the second layer (64 | 128)
+    int relu2;
+    int pad_;
+};
+int conv_pair_launch(const PairArgs& a, int groups, hipStream_t stream);
+bool conv_pair_supported(int cin, int cmid, int cout_pad);
 // K slices for a launch of `variant` (S = 1: no split); forced > 0 asks for that many (near-)even slices
 SplitPlan conv_pick_ksplit(int variant, int H, int W, int B, int groups, int cout_pad, int nch, int pool, int forced);
 

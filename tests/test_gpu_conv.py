@@ -168,6 +168,7 @@ def test_v6_network_equals_v5_network_bitwise(engine):
     eng = native.Engine(0, max_batch=32, max_h=368, max_w=368)
     eng.set_weights(w)
     img = np.random.default_rng(7).integers(0, 256, (32, 368, 368, 3), dtype=np.uint8)
+    eng.set_option('ksplit', 1)             # one K order everywhere (the v5 strip launches of generation 5 could be split)
     eng.set_option('kernel_gen', 5)
     eng.forward_u8(img)
     p5, h5 = eng.get_maps()
@@ -281,3 +282,29 @@ def test_random_shapes_v6(engine, seed, variant, B, h, slabs, cin, cout, relu):
     if pool:
         h = max(2, h - h % 2)
     _case(engine, B, cin, h, 46 * slabs, cout, k, relu, pool, seed=seed, variant=variant)
+
+
+@pytest.mark.parametrize('arch,B,hw', [('posenet', 1, (64, 96)), ('posenet', 5, (184, 120)), ('posenet', 32, (368, 368)),
+                                       ('facenet', 2, (96, 96)), ('handnet', 3, (72, 104))])
+def test_fused_1x1_pairs_equal_separate_layers_bitwise(native, arch, B, hw):
+    """conv5_4 -> conv5_5 and Mconv6 -> Mconv7 (conv6_1 -> conv6_2 for the CPM nets) as ONE launch (conv1x1_pair_kernel: hidden
+    map through LDS) == the two single-layer launches, bit for bit: every output walks K in the same order."""
+    from conftest import pkg
+    eng = native.Engine(0, max_batch=B, max_h=hw[0], max_w=hw[1], arch=arch)
+    eng.set_weights(pkg('weights').synthetic_weights(2, arch))
+    imgs = np.random.default_rng(B).integers(0, 256, (B,) + hw + (3,), dtype=np.uint8)
+    outs = {}
+    for fuse in (0, 1):
+        eng.set_option('fuse_pairs', fuse)
+        eng.profile_reset()
+        eng.profile_enable(True)
+        eng.forward_u8(imgs)
+        names = {e['kernel'] for e in eng.profile()}
+        eng.profile_enable(False)
+        assert any('pair' in k for k in names) == bool(fuse), names
+        outs[fuse] = eng.get_maps()
+    eng.close()
+    if arch == 'posenet':
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    else:
+        assert np.array_equal(outs[0], outs[1])
