@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Condense the rocprofv3 outputs of tools/gpu_round_run.sh (gpurun_out/) into small tracked files under profiles/.
 
-    python tools/summarize_profiles.py r01
+    python tools/summarize_profiles.py r02 [subdir of gpurun_out]
 
 Writes profiles/<round>_kernel_stats.csv   (rocprofv3 --kernel-trace --stats summary, verbatim)
        profiles/<round>_pmc_summary.json   (per-kernel means of every PMC pass + derived figures)
@@ -20,7 +20,7 @@ import statistics
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-G = os.path.join(ROOT, 'gpurun_out')
+G = os.path.join(ROOT, 'gpurun_out', sys.argv[2]) if len(sys.argv) > 2 else os.path.join(ROOT, 'gpurun_out')
 P = os.path.join(ROOT, 'profiles')
 rnd = sys.argv[1] if len(sys.argv) > 1 else 'r01'
 os.makedirs(P, exist_ok=True)
@@ -43,7 +43,7 @@ for d in sorted(os.listdir(G)):
         agg[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
         agg[r['Kernel_Name']]['_dur_ns_' + d].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
     for k, cs in agg.items():
-        if 'conv_mfma' not in k and not k.startswith('pp_') and 'prep' not in k:
+        if not any(t in k for t in ('conv_mfma', 'conv1x1_pair', 'conv3x3_c3', 'conv_splitk', 'prep')) and not k.startswith('pp_'):
             continue
         e = summary['kernels'].setdefault(k, {})
         for c, vals in cs.items():
