@@ -33,8 +33,14 @@ params = dict(
     limb_length_ratio=1.0, length_penalty_value=1,
     n_subset_limbs_thresh=3, subset_score_thresh=0.2,
     limbs_point=[[JointType[a], JointType[b]] for a, b in (pair.split('-') for pair in _LIMBS)],
+    # COCO annotation order -> JointType (reference entity.py:106-124; the Neck has no COCO counterpart)
+    coco_joint_indices=[JointType[n] for n in ('Nose LeftEye RightEye LeftEar RightEar LeftShoulder RightShoulder LeftElbow RightElbow '
+                                               'LeftHand RightHand LeftWaist RightWaist LeftKnee RightKnee LeftFoot RightFoot').split()],
     # face / hand key-point detectors (reference entity.py:126-151)
-    face_inference_img_size=368, face_heatmap_peak_thresh=0.1,
+    face_inference_img_size=368, face_heatmap_peak_thresh=0.1, face_crop_scale=1.5,
+    # 68-point face polylines: jaw 0-16, brows 17-21 / 22-26, nose 27-30 / 31-35 (open), eyes 36-41 / 42-47 and lips 48-59 / 60-67 (closed)
+    face_line_indices=([[i, i + 1] for a, b in ((0, 16), (17, 21), (22, 26), (27, 30), (31, 35)) for i in range(a, b)] +
+                       [[i, i + 1 if i < b else a] for a, b in ((36, 41), (42, 47), (48, 59), (60, 67)) for i in range(a, b + 1)]),
     hand_inference_img_size=368, hand_heatmap_peak_thresh=0.1,
     fingers_indices=[[[0 if k == 0 else 4 * f + k, 4 * f + k + 1] for k in range(4)] for f in range(5)],
     # name -> network architecture handled by the native library (reference entity.py:50-54)

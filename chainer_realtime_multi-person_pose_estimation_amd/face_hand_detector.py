@@ -80,3 +80,56 @@ class HandDetector(_KeypointDetector):
             w = hand_img.shape[1]
             return [None if k is None else [w - 1 - k[0], k[1], k[2]] for k in kps]
         return self._detect(hand_img)
+
+
+# ---- visualisation / crop helpers of the reference modules (host-only; cv2.circle / cv2.line rasters are stand-ins) -----------
+def _shifted(kp, left_top):
+    return (kp[0] + left_top[0], kp[1] + left_top[1])
+
+
+def draw_face_keypoints(orig_img, face_keypoints, left_top):
+    """reference face_detector.py:79-97: the 70 key points as radius-2 discs and the `face_line_indices` polylines
+    (thickness 1), colour (255, 255, 0), on a copy of the image; `left_top` = origin of the face crop."""
+    from .pose_detector import _draw_disc, _draw_line
+    img = np.array(orig_img, copy=True)
+    for kp in face_keypoints:
+        if kp:
+            _draw_disc(img, _shifted(kp, left_top), 2, (255, 255, 0))
+    for a, b in params['face_line_indices']:
+        if face_keypoints[a] and face_keypoints[b]:
+            _draw_line(img, _shifted(face_keypoints[a], left_top), _shifted(face_keypoints[b], left_top), (255, 255, 0), 1)
+    return img
+
+
+FINGER_COLORS = [(0, 0, 255), (0, 255, 255), (0, 255, 0), (255, 0, 0), (255, 0, 255)]
+
+
+def draw_hand_keypoints(orig_img, hand_keypoints, left_top):
+    """reference hand_detector.py:89-115: per finger, radius-3 discs at both ends of every bone whose key point exists and
+    a thickness-1 line where both exist."""
+    from .pose_detector import _draw_disc, _draw_line
+    img = np.array(orig_img, copy=True)
+    for color, bones in zip(FINGER_COLORS, params['fingers_indices']):
+        for a, b in bones:
+            ka, kb = hand_keypoints[a], hand_keypoints[b]
+            for k in (ka, kb):
+                if k:
+                    _draw_disc(img, _shifted(k, left_top), 3, color)
+            if ka and kb:
+                _draw_line(img, _shifted(ka, left_top), _shifted(kb, left_top), color, 1)
+    return img
+
+
+def crop_face(img, rect):
+    """reference face_detector.py:99-114 (camera_face_demo.py): `rect` = (x, y, w, h) of a face box; the box is scaled by
+    `face_crop_scale` about its centre, clipped to the image and zero-padded to a square.  -> (crop, (left, top))."""
+    h, w = img.shape[:2]
+    cx, cy = rect[0] + rect[2] / 2, rect[1] + rect[3] / 2
+    half_w, half_h = rect[2] * params['face_crop_scale'] / 2, rect[3] * params['face_crop_scale'] / 2
+    left, top = max(0, int(cx - half_w)), max(0, int(cy - half_h))
+    right, bottom = min(w - 1, int(cx + half_w)), min(h - 1, int(cy + half_h))
+    face = img[top:bottom, left:right]
+    edge = max(face.shape[:2])
+    out = np.zeros((edge, edge, face.shape[2]), dtype=np.uint8)
+    out[:face.shape[0], :face.shape[1]] = face
+    return out, (left, top)

@@ -201,6 +201,8 @@ class Engine(object):
         taps = np.ascontiguousarray(taps, dtype=np.float64)
         self._check(self.lib.pmx_set_gaussian(self._ctx, _ptr(taps), radius))
         self._B = 0
+        # host-side record of what was installed, so that a larger context can take over (PoseDetector._grow)
+        self._layers, self._options, self._stream_ptr, self._caps_set = {}, {}, None, None
 
     def _check(self, rc):
         if rc != 0:
@@ -220,9 +222,23 @@ class Engine(object):
     # ---- options / weights -------------------------------------------------------------------------
     def set_option(self, key, value):
         self._check(self.lib.pmx_set_option(self._ctx, key.encode(), int(value)))
+        self._options[key] = int(value)
 
     def set_stream(self, stream_ptr):
         self._check(self.lib.pmx_set_stream(self._ctx, C.c_void_p(stream_ptr)))
+        self._stream_ptr = stream_ptr
+
+    def copy_state_to(self, other):
+        """Install this engine's weights, options, stream and (grown) capacities in `other` (a larger context)."""
+        for name, (W, b) in self._layers.items():
+            other.set_layer(name, W, b)
+        for k, v in self._options.items():
+            other.set_option(k, v)
+        if self._stream_ptr:
+            other.set_stream(self._stream_ptr)
+        caps = self.capacities()
+        if (caps['peaks_per_joint'], caps['subsets'], caps['people']) != (INIT_PEAKS_PER_JOINT, INIT_SUBSETS, INIT_PEOPLE) or caps['candidates']:
+            other.set_capacities(caps['peaks_per_joint'], caps['subsets'], caps['people'], caps['candidates'])
 
     def synchronize(self):
         self._check(self.lib.pmx_synchronize(self._ctx))
@@ -233,6 +249,7 @@ class Engine(object):
         co, ci, kh, kw = W.shape
         assert kh == kw and b.shape == (co,)
         self._check(self.lib.pmx_set_layer(self._ctx, name.encode(), _ptr(W), _ptr(b), co, ci, kh))
+        self._layers[name] = (W, b)
 
     def set_weights(self, weights):
         for name, (W, b) in weights.items():

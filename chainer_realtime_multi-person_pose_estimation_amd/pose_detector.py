@@ -61,12 +61,16 @@ class PoseDetector(object):
         self._make_engine(max_batch, mh, mw)
 
     def _make_engine(self, max_batch, mh, mw):
-        if self.engine is not None:
-            self.engine.close()
+        old = self.engine
         self._cap = (max_batch, mh, mw)
         self.engine = native.Engine(self._gpu, max_batch=max_batch, max_h=mh, max_w=mw,
                                     gaussian_sigma=params['gaussian_sigma'])
-        if self._weights is not None:
+        if old is not None:
+            # growth keeps the engine's state: weights (also those installed through detector.engine.set_weights / set_layer),
+            # options, stream, capacities
+            old.copy_state_to(self.engine)
+            old.close()
+        elif self._weights is not None:
             self.engine.set_weights(self._weights)
         if self._gpu_branch_peaks:
             # the reference's own GPU branch of compute_peaks_from_heatmaps (:111-133): 17x17 un-normalised kernel, zero
@@ -220,6 +224,41 @@ class PoseDetector(object):
     def get_unit_length(self, person_pose):
         """reference :293-297 (called by demo.py:32)"""
         return self.compute_unit_length(self.compute_limbs_length(person_pose)[0])
+
+    # row j: how far (in unit lengths) the person's box extends above / below joint j when j is the top / bottom anchor,
+    # and the preference of joint j as top / bottom anchor (smaller = preferred)   (reference :312-313, :342-343)
+    _PERSON_TOP = ((0.9, 4), (1.9, 5), (1.9, 6), (2.9, 12), (3.7, 16), (1.9, 7), (2.9, 13), (3.7, 17), (4.0, 8), (5.5, 10), (7.0, 14),
+                   (4.0, 9), (5.5, 11), (7.0, 15), (0.7, 2), (0.8, 3), (0.7, 0), (0.8, 1))
+    _PERSON_BOTTOM = ((6.9, 9), (5.9, 6), (5.9, 7), (4.9, 14), (4.1, 16), (5.9, 8), (4.9, 15), (4.1, 17), (3.8, 4), (2.3, 2), (0.8, 0),
+                      (3.8, 5), (2.3, 3), (0.8, 1), (7.1, 10), (7.0, 11), (7.1, 12), (7.0, 13))
+
+    def crop_person(self, img, person_pose, unit_length):
+        """reference :311-352: box around all visible joints -- 0.3 units to the sides, above / below by the padding of the
+        preferred anchor joints.  One pass like the reference's, including its `elif` coupling: a joint that becomes the
+        top anchor (or the new minimum) is not considered as bottom anchor (or maximum) in the same step."""
+        top_i = bot_i = None                    # None = nothing chosen yet (the reference's sentinel of priority sys.maxsize)
+        top_pos, left_pos = float('inf'), float('inf')
+        bottom_pos, right_pos = 0, 0
+        for i, joint in enumerate(person_pose):
+            if not joint[2] > 0:
+                continue
+            if top_i is None or self._PERSON_TOP[i][1] < self._PERSON_TOP[top_i][1]:
+                top_i = i
+            elif bot_i is None or self._PERSON_BOTTOM[i][1] < self._PERSON_BOTTOM[bot_i][1]:
+                bot_i = i
+            if joint[1] < top_pos:
+                top_pos = joint[1]
+            elif joint[1] > bottom_pos:
+                bottom_pos = joint[1]
+            if joint[0] < left_pos:
+                left_pos = joint[0]
+            elif joint[0] > right_pos:
+                right_pos = joint[0]
+        if top_i is None or bot_i is None:      # the reference indexes its 18-entry padding tables with the sentinel 18
+            raise IndexError('list index out of range')
+        bbox = (int(left_pos - 0.3 * unit_length), int(top_pos - self._PERSON_TOP[top_i][0] * unit_length),
+                int(right_pos + 0.3 * unit_length), int(bottom_pos + self._PERSON_BOTTOM[bot_i][0] * unit_length))
+        return self.crop_image(img, bbox), bbox
 
     def crop_image(self, img, bbox):
         """reference :401-424 -- crop with zero padding where the box leaves the image."""

@@ -23,6 +23,8 @@ What is pinned ("outputs of the reference itself run here", SURVEY.md section 8c
                            a tie that fp32 summation-order noise (~1e-6) could flip.
   e2e_precise_<image>.npz  `PoseDetector(..., precise=True)` (pose_detector.py:433-482) on a down-scaled crop, same contents.
   kp_face.npz / kp_hand.npz  the reference FaceDetector / HandDetector on data/face.png / data/hand.png.
+  demo_chain_dinner.npz    reference demo.py:27-55 on data/dinner.png (image stored in e2e_dinner.npz): poses -> unit length ->
+                           face / hand crops -> key points, for the three people with the most crops.
 
 Third-party steps inside these runs that are restated, not reference-run (named): cv2.resize (OpenCV unpinned),
 F.resize_images (Chainer unpinned), the convolution primitive (torch-CPU conv2d standing in for Chainer's im2col + BLAS).
@@ -154,6 +156,64 @@ def keypoint_case(name, arch, img, seed, hand_type=None):
     print('%-22s %s: %d key points, %d valid, max conf %.3g' % (name, arch, len(rows), int(rows[:, 3].sum()), rows[:, 2].max()))
 
 
+def demo_chain_case(name, img, n_persons=3, seed=0, face_seed=4, hand_seed=5):
+    """reference demo.py:27-55 as a whole: PoseDetector -> get_unit_length -> crop_face / crop_hands -> FaceDetector / HandDetector,
+    every step the reference's own code; the first `n_persons` people of the image."""
+    import contextlib
+    import io
+    from oracle import face_hand_ref as FH
+    m = R.import_reference_modules()
+    weights, _ = calibrated_weights(img, seed)
+    det = R.ref_pose_detector(weights)
+    poses, _ = R.ref_call(det, img)
+    fw, hw = W.synthetic_weights(face_seed, 'facenet'), W.synthetic_weights(hand_seed, 'handnet')
+    with tempfile.TemporaryDirectory() as td:
+        W.save_npz(os.path.join(td, 'f.npz'), fw)
+        W.save_npz(os.path.join(td, 'h.npz'), hw)
+        with contextlib.redirect_stdout(io.StringIO()):
+            fdet = m['face_detector'].FaceDetector('facenet', os.path.join(td, 'f.npz'), device=-1)
+            hdet = m['hand_detector'].HandDetector('handnet', os.path.join(td, 'h.npz'), device=-1)
+
+    def rows_and_gaps(kps, crop, weights_, thresh, hand_type='right'):
+        rows = np.array([[k[0], k[1], k[2], 1.0] if k is not None else [0, 0, 0, 0] for k in kps], dtype=np.float64)
+        kps2, up = FH.detect(lambda x: FH.cpm_forward(weights_, x)[-1], crop, thresh, hand_type=hand_type)
+        gaps = []
+        for i in range(up.shape[0] - 1):
+            f = np.sort(P.gaussian_filter_ref(up[i]).ravel())
+            gaps.append((f[-1] - f[-2]) / max(abs(f[-1]), 1e-30))
+        return rows, np.array(gaps)
+    out = {'seed': seed,          # (the image itself is in e2e_<image>.npz)
+           'face_seed': face_seed, 'hand_seed': hand_seed, 'n_persons': n_persons,
+           'head_W1': weights[HEAD[0]][0], 'head_b1': weights[HEAD[0]][1], 'head_W2': weights[HEAD[1]][0], 'head_b2': weights[HEAD[1]][1],
+           'poses': np.asarray(poses, dtype=np.float64)}
+    # the people with the most face / hand crops (random-weight skeletons often lack a nose or wrists)
+    def n_crops_of(pose):
+        return int(pose[0][2] > 0) + int(pose[4][2] > 0) + int(pose[7][2] > 0)
+    chosen = sorted(range(len(poses)), key=lambda i: -n_crops_of(poses[i]))[:n_persons]
+    out['persons'] = np.array(chosen)
+    n_crops = 0
+    for i in chosen:
+        pose = poses[i].copy()
+        unit = det.get_unit_length(pose)
+        out['unit_%d' % i] = np.float64(unit)
+        face, bbox = det.crop_face(img, pose, unit)
+        out['face_bbox_%d' % i] = np.array(bbox if bbox is not None else (0, 0, 0, 0))
+        if face is not None:
+            k, g = rows_and_gaps(fdet(face), face, fw, m['entity'].params['face_heatmap_peak_thresh'])
+            out['face_kp_%d' % i], out['face_gap_%d' % i] = k, g
+            n_crops += 1
+        hands = det.crop_hands(img, pose, unit)
+        for side in ('left', 'right'):
+            if hands[side] is not None:
+                out['%s_bbox_%d' % (side, i)] = np.array(hands[side]['bbox'])
+                k, g = rows_and_gaps(hdet(hands[side]['img'], hand_type=side), hands[side]['img'], hw,
+                                     m['entity'].params['hand_heatmap_peak_thresh'], hand_type=side)
+                out['%s_kp_%d' % (side, i)], out['%s_gap_%d' % (side, i)] = k, g
+                n_crops += 1
+    np.savez_compressed(os.path.join(GOLDEN, name + '.npz'), **out)
+    print('%-22s persons %s, %d face / hand crops through the reference chain' % (name, chosen, n_crops))
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     m = R.import_reference_modules()
@@ -175,6 +235,8 @@ def main():
     keypoint_case('kp_face', 'facenet', cv2.imread(os.path.join(data, 'face.png')), 4)
     keypoint_case('kp_hand', 'handnet', cv2.imread(os.path.join(data, 'hand.png')), 5)
     keypoint_case('kp_hand_left', 'handnet', cv2.imread(os.path.join(data, 'hand.png')), 5, hand_type='left')
+    # ---- the demo.py chain as a whole -----------------------------------------------------------------------------------
+    demo_chain_case('demo_chain_dinner', cv2.imread(os.path.join(data, 'dinner.png')))
     print('golden fixtures written to', GOLDEN)
 
 

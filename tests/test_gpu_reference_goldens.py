@@ -113,3 +113,55 @@ def test_keypoint_detectors_match_reference_goldens(native, name, arch, cls):
             assert gap < 1e-4 and abs(k[0] - r[0]) <= 1 and abs(k[1] - r[1]) <= 1, (k, r, gap)
             moved += 1
     assert moved <= 2
+
+
+def test_demo_chain_matches_reference_chain(native):
+    """reference demo.py:27-55 as a whole on data/dinner.png: PoseDetector -> get_unit_length -> crop_face / crop_hands ->
+    FaceDetector / HandDetector (-> draw_*), every product step against what the reference's own chain produced."""
+    PD, FH, W = pkg('pose_detector'), pkg('face_hand_detector'), pkg('weights')
+    g = load_e2e('e2e_dinner')
+    z = np.load(os.path.join(GOLDEN, 'demo_chain_dinner.npz'))
+    img = g['img']
+    det = PD.PoseDetector(weights=g['weights'], device=0)
+    poses, _ = det(img)
+    assert np.array_equal(np.asarray(poses), z['poses'])
+    fdet = FH.FaceDetector('facenet', weights=W.synthetic_weights(int(z['face_seed']), 'facenet'), device=0)
+    hdet = FH.HandDetector('handnet', weights=W.synthetic_weights(int(z['hand_seed']), 'handnet'), device=0)
+
+    def check(kps, ref, gaps):
+        assert len(kps) == len(ref)
+        for k, r, gap in zip(kps, ref, gaps):
+            assert (k is None) == (r[3] == 0)
+            if k is None:
+                continue
+            assert abs(float(k[2]) - r[2]) <= 1e-4 * max(1.0, abs(r[2]))
+            if k[0] != r[0] or k[1] != r[1]:        # an arg-max within 1e-4 of a tie may move by a pixel
+                assert gap < 1e-4 and abs(k[0] - r[0]) <= 1 and abs(k[1] - r[1]) <= 1, (k, r, gap)
+    canvas = PD.draw_person_pose(img, poses)
+    crops = 0
+    for i in z['persons']:
+        pose = np.asarray(poses[int(i)]).copy()
+        unit = det.get_unit_length(pose)
+        assert unit == float(z['unit_%d' % i])
+        face, bbox = det.crop_face(img, pose, unit)
+        if 'face_kp_%d' % i in z.files:
+            assert tuple(bbox) == tuple(int(v) for v in z['face_bbox_%d' % i])
+            kps = fdet(face)
+            check(kps, z['face_kp_%d' % i], z['face_gap_%d' % i])
+            canvas = FH.draw_face_keypoints(canvas, kps, (bbox[0], bbox[1]))
+            crops += 1
+        else:
+            assert face is None
+        hands = det.crop_hands(img, pose, unit)
+        for side in ('left', 'right'):
+            if '%s_kp_%d' % (side, i) in z.files:
+                assert tuple(hands[side]['bbox']) == tuple(int(v) for v in z['%s_bbox_%d' % (side, i)])
+                kps = hdet(hands[side]['img'], hand_type=side)
+                check(kps, z['%s_kp_%d' % (side, i)], z['%s_gap_%d' % (side, i)])
+                canvas = FH.draw_hand_keypoints(canvas, kps, hands[side]['bbox'][:2])
+                crops += 1
+            else:
+                assert hands[side] is None
+    assert crops >= 3 and canvas.shape == img.shape and not np.array_equal(canvas, img)
+    for d in (det, fdet, hdet):
+        d.engine.close()

@@ -79,3 +79,46 @@ def test_demo_chain_helpers_match_reference():
                 assert hr[side]['bbox'] == hm[side]['bbox'] and np.array_equal(hr[side]['img'], hm[side]['img'])
         compared += 1
     assert compared > 100
+
+
+def test_crop_person_and_rect_crop_face_match_reference():
+    """PoseDetector.crop_person (pose_detector.py:311-352) and face_detector.crop_face(img, rect) (:99-114) vs the verbatim
+    reference.  The reference's crop_person uses `sys.maxsize` without importing sys (NameError as shipped): the module gets
+    `sys` injected here so that its logic can be compared."""
+    import sys
+    from conftest import pkg
+    m = R.import_reference_modules()
+    _, _, det_ref, _ = R.import_reference()
+    m['pose_detector'].sys = sys
+    PD, FH = pkg('pose_detector'), pkg('face_hand_detector')
+    mine = PD.PoseDetector.__new__(PD.PoseDetector)
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (240, 320, 3), dtype=np.uint8)
+    compared = 0
+    for _ in range(400):
+        pose = np.zeros((18, 3))
+        pose[:, :2] = rng.uniform(5, 300, (18, 2))
+        pose[:, 2] = (rng.random(18) > rng.choice([0.2, 0.6, 0.9])) * 2
+        u = np.float64(rng.uniform(5, 40))
+        try:
+            r = det_ref.crop_person(img, pose.copy(), u)
+        except (IndexError, ValueError, AttributeError):
+            continue          # fewer than two usable joints / box outside the image: the reference fails in its own ways
+        g = mine.crop_person(img, pose.copy(), u)
+        assert tuple(int(v) for v in r[1]) == tuple(g[1]) and np.array_equal(r[0], g[0])
+        compared += 1
+    assert compared > 200
+    for _ in range(200):
+        rect = (int(rng.integers(0, 300)), int(rng.integers(0, 220)), int(rng.integers(4, 120)), int(rng.integers(4, 120)))
+        try:
+            a = m['face_detector'].crop_face(img, rect)
+        except ValueError:
+            continue
+        b = FH.crop_face(img, rect)
+        assert a[1] == b[1] and np.array_equal(a[0], b[0])
+    # constants of the face / hand drawing helpers
+    ent = pkg('entity')
+    for k in ('face_crop_scale', 'fingers_indices'):
+        assert ent.params[k] == m['entity'].params[k]
+    assert [list(map(int, v)) for v in ent.params['face_line_indices']] == [list(map(int, v)) for v in m['entity'].params['face_line_indices']]
+    assert [int(v) for v in ent.params['coco_joint_indices']] == [int(v) for v in m['entity'].params['coco_joint_indices']]
