@@ -90,6 +90,7 @@ struct PackedLayer {
     bool set = false;
     float* d_w = nullptr;
     float* d_b = nullptr;
+    void* d_w3 = nullptr;        // bf16x3 pack [tap][chunk][plane hi|mid|lo][cout_pad][16] (3x3 / 7x7 layers; option "precision" = 1)
     int cin = 0, cout = 0, ks = 0, cin_pad = 0, cout_pad = 0, nch = 0;
 };
 
@@ -111,6 +112,38 @@ static void pack_weights(const float* w, const float* bias, int cout, int cin, i
             for (int n = 0; n < cout; ++n)
                 wp[(((size_t)tap * nch + ch) * cout_pad + n) * CK + c] = w[((size_t)n * cin + src) * T + tap];
         }
+}
+
+// fp32 -> three bf16 terms, each the round-to-nearest-even bf16 of what is left (as conv_bf16x3_kernel splits the activations)
+static inline uint16_t bf16_rn(float x)
+{
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float bf16_f(uint16_t h)
+{
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// packed fp32 weights [tap][chunk][cout_pad][16] -> bf16x3 [tap][chunk][plane][cout_pad][16]
+static void pack_bf16x3(const std::vector<float>& wp, int T, int nch, int cout_pad, std::vector<uint16_t>& out)
+{
+    out.assign((size_t)T * nch * 3 * cout_pad * CK, 0);
+    for (size_t pc = 0; pc < (size_t)T * nch; ++pc)
+        for (int n = 0; n < cout_pad; ++n)
+            for (int k = 0; k < CK; ++k) {
+                const float x = wp[(pc * cout_pad + n) * CK + k];
+                const uint16_t h = bf16_rn(x);
+                const float r1 = x - bf16_f(h);
+                const uint16_t m = bf16_rn(r1);
+                const uint16_t l = bf16_rn(r1 - bf16_f(m));
+                const size_t base = pc * 3 * cout_pad * CK + (size_t)n * CK + k;
+                out[base] = h; out[base + (size_t)cout_pad * CK] = m; out[base + 2 * (size_t)cout_pad * CK] = l;
+            }
 }
 
 static std::vector<int> identity_map(int cin)
@@ -204,6 +237,8 @@ struct pmx_ctx {
     int opt_force[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // by ksize
     int opt_gpu_branch_peaks = 0;    // reference GPU-branch peak extraction (non-golden variant)
     int opt_keep_smoothed = 0, opt_stop_stage = 6, opt_kernel_gen = 6;
+    int opt_precision = 0;           // 0: fp32 MFMA everywhere (the path whose results are specified); 1: bf16x3 kernels where a
+                                     // v6 kernel would run (fp32-grade accuracy at 2.67x the matrix rate, NOT the fp32 FMA chain)
     int opt_fuse_pairs = 1;          // the two 1x1 layers that end every stage run as one launch (conv1x1_pair_kernel)
     int opt_ksplit = 0;              // 0: automatic split-K for small launches; n > 0: force n K slices where split-K applies
     // split-K scratch: partial-sum slabs of the current launch + a zero bias vector for the slice blocks
@@ -415,7 +450,7 @@ extern "C" void pmx_destroy(pmx_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (auto& l : c->layers) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); }
+    for (auto& l : c->layers) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); if (l.d_w3) (void)hipFree(l.d_w3); }
     pp_free(c);
     void* ptrs[] = {c->sk_scratch, c->sk_zero_bias, c->pr_tmp, c->pr_tab, c->d_kp, c->u8_src, c->rs_tab, c->in16, c->act0, c->act1, c->cat, c->brA, c->brB, c->brT, c->nchw_tmp, c->u8_tmp, c->ext_paf, c->ext_heat,
                     c->pp.smoothed, c->d_scale, c->tab.xi0, c->tab.xi1, c->tab.xlo, c->tab.xhi, c->tab.yi0, c->tab.yi1,
@@ -457,6 +492,7 @@ extern "C" int pmx_set_option(pmx_ctx* c, const char* key, int value)
     else if (!strcmp(key, "stop_stage")) c->opt_stop_stage = value;
     else if (!strcmp(key, "kernel_gen")) c->opt_kernel_gen = value;
     else if (!strcmp(key, "fuse_pairs")) c->opt_fuse_pairs = value;
+    else if (!strcmp(key, "precision")) c->opt_precision = value;
     else if (!strcmp(key, "ksplit")) c->opt_ksplit = value;
     else if (!strcmp(key, "ksplit_plan")) c->opt_ksplit = value > 0 ? -value : 0;     // decimal digits = chunks per slice, e.g. 3221
     else if (!strcmp(key, "conv_min_lds")) conv_set_min_lds(value);
@@ -487,6 +523,12 @@ extern "C" int pmx_set_layer(pmx_ctx* c, const char* name, const float* w, const
     if (!L.d_b) PMX_HIP(hipMalloc((void**)&L.d_b, bp.size() * sizeof(float)));
     PMX_HIP(hipMemcpy(L.d_w, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice));
     PMX_HIP(hipMemcpy(L.d_b, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (ks > 1 && cpad % 128 == 0) {       // the layers the bf16x3 kernels can take
+        std::vector<uint16_t> w3;
+        pack_bf16x3(wp, ks * ks, (int)cmap.size() / CK, cpad, w3);
+        if (!L.d_w3) PMX_HIP(hipMalloc(&L.d_w3, w3.size() * sizeof(uint16_t)));
+        PMX_HIP(hipMemcpy(L.d_w3, w3.data(), w3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
     L.set = true; L.cin = cin; L.cout = cout; L.ks = ks;
     L.cin_pad = (int)cmap.size(); L.cout_pad = cpad; L.nch = L.cin_pad / CK;
     return PMX_OK;
@@ -565,7 +607,13 @@ static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float
     }
     a.B = B; a.H = H; a.W = W; a.lda = lda; a.ldc = ldc; a.nch = L0.nch; a.cout_pad = L0.cout_pad;
     a.relu = relu; a.pool = pool;
-    const int v = conv_pick_variant(L0.ks, L0.cout_pad, H, W, B * groups, c->opt_force[L0.ks], c->opt_kernel_gen, pool, groups == 1 ? L0.cin : 9999);
+    int v = conv_pick_variant(L0.ks, L0.cout_pad, H, W, B * groups, c->opt_force[L0.ks], c->opt_kernel_gen, pool, groups == 1 ? L0.cin : 9999,
+                              c->opt_precision == 1 && L0.d_w3 != nullptr);
+    if (c->opt_precision == 1 && conv_bf16x3_twin(v) >= 0 && L0.d_w3 && (groups == 1 || c->layers[li1].d_w3)) {
+        v = conv_bf16x3_twin(v);
+        a.g[0].w = (const float*)L0.d_w3;
+        if (groups == 2) a.g[1].w = (const float*)c->layers[li1].d_w3;
+    }
     SplitPlan plan = conv_pick_ksplit(v, H, W, B, groups, L0.cout_pad, L0.nch, pool, c->opt_ksplit);
     if (L0.cout % 4 != 0 || ldc % 4 != 0 || (groups == 2 && c->layers[li1].cout != L0.cout)) plan.S = 1;
     int rc;
@@ -1570,15 +1618,25 @@ extern "C" int pmx_conv2d(pmx_ctx* c, const float* x, const float* w, const floa
     memset(&a, 0, sizeof a);
     a.g[0].in = d_xn; a.g[0].w = d_w; a.g[0].bias = d_b; a.g[0].out = d_yn; a.g[0].cout = cout;
     a.B = B; a.H = H; a.W = W; a.lda = cin_pad; a.ldc = cout; a.nch = cin_pad / CK; a.cout_pad = cpad; a.relu = relu; a.pool = pool;
-    const int v = conv_pick_variant(ks, cpad, H, W, B, c->opt_force[ks], c->opt_kernel_gen, pool, cin);
-    SplitPlan plan = conv_pick_ksplit(v, H, W, B, 1, cpad, cin_pad / CK, pool, c->opt_ksplit);
+    const int v = conv_pick_variant(ks, cpad, H, W, B, c->opt_force[ks], c->opt_kernel_gen, pool, cin, c->opt_precision == 1 && ks > 1 && cpad % 128 == 0);
+    void* d_w3 = nullptr;
+    int v_run = v;
+    if (c->opt_precision == 1 && conv_bf16x3_twin(v) >= 0 && ks > 1 && cpad % 128 == 0) {
+        std::vector<uint16_t> w3;
+        pack_bf16x3(wp, ks * ks, cin_pad / CK, cpad, w3);
+        PMX_HIP(hipMalloc(&d_w3, w3.size() * sizeof(uint16_t)));
+        PMX_HIP(hipMemcpy(d_w3, w3.data(), w3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        a.g[0].w = (const float*)d_w3;
+        v_run = conv_bf16x3_twin(v);
+    }
+    SplitPlan plan = conv_pick_ksplit(v_run, H, W, B, 1, cpad, cin_pad / CK, pool, c->opt_ksplit);
     if (cout % 4 != 0) plan.S = 1;
-    if (!rc) rc = launch_conv(c, a, 1, v, plan);
+    if (!rc) rc = launch_conv(c, a, 1, v_run, plan);
     if (!rc && iters > 0) {
         hipEvent_t e0, e1;
         PMX_HIP(hipEventCreate(&e0)); PMX_HIP(hipEventCreate(&e1));
         PMX_HIP(hipEventRecord(e0, c->stream));
-        for (int i = 0; i < iters && !rc; ++i) rc = launch_conv(c, a, 1, v, plan);
+        for (int i = 0; i < iters && !rc; ++i) rc = launch_conv(c, a, 1, v_run, plan);
         PMX_HIP(hipEventRecord(e1, c->stream));
         PMX_HIP(hipEventSynchronize(e1));
         float ms = 0.f;
@@ -1596,5 +1654,6 @@ extern "C" int pmx_conv2d(pmx_ctx* c, const float* x, const float* w, const floa
         if (e != hipSuccess) { pmx_set_error("pmx_conv2d: %s", hipGetErrorString(e)); rc = PMX_ERR_HIP; }
     }
     (void)hipFree(d_x); (void)hipFree(d_xn); (void)hipFree(d_w); (void)hipFree(d_b); (void)hipFree(d_y); (void)hipFree(d_yn);
+    if (d_w3) (void)hipFree(d_w3);
     return rc;
 }

@@ -116,12 +116,13 @@ struct ConvVariant {
     const char* name;
 };
 // picks a kernel variant for (ksize, cout, B*H*W); returns index into the variant table
-int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen, int pool, int cin);
+int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen, int pool, int cin, int bf16x3);
 const ConvVariant& conv_variant(int idx);
 int conv_num_variants();
 // launches the variant; groups = 1 or 2 (blockIdx.z)
 int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream);
 void conv_set_min_lds(int bytes);
+int conv_bf16x3_twin(int variant);      // the bf16x3 kernel with the geometry of a v6 variant, or -1
 void conv_set_num_cus(int n);     // compute units of the device the contexts run on (tile / kernel selection heuristics)
 // packed weight geometry helpers
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }

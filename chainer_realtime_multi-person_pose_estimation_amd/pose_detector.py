@@ -33,7 +33,7 @@ from .entity import JointType, params
 
 class PoseDetector(object):
     def __init__(self, arch=None, weights_file=None, model=None, device=-1, precise=False, weights=None,
-                 max_batch=1, max_size=None, gpu_branch_peaks=False):
+                 max_batch=1, max_size=None, gpu_branch_peaks=False, precision='f32'):
         self.arch = arch
         self.precise = precise
         self.device = device
@@ -57,6 +57,10 @@ class PoseDetector(object):
         mh, mw = (size, size) if max_size is None else max_size
         self._weights = w
         self._gpu_branch_peaks = bool(gpu_branch_peaks)
+        if precision not in ('f32', 'bf16x3'):
+            raise ValueError("precision must be 'f32' (default: the fp32 FMA chain the parity tests specify) or 'bf16x3' (large batches: "
+                             "3x3 / 7x7 layers on the bf16 matrix cores with three-term splits, fp32-grade accuracy, ~1.7x the throughput)")
+        self._precision = precision
         self.engine = None
         self._make_engine(max_batch, mh, mw)
 
@@ -72,6 +76,8 @@ class PoseDetector(object):
             old.close()
         elif self._weights is not None:
             self.engine.set_weights(self._weights)
+        if self._precision == 'bf16x3':
+            self.engine.set_option('precision', 1)
         if self._gpu_branch_peaks:
             # the reference's own GPU branch of compute_peaks_from_heatmaps (:111-133): 17x17 un-normalised kernel, zero
             # padding, '>=' NMS -- NOT the golden CPU semantics; off by default

@@ -96,6 +96,10 @@ int pmx_synchronize(pmx_ctx* ctx);                    /* cuda.get_device_from_id
  *   "kernel_gen" 1 | 5 | 6     conv kernel generation: 1 = LDS-staged weights (v1) everywhere, 5 = v5 for 3x3 / 7x7,
  *                              6 = default (v6 / conv1_1 kernel where they apply, else v5); all compute identical bits
  *   "force_variant_k1|k3|k7"   force one entry of the conv variant table for that kernel size (-1 = automatic)
+ *   "precision" 0 | 1          0 (default): every convolution is the fp32 FMA chain the parity tests specify.  1: the 3x3 / 7x7
+ *                              layers that run on the one-block-per-CU kernels use the bf16 matrix cores with every fp32 value
+ *                              split into three bf16 terms (six products, fp32 accumulate): fp32-grade accuracy, 2.67x the
+ *                              matrix rate, results equal to the fp32 path only to summation-order-sized noise
  *   "fuse_pairs" 1 | 0         the two 1x1 layers that end every stage as one launch (default) or as two; identical bits
  *   "ksplit" 0 | 1 | n         split-K of the 3x3 / 7x7 launches that cannot fill the chip (single images): 0 = automatic,
  *                              1 = never, n = n K slices wherever split-K applies.  The slices are combined in a fixed

@@ -1,0 +1,92 @@
+"""GPU: the opt-in bf16x3 mode ("precision" = 1): 3x3 / 7x7 layers of large batches on the bf16 matrix cores, every fp32 value
+split into three bf16 terms (hi + mid + lo), six products, fp32 accumulation.  It is NOT the fp32 FMA chain of the default
+path (no bit-exact oracle); the bar is fp32-GRADE accuracy: each convolution as close to a float64 reference as the fp32
+path is (within a small factor), whole-network maps within 1e-4 of the reference goldens, and the detector's results on the
+reference's own images unchanged."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, pkg
+from test_reference_network import load_e2e
+
+pytestmark = pytest.mark.gpu
+
+
+def _f64_conv(x, w, b, relu, pool):
+    import torch
+    with torch.no_grad():
+        y = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
+                                       padding=w.shape[-1] // 2)
+        if relu:
+            y = torch.relu(y)
+        if pool:
+            y = torch.nn.functional.max_pool2d(y, 2, 2)
+    return y.numpy()
+
+
+@pytest.mark.parametrize('cin,h,w,cout,k,pool,force', [
+    (128, 46, 46, 128, 7, False, 17), (185, 13, 46, 256, 7, False, 17), (48, 20, 46, 128, 7, False, 21),      # 7x7: 17- and 9-tile blocks
+    (256, 24, 92, 256, 3, False, 18), (128, 24, 92, 128, 3, True, 19), (64, 30, 46, 128, 3, False, 18),       # 3x3, pooled, 4 input chunks
+    (100, 14, 46, 200, 3, True, 23)])                                                                          # partial chunk / channels
+def test_bf16x3_conv_is_fp32_grade(native, cin, h, w, cout, k, pool, force):
+    eng = native.Engine(0, max_batch=3, max_h=368, max_w=368)
+    rng = np.random.default_rng(cin + h)
+    x = rng.standard_normal((3, cin, h, w)).astype('f')
+    wt = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype('f')
+    b = rng.standard_normal(cout).astype('f')
+    ref = _f64_conv(x, wt, b, True, pool)
+    eng.set_option('ksplit', 1)
+    eng.set_option('force_variant_k%d' % k, force)
+    y32 = eng.conv2d(x, wt, b, relu=True, pool=pool)
+    eng.set_option('precision', 1)
+    y3 = eng.conv2d(x, wt, b, relu=True, pool=pool)
+    eng.close()
+    scale = np.abs(ref).max()
+    e32, e3 = np.abs(y32 - ref).max() / scale, np.abs(y3 - ref).max() / scale
+    assert np.isfinite(y3).all()
+    assert not np.array_equal(y3, y32), 'the bf16x3 kernel did not run'
+    assert e3 <= 3e-6 and e3 <= 3 * e32 + 2e-7, (e32, e3)          # as close to float64 as the fp32 FMA chain is
+
+
+def test_bf16x3_network_matches_reference_golden_and_fp32_path(native):
+    """batch 32 x 368 x 368 (the shapes the bf16x3 kernels are chosen for): the kernels really run, the maps stay within 1e-4 of the
+    fp32 path (summation-order-sized noise through 92 layers)."""
+    W = pkg('weights')
+    eng = native.Engine(0, max_batch=32, max_h=368, max_w=368)
+    eng.set_weights(W.synthetic_weights(0))
+    imgs = np.random.default_rng(3).integers(0, 256, (32, 368, 368, 3), dtype=np.uint8)
+    eng.forward_u8(imgs)
+    p32, h32 = eng.get_maps()
+    eng.set_option('precision', 1)
+    eng.profile_enable(True)
+    eng.forward_u8(imgs)
+    names = {e['kernel'] for e in eng.profile()}
+    eng.profile_enable(False)
+    p3, h3 = eng.get_maps()
+    eng.close()
+    assert sum('bf16x3' in k for k in names) >= 3, names
+    assert np.abs(p3 - p32).max() <= 1e-4 * max(1.0, np.abs(p32).max())
+    assert np.abs(h3 - h32).max() <= 1e-4 * max(1.0, np.abs(h32).max())
+
+
+@pytest.mark.parametrize('name', ['e2e_person', 'e2e_people'])
+def test_bf16x3_detector_on_reference_images(native, name):
+    """The reference's own images replicated to a batch of 32 (so that the bf16x3 kernels are selected): peak indices and poses
+    equal the reference run's, scores within 1e-4."""
+    PD = pkg('pose_detector')
+    g = load_e2e(name)
+    det = PD.PoseDetector(weights=g['weights'], device=0, max_batch=32, precision='bf16x3')
+    det.engine.profile_enable(True)
+    out = det.detect_batch([g['img']] * 32)
+    names = {e['kernel'] for e in det.engine.profile()}
+    det.engine.profile_enable(False)
+    assert any('bf16x3' in k for k in names), names
+    peaks = det.engine.peaks(31)
+    det.engine.close()
+    assert peaks.shape == g['all_peaks'].shape and np.array_equal(peaks[:, [0, 1, 2, 4]], g['all_peaks'][:, [0, 1, 2, 4]])
+    assert np.abs(peaks[:, 3] - g['all_peaks'][:, 3]).max() <= 1e-4
+    for poses, scores in (out[0], out[31]):
+        assert np.array_equal(np.asarray(poses), g['poses'])
+        assert np.abs(np.asarray(scores) - g['scores']).max() <= 1e-4

@@ -63,6 +63,9 @@ files = hwmon_files()
 print('hwmon files:', files, flush=True)
 print('rocm-smi idle:', json.dumps(smi_once())[:600], flush=True)
 eng = native.Engine(0, max_batch=32, max_h=368, max_w=368)
+if '--bf16x3' in sys.argv:
+    eng.set_option('precision', 1)
+    print('precision = bf16x3 (v7 kernels where a v6 kernel would run)', flush=True)
 rng = np.random.default_rng(0)
 SHAPES = [  # name, cin, H, W, cout, k, pool
     ('conv1_2  64->64   368 pool', 64, 368, 368, 64, 3, True), ('conv2_1  64->128  184', 64, 184, 184, 128, 3, False),

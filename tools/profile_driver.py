@@ -23,6 +23,7 @@ ap.add_argument('--k7', type=int, default=-1, help='force a 7x7 kernel variant')
 ap.add_argument('--k3', type=int, default=-1)
 ap.add_argument('--gen', type=int, default=0, help='kernel generation (0 = library default)')
 ap.add_argument('--profile-json', default=None)
+ap.add_argument('--precision', type=int, default=0, help='1 = bf16x3 kernels where a v6 kernel would run')
 a = ap.parse_args()
 native = importlib.import_module(PKG + '.native')
 weights_mod = importlib.import_module(PKG + '.weights')
@@ -39,6 +40,8 @@ eng.set_option('force_variant_k7', a.k7)
 eng.set_option('force_variant_k3', a.k3)
 if a.gen:
     eng.set_option('kernel_gen', a.gen)
+if a.precision:
+    eng.set_option('precision', a.precision)
 imgs = np.random.default_rng(1).integers(0, 256, (B, S, S, 3), dtype=np.uint8)
 if a.profile_json:
     eng.profile_enable(True)
