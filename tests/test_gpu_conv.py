@@ -308,3 +308,38 @@ def test_fused_1x1_pairs_equal_separate_layers_bitwise(native, arch, B, hw):
         assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     else:
         assert np.array_equal(outs[0], outs[1])
+
+
+@settings(max_examples=_FUZZ or 20, derandomize=not _FUZZ, deadline=None, database=None,
+          suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(seed=st.integers(0, 10 ** 6), k=st.sampled_from([3, 7]), B=st.integers(1, 2), h=st.integers(2, 24), w=st.integers(2, 40),
+       nch=st.integers(2, 9), cout=st.sampled_from([64, 128, 192]), pool=st.booleans(), cuts=st.lists(st.integers(1, 8), min_size=1, max_size=4))
+def test_random_split_k_plans_bit_exact(engine, seed, k, B, h, w, nch, cout, pool, cuts):
+    """Random explicit slice plans (uneven, any order) on random shapes: the slice kernels + the combine kernel equal the plain-C
+    oracle with the same plan, bit for bit."""
+    from oracle import conv_fma_ref as R
+    # a plan = chunk counts >= 1 summing to nch
+    sizes, left = [], nch
+    for c in cuts:
+        if left <= 1:
+            break
+        s = min(c, left - 1)
+        sizes.append(s)
+        left -= s
+    sizes.append(left)
+    if len(sizes) < 2:
+        sizes = [nch - 1, 1]
+    if pool:
+        h, w = 2 * ((h + 1) // 2), 2 * ((w + 1) // 2)
+    cin = 16 * nch - int(seed % 5)          # partial last chunk now and then
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, cin, h, w)).astype('f')
+    wt = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype('f')
+    b = rng.standard_normal(cout).astype('f')
+    engine.set_option('kernel_gen', 5)
+    engine.set_option('ksplit_plan', int(''.join(str(v) for v in sizes)))
+    y = engine.conv2d(x, wt, b, relu=True, pool=pool)
+    engine.set_option('ksplit', 0)
+    engine.set_option('kernel_gen', 6)
+    ref = R.conv_fma(x, wt, b, relu=True, pool=pool, splitk=sizes)
+    assert np.array_equal(y, ref), (sizes, np.abs(y - ref).max())
