@@ -246,7 +246,7 @@ struct pmx_ctx {
     float* sk_zero_bias = nullptr;
     // timing / profiling
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    bool prof_on = false;
+    int prof_on = 0;                 // 0 off | 1 every launch | 2 only the 7x7 convolutions (the dominant kernel: fewest events in a timed region)
     std::vector<ProfEntry> prof;
     std::map<std::string, int> prof_index;
     std::vector<ProfPending> pending;
@@ -617,7 +617,8 @@ static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float
     SplitPlan plan = conv_pick_ksplit(v, H, W, B, groups, L0.cout_pad, L0.nch, pool, c->opt_ksplit);
     if (L0.cout % 4 != 0 || ldc % 4 != 0 || (groups == 2 && c->layers[li1].cout != L0.cout)) plan.S = 1;
     int rc;
-    if (c->prof_on) {
+    const bool prof_this = c->prof_on == 1 || (c->prof_on == 2 && L0.ks == 7);
+    if (prof_this) {
         const double bytes = 4.0 * B * H * W * ((double)L0.cin * groups + (double)L0.cout * groups / (pool ? 4 : 1));
         std::string kn = conv_variant(v).name;
         if (plan.S > 1) {       // "/k<chunks of slice 0>-<slice 1>-...": the K slices (+ the combine kernel) are part of the launch
@@ -627,7 +628,7 @@ static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float
         if ((rc = prof_begin(c, std::string(label) + "|" + kn, flops, bytes))) return rc;
     }
     if ((rc = launch_conv(c, a, groups, v, plan))) return rc;
-    return prof_end(c);
+    return prof_this ? prof_end(c) : PMX_OK;
 }
 
 // the two 1x1 layers that end a stage (A: 128 -> cmid + ReLU, B: cmid -> cout [+ ReLU]) as ONE launch when the shapes allow
@@ -657,7 +658,7 @@ static int run_pair(pmx_ctx* c, const char* labelA, const char* labelB, int a0, 
         flops += 2.0 * B * H * W * ((double)A.cout * A.cin + (double)Bl.cout * Bl.cin);
     }
     p.npix = (long long)B * H * W; p.lda = lda; p.ldc = ldc; p.cmid = LA.cout; p.cout_pad = LB.cout_pad; p.relu2 = reluB;
-    if (c->prof_on) {
+    if (c->prof_on == 1) {
         const std::string kn = "conv1x1_pair_c" + std::to_string(LA.cout) + "_n" + std::to_string(LB.cout_pad);
         if ((rc = prof_begin(c, std::string(labelA) + "+" + labelB + "|" + kn, flops, 4.0 * B * H * W * groups * (LA.cin + LB.cout)))) return rc;
     }
@@ -798,7 +799,7 @@ extern "C" int pmx_forward_u8(pmx_ctx* c, const uint8_t* img, int B, int H, int 
         PMX_HIP(hipMemcpyAsync(c->u8_tmp, img, (size_t)B * H * W * 3, hipMemcpyHostToDevice, c->stream));
         d = c->u8_tmp;
     }
-    if ((rc = prof_begin(c, "prep_u8|prep_u8", 0, (double)B * H * W * (3 + 64)))) return rc;
+    if (c->prof_on == 1 && (rc = prof_begin(c, "prep_u8|prep_u8", 0, (double)B * H * W * (3 + 64)))) return rc;
     if ((rc = launch_prep_u8(d, c->in16, B, H, W, c->kind == NET_POSE ? 255.0f : 256.0f, c->stream))) return rc;
     if ((rc = prof_end(c))) return rc;
     return forward_from_in16(c, B, H, W);
@@ -872,7 +873,7 @@ extern "C" int pmx_forward_u8_resized(pmx_ctx* c, const uint8_t* img, int B, int
     make_resize_table(h, src_h, tab.data() + 4 * w);
     PMX_HIP(hipStreamSynchronize(c->stream));     // the table buffer may still be in use by a queued resize
     PMX_HIP(hipMemcpy(c->rs_tab, tab.data(), ntab * sizeof(int), hipMemcpyHostToDevice));
-    if ((rc = prof_begin(c, "resize_u8|resize_linear_u8", 0, (double)nsrc + (double)B * h * w * 3))) return rc;
+    if (c->prof_on == 1 && (rc = prof_begin(c, "resize_u8|resize_linear_u8", 0, (double)nsrc + (double)B * h * w * 3))) return rc;
     if ((rc = launch_resize_linear_u8(d, c->u8_tmp, c->rs_tab, c->rs_tab + 4 * w, B, src_h, src_w, h, w, c->stream))) return rc;
     if ((rc = prof_end(c))) return rc;
     return pmx_forward_u8(c, c->u8_tmp, B, h, w, 1);
@@ -1059,7 +1060,7 @@ extern "C" int pmx_postprocess(pmx_ctx* c, int B, int map_h, int map_w, double i
         dscale = c->d_scale;
     }
     rc = pp_launch(m, c->tab, c->pp, B, map_h, map_w, img_len, dscale, c->opt_keep_smoothed && c->pp.smoothed, c->stream,
-                   c->prof_on ? pp_prof_cb : nullptr, c);
+                   c->prof_on == 1 ? pp_prof_cb : nullptr, c);
     if (rc) return rc;
     c->pp_valid = true; c->pp_final = false; c->pp_B = B; c->pp_h = map_h; c->pp_w = map_w;
     c->pp_maps = m; c->pp_img_len = img_len; c->pp_has_scale = scale_xy != nullptr;
@@ -1553,7 +1554,7 @@ extern "C" int pmx_profile_enable(pmx_ctx* c, int on)
     PMX_CHECK(c, PMX_ERR_INVALID, "null ctx");
     PMX_DEV(c);
     int rc = prof_collect(c);
-    c->prof_on = on != 0;
+    c->prof_on = on < 0 ? 0 : (on > 2 ? 1 : on);
     return rc;
 }
 extern "C" int pmx_profile_reset(pmx_ctx* c)

@@ -453,7 +453,8 @@ class Engine(object):
         return ms.value
 
     def profile_enable(self, on=True):
-        self._check(self.lib.pmx_profile_enable(self._ctx, 1 if on else 0))
+        """True / 1: HIP-event pairs around every kernel launch; 2: only around the 7x7 convolutions (dominant kernel)."""
+        self._check(self.lib.pmx_profile_enable(self._ctx, int(on)))
 
     def profile_reset(self):
         self._check(self.lib.pmx_profile_reset(self._ctx))

@@ -192,7 +192,8 @@ int pmx_get_smoothed(pmx_ctx* ctx, int image, int joint, float* out, int map_h, 
  * HIP-event timing on the stream the kernels are launched on. */
 int pmx_timer_start(pmx_ctx* ctx);
 int pmx_timer_stop(pmx_ctx* ctx, double* ms);          /* synchronises */
-int pmx_profile_enable(pmx_ctx* ctx, int on);          /* per-launch event pairs around every kernel */
+int pmx_profile_enable(pmx_ctx* ctx, int on);          /* 1: event pairs around every kernel launch; 2: only around the 7x7
+                                                          convolutions (the dominant kernel; fewest events inside a timed region) */
 int pmx_profile_reset(pmx_ctx* ctx);
 int pmx_profile_count(pmx_ctx* ctx, int* n);
 int pmx_profile_entry(pmx_ctx* ctx, int i, char* name, int name_cap, double* total_ms,
