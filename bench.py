@@ -449,9 +449,19 @@ def bf16x3_mode(eng, torch, dev, d_imgs, B, S, map_s, steps, frames=256):
                 st['max_abs_person_score_diff'] = max(st['max_abs_person_score_diff'], float(np.abs(r0['scores'] - r1['scores']).max()))
         for m0, m1 in zip(res[0][2], res[1][2]):
             st['max_rel_map_diff'] = max(st['max_rel_map_diff'], float(np.abs(m0 - m1).max() / max(1e-30, np.abs(m0).max())))
+    # single image in this mode (v8 small-tile kernels + K slices)
+    eng.set_option('precision', 1)
+    for _ in range(3):
+        eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(1, S, S), map_h=map_s, map_w=map_s)
+        eng.results()
+    t1 = time.perf_counter()
+    for _ in range(30):
+        eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(1, S, S), map_h=map_s, map_w=map_s)
+        eng.results()
+    one_ms = (time.perf_counter() - t1) / 30 * 1e3
     eng.set_option('precision', 0)
     flop = FLOP_PER_FRAME * (S * S / (368.0 * 368.0))
-    return {'value': B * steps / dt, 'unit': 'frames/s', 'ms_per_step': dt / steps * 1e3, 'steps': steps, 'dtype': 'bf16x3/f32acc',
+    return {'value': B * steps / dt, 'single_image_ms_per_call': one_ms, 'unit': 'frames/s', 'ms_per_step': dt / steps * 1e3, 'steps': steps, 'dtype': 'bf16x3/f32acc',
             'fp32_equivalent_tflops': flop * B * steps / dt / 1e12,
             'note': 'opt-in mode, never the headline: fp32 values as hi + mid + lo bf16, products hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid on '
                     'v_mfma_f32_32x32x16_bf16 with fp32 accumulation; conv1_1, conv1_2 and the 1x1 pairs stay on the fp32 MFMA',

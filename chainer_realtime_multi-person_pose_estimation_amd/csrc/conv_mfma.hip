@@ -1031,6 +1031,173 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_kernel(const ConvArgs a)
     }
 }
 
+// ---- v8: the bf16x3 arithmetic of v7 on the small tiles of v5 (single images / small batches; split-K capable) ------------------
+// Block = 8 x 8 pixels x 64 channels, 2 x 2 waves of one 32 x 32 tile each (the v5 "small" geometry, 2 blocks per CU), halo
+// (8 + KS - 1)^2 pixels x [3 planes x 16 ch bf16] at the 112-byte pitch, double-buffered, converted from fp32 while it is staged.
+// With one tile per wave a tap is only 6 MFMAs = 192 cycles, less than an L2 round trip: the weight fragments of a tap (3 planes)
+// are fetched RB taps ahead into a register ring, the A fragments one tap ahead.  All KS * KS taps of a chunk are unrolled.
+// K slices / slabs / combine kernel exactly as in the v5 kernels (ConvArgs::ksplit, kbounds, slab_stride).
+template <int KS>
+__global__ __launch_bounds__(256, 2) void conv_bf16x3_small_kernel(const ConvArgs a)
+{
+    using C = ConvCfg<KS, 8, 8, 64, 16, 2, 2>;
+    constexpr int TW = 8, CK = 16, PITCH = 112, T = KS * KS, RB = 8, RA = 3;      // weight ring: RB - 1 taps ahead (L2); A ring: RA - 1 taps ahead (LDS)
+    constexpr int IN_BYTES = C::HALO_H * C::HALO_W * PITCH;
+    constexpr int NHF = (C::HALO_H * C::HALO_W * (CK / 4) + 255) / 256;
+    extern __shared__ float4 smem4[];
+    char* const s_in = reinterpret_cast<char*>(smem4);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, li = lane & 31, kh = lane >> 5;
+    const int kslice = a.ksplit > 1 ? (a.ngroups > 1 ? (int)blockIdx.z >> 1 : (int)blockIdx.z) : 0;
+    const int zgrp = a.ksplit > 1 ? (a.ngroups > 1 ? (int)blockIdx.z & 1 : 0) : (int)blockIdx.z;
+    const bool g1 = zgrp != 0;
+    ConvGroupArgs G;
+    G.in = g1 ? a.g[1].in : a.g[0].in;
+    G.w = g1 ? a.g[1].w : a.g[0].w;              // bf16x3 pack
+    G.bias = g1 ? a.g[1].bias : a.g[0].bias;
+    G.out = (g1 ? a.g[1].out : a.g[0].out) + (size_t)kslice * a.slab_stride;
+    G.cout = g1 ? a.g[1].cout : a.g[0].cout;
+    const int H = a.H, W = a.W;
+    const int c0 = a.ksplit > 1 ? (int)((a.kbounds >> (8 * kslice)) & 0xffull) : 0;
+    const int c1 = (a.ksplit > 1 && kslice + 1 < a.ksplit) ? (int)((a.kbounds >> (8 * (kslice + 1))) & 0xffull) : a.nch;
+
+    int tile;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int bimg = tile / tiles_per_img;
+    const int trem = tile - bimg * tiles_per_img;
+    const int y0 = (trem / a.tiles_x) * 8, x0 = (trem % a.tiles_x) * 8;
+    const int n0 = blockIdx.y * 64;
+    const float* in_b = G.in + (size_t)bimg * H * W * a.lda + c0 * CK;
+    float biasv[1];
+    conv_load_bias<C>(biasv, G.bias, n0, wn, li);
+
+    // this lane's pixel (MFMA row m <-> pixel of 2x2 window m >> 2, as in every other kernel: the pool happens in registers)
+    int a_base;
+    {
+        const int m = wm * 32 + li, q = m >> 2, r = m & 3;
+        const int py = 2 * (q / (TW / 2)) + (r >> 1), px = 2 * (q % (TW / 2)) + (r & 1);
+        a_base = (py * C::HALO_W + px) * PITCH + kh * 16;
+    }
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G.w), 0, 0x7fffffff, 0x00020000);
+    const unsigned b_off = (unsigned)((n0 + wn * 32 + li) * 32 + kh * 16);
+    const unsigned plane_b = (unsigned)a.cout_pad * 32u, panel_b = 3u * plane_b, tap_b = panel_b * (unsigned)a.nch;
+
+    int h_goff[NHF], h_lds[NHF];
+    unsigned h_ok = 0;
+#pragma unroll
+    for (int r = 0; r < NHF; ++r) {
+        const int f = tid + r * 256;
+        const bool slot = f < C::HALO_H * C::HALO_W * (CK / 4);
+        const int hp = slot ? f / (CK / 4) : 0, c4 = f % (CK / 4);
+        const int hy = hp / C::HALO_W, hx = hp - hy * C::HALO_W;
+        const int gy = y0 + hy - C::PADK, gx = x0 + hx - C::PADK;
+        const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+        h_goff[r] = (cy * W + cx) * a.lda + c4 * 4;
+        h_lds[r] = slot ? hp * PITCH + c4 * 8 : -1;
+        h_ok |= (slot && inb) ? (1u << r) : 0u;
+    }
+    auto halo_store = [&](char* buf, const float4 (&hv)[NHF]) {
+#pragma unroll
+        for (int r = 0; r < NHF; ++r) {
+            float4 v = hv[r];
+            if (!((h_ok >> r) & 1)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (h_lds[r] >= 0) split3_store(buf + h_lds[r], v);
+        }
+    };
+
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[0][0][i] = 0.f;
+
+    // weight ring: tap t of the running tap sequence sits in slot t % RB
+    f32x4 bw[RB][3];
+    auto load_b = [&](f32x4 (&dst)[3], unsigned soff) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) dst[pl] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off, soff + pl * plane_b, 0));
+    };
+    const unsigned first_b = (unsigned)c0 * panel_b;
+#pragma unroll
+    for (int i = 0; i < RB - 1; ++i) load_b(bw[i], first_b + (unsigned)i * tap_b);      // taps 0 .. RB-2 of the first chunk (T >= RB - 1)
+    {
+        float4 hv[NHF];
+#pragma unroll
+        for (int r = 0; r < NHF; ++r) hv[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r]);
+        halo_store(s_in, hv);
+    }
+    __syncthreads();
+
+    f32x4 ar[RA][3];
+    for (int ch = c0; ch < c1; ++ch) {
+        const char* cur = s_in + ((ch - c0) & 1) * IN_BYTES;
+        char* nxt = s_in + ((ch - c0 + 1) & 1) * IN_BYTES;
+        const bool more_ch = ch + 1 < c1;
+        float4 hreg[NHF];
+        {
+            const int cn = (more_ch ? ch + 1 : ch) - c0;
+#pragma unroll
+            for (int r = 0; r < NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + cn * CK);
+        }
+#pragma unroll
+        for (int i = 0; i < RA - 1; ++i) {          // taps 0 .. RA-2 of this chunk
+            const int toff = ((i / KS) * C::HALO_W + i % KS) * PITCH;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) ar[i][pl] = *reinterpret_cast<const f32x4*>(cur + a_base + toff + pl * 32);
+        }
+        const unsigned chunk_b = (unsigned)ch * panel_b;
+        // T % RB taps shift the ring position from chunk to chunk; the ring index is kept compile-time by rotating the
+        // registers at the chunk end (3 * (T % RB) moves per chunk)
+#pragma unroll
+        for (int tap = 0; tap < T; ++tap) {
+            {   // weights RB - 1 taps ahead: a later tap of this chunk, or an early tap of the next chunk (or harmlessly this one again)
+                const int tn = tap + RB - 1;
+                unsigned so;
+                if (tn < T) so = chunk_b + (unsigned)tn * tap_b;
+                else so = (more_ch ? chunk_b + panel_b : chunk_b) + (unsigned)(tn - T) * tap_b;
+                load_b(bw[tn % RB], so);
+            }
+            {   // A fragments RA - 1 taps ahead
+                const int tx = tap + RA - 1 < T ? tap + RA - 1 : T - 1;
+                const int toff = ((tx / KS) * C::HALO_W + tx % KS) * PITCH;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) ar[(tap + RA - 1) % RA][pl] = *reinterpret_cast<const f32x4*>(cur + a_base + toff + pl * 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 (&A)[3] = ar[tap % RA];
+            const f32x4 (&Bf)[3] = bw[tap % RB];
+            f32x16& c = acc[0][0];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[1]), __builtin_bit_cast(bf16x8, Bf[1]), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[2]), __builtin_bit_cast(bf16x8, Bf[0]), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[0]), __builtin_bit_cast(bf16x8, Bf[2]), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[1]), __builtin_bit_cast(bf16x8, Bf[0]), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[0]), __builtin_bit_cast(bf16x8, Bf[1]), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[0]), __builtin_bit_cast(bf16x8, Bf[0]), c, 0, 0, 0);
+        }
+        // rotate the weight ring so that the next chunk's tap 0 is in slot 0 again: slot (T + i) % RB -> slot i
+        if (T % RB) {
+            f32x4 tmp[RB][3];
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) tmp[i][pl] = bw[(T + i) % RB][pl];
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bw[i][pl] = tmp[i][pl];
+        }
+        if (more_ch) {
+            halo_store(nxt, hreg);
+            __syncthreads();
+        }
+    }
+    conv_epilogue<C, TW>(acc, biasv, a, G.out, G.cout, bimg, y0, x0, n0, wm, wn, li, kh);
+}
+
 // ---- conv1_1: 3 input channels ---------------------------------------------------------------------------------------
 // The generic kernels spend a whole 16-channel chunk (8 MFMA k-pairs per tap) on 3 real channels.  Here K = 27 is packed
 // tap-major / channel-minor into 14 k-pairs (the 28th k is zero) - the order in which the generic kernels meet the three
@@ -1190,10 +1357,13 @@ static const ConvVariant g_variants[] = {
     {7, 9, 32, 128, 16, "conv7x7_v7bf16x3_t9x32_n128"},     // 30
     {3, 9, 32, 128, 16, "conv3x3_v7bf16x3_t9x32_n128"},     // 31
     {3, 9, 32, 128, 16, "conv3x3_v7bf16x3p_t9x32_n128"},    // 32
+    // v8: bf16x3 on the small v5 tiles (single images / small batches, split-K capable)
+    {7, 8, 8, 64, 16, "conv7x7_v8bf16x3_t8x8_n64"},         // 33
+    {3, 8, 8, 64, 16, "conv3x3_v8bf16x3_t8x8_n64"},         // 34
 };
 enum { V5_K7_STRIP = 10, V5_K3_STRIP = 11, V5_K7 = 12, V5_K3 = 13, V5_K3_N64 = 14, V5_K7_SMALL = 15, V5_K3_SMALL = 16,
        V6_K7 = 17, V6_K3 = 18, V6_K3_POOL = 19, C3 = 20, V6M9_K7 = 21, V6M9_K3 = 22, V6M9_K3_POOL = 23, V5T_K7 = 24, V5T_K3 = 25, V5T_K3_N64 = 26,
-       V7_K7 = 27, V7_K3 = 28, V7_K3_POOL = 29, V7M9_K7 = 30, V7M9_K3 = 31, V7M9_K3_POOL = 32 };
+       V7_K7 = 27, V7_K3 = 28, V7_K3_POOL = 29, V7M9_K7 = 30, V7M9_K3 = 31, V7M9_K3_POOL = 32, V8_K7_SMALL = 33, V8_K3_SMALL = 34 };
 
 // the bf16x3 twin of a v6 variant (same block geometry), or -1
 int conv_bf16x3_twin(int v)
@@ -1201,6 +1371,7 @@ int conv_bf16x3_twin(int v)
     switch (v) {
         case V6_K7: return V7_K7; case V6_K3: return V7_K3; case V6_K3_POOL: return V7_K3_POOL;
         case V6M9_K7: return V7M9_K7; case V6M9_K3: return V7M9_K3; case V6M9_K3_POOL: return V7M9_K3_POOL;
+        case V5_K7_SMALL: return V8_K7_SMALL; case V5_K3_SMALL: return V8_K3_SMALL;
     }
     return -1;
 }
@@ -1262,7 +1433,7 @@ int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen
     return small ? 7 : (cout <= 64 ? 4 : 3);
 }
 
-static bool is_v5_variant(int v) { return (v >= V5_K7_STRIP && v <= V5_K3_SMALL) || (v >= V5T_K7 && v <= V5T_K3_N64); }
+static bool is_v5_variant(int v) { return (v >= V5_K7_STRIP && v <= V5_K3_SMALL) || (v >= V5T_K7 && v <= V5T_K3_N64) || v == V8_K7_SMALL || v == V8_K3_SMALL; }
 
 // Split-K for launches that cannot fill the chip (single images): nblk blocks over ncu CUs leave CUs idle or quantise badly
 // (144 blocks of a 7x7 layer at batch 1: 112 CUs idle; 288 blocks of conv4_2: a second round on 32 CUs).  With S K-slices
@@ -1688,9 +1859,35 @@ static int launch_v7(const ConvArgs& a0, int groups, hipStream_t stream)
     return PMX_OK;
 }
 
+template <int KS>
+static int launch_v8(const ConvArgs& a0, int groups, hipStream_t stream)
+{
+    using C = ConvCfg<KS, 8, 8, 64, 16, 2, 2>;
+    ConvArgs a = a0;
+    a.tiles_x = (a.W + 7) / 8;
+    a.tiles_y = (a.H + 7) / 8;
+    PMX_CHECK(a.cout_pad % 64 == 0, PMX_ERR_INVALID, "conv: cout_pad %d not a multiple of 64", a.cout_pad);
+    PMX_CHECK(!a.pool || (a.H % 2 == 0 && a.W % 2 == 0), PMX_ERR_INVALID, "conv: pooled layer needs even H, W");
+    PMX_CHECK((long long)a.H * a.W * a.lda < (1ll << 31), PMX_ERR_INVALID, "conv: image too large for 32-bit offsets");
+    if (a.ksplit < 1) a.ksplit = 1;
+    a.ngroups = groups;
+    PMX_CHECK(a.ksplit <= a.nch && a.ksplit <= 8, PMX_ERR_INVALID, "conv: %d K slices for %d chunks", a.ksplit, a.nch);
+    auto kern = conv_bf16x3_small_kernel<KS>;
+    int lds = 2 * C::HALO_H * C::HALO_W * 112;
+    if (lds < g_v5_lds) lds = g_v5_lds;         // at most two blocks per CU, as for the v5 kernels
+    static bool attr_set[PMX_MAX_DEVICES] = {};
+    if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(kern), attr_set)) return rc;
+    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / 64), (unsigned)(groups * a.ksplit));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
 int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream)
 {
     switch (variant) {
+        case V8_K7_SMALL: return launch_v8<7>(a, groups, stream);
+        case V8_K3_SMALL: return launch_v8<3>(a, groups, stream);
         case V7_K7: return launch_v7<7, 17, 0>(a, groups, stream);
         case V7_K3: return launch_v7<3, 17, 0>(a, groups, stream);
         case V7_K3_POOL: return launch_v7<3, 17, 1>(a, groups, stream);

@@ -523,7 +523,7 @@ extern "C" int pmx_set_layer(pmx_ctx* c, const char* name, const float* w, const
     if (!L.d_b) PMX_HIP(hipMalloc((void**)&L.d_b, bp.size() * sizeof(float)));
     PMX_HIP(hipMemcpy(L.d_w, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice));
     PMX_HIP(hipMemcpy(L.d_b, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (ks > 1 && cpad % 128 == 0) {       // the layers the bf16x3 kernels can take
+    if (ks > 1) {       // the layers the bf16x3 kernels can take (3x3 / 7x7)
         std::vector<uint16_t> w3;
         pack_bf16x3(wp, ks * ks, (int)cmap.size() / CK, cpad, w3);
         if (!L.d_w3) PMX_HIP(hipMalloc(&L.d_w3, w3.size() * sizeof(uint16_t)));
@@ -1619,10 +1619,10 @@ extern "C" int pmx_conv2d(pmx_ctx* c, const float* x, const float* w, const floa
     memset(&a, 0, sizeof a);
     a.g[0].in = d_xn; a.g[0].w = d_w; a.g[0].bias = d_b; a.g[0].out = d_yn; a.g[0].cout = cout;
     a.B = B; a.H = H; a.W = W; a.lda = cin_pad; a.ldc = cout; a.nch = cin_pad / CK; a.cout_pad = cpad; a.relu = relu; a.pool = pool;
-    const int v = conv_pick_variant(ks, cpad, H, W, B, c->opt_force[ks], c->opt_kernel_gen, pool, cin, c->opt_precision == 1 && ks > 1 && cpad % 128 == 0);
+    const int v = conv_pick_variant(ks, cpad, H, W, B, c->opt_force[ks], c->opt_kernel_gen, pool, cin, c->opt_precision == 1 && ks > 1);
     void* d_w3 = nullptr;
     int v_run = v;
-    if (c->opt_precision == 1 && conv_bf16x3_twin(v) >= 0 && ks > 1 && cpad % 128 == 0) {
+    if (c->opt_precision == 1 && conv_bf16x3_twin(v) >= 0 && ks > 1) {
         std::vector<uint16_t> w3;
         pack_bf16x3(wp, ks * ks, cin_pad / CK, cpad, w3);
         PMX_HIP(hipMalloc(&d_w3, w3.size() * sizeof(uint16_t)));

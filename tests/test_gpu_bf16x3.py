@@ -50,6 +50,45 @@ def test_bf16x3_conv_is_fp32_grade(native, cin, h, w, cout, k, pool, force):
     assert e3 <= 3e-6 and e3 <= 3 * e32 + 2e-7, (e32, e3)          # as close to float64 as the fp32 FMA chain is
 
 
+@pytest.mark.parametrize('cin,h,w,cout,k,pool,force,ksplit', [
+    (128, 46, 46, 128, 7, False, 15, 1), (128, 46, 46, 256, 7, False, 15, 4), (192, 20, 30, 128, 7, False, 15, 3),
+    (512, 23, 23, 256, 3, False, 16, 5), (256, 24, 40, 128, 3, True, 16, 2), (70, 9, 13, 64, 3, False, 16, 1)])
+def test_bf16x3_small_tile_kernel_is_fp32_grade(native, cin, h, w, cout, k, pool, force, ksplit):
+    """v8: the bf16x3 arithmetic on the 8 x 8 x 64 tiles of single-image launches, with and without K slices."""
+    eng = native.Engine(0, max_batch=2, max_h=368, max_w=368)
+    rng = np.random.default_rng(cin + h + ksplit)
+    x = rng.standard_normal((1, cin, h, w)).astype('f')
+    wt = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype('f')
+    b = rng.standard_normal(cout).astype('f')
+    ref = _f64_conv(x, wt, b, True, pool)
+    eng.set_option('ksplit', ksplit)
+    eng.set_option('force_variant_k%d' % k, force)
+    y32 = eng.conv2d(x, wt, b, relu=True, pool=pool)
+    eng.set_option('precision', 1)
+    y3 = eng.conv2d(x, wt, b, relu=True, pool=pool)
+    eng.close()
+    scale = np.abs(ref).max()
+    e32, e3 = np.abs(y32 - ref).max() / scale, np.abs(y3 - ref).max() / scale
+    assert np.isfinite(y3).all() and not np.array_equal(y3, y32)
+    assert e3 <= 3e-6 and e3 <= 3 * e32 + 2e-7, (e32, e3)
+
+
+def test_bf16x3_single_image_detector(native):
+    """BASELINE config 2 in the bf16x3 mode: a single 368 x 368 image uses the v8 kernels (+ K slices); result vs the reference run."""
+    PD = pkg('pose_detector')
+    g = load_e2e('e2e_people')
+    det = PD.PoseDetector(weights=g['weights'], device=0, precision='bf16x3')
+    det.engine.profile_enable(True)
+    poses, scores = det(g['img'])
+    names = {e['kernel'] for e in det.engine.profile()}
+    det.engine.profile_enable(False)
+    peaks = det.engine.peaks(0)
+    det.engine.close()
+    assert any('v8bf16x3' in k for k in names), names
+    assert peaks.shape == g['all_peaks'].shape and np.array_equal(peaks[:, [0, 1, 2, 4]], g['all_peaks'][:, [0, 1, 2, 4]])
+    assert np.array_equal(np.asarray(poses), g['poses']) and np.abs(np.asarray(scores) - g['scores']).max() <= 1e-4
+
+
 def test_bf16x3_network_matches_reference_golden_and_fp32_path(native):
     """batch 32 x 368 x 368 (the shapes the bf16x3 kernels are chosen for): the kernels really run, the maps stay within 1e-4 of the
     fp32 path (summation-order-sized noise through 92 layers)."""

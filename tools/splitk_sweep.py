@@ -12,11 +12,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batches', type=int, nargs='+', default=[1, 2, 4])
 ap.add_argument('--ksplit', type=int, nargs='+', default=[1, 0, 2, 4, 8])
 ap.add_argument('--json', default=None)
+ap.add_argument('--precision', type=int, default=0)
 a = ap.parse_args()
 native = importlib.import_module(PKG + '.native')
 W = importlib.import_module(PKG + '.weights')
 eng = native.Engine(0, max_batch=max(a.batches), max_h=368, max_w=368)
 w = W.synthetic_weights(0); eng.set_weights(w)
+if a.precision:
+    eng.set_option('precision', a.precision)
 cal = np.random.default_rng(1234).integers(0, 256, (1, 368, 368, 3), dtype=np.uint8)
 eng.forward_u8(cal); paf, heat = eng.get_maps()
 w = W.calibrate_head(w, paf[0], heat[0]); eng.set_weights({k: w[k] for k in ('Mconv7_stage6_L1', 'Mconv7_stage6_L2')})

@@ -9,11 +9,14 @@ sys.path.insert(0, ROOT)
 PKG = 'chainer_realtime_multi-person_pose_estimation_amd'
 ap = argparse.ArgumentParser()
 ap.add_argument('--batches', type=int, nargs='+', default=[1, 2, 3, 4])
+ap.add_argument('--precision', type=int, default=0)
 a = ap.parse_args()
 native = importlib.import_module(PKG + '.native')
 W = importlib.import_module(PKG + '.weights')
 eng = native.Engine(0, max_batch=max(a.batches), max_h=368, max_w=368)
 eng.set_weights(W.synthetic_weights(0))
+if a.precision:
+    eng.set_option('precision', a.precision)
 
 
 def partitions(n, parts, maxpart):
