@@ -11,6 +11,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
 #include <map>
 
 // ------------------------------------------------------------------------------------------- errors
@@ -236,6 +237,8 @@ struct pmx_ctx {
     // options
     int opt_force[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // by ksize
     int opt_gpu_branch_peaks = 0;    // reference GPU-branch peak extraction (non-golden variant)
+    int opt_kp_flip_x = 0;           // pmx_keypoints: mirror the resized heat maps left-right before the peaks (hand_detector.py:46-47)
+    int tab_flip = 0;
     int opt_keep_smoothed = 0, opt_stop_stage = 6, opt_kernel_gen = 6;
     int opt_precision = 0;           // 0: fp32 MFMA everywhere (the path whose results are specified); 1: bf16x3 kernels where a
                                      // v6 kernel would run (fp32-grade accuracy at 2.67x the matrix rate, NOT the fp32 FMA chain)
@@ -498,6 +501,7 @@ extern "C" int pmx_set_option(pmx_ctx* c, const char* key, int value)
     else if (!strcmp(key, "conv_min_lds")) conv_set_min_lds(value);
     else if (!strcmp(key, "pp_generic")) pp_set_generic(value);
     else if (!strcmp(key, "peaks_gpu_branch")) { c->opt_gpu_branch_peaks = value; c->tab_in_h = -1; }
+    else if (!strcmp(key, "kp_flip_x")) c->opt_kp_flip_x = value != 0;
     else { pmx_set_error("pmx_set_option: unknown key '%s'", key); return PMX_ERR_INVALID; }
     return PMX_OK;
 }
@@ -977,9 +981,9 @@ static void make_grid(int in, int out, std::vector<int>& i0, std::vector<int>& i
     }
 }
 
-static int ensure_tables(pmx_ctx* c, int in_h, int in_w, int out_h, int out_w)
+static int ensure_tables(pmx_ctx* c, int in_h, int in_w, int out_h, int out_w, int flip_x = 0)
 {
-    if (c->tab_in_h == in_h && c->tab_in_w == in_w && c->tab_out_h == out_h && c->tab_out_w == out_w) return PMX_OK;
+    if (c->tab_in_h == in_h && c->tab_in_w == in_w && c->tab_out_h == out_h && c->tab_out_w == out_w && c->tab_flip == flip_x) return PMX_OK;
     const int cap = out_h > out_w ? out_h : out_w;
     PPTables& t = c->tab;
     if (cap > c->tab_cap) {
@@ -996,6 +1000,10 @@ static int ensure_tables(pmx_ctx* c, int in_h, int in_w, int out_h, int out_w)
     std::vector<int> i0, i1; std::vector<double> lo, hi;
     PMX_HIP(hipStreamSynchronize(c->stream));
     make_grid(in_w, out_w, i0, i1, lo, hi);
+    if (flip_x) {       // column x of the mirrored map = column out_w - 1 - x of the resized one: same samples, same arithmetic
+        std::reverse(i0.begin(), i0.end()); std::reverse(i1.begin(), i1.end());
+        std::reverse(lo.begin(), lo.end()); std::reverse(hi.begin(), hi.end());
+    }
     PMX_HIP(hipMemcpy(t.xi0, i0.data(), out_w * sizeof(int), hipMemcpyHostToDevice));
     PMX_HIP(hipMemcpy(t.xi1, i1.data(), out_w * sizeof(int), hipMemcpyHostToDevice));
     PMX_HIP(hipMemcpy(t.xlo, lo.data(), out_w * sizeof(double), hipMemcpyHostToDevice));
@@ -1018,7 +1026,7 @@ static int ensure_tables(pmx_ctx* c, int in_h, int in_w, int out_h, int out_w)
         PMX_HIP(hipMemcpy(t.gauss, c->gauss.data(), c->gauss.size() * sizeof(double), hipMemcpyHostToDevice));
         t.radius = ((int)c->gauss.size() - 1) / 2; t.border_zero = 0; t.nms_ge = 0;
     }
-    c->tab_in_h = in_h; c->tab_in_w = in_w; c->tab_out_h = out_h; c->tab_out_w = out_w;
+    c->tab_in_h = in_h; c->tab_in_w = in_w; c->tab_out_h = out_h; c->tab_out_w = out_w; c->tab_flip = flip_x;
     return PMX_OK;
 }
 
@@ -1334,7 +1342,7 @@ extern "C" int pmx_keypoints(pmx_ctx* c, int B, int out_h, int out_w, double thr
     PMX_CHECK(out_h >= 1 && out_w >= 1 && (long long)out_h * out_w < (1ll << 31), PMX_ERR_INVALID, "pmx_keypoints: bad size");
     PMX_DEV(c);
     int rc;
-    if ((rc = ensure_tables(c, c->cur_fh, c->cur_fw, out_h, out_w))) return rc;
+    if ((rc = ensure_tables(c, c->cur_fh, c->cur_fw, out_h, out_w, c->opt_kp_flip_x))) return rc;
     const int n_ch = c->n_heat - 1;
     const long long fhw = (long long)c->cur_fh * c->cur_fw;
     PPMaps m;

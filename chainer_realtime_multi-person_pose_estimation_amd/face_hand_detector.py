@@ -38,7 +38,7 @@ class _KeypointDetector(object):
         if w is not None:
             self.engine.set_weights(w)
 
-    def _detect(self, img):
+    def _detect(self, img, flip_maps=False):
         img = np.ascontiguousarray(img, dtype=np.uint8)
         h, w, _ = img.shape
         size = params[self.SIZE_KEY]
@@ -51,6 +51,7 @@ class _KeypointDetector(object):
             x = np.array(resized[np.newaxis], dtype=np.float32).transpose(0, 3, 1, 2) / 256 - 0.5     # :32
             hs = self.model(x)
             self.engine.set_heat(np.asarray(getattr(hs[-1], 'data', hs[-1]), dtype=np.float32))
+        self.engine.set_option('kp_flip_x', int(flip_maps))               # cv2.flip(heatmaps, 1) for left hands (hand_detector.py:46-47)
         kp = self.engine.keypoints(h, w, params[self.THRESH_KEY])[0]      # F.resize_images + peaks (:37-38)
         out = []
         for x, y, conf, valid in kp:
@@ -70,15 +71,12 @@ class HandDetector(_KeypointDetector):
     ARCH, SIZE_KEY, THRESH_KEY = 'handnet', 'hand_inference_img_size', 'hand_heatmap_peak_thresh'
 
     def __call__(self, hand_img, fast_mode=False, hand_type="right"):
-        """reference hand_detector.py:28-50: a left hand is mirrored (cv2.flip(img, 1)) before the network and its heat
-        maps are mirrored back before the peaks are taken; the Gaussian and the arg-max commute with the mirror (reflect
-        border, commutative pair sums), so the key points of the mirrored maps are mirrored back instead: x -> W - 1 - x
-        (only the row-major tie order of exactly equal maxima could differ)."""
+        """reference hand_detector.py:28-50: a left hand is mirrored (cv2.flip(img, 1)) before the network and its resized
+        heat maps are mirrored back before the Gaussian and the arg-max -- here on the device (the column tables of the
+        resize are reversed: the same samples, so also the same row-major order among exactly equal maxima)."""
         hand_img = np.asarray(hand_img)
         if hand_type == "left":
-            kps = self._detect(hand_img[:, ::-1])
-            w = hand_img.shape[1]
-            return [None if k is None else [w - 1 - k[0], k[1], k[2]] for k in kps]
+            return self._detect(hand_img[:, ::-1], flip_maps=True)
         return self._detect(hand_img)
 
 

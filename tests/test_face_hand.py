@@ -67,7 +67,21 @@ def test_keypoint_tie_quirk_and_threshold(native):
     assert ref[0] is not None and ref[1] is None
     assert got[0][:2] == ref[0][:2] and got[0][2] == ref[0][2]
     assert got[1] is None
+    # left hand: the reference mirrors the resized maps before the peaks (hand_detector.py:46-47), so the row-major order among
+    # the two exactly equal maxima is taken on the MIRRORED map -- reproduced on the device by reversing the resize columns
+    maps2 = maps.copy()
+    maps2[0, 2, 12, 5] = 8.0
+    maps2[0, 2, 30, 5] = 8.0           # two equal maxima in one column: rows decide, the mirror changes nothing
+    maps2[0, 3, 7, 9] = 8.0
+    maps2[0, 3, 7, 30] = 8.0           # two equal maxima in one row: the mirror swaps their order
+    det2 = D.HandDetector('handnet', model=lambda x: [maps2], device=0)
+    img2 = np.zeros((40, 40, 3), np.uint8)
+    got_l = det2(img2, hand_type='left')
+    ref_l, _ = FH.detect(lambda x: maps2, img2, 0.1, hand_type='left')
+    for c in (0, 2, 3):
+        assert ref_l[c] is not None and got_l[c][:2] == ref_l[c][:2] and got_l[c][2] == ref_l[c][2], (c, got_l[c], ref_l[c])
     det.engine.close()
+    det2.engine.close()
 
 
 @pytest.mark.gpu
