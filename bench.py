@@ -464,7 +464,7 @@ def bf16x3_mode(eng, torch, dev, d_imgs, B, S, map_s, steps, frames=256):
     return {'value': B * steps / dt, 'single_image_ms_per_call': one_ms, 'unit': 'frames/s', 'ms_per_step': dt / steps * 1e3, 'steps': steps, 'dtype': 'bf16x3/f32acc',
             'fp32_equivalent_tflops': flop * B * steps / dt / 1e12,
             'note': 'opt-in mode, never the headline: fp32 values as hi + mid + lo bf16, products hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid on '
-                    'v_mfma_f32_32x32x16_bf16 with fp32 accumulation; conv1_1, conv1_2 and the 1x1 pairs stay on the fp32 MFMA',
+                    'v_mfma_f32_32x32x16_bf16 with fp32 accumulation; conv1_1 and the 1x1 pairs stay on the fp32 MFMA',
             'agreement_with_f32_path': st}
 
 

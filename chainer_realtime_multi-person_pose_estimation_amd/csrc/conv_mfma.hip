@@ -1372,6 +1372,7 @@ int conv_bf16x3_twin(int v)
         case V6_K7: return V7_K7; case V6_K3: return V7_K3; case V6_K3_POOL: return V7_K3_POOL;
         case V6M9_K7: return V7M9_K7; case V6M9_K3: return V7M9_K3; case V6M9_K3_POOL: return V7M9_K3_POOL;
         case V5_K7_SMALL: return V8_K7_SMALL; case V5_K3_SMALL: return V8_K3_SMALL;
+        case V5_K3_N64: case V5T_K3_N64: return V8_K3_SMALL;      // 64-output-channel layers (conv1_2): 2.45 -> 1.87 ms at batch 32
     }
     return -1;
 }
