@@ -124,3 +124,39 @@ def test_hypothesis_postprocess_matches_oracle(engine, seed, n, fh, fw, up, nois
     if n_ref:
         assert np.array_equal(rec['poses'][:n_ref], np.asarray(ref['poses'], dtype=np.float64))
         assert np.allclose(rec['scores'][:n_ref], ref['scores'], rtol=0, atol=1e-9)
+
+
+@settings(max_examples=_FUZZ or 12, derandomize=not _FUZZ, deadline=None, database=None,
+          suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(seed=st.integers(0, 10 ** 6), n=st.integers(1, 14), fh=st.integers(16, 46), fw=st.integers(16, 46), up=st.sampled_from([3, 5, 7]),
+       noise=st.sampled_from([0.0, 0.02, 0.05]), cap_pk=st.integers(1, 12), cap_sub=st.integers(1, 6), cap_ppl=st.integers(1, 4),
+       cap_cand=st.sampled_from([0, 0, 16, 64]))
+def test_hypothesis_capacity_growth_matches_oracle(native, seed, n, fh, fw, up, noise, cap_pk, cap_sub, cap_ppl, cap_cand):
+    """Random crowds through contexts with random TINY capacities (peaks / joint, subsets, people per record, device-memory
+    candidate store): whatever has to grow, however many rounds it takes, the result equals the oracle's."""
+    heat, paf, _ = Fx.synthetic_maps(seed, n, fh, fw, 1.0, 0.9, noise=noise, height_range=(0.3, 0.8), drop_prob=0.2)
+    mh, mw = fh * up, fw * up
+    try:
+        ref = P.postprocess_from_net_output(paf, heat, mh, mw)
+    except IndexError:
+        ref = None
+    e = native.Engine(0, max_batch=1, max_h=64, max_w=64)
+    e.set_capacities(peaks_per_joint=cap_pk, subsets=cap_sub, people=cap_ppl, candidates=cap_cand)
+    e.set_maps(paf[None], heat[None])
+    e.postprocess(mh, mw, img_len=mw)
+    rec = e.results()[0]
+    try:
+        if ref is None:
+            assert rec['status'] & 8
+            return
+        assert rec['status'] == 0
+        assert np.array_equal(e.peaks(0), ref['all_peaks'])
+        subs = e.subsets(0)
+        assert subs.shape == ref['subsets'].shape and np.array_equal(subs[:, :18], ref['subsets'][:, :18])
+        n_ref = len(ref['subsets'])
+        assert rec['n_people'] == n_ref
+        if n_ref:
+            assert np.array_equal(rec['poses'][:n_ref], np.asarray(ref['poses'], dtype=np.float64))
+            assert np.allclose(rec['scores'][:n_ref], ref['scores'], rtol=0, atol=1e-9)
+    finally:
+        e.close()
