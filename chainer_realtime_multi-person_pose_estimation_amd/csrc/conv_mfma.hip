@@ -1282,6 +1282,145 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(const ConvArgs a)
     }
 }
 
+// ---- conv1_1 + conv1_2 in one launch ----------------------------------------------------------------------------------------
+// conv1_1 (3 -> 64) is HBM-bound: it writes 64 channels per input pixel (1.1 GB per batch of 32 at 368 x 368) that conv1_2 reads
+// straight back.  Here a block owns an 8 x 16 tile of conv1_2's (pre-pool) output and first RECOMPUTES conv1_1 on the
+// 10 x 18 halo of that tile from a 12 x 20 x 3 input patch (12 MFMA tiles x 14 k-pairs: +7 % matrix work), bias + ReLU, zero
+// outside the image (= conv1_2's zero padding), into an LDS tile holding all 64 channels; conv1_2 then runs its 4 chunks x 9
+// taps from LDS with no staging and no barrier, weights L2 -> registers one tap ahead, epilogue (bias, ReLU, 2x2 max-pool) as
+// every other kernel.  Both layers walk K exactly like conv3x3_c3_kernel and the v5 kernels -> bit-identical to running them apart.
+// Arguments: a.g[0] = conv1_2 (w, bias, out, cout; in = the 16-channel padded network input), a.g[1].w / .bias = conv1_1's.
+__global__ __launch_bounds__(256, 2) void conv1_fused_kernel(const ConvArgs a)
+{
+    using C = ConvCfg<3, 8, 16, 64, 16, 2, 2>;
+    constexpr int TH = 8, TW = 16, HH = TH + 2, HW = TW + 2, NPX = HH * HW, PH = HH + 2, PW = HW + 2, LDA = 68;
+    __shared__ float s_patch[PH * PW * 3];
+    extern __shared__ float4 smem4[];
+    float* const s_act = reinterpret_cast<float*>(smem4);                  // [192][LDA]: conv1_1 output on the halo, 64 channels
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int H = a.H, W = a.W;
+    int tile;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int bimg = tile / tiles_per_img;
+    const int trem = tile - bimg * tiles_per_img;
+    const int y0 = (trem / a.tiles_x) * TH, x0 = (trem % a.tiles_x) * TW;
+    const float* in_b = a.g[0].in + (size_t)bimg * H * W * a.lda;
+
+    // ---- input patch: 12 x 20 pixels x 3 channels, zero outside the image (conv1_1's padding)
+    for (int f = tid; f < PH * PW; f += 256) {
+        const int py = f / PW, px = f - py * PW;
+        const int gy = y0 - 2 + py, gx = x0 - 2 + px;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = *reinterpret_cast<const float4*>(in_b + ((size_t)gy * W + gx) * a.lda);
+        s_patch[f * 3 + 0] = v.x; s_patch[f * 3 + 1] = v.y; s_patch[f * 3 + 2] = v.z;
+    }
+    // conv1_1 weights of this wave's 32 output channels (column tile ct = wave & 1), K = 27 packed into 14 k-pairs
+    const int ct = wave & 1;
+    float wv[14];
+    int koff[14];
+    {
+        const float* wp = a.g[1].w;                     // packed [tap][1 chunk][64][16]
+#pragma unroll
+        for (int s = 0; s < 14; ++s) {
+            const int k = 2 * s + kh, kk = k < 27 ? k : 26;
+            const float w = wp[(size_t)((kk / 3) * 64 + ct * 32 + li) * 16 + kk % 3];
+            wv[s] = k < 27 ? w : 0.f;
+            const int tap = kk / 3;
+            koff[s] = ((tap / 3) * PW + tap % 3) * 3 + kk % 3;
+        }
+    }
+    const float bias1 = a.g[1].bias[ct * 32 + li];
+    // conv1_2: this lane's output channel, bias, weight stream
+    float biasv[1];
+    conv_load_bias<C>(biasv, a.g[0].bias, 0, wn, li);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g[0].w), 0, 0x7fffffff, 0x00020000);
+    const unsigned b_off = (unsigned)(((wn * 32 + li) * 16 + kh * 4) * 4);
+    const unsigned panel_b = 64u * 16u * 4u;           // bytes of one (tap, chunk) panel: [64][16] floats
+    f32x4 bA[2];
+    bA[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off, 0u, 0));
+    bA[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off + 32, 0u, 0));
+    __syncthreads();
+
+    // ---- conv1_1 on the halo: row tiles rt = (wave >> 1) + 2 i, i = 0..2 (192 rows cover the 180 halo pixels)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int rt = (wave >> 1) + 2 * i;
+        int m = rt * 32 + li;
+        if (m >= NPX) m = NPX - 1;
+        const int hy = m / HW, hx = m - hy * HW;
+        const int pbase = (hy * PW + hx) * 3;
+        f32x16 acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 14; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(s_patch[pbase + koff[s]], wv[s], acc1, 0, 0, 0);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int mr = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+            if (mr < NPX) {
+                const int ry = mr / HW, rx = mr - ry * HW;
+                const int gy = y0 - 1 + ry, gx = x0 - 1 + rx;
+                float v = fmaxf(acc1[reg] + bias1, 0.f);
+                if (!((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)) v = 0.f;       // conv1_2's zero padding
+                s_act[mr * LDA + ct * 32 + li] = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- conv1_2 from the LDS tile: 4 chunks x 9 taps, no barrier; the v5 tap schedule (one memory instruction per MFMA gap,
+    //      weights one tap ahead through the buffer resource, A fragments one k-step ahead)
+    int a_base[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int m = (wm * 2 + t) * 32 + li, q = m >> 2, r = m & 3;
+        const int py = 2 * (q / (TW / 2)) + (r >> 1), px = 2 * (q % (TW / 2)) + (r & 1);
+        a_base[t] = (py * HW + px) * LDA + kh * 4;
+    }
+    f32x16 acc[2][1];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][0][r] = 0.f;
+    f32x4 bX[1][2], bY[1][2];
+    bX[0][0] = bA[0]; bX[0][1] = bA[1];
+    const unsigned b_offs[1] = {b_off};
+    f32x4 av0[2], av1[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) av0[t] = *reinterpret_cast<const f32x4*>(&s_act[a_base[t]]);
+#pragma unroll
+    for (int u = 0; u < 36; ++u) {                      // u = chunk * 9 + tap; panels are [tap][chunk] in memory
+        const int ch = u / 9, tap = u % 9;
+        const int un = u + 1 < 36 ? u + 1 : u;
+        const int toff = ((tap / 3) * HW + tap % 3) * LDA + ch * 16;
+        const int toff_n = (((un % 9) / 3) * HW + (un % 9) % 3) * LDA + (un / 9) * 16;
+        const unsigned wnext = (unsigned)((un % 9) * 4 + un / 9) * panel_b;
+        if (u & 1) TapBody<C, 3>::run_u(acc, av0, av1, bY, bX, wrsrc, wnext, b_offs, s_act, a_base, toff, toff_n);
+        else TapBody<C, 3>::run_u(acc, av0, av1, bX, bY, wrsrc, wnext, b_offs, s_act, a_base, toff, toff_n);
+    }
+    conv_epilogue<C, TW>(acc, biasv, a, a.g[0].out, a.g[0].cout, bimg, y0, x0, 0, wm, wn, li, kh);
+}
+
+int conv1_fused_launch(const ConvArgs& a0, hipStream_t stream)
+{
+    ConvArgs a = a0;
+    PMX_CHECK(a.cout_pad == 64 && a.nch == 4 && a.lda >= 4, PMX_ERR_INVALID, "conv1 fused: needs conv1_2 = 64 -> 64 and a >= 4-channel padded input");
+    PMX_CHECK(!a.pool || (a.H % 2 == 0 && a.W % 2 == 0), PMX_ERR_INVALID, "conv: pooled layer needs even H, W");
+    PMX_CHECK((long long)a.H * a.W * a.lda < (1ll << 31), PMX_ERR_INVALID, "conv: image too large for 32-bit offsets");
+    a.tiles_x = (a.W + 15) / 16;
+    a.tiles_y = (a.H + 7) / 8;
+    a.ksplit = 1;
+    hipLaunchKernelGGL(conv1_fused_kernel, dim3((unsigned)(a.tiles_x * a.tiles_y * a.B)), dim3(256), 192 * 68 * 4, stream, a);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
 static int launch_c3(const ConvArgs& a0, int groups, hipStream_t stream)
 {
     ConvArgs a = a0;

@@ -242,6 +242,7 @@ struct pmx_ctx {
     int opt_keep_smoothed = 0, opt_stop_stage = 6, opt_kernel_gen = 6;
     int opt_precision = 0;           // 0: fp32 MFMA everywhere (the path whose results are specified); 1: bf16x3 kernels where a
                                      // v6 kernel would run (fp32-grade accuracy at 2.67x the matrix rate, NOT the fp32 FMA chain)
+    int opt_fuse_conv1 = 1;          // conv1_1 recomputed on conv1_2's halo tile, one launch (conv1_fused_kernel); identical bits
     int opt_fuse_pairs = 1;          // the two 1x1 layers that end every stage run as one launch (conv1x1_pair_kernel)
     int opt_ksplit = 0;              // 0: automatic split-K for small launches; n > 0: force n K slices where split-K applies
     // split-K scratch: partial-sum slabs of the current launch + a zero bias vector for the slice blocks
@@ -495,6 +496,7 @@ extern "C" int pmx_set_option(pmx_ctx* c, const char* key, int value)
     else if (!strcmp(key, "stop_stage")) c->opt_stop_stage = value;
     else if (!strcmp(key, "kernel_gen")) c->opt_kernel_gen = value;
     else if (!strcmp(key, "fuse_pairs")) c->opt_fuse_pairs = value;
+    else if (!strcmp(key, "fuse_conv1")) c->opt_fuse_conv1 = value;
     else if (!strcmp(key, "precision")) c->opt_precision = value;
     else if (!strcmp(key, "ksplit")) c->opt_ksplit = value;
     else if (!strcmp(key, "ksplit_plan")) c->opt_ksplit = value > 0 ? -value : 0;     // decimal digits = chunks per slice, e.g. 3221
@@ -670,6 +672,33 @@ static int run_pair(pmx_ctx* c, const char* labelA, const char* labelB, int a0, 
     return prof_end(c);
 }
 
+// conv1_1 -> conv1_2 (+ pool): one launch when conv1_2 would take the 8 x 16 x 64 fp32 tiles (large maps), else two
+static int run_conv1(pmx_ctx* c, int B, int H, int W)
+{
+    const int i1 = c->index.at("conv1_1"), i2 = c->index.at("conv1_2");
+    const PackedLayer& L1 = c->layers[i1];
+    const PackedLayer& L2 = c->layers[i2];
+    const int v2 = conv_pick_variant(3, L2.cout_pad, H, W, B, c->opt_force[3], c->opt_kernel_gen, 1, L2.cin, 0);
+    const bool fuse = c->opt_fuse_conv1 && c->opt_kernel_gen >= 6 && c->opt_precision == 0 && c->opt_force[3] < 0 && L1.cin == 3 && L1.cout == 64 &&
+                      L2.cin == 64 && L2.cout == 64 && !strcmp(conv_variant(v2).name, "conv3x3_v5_t8x16_n64");
+    int rc;
+    if (!fuse) {
+        if ((rc = run_conv(c, "conv1_1", i1, -1, c->in16, nullptr, PMX_IN_C, c->act0, nullptr, 64, B, H, W, 1, 0))) return rc;
+        return run_conv(c, "conv1_2", i2, -1, c->act0, nullptr, 64, c->act1, nullptr, 64, B, H, W, 1, 1);
+    }
+    ConvArgs a;
+    memset(&a, 0, sizeof a);
+    a.g[0].in = c->in16; a.g[0].w = L2.d_w; a.g[0].bias = L2.d_b; a.g[0].out = c->act1; a.g[0].cout = L2.cout;
+    a.g[1].w = L1.d_w; a.g[1].bias = L1.d_b;
+    a.B = B; a.H = H; a.W = W; a.lda = PMX_IN_C; a.ldc = 64; a.nch = L2.nch; a.cout_pad = L2.cout_pad; a.relu = 1; a.pool = 1;
+    if (c->prof_on == 1) {
+        const double flops = 2.0 * B * H * W * 9.0 * ((double)L1.cout * L1.cin + (double)L2.cout * L2.cin);
+        if ((rc = prof_begin(c, "conv1_1+conv1_2|conv1_fused_t8x16_n64", flops, 4.0 * B * H * W * (3 + 64 / 4)))) return rc;
+    }
+    if ((rc = conv1_fused_launch(a, c->stream))) return rc;
+    return prof_end(c);
+}
+
 // FaceNet / HandNet forward (models/FaceNet.py:78-160): one branch, groups = 1 everywhere
 static int forward_cpm(pmx_ctx* c, int B, int H, int W)
 {
@@ -681,8 +710,7 @@ static int forward_cpm(pmx_ctx* c, int B, int H, int W)
     float* heat = cat + c->cat_heat;
 #define RUN1(name, in, lda, out, ldc, h, w, relu, pool) \
     do { if ((rc = run_conv(c, name, id(name), -1, in, nullptr, lda, out, nullptr, ldc, B, h, w, relu, pool))) return rc; } while (0)
-    RUN1("conv1_1", c->in16, PMX_IN_C, c->act0, 64, H, W, 1, 0);
-    RUN1("conv1_2", c->act0, 64, c->act1, 64, H, W, 1, 1);
+    if ((rc = run_conv1(c, B, H, W))) return rc;
     RUN1("conv2_1", c->act1, 64, c->act0, 128, H2, W2, 1, 0);
     RUN1("conv2_2", c->act0, 128, c->act1, 128, H2, W2, 1, 1);
     RUN1("conv3_1", c->act1, 128, c->act0, 256, H4, W4, 1, 0);
@@ -730,8 +758,7 @@ static int forward_from_in16(pmx_ctx* c, int B, int H, int W)
     const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
 #define RUN(...) do { if ((rc = run_conv(c, __VA_ARGS__))) return rc; } while (0)
     // stem (CocoPoseNet.py:136-151)
-    RUN("conv1_1", id("conv1_1"), -1, c->in16, nullptr, PMX_IN_C, c->act0, nullptr, 64, B, H, W, 1, 0);
-    RUN("conv1_2", id("conv1_2"), -1, c->act0, nullptr, 64, c->act1, nullptr, 64, B, H, W, 1, 1);
+    if ((rc = run_conv1(c, B, H, W))) return rc;
     RUN("conv2_1", id("conv2_1"), -1, c->act1, nullptr, 64, c->act0, nullptr, 128, B, H2, W2, 1, 0);
     RUN("conv2_2", id("conv2_2"), -1, c->act0, nullptr, 128, c->act1, nullptr, 128, B, H2, W2, 1, 1);
     RUN("conv3_1", id("conv3_1"), -1, c->act1, nullptr, 128, c->act0, nullptr, 256, B, H4, W4, 1, 0);

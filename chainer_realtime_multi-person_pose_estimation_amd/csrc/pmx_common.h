@@ -108,6 +108,9 @@ struct PairArgs {
 };
 int conv_pair_launch(const PairArgs& a, int groups, hipStream_t stream);
 bool conv_pair_supported(int cin, int cmid, int cout_pad);
+// conv1_1 (3 -> 64) recomputed on the halo + conv1_2 (64 -> 64 [+ pool]) in one launch: a.g[0] = conv1_2 (in = padded network input),
+// a.g[1].w / .bias = conv1_1's packed weights / bias
+int conv1_fused_launch(const ConvArgs& a, hipStream_t stream);
 // K slices for a launch of `variant` (S = 1: no split); forced > 0 asks for that many (near-)even slices
 SplitPlan conv_pick_ksplit(int variant, int H, int W, int B, int groups, int cout_pad, int nch, int pool, int forced);
 

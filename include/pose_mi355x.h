@@ -100,6 +100,7 @@ int pmx_synchronize(pmx_ctx* ctx);                    /* cuda.get_device_from_id
  *                              layers that run on the one-block-per-CU kernels use the bf16 matrix cores with every fp32 value
  *                              split into three bf16 terms (six products, fp32 accumulate): fp32-grade accuracy, 2.67x the
  *                              matrix rate, results equal to the fp32 path only to summation-order-sized noise
+ *   "fuse_conv1" 1 | 0         conv1_1 recomputed on conv1_2's halo tiles, one launch instead of two (default 1); identical bits
  *   "fuse_pairs" 1 | 0         the two 1x1 layers that end every stage as one launch (default) or as two; identical bits
  *   "ksplit" 0 | 1 | n         split-K of the 3x3 / 7x7 launches that cannot fill the chip (single images): 0 = automatic,
  *                              1 = never, n = n K slices wherever split-K applies.  The slices are combined in a fixed

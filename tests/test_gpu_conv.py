@@ -343,3 +343,28 @@ def test_random_split_k_plans_bit_exact(engine, seed, k, B, h, w, nch, cout, poo
     engine.set_option('kernel_gen', 6)
     ref = R.conv_fma(x, wt, b, relu=True, pool=pool, splitk=sizes)
     assert np.array_equal(y, ref), (sizes, np.abs(y - ref).max())
+
+
+@pytest.mark.parametrize('arch,B,hw', [('posenet', 1, (368, 368)), ('posenet', 3, (184, 248)), ('posenet', 32, (368, 368)), ('handnet', 2, (368, 368))])
+def test_fused_conv1_equals_separate_layers_bitwise(native, arch, B, hw):
+    """conv1_1 recomputed on the halo of conv1_2's tiles (conv1_fused_kernel: 3 -> 64 through LDS, then 64 -> 64 + pool) == the two
+    launches, bit for bit: both layers keep their K walk.  Image borders, odd tile counts and the batch are all exercised."""
+    from conftest import pkg
+    eng = native.Engine(0, max_batch=B, max_h=hw[0], max_w=hw[1], arch=arch)
+    eng.set_weights(pkg('weights').synthetic_weights(4, arch))
+    imgs = np.random.default_rng(B + hw[1]).integers(0, 256, (B,) + hw + (3,), dtype=np.uint8)
+    outs = {}
+    for fuse in (0, 1):
+        eng.set_option('fuse_conv1', fuse)
+        eng.profile_reset()
+        eng.profile_enable(True)
+        eng.forward_u8(imgs)
+        names = {e['kernel'] for e in eng.profile()}
+        eng.profile_enable(False)
+        assert any('conv1_fused' in k for k in names) == bool(fuse), names
+        outs[fuse] = eng.get_maps()
+    eng.close()
+    if arch == 'posenet':
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    else:
+        assert np.array_equal(outs[0], outs[1])
