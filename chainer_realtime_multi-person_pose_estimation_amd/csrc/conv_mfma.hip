@@ -1834,8 +1834,10 @@ __global__ __launch_bounds__(256) void conv1x1_pair_kernel(const PairArgs a)
 {
     constexpr int CIN = 128, LDX = CIN + 4, LDH = CMID + 4, NT1 = CMID / 128;     // col tiles of the hidden layer per wave
     extern __shared__ float4 smem4[];
+    // the hidden tile is written only after every wave has finished reading X (barrier below), so the two tiles share the
+    // LDS space: 66 KB instead of 83 KB for CMID = 512 -> two blocks per CU
     float* const sX = reinterpret_cast<float*>(smem4);          // [32][LDX]
-    float* const sH = sX + 32 * LDX;                            // [32][LDH]
+    float* const sH = sX;                                       // [32][LDH]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
     const bool g1 = blockIdx.z != 0;
     const float* in = g1 ? a.g[1].in : a.g[0].in;
@@ -1883,6 +1885,7 @@ __global__ __launch_bounds__(256) void conv1x1_pair_kernel(const PairArgs a)
                 for (int e = 0; e < 4; ++e) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bw[u][s][e], acc[u], 0, 0, 0);
         }
     }
+    __syncthreads();            // all waves are done with the X tile: the hidden tile may overwrite it
     // bias + ReLU -> hidden tile in LDS (C layout: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * kh)
 #pragma unroll
     for (int u = 0; u < NT1; ++u)
@@ -1938,7 +1941,7 @@ bool conv_pair_supported(int cin, int cmid, int cout_pad)
 template <int CMID, int N2T>
 static int launch_pair(const PairArgs& a, int groups, hipStream_t stream)
 {
-    constexpr int LDS = (32 * (128 + 4) + 32 * (CMID + 4)) * 4;
+    constexpr int LDS = 32 * ((CMID > 128 ? CMID : 128) + 4) * 4;       // X tile and hidden tile share the space
     auto kern = conv1x1_pair_kernel<CMID, N2T>;
     static bool attr_set[PMX_MAX_DEVICES] = {};
     if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(kern), attr_set)) return rc;
