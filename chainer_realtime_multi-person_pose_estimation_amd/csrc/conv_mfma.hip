@@ -1290,13 +1290,13 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(const ConvArgs a)
 // taps from LDS with no staging and no barrier, weights L2 -> registers one tap ahead, epilogue (bias, ReLU, 2x2 max-pool) as
 // every other kernel.  Both layers walk K exactly like conv3x3_c3_kernel and the v5 kernels -> bit-identical to running them apart.
 // Arguments: a.g[0] = conv1_2 (w, bias, out, cout; in = the 16-channel padded network input), a.g[1].w / .bias = conv1_1's.
-__global__ __launch_bounds__(256, 2) void conv1_fused_kernel(const ConvArgs a)
+__global__ __launch_bounds__(256, 3) void conv1_fused_kernel(const ConvArgs a)
 {
     using C = ConvCfg<3, 8, 16, 64, 16, 2, 2>;
     constexpr int TH = 8, TW = 16, HH = TH + 2, HW = TW + 2, NPX = HH * HW, PH = HH + 2, PW = HW + 2, LDA = 68;
     __shared__ float s_patch[PH * PW * 3];
     extern __shared__ float4 smem4[];
-    float* const s_act = reinterpret_cast<float*>(smem4);                  // [192][LDA]: conv1_1 output on the halo, 64 channels
+    float* const s_act = reinterpret_cast<float*>(smem4);                  // [180][LDA]: conv1_1 output on the halo, 64 channels
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int H = a.H, W = a.W;
@@ -1416,7 +1416,7 @@ int conv1_fused_launch(const ConvArgs& a0, hipStream_t stream)
     a.tiles_x = (a.W + 15) / 16;
     a.tiles_y = (a.H + 7) / 8;
     a.ksplit = 1;
-    hipLaunchKernelGGL(conv1_fused_kernel, dim3((unsigned)(a.tiles_x * a.tiles_y * a.B)), dim3(256), 192 * 68 * 4, stream, a);
+    hipLaunchKernelGGL(conv1_fused_kernel, dim3((unsigned)(a.tiles_x * a.tiles_y * a.B)), dim3(256), 180 * 68 * 4, stream, a);      // 49 KB + 2.9 KB static: three blocks per CU
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
