@@ -1453,6 +1453,8 @@ static int conv_allow_big_lds(const void* kern, bool (&done)[PMX_MAX_DEVICES])
 // loses ~20% with 3+ waves per SIMD)
 static int g_min_lds = 0;
 void conv_set_min_lds(int bytes) { g_min_lds = bytes; }
+static int g_v5_lds = 56 * 1024;     // dynamic LDS floor of the v5 kernels: 3 x 56 KB > 160 KB -> at most 2 blocks per CU
+void conv_set_v5_lds(int bytes) { g_v5_lds = bytes; }
 
 // ---- variant table ---------------------------------------------------------------------------------------
 // {ksize, tile rows (v6: row tiles per block), tile cols (v6: 32), BN, CK, name}
@@ -1741,8 +1743,6 @@ static int launch_cfg(const ConvArgs& a0, int groups, hipStream_t stream)
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
-
-static int g_v5_lds = 56 * 1024;     // dynamic LDS floor of the v5 kernels: 3 x 56 KB > 160 KB -> at most 2 blocks per CU
 
 template <int KS, int TH, int TW, int BN, int CK, int WM, int WN>
 static int launch_v5(const ConvArgs& a0, int groups, hipStream_t stream)

@@ -501,6 +501,7 @@ extern "C" int pmx_set_option(pmx_ctx* c, const char* key, int value)
     else if (!strcmp(key, "ksplit")) c->opt_ksplit = value;
     else if (!strcmp(key, "ksplit_plan")) c->opt_ksplit = value > 0 ? -value : 0;     // decimal digits = chunks per slice, e.g. 3221
     else if (!strcmp(key, "conv_min_lds")) conv_set_min_lds(value);
+    else if (!strcmp(key, "conv_v5_lds")) conv_set_v5_lds(value);
     else if (!strcmp(key, "pp_generic")) pp_set_generic(value);
     else if (!strcmp(key, "peaks_gpu_branch")) { c->opt_gpu_branch_peaks = value; c->tab_in_h = -1; }
     else if (!strcmp(key, "kp_flip_x")) c->opt_kp_flip_x = value != 0;

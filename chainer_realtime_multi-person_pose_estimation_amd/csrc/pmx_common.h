@@ -125,6 +125,7 @@ int conv_num_variants();
 // launches the variant; groups = 1 or 2 (blockIdx.z)
 int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream);
 void conv_set_min_lds(int bytes);
+void conv_set_v5_lds(int bytes);        // LDS floor of the v5 / v8 kernels (caps the blocks per CU; tuning)
 int conv_bf16x3_twin(int variant);      // the bf16x3 kernel with the geometry of a v6 variant, or -1
 void conv_set_num_cus(int n);     // compute units of the device the contexts run on (tile / kernel selection heuristics)
 // packed weight geometry helpers

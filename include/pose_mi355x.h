@@ -112,7 +112,7 @@ int pmx_synchronize(pmx_ctx* ctx);                    /* cuda.get_device_from_id
  *   "kp_flip_x" 0 | 1          pmx_keypoints: mirror the resized heat maps left-right before the peaks are taken (the reference's
  *                              `cv2.flip(heatmaps, 1)` for left hands, hand_detector.py:46-47)
  *   "peaks_gpu_branch"         the reference's GPU-branch peak extraction (17 x 17 un-normalised kernel, zero pad, >=)
- *   "conv_min_lds", "pp_generic"   ablation switches, PROCESS-wide (not per context) */
+ *   "conv_min_lds", "conv_v5_lds", "pp_generic"   ablation switches, PROCESS-wide (not per context) */
 int pmx_set_option(pmx_ctx* ctx, const char* key, int value);
 
 /* ---- weights: serializers.load_npz (pose_detector.py:26) --------------------------------------
