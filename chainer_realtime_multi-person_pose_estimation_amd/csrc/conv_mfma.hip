@@ -1198,6 +1198,202 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_small_kernel(const ConvArg
     conv_epilogue<C, TW>(acc, biasv, a, G.out, G.cout, bimg, y0, x0, n0, wm, wn, li, kh);
 }
 
+// ---- Winograd F(2x2, 3x3) for the 3x3 layers of large launches (fp32, opt-in: option "conv_algo" = 1) -----------------------------
+// Y = A^T [ (G g G^T) (.) (B^T d B) ] A: a 2 x 2 output tile from a 4 x 4 input window costs 16 multiplies per channel pair instead of
+// 36 -> 2.25x less matrix work; the transforms are additions only (B^T, A^T) or done once on the host (G g G^T, in double, rounded
+// to fp32).  Block = 32 Winograd tiles (4 rows x 8 columns of 2 x 2 = an 8 x 16 pixel output tile) x 128 output channels; wave w owns
+// 32 channels and all 16 "frequencies": 16 accumulator tiles of 32 (Winograd tiles) x 32 (channels) = 256 AGPRs, one block per CU.
+// Per 32-channel chunk: raw 10 x 18 halo -> LDS, every thread transforms one (tile, 4 channels) item (32 additions) into
+// U[frequency][tile][channel] in LDS, then 16 frequencies x 4 k8-steps x 4 MFMAs per wave with the transformed weights streamed
+// from L2 one frequency ahead.  Epilogue: A^T M A per lane (the 16 frequencies of a (tile, channel) sit in one lane's registers),
+// bias, ReLU, 2x2 max-pool = max over the tile's four outputs.
+// The arithmetic is DEFINED -- transform additions in a fixed order, one sequential FMA chain per frequency over the channels (chunk
+// -> k8-step -> k) -- and oracle/conv_fma_ref.c::conv_wino_ref restates it; it is not the direct kernels' chain (results agree to
+// Winograd's fp32 rounding, ~1e-6 of the map scale).
+struct WinoCfg {
+    static constexpr int TH = 8, TW = 16, HH = TH + 2, HW = TW + 2, NPX = HH * HW, CKW = 32, LDR = CKW + 4, LDU = CKW + 4;
+    static constexpr int RAW_ELEMS = NPX * LDR, U_ELEMS = 16 * 32 * LDU;
+    static constexpr int LDS_BYTES = (RAW_ELEMS + U_ELEMS) * 4;
+    static constexpr int NHF = (NPX * (CKW / 4) + 255) / 256;
+};
+
+template <int POOL>
+__global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
+{
+    using C = WinoCfg;
+    extern __shared__ float4 smem4[];
+    float* const s_raw = reinterpret_cast<float*>(smem4);
+    float* const s_u = s_raw + C::RAW_ELEMS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
+    const bool g1 = blockIdx.z != 0;
+    ConvGroupArgs G;
+    G.in = g1 ? a.g[1].in : a.g[0].in;
+    G.w = g1 ? a.g[1].w : a.g[0].w;              // transformed weights [freq 16][chunk32][cout_pad][32]
+    G.bias = g1 ? a.g[1].bias : a.g[0].bias;
+    G.out = g1 ? a.g[1].out : a.g[0].out;
+    G.cout = g1 ? a.g[1].cout : a.g[0].cout;
+    const int H = a.H, W = a.W;
+    int tile;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int bimg = tile / tiles_per_img;
+    const int trem = tile - bimg * tiles_per_img;
+    const int y0 = (trem / a.tiles_x) * C::TH, x0 = (trem % a.tiles_x) * C::TW;
+    const int n0 = blockIdx.y * 128;
+    const int n = n0 + wave * 32 + li;
+    const float* in_b = G.in + (size_t)bimg * H * W * a.lda;
+    float bias = G.bias[n];
+    asm volatile("" : "+v"(bias));
+    const int nch = a.nch;                        // chunks of 32 input channels
+
+    // raw halo staging slots
+    int h_goff[C::NHF], h_lds[C::NHF];
+    unsigned h_ok = 0;
+#pragma unroll
+    for (int r = 0; r < C::NHF; ++r) {
+        const int f = tid + r * 256;
+        const bool slot = f < C::NPX * (C::CKW / 4);
+        const int hp = slot ? f / (C::CKW / 4) : 0, c4 = f % (C::CKW / 4);
+        const int hy = hp / C::HW, hx = hp - hy * C::HW;
+        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+        h_goff[r] = (cy * W + cx) * a.lda + c4 * 4;
+        h_lds[r] = slot ? hp * C::LDR + c4 * 4 : -1;
+        h_ok |= (slot && inb) ? (1u << r) : 0u;
+    }
+    // transform item of this thread: Winograd tile tt (4 x 8 grid), channels 4 * tc .. + 3 of the chunk
+    const int tt = tid >> 3, tc = tid & 7;
+    const int t_raw = ((2 * (tt >> 3)) * C::HW + 2 * (tt & 7)) * C::LDR + tc * 4;        // top-left pixel of the 4 x 4 window
+    const int t_u = tt * C::LDU + tc * 4;
+
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G.w), 0, 0x7fffffff, 0x00020000);
+    const unsigned b_off = (unsigned)((n * C::CKW + kh * 4) * 4);
+    const unsigned panel_b = (unsigned)a.cout_pad * C::CKW * 4u;          // bytes of one (freq, chunk) panel
+    const unsigned freq_b = panel_b * (unsigned)nch;                       // bytes between frequencies
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[f][i] = 0.f;
+
+    float4 hreg[C::NHF];
+#pragma unroll
+    for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r]);
+    const int a_off = li * C::LDU + kh * 4;
+    // weight fragments: ring of 4 frequencies, loaded two frequencies (32 MFMAs, ~2000 cycles) ahead and across the chunk boundary
+    f32x4 bw[4][4];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+            bw[f][st] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off + st * 32, (unsigned)f * freq_b, 0));
+
+    for (int ch = 0; ch < nch; ++ch) {
+        if (ch) __syncthreads();                   // the previous chunk's MFMAs are done with U
+        // ---- raw halo of this chunk -> LDS
+#pragma unroll
+        for (int r = 0; r < C::NHF; ++r) {
+            float4 v = hreg[r];
+            if (!((h_ok >> r) & 1)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (h_lds[r] >= 0) *reinterpret_cast<float4*>(&s_raw[h_lds[r]]) = v;
+        }
+        __syncthreads();
+        {   // next chunk's raw halo: global -> registers, lands under this chunk's MFMAs
+            const int cn = ch + 1 < nch ? ch + 1 : ch;
+#pragma unroll
+            for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + cn * C::CKW);
+        }
+        // ---- input transform V = B^T d B of this thread's (tile, 4 channels): rows first, then columns
+        {
+            f32x4 d[4][4], wv4[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const f32x4*>(&s_raw[t_raw + (i * C::HW + j) * C::LDR]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                wv4[0][j] = d[0][j] - d[2][j];
+                wv4[1][j] = d[1][j] + d[2][j];
+                wv4[2][j] = d[2][j] - d[1][j];
+                wv4[3][j] = d[1][j] - d[3][j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 v0 = wv4[i][0] - wv4[i][2];
+                const f32x4 v1 = wv4[i][1] + wv4[i][2];
+                const f32x4 v2 = wv4[i][2] - wv4[i][1];
+                const f32x4 v3 = wv4[i][1] - wv4[i][3];
+                *reinterpret_cast<f32x4*>(&s_u[(4 * i + 0) * 32 * C::LDU + t_u]) = v0;
+                *reinterpret_cast<f32x4*>(&s_u[(4 * i + 1) * 32 * C::LDU + t_u]) = v1;
+                *reinterpret_cast<f32x4*>(&s_u[(4 * i + 2) * 32 * C::LDU + t_u]) = v2;
+                *reinterpret_cast<f32x4*>(&s_u[(4 * i + 3) * 32 * C::LDU + t_u]) = v3;
+            }
+        }
+        __syncthreads();
+        // ---- 16 frequencies x 4 k8-steps x 4 MFMAs; one weight load and one A read per 4 MFMAs, pinned between them
+        const unsigned chunk_b = (unsigned)ch * panel_b;
+        const unsigned next_b = (unsigned)(ch + 1 < nch ? ch + 1 : ch) * panel_b;
+        f32x4 av[2];
+        av[0] = *reinterpret_cast<const f32x4*>(&s_u[a_off]);
+#pragma unroll
+        for (int f = 0; f < 16; ++f) {
+            const unsigned so = f + 2 < 16 ? chunk_b + (unsigned)(f + 2) * freq_b : next_b + (unsigned)(f + 2 - 16) * freq_b;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st & 1][e], bw[f & 3][st][e], acc[f], 0, 0, 0);
+                    if (e == 0) {
+                        bw[(f + 2) & 3][st] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off + st * 32, so, 0));
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if (e == 1 && !(f == 15 && st == 3)) {
+                        const int fn = st == 3 ? f + 1 : f, sn = (st + 1) & 3;
+                        av[(st + 1) & 1] = *reinterpret_cast<const f32x4*>(&s_u[fn * 32 * C::LDU + a_off + sn * 8]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- output transform Y = A^T M A per (tile, channel), bias, ReLU, (pool), store
+    const bool nok = n < G.cout;
+    const int Hp = H >> 1, Wp = W >> 1;
+    float* out_b = G.out + (size_t)bimg * (POOL ? Hp * Wp : H * W) * a.ldc + n;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int mr = (reg & 3) + 8 * (reg >> 2) + 4 * kh;          // Winograd tile of this register row
+        const int ty = mr >> 3, tx = mr & 7;
+        float t0[4], t1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t0[j] = (acc[0 + j][reg] + acc[4 + j][reg]) + acc[8 + j][reg];
+            t1[j] = (acc[4 + j][reg] - acc[8 + j][reg]) - acc[12 + j][reg];
+        }
+        float y00 = (t0[0] + t0[1]) + t0[2], y01 = (t0[1] - t0[2]) - t0[3];
+        float y10 = (t1[0] + t1[1]) + t1[2], y11 = (t1[1] - t1[2]) - t1[3];
+        const int gy = y0 + 2 * ty, gx = x0 + 2 * tx;
+        if (POOL) {
+            float v = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)) + bias;
+            if (a.relu) v = fmaxf(v, 0.f);
+            if (nok && (gy >> 1) < Hp && (gx >> 1) < Wp) out_b[((size_t)(gy >> 1) * Wp + (gx >> 1)) * a.ldc] = v;
+        } else {
+            y00 += bias; y01 += bias; y10 += bias; y11 += bias;
+            if (a.relu) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
+            if (nok && gy < H && gx < W) out_b[((size_t)gy * W + gx) * a.ldc] = y00;
+            if (nok && gy < H && gx + 1 < W) out_b[((size_t)gy * W + gx + 1) * a.ldc] = y01;
+            if (nok && gy + 1 < H && gx < W) out_b[((size_t)(gy + 1) * W + gx) * a.ldc] = y10;
+            if (nok && gy + 1 < H && gx + 1 < W) out_b[((size_t)(gy + 1) * W + gx + 1) * a.ldc] = y11;
+        }
+    }
+}
+
 // ---- conv1_1: 3 input channels ---------------------------------------------------------------------------------------
 // The generic kernels spend a whole 16-channel chunk (8 MFMA k-pairs per tap) on 3 real channels.  Here K = 27 is packed
 // tap-major / channel-minor into 14 k-pairs (the 28th k is zero) - the order in which the generic kernels meet the three
@@ -1523,6 +1719,7 @@ const ConvVariant& conv_variant(int idx) { return g_variants[idx]; }
 
 static int g_num_cus = 256;
 void conv_set_num_cus(int n) { if (n > 0) g_num_cus = n; }
+int conv_num_cus() { return g_num_cus; }
 
 // gen: 1 = v1 kernels everywhere, 5 = v5 for 3x3 / 7x7, 6 (default) = v6 / c3 where they apply, else v5
 int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen, int pool, int cin, int bf16x3)
@@ -2068,3 +2265,29 @@ int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream)
     pmx_set_error("conv_launch: unknown variant %d", variant);
     return PMX_ERR_INVALID;
 }
+
+template <int POOL>
+static int launch_wino(const ConvArgs& a0, int groups, hipStream_t stream)
+{
+    ConvArgs a = a0;
+    PMX_CHECK(!!a.pool == !!POOL, PMX_ERR_INVALID, "conv wino: pool mismatch");
+    PMX_CHECK(!POOL || (a.H % 2 == 0 && a.W % 2 == 0), PMX_ERR_INVALID, "conv: pooled layer needs even H, W");
+    PMX_CHECK(a.cout_pad % 128 == 0, PMX_ERR_INVALID, "conv wino: cout_pad %d not a multiple of 128", a.cout_pad);
+    PMX_CHECK((long long)a.H * a.W * a.lda < (1ll << 31), PMX_ERR_INVALID, "conv: image too large for 32-bit offsets");
+    a.tiles_x = (a.W + WinoCfg::TW - 1) / WinoCfg::TW;
+    a.tiles_y = (a.H + WinoCfg::TH - 1) / WinoCfg::TH;
+    auto kern = conv_wino_kernel<POOL>;
+    static bool attr_set[PMX_MAX_DEVICES] = {};
+    if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(kern), attr_set)) return rc;
+    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / 128), (unsigned)groups);
+    hipLaunchKernelGGL(kern, grid, dim3(256), WinoCfg::LDS_BYTES, stream, a);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+// a.nch = input channels / 32 (chunks of the Winograd kernel), a.g[].w = transformed weights
+int conv_wino_launch(const ConvArgs& a, int groups, hipStream_t stream)
+{
+    return a.pool ? launch_wino<1>(a, groups, stream) : launch_wino<0>(a, groups, stream);
+}
+

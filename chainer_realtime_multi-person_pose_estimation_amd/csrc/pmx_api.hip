@@ -91,6 +91,7 @@ struct PackedLayer {
     bool set = false;
     float* d_w = nullptr;
     float* d_b = nullptr;
+    float* d_ww = nullptr;       // Winograd F(2x2,3x3) pack [freq 16][chunk32][cout_pad][32] = G g G^T (3x3 layers; option "conv_algo" = 1)
     void* d_w3 = nullptr;        // bf16x3 pack [tap][chunk][plane hi|mid|lo][cout_pad][16] (3x3 / 7x7 layers; option "precision" = 1)
     int cin = 0, cout = 0, ks = 0, cin_pad = 0, cout_pad = 0, nch = 0;
 };
@@ -131,6 +132,28 @@ static inline float bf16_f(uint16_t h)
     return f;
 }
 // packed fp32 weights [tap][chunk][cout_pad][16] -> bf16x3 [tap][chunk][plane][cout_pad][16]
+// Winograd F(2x2, 3x3) weights: U = G g G^T per (cout, cin), G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]], evaluated in double and
+// rounded once to fp32 (oracle/conv_fma_ref.c::wino_weights does the same); layout [freq = 4i + j][chunk of 32 cin][cout_pad][32]
+static bool wino_eligible(int ks, int cin_pad, int cout_pad) { return ks == 3 && cin_pad % 32 == 0 && cout_pad % 128 == 0; }
+static void pack_wino(const std::vector<float>& wp, int nch16, int cout_pad, std::vector<float>& out)
+{
+    static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int cin_pad = nch16 * CK, nch32 = cin_pad / 32;
+    out.assign((size_t)16 * nch32 * cout_pad * 32, 0.f);
+    for (int n = 0; n < cout_pad; ++n)
+        for (int ci = 0; ci < cin_pad; ++ci) {
+            double g[3][3], gg[4][3];
+            for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = wp[(((size_t)t * nch16 + ci / CK) * cout_pad + n) * CK + ci % CK];
+            for (int i = 0; i < 4; ++i)
+                for (int kx = 0; kx < 3; ++kx) gg[i][kx] = (Gm[i][0] * g[0][kx] + Gm[i][1] * g[1][kx]) + Gm[i][2] * g[2][kx];
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) {
+                    const double u = (gg[i][0] * Gm[j][0] + gg[i][1] * Gm[j][1]) + gg[i][2] * Gm[j][2];
+                    out[((((size_t)(4 * i + j)) * nch32 + ci / 32) * cout_pad + n) * 32 + ci % 32] = (float)u;
+                }
+        }
+}
+
 static void pack_bf16x3(const std::vector<float>& wp, int T, int nch, int cout_pad, std::vector<uint16_t>& out)
 {
     out.assign((size_t)T * nch * 3 * cout_pad * CK, 0);
@@ -240,6 +263,8 @@ struct pmx_ctx {
     int opt_kp_flip_x = 0;           // pmx_keypoints: mirror the resized heat maps left-right before the peaks (hand_detector.py:46-47)
     int tab_flip = 0;
     int opt_keep_smoothed = 0, opt_stop_stage = 6, opt_kernel_gen = 6;
+    int opt_conv_algo = 0;           // 1: Winograd F(2x2,3x3) fp32 kernel for the 3x3 layers of large launches (defined arithmetic, its own
+                                     // rounding: ~1e-6 of the map scale away from the direct kernels); 0: direct kernels everywhere
     int opt_precision = 0;           // 0: fp32 MFMA everywhere (the path whose results are specified); 1: bf16x3 kernels where a
                                      // v6 kernel would run (fp32-grade accuracy at 2.67x the matrix rate, NOT the fp32 FMA chain)
     int opt_fuse_conv1 = 1;          // conv1_1 recomputed on conv1_2's halo tile, one launch (conv1_fused_kernel); identical bits
@@ -454,7 +479,7 @@ extern "C" void pmx_destroy(pmx_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (auto& l : c->layers) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); if (l.d_w3) (void)hipFree(l.d_w3); }
+    for (auto& l : c->layers) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); if (l.d_w3) (void)hipFree(l.d_w3); if (l.d_ww) (void)hipFree(l.d_ww); }
     pp_free(c);
     void* ptrs[] = {c->sk_scratch, c->sk_zero_bias, c->pr_tmp, c->pr_tab, c->d_kp, c->u8_src, c->rs_tab, c->in16, c->act0, c->act1, c->cat, c->brA, c->brB, c->brT, c->nchw_tmp, c->u8_tmp, c->ext_paf, c->ext_heat,
                     c->pp.smoothed, c->d_scale, c->tab.xi0, c->tab.xi1, c->tab.xlo, c->tab.xhi, c->tab.yi0, c->tab.yi1,
@@ -498,6 +523,7 @@ extern "C" int pmx_set_option(pmx_ctx* c, const char* key, int value)
     else if (!strcmp(key, "fuse_pairs")) c->opt_fuse_pairs = value;
     else if (!strcmp(key, "fuse_conv1")) c->opt_fuse_conv1 = value;
     else if (!strcmp(key, "precision")) c->opt_precision = value;
+    else if (!strcmp(key, "conv_algo")) c->opt_conv_algo = value;
     else if (!strcmp(key, "ksplit")) c->opt_ksplit = value;
     else if (!strcmp(key, "ksplit_plan")) c->opt_ksplit = value > 0 ? -value : 0;     // decimal digits = chunks per slice, e.g. 3221
     else if (!strcmp(key, "conv_min_lds")) conv_set_min_lds(value);
@@ -535,6 +561,12 @@ extern "C" int pmx_set_layer(pmx_ctx* c, const char* name, const float* w, const
         pack_bf16x3(wp, ks * ks, (int)cmap.size() / CK, cpad, w3);
         if (!L.d_w3) PMX_HIP(hipMalloc(&L.d_w3, w3.size() * sizeof(uint16_t)));
         PMX_HIP(hipMemcpy(L.d_w3, w3.data(), w3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+    if (wino_eligible(ks, (int)cmap.size(), cpad)) {
+        std::vector<float> ww;
+        pack_wino(wp, (int)cmap.size() / CK, cpad, ww);
+        if (!L.d_ww) PMX_HIP(hipMalloc((void**)&L.d_ww, ww.size() * sizeof(float)));
+        PMX_HIP(hipMemcpy(L.d_ww, ww.data(), ww.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     L.set = true; L.cin = cin; L.cout = cout; L.ks = ks;
     L.cin_pad = (int)cmap.size(); L.cout_pad = cpad; L.nch = L.cin_pad / CK;
@@ -597,6 +629,16 @@ static int launch_conv(pmx_ctx* c, const ConvArgs& a0, int groups, int v, const 
     return conv_splitk_reduce(r, groups, c->stream);
 }
 
+// Winograd takes a 3x3 layer when the option asks for it, the fp32 path is selected, and the launch fills the chip a few times over
+// (one 8 x 16 x 128 block per CU at a time; small launches stay on the direct kernels and their split-K plans)
+static bool wino_use(const pmx_ctx* c, int ks, int cin_pad, int cout_pad, int images, int H, int W)
+{
+    if (c->opt_conv_algo < 1 || c->opt_precision != 0 || c->opt_force[3] >= 0 || !wino_eligible(ks, cin_pad, cout_pad)) return false;
+    if (c->opt_conv_algo == 2) return true;       // tests: every eligible 3x3 layer, whatever the launch size
+    const long long blocks = (long long)((H + 7) / 8) * ((W + 15) / 16) * images * (cout_pad / 128);
+    return blocks >= 2ll * conv_num_cus();
+}
+
 // one launch of 1 or 2 groups (same geometry); in/out pointers are already offset to the group's channels
 static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float* in0, const float* in1, int lda,
                     float* out0, float* out1, int ldc, int B, int H, int W, int relu, int pool)
@@ -621,10 +663,21 @@ static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float
         a.g[0].w = (const float*)L0.d_w3;
         if (groups == 2) a.g[1].w = (const float*)c->layers[li1].d_w3;
     }
-    SplitPlan plan = conv_pick_ksplit(v, H, W, B, groups, L0.cout_pad, L0.nch, pool, c->opt_ksplit);
-    if (L0.cout % 4 != 0 || ldc % 4 != 0 || (groups == 2 && c->layers[li1].cout != L0.cout)) plan.S = 1;
     int rc;
     const bool prof_this = c->prof_on == 1 || (c->prof_on == 2 && L0.ks == 7);
+    if (wino_use(c, L0.ks, L0.cin_pad, L0.cout_pad, B * groups, H, W) && L0.d_ww && (groups == 1 || c->layers[li1].d_ww)) {
+        a.nch = L0.cin_pad / 32;
+        a.g[0].w = L0.d_ww;
+        if (groups == 2) a.g[1].w = c->layers[li1].d_ww;
+        if (prof_this) {
+            const double bytes = 4.0 * B * H * W * ((double)L0.cin * groups + (double)L0.cout * groups / (pool ? 4 : 1));
+            if ((rc = prof_begin(c, std::string(label) + "|conv_wino_f2x2_3x3", flops, bytes))) return rc;
+        }
+        if ((rc = conv_wino_launch(a, groups, c->stream))) return rc;
+        return prof_this ? prof_end(c) : PMX_OK;
+    }
+    SplitPlan plan = conv_pick_ksplit(v, H, W, B, groups, L0.cout_pad, L0.nch, pool, c->opt_ksplit);
+    if (L0.cout % 4 != 0 || ldc % 4 != 0 || (groups == 2 && c->layers[li1].cout != L0.cout)) plan.S = 1;
     if (prof_this) {
         const double bytes = 4.0 * B * H * W * ((double)L0.cin * groups + (double)L0.cout * groups / (pool ? 4 : 1));
         std::string kn = conv_variant(v).name;
@@ -1668,6 +1721,18 @@ extern "C" int pmx_conv2d(pmx_ctx* c, const float* x, const float* w, const floa
     }
     SplitPlan plan = conv_pick_ksplit(v_run, H, W, B, 1, cpad, cin_pad / CK, pool, c->opt_ksplit);
     if (cout % 4 != 0) plan.S = 1;
+    float* d_ww = nullptr;
+    const bool wino = wino_use(c, ks, cin_pad, cpad, B, H, W);
+    if (wino) {
+        std::vector<float> ww;
+        pack_wino(wp, cin_pad / CK, cpad, ww);
+        PMX_HIP(hipMalloc((void**)&d_ww, ww.size() * sizeof(float)));
+        PMX_HIP(hipMemcpy(d_ww, ww.data(), ww.size() * sizeof(float), hipMemcpyHostToDevice));
+        a.g[0].w = d_ww; a.nch = cin_pad / 32;
+    }
+    auto launch_conv = [&](pmx_ctx* cc, const ConvArgs& aa, int gg, int vv, const SplitPlan& pp) {
+        return wino ? conv_wino_launch(aa, gg, cc->stream) : ::launch_conv(cc, aa, gg, vv, pp);
+    };
     if (!rc) rc = launch_conv(c, a, 1, v_run, plan);
     if (!rc && iters > 0) {
         hipEvent_t e0, e1;
@@ -1692,5 +1757,6 @@ extern "C" int pmx_conv2d(pmx_ctx* c, const float* x, const float* w, const floa
     }
     (void)hipFree(d_x); (void)hipFree(d_xn); (void)hipFree(d_w); (void)hipFree(d_b); (void)hipFree(d_y); (void)hipFree(d_yn);
     if (d_w3) (void)hipFree(d_w3);
+    if (d_ww) (void)hipFree(d_ww);
     return rc;
 }

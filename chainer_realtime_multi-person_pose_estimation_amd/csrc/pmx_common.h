@@ -111,6 +111,8 @@ bool conv_pair_supported(int cin, int cmid, int cout_pad);
 // conv1_1 (3 -> 64) recomputed on the halo + conv1_2 (64 -> 64 [+ pool]) in one launch: a.g[0] = conv1_2 (in = padded network input),
 // a.g[1].w / .bias = conv1_1's packed weights / bias
 int conv1_fused_launch(const ConvArgs& a, hipStream_t stream);
+// Winograd F(2x2, 3x3): a.nch = cin / 32, a.g[].w = transformed weights [freq 16][chunk32][cout_pad][32] (G g G^T, host)
+int conv_wino_launch(const ConvArgs& a, int groups, hipStream_t stream);
 // K slices for a launch of `variant` (S = 1: no split); forced > 0 asks for that many (near-)even slices
 SplitPlan conv_pick_ksplit(int variant, int H, int W, int B, int groups, int cout_pad, int nch, int pool, int forced);
 
@@ -128,6 +130,7 @@ void conv_set_min_lds(int bytes);
 void conv_set_v5_lds(int bytes);        // LDS floor of the v5 / v8 kernels (caps the blocks per CU; tuning)
 int conv_bf16x3_twin(int variant);      // the bf16x3 kernel with the geometry of a v6 variant, or -1
 void conv_set_num_cus(int n);     // compute units of the device the contexts run on (tile / kernel selection heuristics)
+int conv_num_cus();
 // packed weight geometry helpers
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 

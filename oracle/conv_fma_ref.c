@@ -60,3 +60,103 @@ void conv_fma_ref(const float* x, const float* w, const float* bias, float* y, i
                     y[(((size_t)b * cout + n) * Ho + oy) * Wo + ox] = v;
                 }
 }
+
+/* Winograd F(2x2, 3x3) twin of csrc/conv_mfma.hip::conv_wino_kernel (option "conv_algo" = 1; 3x3 layers, cin % 32 == 0):
+ *   U = G g G^T in double, rounded once to fp32 (csrc/pmx_api.hip::pack_wino);
+ *   V = B^T d B in fp32, rows first then columns, each entry one add/subtract of two terms;
+ *   16 frequency-wise sequential fmaf chains over the channels: 32-channel chunk -> 8-channel step -> e in 0..3: k = e, then e + 4;
+ *   Y = A^T M A in fp32: t0j = (m0j + m1j) + m2j, t1j = (m1j - m2j) - m3j, y_i0 = (t_i0 + t_i1) + t_i2, y_i1 = (t_i1 - t_i2) - t_i3;
+ *   max-pool = max of the tile's four outputs (before the bias, like the kernel), + bias, ReLU.
+ * The window of output tile (ty, tx) covers input rows 2ty-1 .. 2ty+2, columns 2tx-1 .. 2tx+2, zeros outside the image. */
+#include <stdlib.h>
+void conv_wino_ref(const float* x, const float* w, const float* bias, float* y, int B, int cin, int H, int W, int cout, int relu,
+                   int pool)
+{
+    static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int TY = (H + 1) / 2, TX = (W + 1) / 2;
+    const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
+    float* U = (float*)malloc((size_t)cout * cin * 16 * sizeof(float));
+    float* V = (float*)malloc((size_t)B * cin * TY * TX * 16 * sizeof(float));
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < cout; ++n)
+        for (int c = 0; c < cin; ++c) {
+            const float* g = w + ((size_t)n * cin + c) * 9;
+            double gg[4][3];
+            for (int i = 0; i < 4; ++i)
+                for (int kx = 0; kx < 3; ++kx)
+                    gg[i][kx] = (Gm[i][0] * (double)g[kx] + Gm[i][1] * (double)g[3 + kx]) + Gm[i][2] * (double)g[6 + kx];
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j)
+                    U[((size_t)n * cin + c) * 16 + 4 * i + j] = (float)((gg[i][0] * Gm[j][0] + gg[i][1] * Gm[j][1]) + gg[i][2] * Gm[j][2]);
+        }
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < cin; ++c)
+            for (int ty = 0; ty < TY; ++ty)
+                for (int tx = 0; tx < TX; ++tx) {
+                    float d[4][4], r[4][4];
+                    for (int i = 0; i < 4; ++i)
+                        for (int j = 0; j < 4; ++j) {
+                            const int iy = 2 * ty - 1 + i, ix = 2 * tx - 1 + j;
+                            d[i][j] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((size_t)b * cin + c) * H + iy) * W + ix] : 0.f;
+                        }
+                    for (int j = 0; j < 4; ++j) {
+                        r[0][j] = d[0][j] - d[2][j];
+                        r[1][j] = d[1][j] + d[2][j];
+                        r[2][j] = d[2][j] - d[1][j];
+                        r[3][j] = d[1][j] - d[3][j];
+                    }
+                    float* v = V + ((((size_t)b * cin + c) * TY + ty) * TX + tx) * 16;
+                    for (int i = 0; i < 4; ++i) {
+                        v[4 * i + 0] = r[i][0] - r[i][2];
+                        v[4 * i + 1] = r[i][1] + r[i][2];
+                        v[4 * i + 2] = r[i][2] - r[i][1];
+                        v[4 * i + 3] = r[i][1] - r[i][3];
+                    }
+                }
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int n = 0; n < cout; ++n)
+            for (int ty = 0; ty < TY; ++ty)
+                for (int tx = 0; tx < TX; ++tx) {
+                    float m[16];
+                    for (int f = 0; f < 16; ++f) m[f] = 0.f;
+                    for (int c8 = 0; c8 < cin; c8 += 8)
+                        for (int e = 0; e < 4; ++e)
+                            for (int hi = 0; hi < 2; ++hi) {
+                                const int c = c8 + e + 4 * hi;
+                                if (c >= cin) continue;
+                                const float* v = V + ((((size_t)b * cin + c) * TY + ty) * TX + tx) * 16;
+                                const float* u = U + ((size_t)n * cin + c) * 16;
+                                for (int f = 0; f < 16; ++f) m[f] = fmaf(v[f], u[f], m[f]);
+                            }
+                    float t0[4], t1[4], yv[2][2];
+                    for (int j = 0; j < 4; ++j) {
+                        t0[j] = (m[j] + m[4 + j]) + m[8 + j];
+                        t1[j] = (m[4 + j] - m[8 + j]) - m[12 + j];
+                    }
+                    yv[0][0] = (t0[0] + t0[1]) + t0[2]; yv[0][1] = (t0[1] - t0[2]) - t0[3];
+                    yv[1][0] = (t1[0] + t1[1]) + t1[2]; yv[1][1] = (t1[1] - t1[2]) - t1[3];
+                    if (pool) {
+                        if (ty < Ho && tx < Wo) {
+                            float best = yv[0][0];
+                            if (yv[0][1] > best) best = yv[0][1];
+                            if (yv[1][0] > best) best = yv[1][0];
+                            if (yv[1][1] > best) best = yv[1][1];
+                            float o = best + bias[n];
+                            if (relu) o = o > 0.f ? o : 0.f;
+                            y[(((size_t)b * cout + n) * Ho + ty) * Wo + tx] = o;
+                        }
+                    } else {
+                        for (int i = 0; i < 2; ++i)
+                            for (int j = 0; j < 2; ++j) {
+                                const int oy = 2 * ty + i, ox = 2 * tx + j;
+                                if (oy >= H || ox >= W) continue;
+                                float o = yv[i][j] + bias[n];
+                                if (relu) o = o > 0.f ? o : 0.f;
+                                y[(((size_t)b * cout + n) * H + oy) * W + ox] = o;
+                            }
+                    }
+                }
+    free(U); free(V);
+}

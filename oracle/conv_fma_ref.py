@@ -52,6 +52,25 @@ def conv_fma(x, w, b, relu=False, pool=False, splitk=1):
     return y
 
 
+def conv_wino(x, w, b, relu=False, pool=False):
+    """The Winograd F(2x2, 3x3) kernel's arithmetic (csrc/conv_mfma.hip::conv_wino_kernel, option "conv_algo" = 1): same
+    shapes as conv_fma, 3x3 only.  Defined order, but not the direct kernels' chain: the two agree to ~1e-6 of the map scale."""
+    global _lib
+    if _lib is None:
+        conv_fma(np.zeros((1, 1, 1, 1), 'f'), np.zeros((1, 1, 1, 1), 'f'), np.zeros(1, 'f'))
+    _lib.conv_wino_ref.restype = None
+    _lib.conv_wino_ref.argtypes = [C.c_void_p] * 4 + [C.c_int] * 7
+    x = np.ascontiguousarray(x, np.float32)
+    w = np.ascontiguousarray(w, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    B, cin, H, W = x.shape
+    cout, _, ks, _ = w.shape
+    assert ks == 3
+    y = np.empty((B, cout, H // 2 if pool else H, W // 2 if pool else W), np.float32)
+    _lib.conv_wino_ref(x.ctypes.data, w.ctypes.data, b.ctypes.data, y.ctypes.data, B, cin, H, W, cout, int(relu), int(pool))
+    return y
+
+
 # ---- the whole network in the kernels' order ---------------------------------------------------------------------------
 # Stage inputs are the "cat" buffer of the HIP path: [feature 0..127 | PAF 128..165 | 0, 0 | heat 168..186 | 0 x 5]
 # (csrc/pmx_api.hip::concat_map); the reference concatenates (PAF, heat, feature) (models/CocoPoseNet.py:168).  K is walked
@@ -78,16 +97,23 @@ def splitk_plan(profile):
     return plan
 
 
-def forward_fma(weights, x, splitk=None):
+def wino_layers(profile):
+    """Layer labels the engine ran with the Winograd kernel (kernel label "conv_wino_f2x2_3x3" in an engine profile)."""
+    return {e['layer'] for e in profile if e['kernel'].startswith('conv_wino')}
+
+
+def forward_fma(weights, x, splitk=None, wino=()):
     """CocoPoseNet forward (models/CocoPoseNet.py:132-262) with every convolution in the HIP kernels' summation order.
     x: (B, 3, H, W) float32 as produced by preprocess; returns (paf (B,38,h,w), heat (B,19,h,w)) of the last stage.
     splitk: {layer label: K slices} of the launch plan the kernels used (splitk_plan); None = no launch was split (large
-    batches)."""
+    batches).  wino: labels of the layers that ran as Winograd F(2x2, 3x3) (wino_layers)."""
     splitk = splitk or {}
 
     def conv(name, h, relu=True, pool=False, cat=False):
         W, b = weights[name]
         label = name[:-3] if name.endswith(('_L1', '_L2')) else name
+        if label in wino:
+            return conv_wino(h, W, b, relu=relu, pool=pool)
         return conv_fma(h, _cat_weights(W) if cat else W, b, relu=relu, pool=pool, splitk=splitk.get(label, 1))
     h = conv('conv1_1', x); h = conv('conv1_2', h, pool=True)
     h = conv('conv2_1', h); h = conv('conv2_2', h, pool=True)
