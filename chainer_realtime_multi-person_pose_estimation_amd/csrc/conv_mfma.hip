@@ -1198,29 +1198,42 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_small_kernel(const ConvArg
     conv_epilogue<C, TW>(acc, biasv, a, G.out, G.cout, bimg, y0, x0, n0, wm, wn, li, kh);
 }
 
-// ---- Winograd F(2x2, 3x3) for the 3x3 layers of large launches (fp32, opt-in: option "conv_algo" = 1) -----------------------------
+// ---- Winograd F(2x2, 3x3) for large launches (fp32, option "conv_algo") ----------------------------------------------------------
 // Y = A^T [ (G g G^T) (.) (B^T d B) ] A: a 2 x 2 output tile from a 4 x 4 input window costs 16 multiplies per channel pair instead of
 // 36 -> 2.25x less matrix work; the transforms are additions only (B^T, A^T) or done once on the host (G g G^T, in double, rounded
 // to fp32).  Block = 32 Winograd tiles (4 rows x 8 columns of 2 x 2 = an 8 x 16 pixel output tile) x 128 output channels; wave w owns
 // 32 channels and all 16 "frequencies": 16 accumulator tiles of 32 (Winograd tiles) x 32 (channels) = 256 AGPRs, one block per CU.
-// Per 32-channel chunk: raw 10 x 18 halo -> LDS, every thread transforms one (tile, 4 channels) item (32 additions) into
+// Per 32-channel chunk: raw halo -> LDS, every thread transforms one (tile, 4 channels) item (32 additions) into
 // U[frequency][tile][channel] in LDS, then 16 frequencies x 4 k8-steps x 4 MFMAs per wave with the transformed weights streamed
-// from L2 one frequency ahead.  Epilogue: A^T M A per lane (the 16 frequencies of a (tile, channel) sit in one lane's registers),
-// bias, ReLU, 2x2 max-pool = max over the tile's four outputs.
-// The arithmetic is DEFINED -- transform additions in a fixed order, one sequential FMA chain per frequency over the channels (chunk
-// -> k8-step -> k) -- and oracle/conv_fma_ref.c::conv_wino_ref restates it; it is not the direct kernels' chain (results agree to
-// Winograd's fp32 rounding, ~1e-6 of the map scale).
+// from L2 two frequencies ahead (the loads are pinned between the MFMAs; left alone the compiler sinks them to one step ahead and the
+// single wave per SIMD stalls on L2).  Epilogue: A^T M A per lane (the 16 frequencies of a (tile, channel) sit in one lane's
+// registers), bias, ReLU, 2x2 max-pool = max over the tile's four outputs.
+// KS = 7 (the 7x7 layers of stages 2-6): the taps (0..5, 0..5) are four 3x3 sub-kernels, each a Winograd product on its own
+// shifted window, all four accumulated in the SAME frequency-domain accumulators (the output transform is linear); the remaining 13
+// taps (row 6, column 6) run as direct MFMAs into the four per-pixel planes of the tile after the output transform (second pass over
+// the chunks).  16 x 4 + 13 x 4 = 116 products per tile and channel pair instead of 196.
+// The arithmetic is DEFINED -- transform additions in a fixed order, one sequential FMA chain per frequency over (chunk, sub-kernel,
+// k8-step, k), then the direct taps chained onto the transformed sums -- and oracle/conv_fma_ref.c::conv_wino_ref restates it; it
+// is not the direct kernels' chain (results agree to Winograd's fp32 rounding, ~1e-6 of the map scale).
+template <int KS>
 struct WinoCfg {
-    static constexpr int TH = 8, TW = 16, HH = TH + 2, HW = TW + 2, NPX = HH * HW, CKW = 32, LDR = CKW + 4, LDU = CKW + 4;
+    static constexpr int TH = 8, TW = 16, PADK = KS / 2, HH = TH + KS - 1, HW = TW + KS - 1, NPX = HH * HW, CKW = 32, LDR = CKW + 4, LDU = CKW + 4;
+    static constexpr int NSUB = KS == 3 ? 1 : 4;                       // 3x3 sub-kernels done as Winograd products
+    static constexpr int NDIR = KS == 3 ? 0 : 13;                      // taps done directly (KS = 7: row 6, column 6)
     static constexpr int RAW_ELEMS = NPX * LDR, U_ELEMS = 16 * 32 * LDU;
     static constexpr int LDS_BYTES = (RAW_ELEMS + U_ELEMS) * 4;
     static constexpr int NHF = (NPX * (CKW / 4) + 255) / 256;
+    static_assert(KS == 3 || KS == 7, "Winograd kernel: 3x3 or 7x7");
 };
+// direct taps of the 7x7 variant, in the order they are chained: row 6 left to right, then column 6 top to bottom
+__device__ constexpr int wino7_tap_ky(int t) { return t < 7 ? 6 : t - 7; }
+__device__ constexpr int wino7_tap_kx(int t) { return t < 7 ? t : 6; }
 
-template <int POOL>
+template <int KS, int POOL>
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
 {
-    using C = WinoCfg;
+    using C = WinoCfg<KS>;
+    static_assert(!(POOL && KS != 3), "pooling only with the 3x3 variant");
     extern __shared__ float4 smem4[];
     float* const s_raw = reinterpret_cast<float*>(smem4);
     float* const s_u = s_raw + C::RAW_ELEMS;
@@ -1228,7 +1241,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     const bool g1 = blockIdx.z != 0;
     ConvGroupArgs G;
     G.in = g1 ? a.g[1].in : a.g[0].in;
-    G.w = g1 ? a.g[1].w : a.g[0].w;              // transformed weights [freq 16][chunk32][cout_pad][32]
+    G.w = g1 ? a.g[1].w : a.g[0].w;              // transformed weights [sub-kernel][freq 16][chunk32][cout_pad][32]
+    G.w2 = g1 ? a.g[1].w2 : a.g[0].w2;           // direct pack [tap][chunk16][cout_pad][16] (KS = 7)
     G.bias = g1 ? a.g[1].bias : a.g[0].bias;
     G.out = g1 ? a.g[1].out : a.g[0].out;
     G.cout = g1 ? a.g[1].cout : a.g[0].cout;
@@ -1250,8 +1264,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     asm volatile("" : "+v"(bias));
     const int nch = a.nch;                        // chunks of 32 input channels
 
-    // raw halo staging slots
-    int h_goff[C::NHF], h_lds[C::NHF];
+    // raw halo staging slots (the LDS offset is recomputed at the write)
+    int h_goff[C::NHF];
     unsigned h_ok = 0;
 #pragma unroll
     for (int r = 0; r < C::NHF; ++r) {
@@ -1259,22 +1273,30 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
         const bool slot = f < C::NPX * (C::CKW / 4);
         const int hp = slot ? f / (C::CKW / 4) : 0, c4 = f % (C::CKW / 4);
         const int hy = hp / C::HW, hx = hp - hy * C::HW;
-        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const int gy = y0 + hy - C::PADK, gx = x0 + hx - C::PADK;
         const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
         const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
         h_goff[r] = (cy * W + cx) * a.lda + c4 * 4;
-        h_lds[r] = slot ? hp * C::LDR + c4 * 4 : -1;
         h_ok |= (slot && inb) ? (1u << r) : 0u;
     }
+    auto halo_store = [&](const float4 (&hv)[C::NHF]) {
+#pragma unroll
+        for (int r = 0; r < C::NHF; ++r) {
+            const int f = tid + r * 256;
+            float4 v = hv[r];
+            if (!((h_ok >> r) & 1)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < C::NPX * (C::CKW / 4)) *reinterpret_cast<float4*>(&s_raw[(f >> 3) * C::LDR + (f & 7) * 4]) = v;
+        }
+    };
     // transform item of this thread: Winograd tile tt (4 x 8 grid), channels 4 * tc .. + 3 of the chunk
     const int tt = tid >> 3, tc = tid & 7;
-    const int t_raw = ((2 * (tt >> 3)) * C::HW + 2 * (tt & 7)) * C::LDR + tc * 4;        // top-left pixel of the 4 x 4 window
+    const int t_raw = ((2 * (tt >> 3)) * C::HW + 2 * (tt & 7)) * C::LDR + tc * 4;        // top-left pixel of sub-kernel 0's 4 x 4 window
     const int t_u = tt * C::LDU + tc * 4;
 
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G.w), 0, 0x7fffffff, 0x00020000);
     const unsigned b_off = (unsigned)((n * C::CKW + kh * 4) * 4);
-    const unsigned panel_b = (unsigned)a.cout_pad * C::CKW * 4u;          // bytes of one (freq, chunk) panel
-    const unsigned freq_b = panel_b * (unsigned)nch;                       // bytes between frequencies
+    const unsigned panel_b = (unsigned)a.cout_pad * C::CKW * 4u;          // bytes of one (plane, chunk) panel
+    const unsigned freq_b = panel_b * (unsigned)nch;                       // bytes between planes (sub-kernel * 16 + frequency)
 
     f32x16 acc[16];
 #pragma unroll
@@ -1286,7 +1308,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
 #pragma unroll
     for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r]);
     const int a_off = li * C::LDU + kh * 4;
-    // weight fragments: ring of 4 frequencies, loaded two frequencies (32 MFMAs, ~2000 cycles) ahead and across the chunk boundary
+    // weight fragments: ring of 4 planes, loaded two planes (32 MFMAs, ~2000 cycles) ahead, across sub-kernel and chunk boundaries
     f32x4 bw[4][4];
 #pragma unroll
     for (int f = 0; f < 2; ++f)
@@ -1295,74 +1317,151 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
             bw[f][st] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off + st * 32, (unsigned)f * freq_b, 0));
 
     for (int ch = 0; ch < nch; ++ch) {
-        if (ch) __syncthreads();                   // the previous chunk's MFMAs are done with U
-        // ---- raw halo of this chunk -> LDS
-#pragma unroll
-        for (int r = 0; r < C::NHF; ++r) {
-            float4 v = hreg[r];
-            if (!((h_ok >> r) & 1)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (h_lds[r] >= 0) *reinterpret_cast<float4*>(&s_raw[h_lds[r]]) = v;
-        }
+        if (ch) __syncthreads();                   // the previous chunk's MFMAs are done with U (and its transforms with the raw halo)
+        halo_store(hreg);
         __syncthreads();
-        {   // next chunk's raw halo: global -> registers, lands under this chunk's MFMAs
-            const int cn = ch + 1 < nch ? ch + 1 : ch;
-#pragma unroll
-            for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + cn * C::CKW);
-        }
-        // ---- input transform V = B^T d B of this thread's (tile, 4 channels): rows first, then columns
-        {
-            f32x4 d[4][4], wv4[4][4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const f32x4*>(&s_raw[t_raw + (i * C::HW + j) * C::LDR]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                wv4[0][j] = d[0][j] - d[2][j];
-                wv4[1][j] = d[1][j] + d[2][j];
-                wv4[2][j] = d[2][j] - d[1][j];
-                wv4[3][j] = d[1][j] - d[3][j];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f32x4 v0 = wv4[i][0] - wv4[i][2];
-                const f32x4 v1 = wv4[i][1] + wv4[i][2];
-                const f32x4 v2 = wv4[i][2] - wv4[i][1];
-                const f32x4 v3 = wv4[i][1] - wv4[i][3];
-                *reinterpret_cast<f32x4*>(&s_u[(4 * i + 0) * 32 * C::LDU + t_u]) = v0;
-                *reinterpret_cast<f32x4*>(&s_u[(4 * i + 1) * 32 * C::LDU + t_u]) = v1;
-                *reinterpret_cast<f32x4*>(&s_u[(4 * i + 2) * 32 * C::LDU + t_u]) = v2;
-                *reinterpret_cast<f32x4*>(&s_u[(4 * i + 3) * 32 * C::LDU + t_u]) = v3;
-            }
-        }
-        __syncthreads();
-        // ---- 16 frequencies x 4 k8-steps x 4 MFMAs; one weight load and one A read per 4 MFMAs, pinned between them
         const unsigned chunk_b = (unsigned)ch * panel_b;
         const unsigned next_b = (unsigned)(ch + 1 < nch ? ch + 1 : ch) * panel_b;
-        f32x4 av[2];
-        av[0] = *reinterpret_cast<const f32x4*>(&s_u[a_off]);
+#pragma unroll 1
+        for (int sub = 0; sub < C::NSUB; ++sub) {
+            if (sub) __syncthreads();              // the previous sub-kernel's MFMAs are done with U
+            // ---- input transform V = B^T d B of this thread's (tile, 4 channels): column by column, then the rows
+            {
+                const int src = t_raw + ((3 * (sub >> 1)) * C::HW + 3 * (sub & 1)) * C::LDR;
+                f32x4 wv4[4][4];
 #pragma unroll
-        for (int f = 0; f < 16; ++f) {
-            const unsigned so = f + 2 < 16 ? chunk_b + (unsigned)(f + 2) * freq_b : next_b + (unsigned)(f + 2 - 16) * freq_b;
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 d[4];
 #pragma unroll
-            for (int st = 0; st < 4; ++st) {
+                    for (int i = 0; i < 4; ++i) d[i] = *reinterpret_cast<const f32x4*>(&s_raw[src + (i * C::HW + j) * C::LDR]);
+                    wv4[0][j] = d[0] - d[2];
+                    wv4[1][j] = d[1] + d[2];
+                    wv4[2][j] = d[2] - d[1];
+                    wv4[3][j] = d[1] - d[3];
+                }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st & 1][e], bw[f & 3][st][e], acc[f], 0, 0, 0);
-                    if (e == 0) {
-                        bw[(f + 2) & 3][st] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off + st * 32, so, 0));
-                        __builtin_amdgcn_sched_barrier(0);
-                    } else if (e == 1 && !(f == 15 && st == 3)) {
-                        const int fn = st == 3 ? f + 1 : f, sn = (st + 1) & 3;
-                        av[(st + 1) & 1] = *reinterpret_cast<const f32x4*>(&s_u[fn * 32 * C::LDU + a_off + sn * 8]);
-                        __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 v0 = wv4[i][0] - wv4[i][2];
+                    const f32x4 v1 = wv4[i][1] + wv4[i][2];
+                    const f32x4 v2 = wv4[i][2] - wv4[i][1];
+                    const f32x4 v3 = wv4[i][1] - wv4[i][3];
+                    *reinterpret_cast<f32x4*>(&s_u[(4 * i + 0) * 32 * C::LDU + t_u]) = v0;
+                    *reinterpret_cast<f32x4*>(&s_u[(4 * i + 1) * 32 * C::LDU + t_u]) = v1;
+                    *reinterpret_cast<f32x4*>(&s_u[(4 * i + 2) * 32 * C::LDU + t_u]) = v2;
+                    *reinterpret_cast<f32x4*>(&s_u[(4 * i + 3) * 32 * C::LDU + t_u]) = v3;
+                }
+            }
+            __syncthreads();
+            const bool last_sub = sub == C::NSUB - 1;
+            if (last_sub) {     // next chunk's raw halo: global -> registers, lands under this phase's MFMAs
+                const int cn = ch + 1 < nch ? ch + 1 : ch;
+#pragma unroll
+                for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + cn * C::CKW);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- 16 frequencies x 4 k8-steps x 4 MFMAs; one weight load and one A read per 4 MFMAs, pinned between them
+            const unsigned plane_b = chunk_b + (unsigned)(sub * 16) * freq_b;                                  // plane sub * 16 + 0 of this chunk
+            const unsigned wrap_b = last_sub ? next_b : chunk_b + (unsigned)((sub + 1) * 16) * freq_b;        // plane 0 of what follows
+            f32x4 av[2];
+            av[0] = *reinterpret_cast<const f32x4*>(&s_u[a_off]);
+#pragma unroll
+            for (int f = 0; f < 16; ++f) {
+                const unsigned so = f + 2 < 16 ? plane_b + (unsigned)(f + 2) * freq_b : wrap_b + (unsigned)(f + 2 - 16) * freq_b;
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st & 1][e], bw[f & 3][st][e], acc[f], 0, 0, 0);
+                        if (e == 0) {
+                            bw[(f + 2) & 3][st] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off + st * 32, so, 0));
+                            __builtin_amdgcn_sched_barrier(0);
+                        } else if (e == 1 && !(f == 15 && st == 3)) {
+                            const int fn = st == 3 ? f + 1 : f, sn = (st + 1) & 3;
+                            av[(st + 1) & 1] = *reinterpret_cast<const f32x4*>(&s_u[fn * 32 * C::LDU + a_off + sn * 8]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                 }
             }
         }
     }
 
-    // ---- output transform Y = A^T M A per (tile, channel), bias, ReLU, (pool), store
+    // ---- output transform Y = A^T M A per (tile, channel): y[2 * i + j] = pixel (i, j) of the tile
+    f32x16 y[4];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        float t0[4], t1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t0[j] = (acc[0 + j][reg] + acc[4 + j][reg]) + acc[8 + j][reg];
+            t1[j] = (acc[4 + j][reg] - acc[8 + j][reg]) - acc[12 + j][reg];
+        }
+        y[0][reg] = (t0[0] + t0[1]) + t0[2]; y[1][reg] = (t0[1] - t0[2]) - t0[3];
+        y[2][reg] = (t1[0] + t1[1]) + t1[2]; y[3][reg] = (t1[1] - t1[2]) - t1[3];
+    }
+
+    if (C::NDIR > 0) {
+        // ---- second pass over the chunks: the direct taps, chained onto y.  Step q = tap * 4 + k8-step: one weight load per step
+        // (from the direct pack, two steps ahead), four pixel planes x 4 MFMAs per step, one A read per plane (two planes ahead)
+        constexpr int NQ = C::NDIR * 4;
+        const __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G.w2), 0, 0x7fffffff, 0x00020000);
+        const unsigned b2_off = (unsigned)((n * 16 + kh * 4) * 4);
+        const unsigned p16_b = (unsigned)a.cout_pad * 16u * 4u;            // bytes of one (tap, chunk16) panel
+        const unsigned tap2_b = p16_b * (unsigned)(2 * nch);               // bytes between taps
+        auto q_soff = [&](int q, int ch) -> unsigned {                     // q compile-time after unrolling
+            const int t = q >> 2, st = q & 3;
+            const int tap = wino7_tap_ky(t) * 7 + wino7_tap_kx(t);
+            return (unsigned)tap * tap2_b + (unsigned)(2 * ch + (st >> 1)) * p16_b + (unsigned)((st & 1) * 32);
+        };
+        __syncthreads();                            // pass 1 is done with the raw halo / U
+#pragma unroll
+        for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r]);
+        f32x4 b2[4];
+        b2[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w2rsrc, b2_off, q_soff(0, 0), 0));
+        b2[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w2rsrc, b2_off, q_soff(1, 0), 0));
+        // this lane's tile: pixel plane p = 2 * i + j sits at halo (2 ty + i + ky, 2 tx + j + kx)
+        const int a2_off = ((2 * (li >> 3)) * C::HW + 2 * (li & 7)) * C::LDR + kh * 4;
+        auto a2_addr = [&](int u) -> int {          // unit u = q * 4 + p (compile-time) -> LDS element offset relative to a2_off
+            const int q = u >> 2, p = u & 3, t = q >> 2, st = q & 3;
+            return ((wino7_tap_ky(t) + (p >> 1)) * C::HW + wino7_tap_kx(t) + (p & 1)) * C::LDR + st * 8;
+        };
+        for (int ch = 0; ch < nch; ++ch) {
+            if (ch) __syncthreads();
+            halo_store(hreg);
+            __syncthreads();
+            {
+                const int cn = ch + 1 < nch ? ch + 1 : ch;
+#pragma unroll
+                for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + cn * C::CKW);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int chn = ch + 1 < nch ? ch + 1 : ch;
+            f32x4 av2[4];
+            av2[0] = *reinterpret_cast<const f32x4*>(&s_raw[a2_off + a2_addr(0)]);
+            av2[1] = *reinterpret_cast<const f32x4*>(&s_raw[a2_off + a2_addr(1)]);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const unsigned so = q + 2 < NQ ? q_soff(q + 2, ch) : q_soff(q + 2 - NQ, chn);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int u = q * 4 + p;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        y[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av2[u & 3][e], b2[q & 3][e], y[p], 0, 0, 0);
+                        if (e == 0 && p == 0) {
+                            b2[(q + 2) & 3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w2rsrc, b2_off, so, 0));
+                            __builtin_amdgcn_sched_barrier(0);
+                        } else if (e == 1 && u + 2 < NQ * 4) {
+                            av2[(u + 2) & 3] = *reinterpret_cast<const f32x4*>(&s_raw[a2_off + a2_addr(u + 2)]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- bias, ReLU, (pool), store
     const bool nok = n < G.cout;
     const int Hp = H >> 1, Wp = W >> 1;
     float* out_b = G.out + (size_t)bimg * (POOL ? Hp * Wp : H * W) * a.ldc + n;
@@ -1370,14 +1469,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     for (int reg = 0; reg < 16; ++reg) {
         const int mr = (reg & 3) + 8 * (reg >> 2) + 4 * kh;          // Winograd tile of this register row
         const int ty = mr >> 3, tx = mr & 7;
-        float t0[4], t1[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            t0[j] = (acc[0 + j][reg] + acc[4 + j][reg]) + acc[8 + j][reg];
-            t1[j] = (acc[4 + j][reg] - acc[8 + j][reg]) - acc[12 + j][reg];
-        }
-        float y00 = (t0[0] + t0[1]) + t0[2], y01 = (t0[1] - t0[2]) - t0[3];
-        float y10 = (t1[0] + t1[1]) + t1[2], y11 = (t1[1] - t1[2]) - t1[3];
+        float y00 = y[0][reg], y01 = y[1][reg], y10 = y[2][reg], y11 = y[3][reg];
         const int gy = y0 + 2 * ty, gx = x0 + 2 * tx;
         if (POOL) {
             float v = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)) + bias;
@@ -2266,28 +2358,30 @@ int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream)
     return PMX_ERR_INVALID;
 }
 
-template <int POOL>
+template <int KS, int POOL>
 static int launch_wino(const ConvArgs& a0, int groups, hipStream_t stream)
 {
+    using C = WinoCfg<KS>;
     ConvArgs a = a0;
     PMX_CHECK(!!a.pool == !!POOL, PMX_ERR_INVALID, "conv wino: pool mismatch");
     PMX_CHECK(!POOL || (a.H % 2 == 0 && a.W % 2 == 0), PMX_ERR_INVALID, "conv: pooled layer needs even H, W");
     PMX_CHECK(a.cout_pad % 128 == 0, PMX_ERR_INVALID, "conv wino: cout_pad %d not a multiple of 128", a.cout_pad);
     PMX_CHECK((long long)a.H * a.W * a.lda < (1ll << 31), PMX_ERR_INVALID, "conv: image too large for 32-bit offsets");
-    a.tiles_x = (a.W + WinoCfg::TW - 1) / WinoCfg::TW;
-    a.tiles_y = (a.H + WinoCfg::TH - 1) / WinoCfg::TH;
-    auto kern = conv_wino_kernel<POOL>;
+    PMX_CHECK(KS == 3 || (a.g[0].w2 && (groups == 1 || a.g[1].w2)), PMX_ERR_INVALID, "conv wino 7x7: direct pack missing");
+    a.tiles_x = (a.W + C::TW - 1) / C::TW;
+    a.tiles_y = (a.H + C::TH - 1) / C::TH;
+    auto kern = conv_wino_kernel<KS, POOL>;
     static bool attr_set[PMX_MAX_DEVICES] = {};
     if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(kern), attr_set)) return rc;
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / 128), (unsigned)groups);
-    hipLaunchKernelGGL(kern, grid, dim3(256), WinoCfg::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, a);
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
 
-// a.nch = input channels / 32 (chunks of the Winograd kernel), a.g[].w = transformed weights
-int conv_wino_launch(const ConvArgs& a, int groups, hipStream_t stream)
+// a.nch = input channels / 32 (chunks of the Winograd kernel), a.g[].w = transformed weights (a.g[].w2 = direct pack, ks = 7)
+int conv_wino_launch(const ConvArgs& a, int ks, int groups, hipStream_t stream)
 {
-    return a.pool ? launch_wino<1>(a, groups, stream) : launch_wino<0>(a, groups, stream);
+    if (ks == 7) return launch_wino<7, 0>(a, groups, stream);
+    return a.pool ? launch_wino<3, 1>(a, groups, stream) : launch_wino<3, 0>(a, groups, stream);
 }
-

@@ -133,25 +133,31 @@ static inline float bf16_f(uint16_t h)
 }
 // packed fp32 weights [tap][chunk][cout_pad][16] -> bf16x3 [tap][chunk][plane][cout_pad][16]
 // Winograd F(2x2, 3x3) weights: U = G g G^T per (cout, cin), G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]], evaluated in double and
-// rounded once to fp32 (oracle/conv_fma_ref.c::wino_weights does the same); layout [freq = 4i + j][chunk of 32 cin][cout_pad][32]
-static bool wino_eligible(int ks, int cin_pad, int cout_pad) { return ks == 3 && cin_pad % 32 == 0 && cout_pad % 128 == 0; }
-static void pack_wino(const std::vector<float>& wp, int nch16, int cout_pad, std::vector<float>& out)
+// rounded once to fp32 (oracle/conv_fma_ref.c::conv_wino_ref does the same); layout [plane = sub-kernel * 16 + 4i + j][chunk of 32
+// cin][cout_pad][32].  ks = 3: one sub-kernel; ks = 7: four, sub-kernel (sy, sx) = taps (3 sy .. 3 sy + 2, 3 sx .. 3 sx + 2) -- row 6
+// and column 6 of the 7x7 kernel stay direct (the kernel reads them from the direct pack)
+static bool wino_eligible(int ks, int cin_pad, int cout_pad) { return (ks == 3 || ks == 7) && cin_pad % 32 == 0 && cout_pad % 128 == 0; }
+static void pack_wino(const std::vector<float>& wp, int ks, int nch16, int cout_pad, std::vector<float>& out)
 {
     static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-    const int cin_pad = nch16 * CK, nch32 = cin_pad / 32;
-    out.assign((size_t)16 * nch32 * cout_pad * 32, 0.f);
-    for (int n = 0; n < cout_pad; ++n)
-        for (int ci = 0; ci < cin_pad; ++ci) {
-            double g[3][3], gg[4][3];
-            for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = wp[(((size_t)t * nch16 + ci / CK) * cout_pad + n) * CK + ci % CK];
-            for (int i = 0; i < 4; ++i)
-                for (int kx = 0; kx < 3; ++kx) gg[i][kx] = (Gm[i][0] * g[0][kx] + Gm[i][1] * g[1][kx]) + Gm[i][2] * g[2][kx];
-            for (int i = 0; i < 4; ++i)
-                for (int j = 0; j < 4; ++j) {
-                    const double u = (gg[i][0] * Gm[j][0] + gg[i][1] * Gm[j][1]) + gg[i][2] * Gm[j][2];
-                    out[((((size_t)(4 * i + j)) * nch32 + ci / 32) * cout_pad + n) * 32 + ci % 32] = (float)u;
+    const int cin_pad = nch16 * CK, nch32 = cin_pad / 32, nsub = ks == 3 ? 1 : 4;
+    out.assign((size_t)nsub * 16 * nch32 * cout_pad * 32, 0.f);
+    for (int sub = 0; sub < nsub; ++sub)
+        for (int n = 0; n < cout_pad; ++n)
+            for (int ci = 0; ci < cin_pad; ++ci) {
+                double g[3][3], gg[4][3];
+                for (int t = 0; t < 9; ++t) {
+                    const int tap = (3 * (sub >> 1) + t / 3) * ks + 3 * (sub & 1) + t % 3;
+                    g[t / 3][t % 3] = wp[(((size_t)tap * nch16 + ci / CK) * cout_pad + n) * CK + ci % CK];
                 }
-        }
+                for (int i = 0; i < 4; ++i)
+                    for (int kx = 0; kx < 3; ++kx) gg[i][kx] = (Gm[i][0] * g[0][kx] + Gm[i][1] * g[1][kx]) + Gm[i][2] * g[2][kx];
+                for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < 4; ++j) {
+                        const double u = (gg[i][0] * Gm[j][0] + gg[i][1] * Gm[j][1]) + gg[i][2] * Gm[j][2];
+                        out[((((size_t)(sub * 16 + 4 * i + j)) * nch32 + ci / 32) * cout_pad + n) * 32 + ci % 32] = (float)u;
+                    }
+            }
 }
 
 static void pack_bf16x3(const std::vector<float>& wp, int T, int nch, int cout_pad, std::vector<uint16_t>& out)
@@ -564,7 +570,7 @@ extern "C" int pmx_set_layer(pmx_ctx* c, const char* name, const float* w, const
     }
     if (wino_eligible(ks, (int)cmap.size(), cpad)) {
         std::vector<float> ww;
-        pack_wino(wp, (int)cmap.size() / CK, cpad, ww);
+        pack_wino(wp, ks, (int)cmap.size() / CK, cpad, ww);
         if (!L.d_ww) PMX_HIP(hipMalloc((void**)&L.d_ww, ww.size() * sizeof(float)));
         PMX_HIP(hipMemcpy(L.d_ww, ww.data(), ww.size() * sizeof(float), hipMemcpyHostToDevice));
     }
@@ -633,7 +639,7 @@ static int launch_conv(pmx_ctx* c, const ConvArgs& a0, int groups, int v, const 
 // (one 8 x 16 x 128 block per CU at a time; small launches stay on the direct kernels and their split-K plans)
 static bool wino_use(const pmx_ctx* c, int ks, int cin_pad, int cout_pad, int images, int H, int W)
 {
-    if (c->opt_conv_algo < 1 || c->opt_precision != 0 || c->opt_force[3] >= 0 || !wino_eligible(ks, cin_pad, cout_pad)) return false;
+    if (c->opt_conv_algo < 1 || c->opt_precision != 0 || c->opt_force[ks] >= 0 || !wino_eligible(ks, cin_pad, cout_pad)) return false;
     if (c->opt_conv_algo == 2) return true;       // tests: every eligible 3x3 layer, whatever the launch size
     const long long blocks = (long long)((H + 7) / 8) * ((W + 15) / 16) * images * (cout_pad / 128);
     return blocks >= 2ll * conv_num_cus();
@@ -667,13 +673,13 @@ static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float
     const bool prof_this = c->prof_on == 1 || (c->prof_on == 2 && L0.ks == 7);
     if (wino_use(c, L0.ks, L0.cin_pad, L0.cout_pad, B * groups, H, W) && L0.d_ww && (groups == 1 || c->layers[li1].d_ww)) {
         a.nch = L0.cin_pad / 32;
-        a.g[0].w = L0.d_ww;
-        if (groups == 2) a.g[1].w = c->layers[li1].d_ww;
+        a.g[0].w = L0.d_ww; a.g[0].w2 = L0.d_w;
+        if (groups == 2) { a.g[1].w = c->layers[li1].d_ww; a.g[1].w2 = c->layers[li1].d_w; }
         if (prof_this) {
             const double bytes = 4.0 * B * H * W * ((double)L0.cin * groups + (double)L0.cout * groups / (pool ? 4 : 1));
-            if ((rc = prof_begin(c, std::string(label) + "|conv_wino_f2x2_3x3", flops, bytes))) return rc;
+            if ((rc = prof_begin(c, std::string(label) + (L0.ks == 7 ? "|conv_wino_f2x2_7x7" : "|conv_wino_f2x2_3x3"), flops, bytes))) return rc;
         }
-        if ((rc = conv_wino_launch(a, groups, c->stream))) return rc;
+        if ((rc = conv_wino_launch(a, L0.ks, groups, c->stream))) return rc;
         return prof_this ? prof_end(c) : PMX_OK;
     }
     SplitPlan plan = conv_pick_ksplit(v, H, W, B, groups, L0.cout_pad, L0.nch, pool, c->opt_ksplit);
@@ -1725,13 +1731,13 @@ extern "C" int pmx_conv2d(pmx_ctx* c, const float* x, const float* w, const floa
     const bool wino = wino_use(c, ks, cin_pad, cpad, B, H, W);
     if (wino) {
         std::vector<float> ww;
-        pack_wino(wp, cin_pad / CK, cpad, ww);
+        pack_wino(wp, ks, cin_pad / CK, cpad, ww);
         PMX_HIP(hipMalloc((void**)&d_ww, ww.size() * sizeof(float)));
         PMX_HIP(hipMemcpy(d_ww, ww.data(), ww.size() * sizeof(float), hipMemcpyHostToDevice));
-        a.g[0].w = d_ww; a.nch = cin_pad / 32;
+        a.g[0].w = d_ww; a.g[0].w2 = d_w; a.nch = cin_pad / 32;
     }
     auto launch_conv = [&](pmx_ctx* cc, const ConvArgs& aa, int gg, int vv, const SplitPlan& pp) {
-        return wino ? conv_wino_launch(aa, gg, cc->stream) : ::launch_conv(cc, aa, gg, vv, pp);
+        return wino ? conv_wino_launch(aa, ks, gg, cc->stream) : ::launch_conv(cc, aa, gg, vv, pp);
     };
     if (!rc) rc = launch_conv(c, a, 1, v_run, plan);
     if (!rc && iters > 0) {

@@ -61,59 +61,66 @@ void conv_fma_ref(const float* x, const float* w, const float* bias, float* y, i
                 }
 }
 
-/* Winograd F(2x2, 3x3) twin of csrc/conv_mfma.hip::conv_wino_kernel (option "conv_algo" = 1; 3x3 layers, cin % 32 == 0):
+/* Winograd F(2x2, 3x3) twin of csrc/conv_mfma.hip::conv_wino_kernel (option "conv_algo"; 3x3 and 7x7 layers, cin % 32 == 0):
  *   U = G g G^T in double, rounded once to fp32 (csrc/pmx_api.hip::pack_wino);
  *   V = B^T d B in fp32, rows first then columns, each entry one add/subtract of two terms;
- *   16 frequency-wise sequential fmaf chains over the channels: 32-channel chunk -> 8-channel step -> e in 0..3: k = e, then e + 4;
+ *   16 frequency-wise sequential fmaf chains over (32-channel chunk -> sub-kernel -> 8-channel step -> e in 0..3: k = e, then e + 4);
  *   Y = A^T M A in fp32: t0j = (m0j + m1j) + m2j, t1j = (m1j - m2j) - m3j, y_i0 = (t_i0 + t_i1) + t_i2, y_i1 = (t_i1 - t_i2) - t_i3;
- *   max-pool = max of the tile's four outputs (before the bias, like the kernel), + bias, ReLU.
- * The window of output tile (ty, tx) covers input rows 2ty-1 .. 2ty+2, columns 2tx-1 .. 2tx+2, zeros outside the image. */
+ *   ks = 7: sub-kernel (sy, sx) = taps (3 sy .. 3 sy + 2, 3 sx .. 3 sx + 2) on the window shifted by (3 sy, 3 sx), all four summed in the
+ *   frequency domain; the other 13 taps (row 6 left to right, then column 6 top to bottom) are chained DIRECTLY onto each y, per
+ *   32-channel chunk -> tap -> 8-channel step -> k, after the output transform;
+ *   max-pool (3x3 only) = max of the tile's four outputs (before the bias, like the kernel), + bias, ReLU.
+ * The window of output tile (ty, tx), sub-kernel (sy, sx), covers input rows 2 ty - pad + 3 sy .. + 3 (columns alike), zeros outside. */
 #include <stdlib.h>
-void conv_wino_ref(const float* x, const float* w, const float* bias, float* y, int B, int cin, int H, int W, int cout, int relu,
-                   int pool)
+void conv_wino_ref(const float* x, const float* w, const float* bias, float* y, int B, int cin, int H, int W, int cout, int ks,
+                   int relu, int pool)
 {
     static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int pad = ks / 2, nsub = ks == 3 ? 1 : 4, ndir = ks == 3 ? 0 : 13;
     const int TY = (H + 1) / 2, TX = (W + 1) / 2;
     const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
-    float* U = (float*)malloc((size_t)cout * cin * 16 * sizeof(float));
-    float* V = (float*)malloc((size_t)B * cin * TY * TX * 16 * sizeof(float));
+    float* U = (float*)malloc((size_t)cout * cin * nsub * 16 * sizeof(float));
+    float* V = (float*)malloc((size_t)B * cin * TY * TX * nsub * 16 * sizeof(float));
 #pragma omp parallel for schedule(static)
     for (int n = 0; n < cout; ++n)
-        for (int c = 0; c < cin; ++c) {
-            const float* g = w + ((size_t)n * cin + c) * 9;
-            double gg[4][3];
-            for (int i = 0; i < 4; ++i)
-                for (int kx = 0; kx < 3; ++kx)
-                    gg[i][kx] = (Gm[i][0] * (double)g[kx] + Gm[i][1] * (double)g[3 + kx]) + Gm[i][2] * (double)g[6 + kx];
-            for (int i = 0; i < 4; ++i)
-                for (int j = 0; j < 4; ++j)
-                    U[((size_t)n * cin + c) * 16 + 4 * i + j] = (float)((gg[i][0] * Gm[j][0] + gg[i][1] * Gm[j][1]) + gg[i][2] * Gm[j][2]);
-        }
+        for (int c = 0; c < cin; ++c)
+            for (int sub = 0; sub < nsub; ++sub) {
+                const float* g = w + ((size_t)n * cin + c) * ks * ks + (3 * (sub >> 1)) * ks + 3 * (sub & 1);
+                double gg[4][3];
+                for (int i = 0; i < 4; ++i)
+                    for (int kx = 0; kx < 3; ++kx)
+                        gg[i][kx] = (Gm[i][0] * (double)g[kx] + Gm[i][1] * (double)g[ks + kx]) + Gm[i][2] * (double)g[2 * ks + kx];
+                for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < 4; ++j)
+                        U[(((size_t)n * cin + c) * nsub + sub) * 16 + 4 * i + j] =
+                            (float)((gg[i][0] * Gm[j][0] + gg[i][1] * Gm[j][1]) + gg[i][2] * Gm[j][2]);
+            }
 #pragma omp parallel for collapse(2) schedule(static)
     for (int b = 0; b < B; ++b)
         for (int c = 0; c < cin; ++c)
             for (int ty = 0; ty < TY; ++ty)
-                for (int tx = 0; tx < TX; ++tx) {
-                    float d[4][4], r[4][4];
-                    for (int i = 0; i < 4; ++i)
+                for (int tx = 0; tx < TX; ++tx)
+                    for (int sub = 0; sub < nsub; ++sub) {
+                        float d[4][4], r[4][4];
+                        for (int i = 0; i < 4; ++i)
+                            for (int j = 0; j < 4; ++j) {
+                                const int iy = 2 * ty - pad + 3 * (sub >> 1) + i, ix = 2 * tx - pad + 3 * (sub & 1) + j;
+                                d[i][j] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((size_t)b * cin + c) * H + iy) * W + ix] : 0.f;
+                            }
                         for (int j = 0; j < 4; ++j) {
-                            const int iy = 2 * ty - 1 + i, ix = 2 * tx - 1 + j;
-                            d[i][j] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((size_t)b * cin + c) * H + iy) * W + ix] : 0.f;
+                            r[0][j] = d[0][j] - d[2][j];
+                            r[1][j] = d[1][j] + d[2][j];
+                            r[2][j] = d[2][j] - d[1][j];
+                            r[3][j] = d[1][j] - d[3][j];
                         }
-                    for (int j = 0; j < 4; ++j) {
-                        r[0][j] = d[0][j] - d[2][j];
-                        r[1][j] = d[1][j] + d[2][j];
-                        r[2][j] = d[2][j] - d[1][j];
-                        r[3][j] = d[1][j] - d[3][j];
+                        float* v = V + (((((size_t)b * cin + c) * TY + ty) * TX + tx) * nsub + sub) * 16;
+                        for (int i = 0; i < 4; ++i) {
+                            v[4 * i + 0] = r[i][0] - r[i][2];
+                            v[4 * i + 1] = r[i][1] + r[i][2];
+                            v[4 * i + 2] = r[i][2] - r[i][1];
+                            v[4 * i + 3] = r[i][1] - r[i][3];
+                        }
                     }
-                    float* v = V + ((((size_t)b * cin + c) * TY + ty) * TX + tx) * 16;
-                    for (int i = 0; i < 4; ++i) {
-                        v[4 * i + 0] = r[i][0] - r[i][2];
-                        v[4 * i + 1] = r[i][1] + r[i][2];
-                        v[4 * i + 2] = r[i][2] - r[i][1];
-                        v[4 * i + 3] = r[i][1] - r[i][3];
-                    }
-                }
 #pragma omp parallel for collapse(2) schedule(static)
     for (int b = 0; b < B; ++b)
         for (int n = 0; n < cout; ++n)
@@ -121,15 +128,17 @@ void conv_wino_ref(const float* x, const float* w, const float* bias, float* y, 
                 for (int tx = 0; tx < TX; ++tx) {
                     float m[16];
                     for (int f = 0; f < 16; ++f) m[f] = 0.f;
-                    for (int c8 = 0; c8 < cin; c8 += 8)
-                        for (int e = 0; e < 4; ++e)
-                            for (int hi = 0; hi < 2; ++hi) {
-                                const int c = c8 + e + 4 * hi;
-                                if (c >= cin) continue;
-                                const float* v = V + ((((size_t)b * cin + c) * TY + ty) * TX + tx) * 16;
-                                const float* u = U + ((size_t)n * cin + c) * 16;
-                                for (int f = 0; f < 16; ++f) m[f] = fmaf(v[f], u[f], m[f]);
-                            }
+                    for (int c32 = 0; c32 < cin; c32 += 32)
+                        for (int sub = 0; sub < nsub; ++sub)
+                            for (int c8 = c32; c8 < c32 + 32; c8 += 8)
+                                for (int e = 0; e < 4; ++e)
+                                    for (int hi = 0; hi < 2; ++hi) {
+                                        const int c = c8 + e + 4 * hi;
+                                        if (c >= cin) continue;
+                                        const float* v = V + (((((size_t)b * cin + c) * TY + ty) * TX + tx) * nsub + sub) * 16;
+                                        const float* u = U + (((size_t)n * cin + c) * nsub + sub) * 16;
+                                        for (int f = 0; f < 16; ++f) m[f] = fmaf(v[f], u[f], m[f]);
+                                    }
                     float t0[4], t1[4], yv[2][2];
                     for (int j = 0; j < 4; ++j) {
                         t0[j] = (m[j] + m[4 + j]) + m[8 + j];
@@ -137,6 +146,23 @@ void conv_wino_ref(const float* x, const float* w, const float* bias, float* y, 
                     }
                     yv[0][0] = (t0[0] + t0[1]) + t0[2]; yv[0][1] = (t0[1] - t0[2]) - t0[3];
                     yv[1][0] = (t1[0] + t1[1]) + t1[2]; yv[1][1] = (t1[1] - t1[2]) - t1[3];
+                    for (int c32 = 0; c32 < cin && ndir; c32 += 32)
+                        for (int t = 0; t < ndir; ++t) {
+                            const int ky = t < 7 ? 6 : t - 7, kx = t < 7 ? t : 6;
+                            for (int c8 = c32; c8 < c32 + 32; c8 += 8)
+                                for (int e = 0; e < 4; ++e)
+                                    for (int hi = 0; hi < 2; ++hi) {
+                                        const int c = c8 + e + 4 * hi;
+                                        if (c >= cin) continue;
+                                        const float wv = w[(((size_t)n * cin + c) * ks + ky) * ks + kx];
+                                        for (int i = 0; i < 2; ++i)
+                                            for (int j = 0; j < 2; ++j) {
+                                                const int iy = 2 * ty + i + ky - pad, ix = 2 * tx + j + kx - pad;
+                                                const float xv = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((size_t)b * cin + c) * H + iy) * W + ix] : 0.f;
+                                                yv[i][j] = fmaf(xv, wv, yv[i][j]);
+                                            }
+                                    }
+                        }
                     if (pool) {
                         if (ty < Ho && tx < Wo) {
                             float best = yv[0][0];

@@ -53,21 +53,22 @@ def conv_fma(x, w, b, relu=False, pool=False, splitk=1):
 
 
 def conv_wino(x, w, b, relu=False, pool=False):
-    """The Winograd F(2x2, 3x3) kernel's arithmetic (csrc/conv_mfma.hip::conv_wino_kernel, option "conv_algo" = 1): same
-    shapes as conv_fma, 3x3 only.  Defined order, but not the direct kernels' chain: the two agree to ~1e-6 of the map scale."""
+    """The Winograd F(2x2, 3x3) kernel's arithmetic (csrc/conv_mfma.hip::conv_wino_kernel, option "conv_algo"): same shapes as
+    conv_fma, 3x3 or 7x7 (four 3x3 sub-kernels in the frequency domain + 13 direct taps).  Defined order, but not the direct
+    kernels' chain: the two agree to ~1e-6 of the map scale."""
     global _lib
     if _lib is None:
         conv_fma(np.zeros((1, 1, 1, 1), 'f'), np.zeros((1, 1, 1, 1), 'f'), np.zeros(1, 'f'))
     _lib.conv_wino_ref.restype = None
-    _lib.conv_wino_ref.argtypes = [C.c_void_p] * 4 + [C.c_int] * 7
+    _lib.conv_wino_ref.argtypes = [C.c_void_p] * 4 + [C.c_int] * 8
     x = np.ascontiguousarray(x, np.float32)
     w = np.ascontiguousarray(w, np.float32)
     b = np.ascontiguousarray(b, np.float32)
     B, cin, H, W = x.shape
     cout, _, ks, _ = w.shape
-    assert ks == 3
+    assert ks in (3, 7) and not (pool and ks == 7)
     y = np.empty((B, cout, H // 2 if pool else H, W // 2 if pool else W), np.float32)
-    _lib.conv_wino_ref(x.ctypes.data, w.ctypes.data, b.ctypes.data, y.ctypes.data, B, cin, H, W, cout, int(relu), int(pool))
+    _lib.conv_wino_ref(x.ctypes.data, w.ctypes.data, b.ctypes.data, y.ctypes.data, B, cin, H, W, cout, ks, int(relu), int(pool))
     return y
 
 
@@ -113,7 +114,7 @@ def forward_fma(weights, x, splitk=None, wino=()):
         W, b = weights[name]
         label = name[:-3] if name.endswith(('_L1', '_L2')) else name
         if label in wino:
-            return conv_wino(h, W, b, relu=relu, pool=pool)
+            return conv_wino(h, _cat_weights(W) if cat else W, b, relu=relu, pool=pool)
         return conv_fma(h, _cat_weights(W) if cat else W, b, relu=relu, pool=pool, splitk=splitk.get(label, 1))
     h = conv('conv1_1', x); h = conv('conv1_2', h, pool=True)
     h = conv('conv2_1', h); h = conv('conv2_2', h, pool=True)
