@@ -56,17 +56,19 @@ def engine(native):
     e.close()
 
 
-def forward_plan(engine, run):
+def forward_plan(engine, run, with_wino=False):
     """Run `run()` (one forward through `engine`) with the per-launch profiler on and return the split-K plan the kernels used
     ({layer label: K slices}, oracle/conv_fma_ref.py::splitk_plan) -- what the order-defined oracle needs to reproduce a
-    small-launch forward bit for bit."""
+    small-launch forward bit for bit.  with_wino: return (plan, labels of the layers that ran as Winograd, out)."""
     from oracle import conv_fma_ref
     engine.profile_reset()
     engine.profile_enable(True)
     try:
         out = run()
-        plan = conv_fma_ref.splitk_plan(engine.profile())
+        prof = engine.profile()
+        plan = conv_fma_ref.splitk_plan(prof)
+        wino = conv_fma_ref.wino_layers(prof)
     finally:
         engine.profile_enable(False)
         engine.profile_reset()
-    return plan, out
+    return (plan, wino, out) if with_wino else (plan, out)

@@ -1,0 +1,145 @@
+"""GPU: the Winograd F(2x2, 3x3) fp32 kernel (csrc/conv_mfma.hip::conv_wino_kernel, option "conv_algo": 1 = the 3x3 / 7x7
+layers of launches that fill the chip, 2 = every eligible layer) -- the replacement for L.Convolution2D on those layers
+(models/CocoPoseNet.py:28-129).  Bars: bit-identical to its plain-C twin (oracle/conv_fma_ref.c::conv_wino_ref: transforms,
+frequency-wise FMA chains and direct taps in the kernel's order); within fp32 rounding of the float64 convolution; the whole
+network and the reference's end-to-end goldens (identical peak indices / poses, scores to 1e-4) also hold with it."""
+import numpy as np
+import pytest
+
+from conftest import forward_plan, pkg
+from oracle import conv_fma_ref as R
+from oracle import network_ref as N
+from oracle import postprocess_ref as P
+from test_reference_network import load_e2e
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def _run(engine, x, w, b, relu, pool, algo):
+    engine.set_option('conv_algo', algo)
+    try:
+        return engine.conv2d(x, w, b, relu=relu, pool=pool)
+    finally:
+        engine.set_option('conv_algo', 0)
+
+
+def _data(seed, B, cin, H, W, cout, k):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, cin, H, W)).astype('f')
+    w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype('f')
+    return x, w, rng.standard_normal(cout).astype('f')
+
+
+@pytest.mark.parametrize('B,cin,H,W,cout,k,relu,pool', [
+    (2, 32, 30, 34, 128, 3, True, False),       # several 8x16 tiles, ragged right / bottom edges
+    (3, 64, 22, 18, 128, 3, False, True),       # fused 2x2 max-pool
+    (1, 96, 17, 33, 256, 3, True, False),       # odd H and W (half-used Winograd tiles), two 128-channel blocks
+    (2, 32, 9, 15, 130, 3, True, False),        # cout not a multiple of 128 (padded to 256)
+    (1, 64, 46, 46, 128, 3, True, False),       # the feature-map size of the network
+    (2, 32, 19, 21, 128, 7, True, False),       # 7x7: four 3x3 sub-kernels + 13 direct taps
+    (1, 64, 46, 46, 128, 7, True, False),
+    (1, 96, 9, 40, 100, 7, False, False),
+    (1, 32, 3, 5, 128, 7, True, False),         # image smaller than the kernel: every window crosses the border
+    (1, 32, 2, 2, 128, 3, True, True)])
+def test_winograd_conv_bit_exact_vs_c_twin(engine, B, cin, H, W, cout, k, relu, pool):
+    x, w, b = _data(B * 1000 + cin + H + k, B, cin, H, W, cout, k)
+    y = _run(engine, x, w, b, relu, pool, 2)
+    yd = _run(engine, x, w, b, relu, pool, 0)
+    ref = R.conv_wino(x, w, b, relu, pool)
+    assert y.shape == ref.shape and np.isfinite(y).all()
+    assert np.array_equal(y, ref), (np.abs(y - ref).max(), int((y != ref).sum()))
+    assert not np.array_equal(y, yd), 'the Winograd kernel did not run'
+    t = N.conv2d_ref(x, w, b, relu=relu, pool=pool)
+    assert np.abs(y - t).max() <= TOL * max(1.0, np.abs(t).max())
+
+
+def test_winograd_is_not_used_where_it_does_not_apply(engine):
+    """cin not a multiple of 32, 1x1 layers, the bf16x3 mode and forced variants keep their kernels (bit-identical to conv_algo 0)."""
+    for (cin, cout, k) in [(48, 128, 3), (64, 128, 1), (3, 64, 3)]:
+        x, w, b = _data(cin + k, 1, cin, 12, 20, cout, k)
+        assert np.array_equal(_run(engine, x, w, b, True, False, 2), _run(engine, x, w, b, True, False, 0)), (cin, cout, k)
+
+
+def test_winograd_large_launch_selection(engine):
+    """conv_algo = 1 takes a layer only when the launch has at least two blocks per CU; the result is the twin's either way."""
+    x, w, b = _data(5, 1, 32, 16, 16, 128, 3)
+    assert np.array_equal(_run(engine, x, w, b, True, False, 1), _run(engine, x, w, b, True, False, 0))      # 4 blocks: direct
+    x, w, b = _data(6, 24, 32, 46, 46, 128, 3)                                                                # 18 * 24 = 432 blocks... still direct
+    y1 = _run(engine, x, w, b, True, False, 1)
+    x2, w2, b2 = _data(7, 32, 32, 46, 46, 128, 3)                                                             # 576 blocks: Winograd
+    y2 = _run(engine, x2, w2, b2, True, False, 1)
+    assert np.array_equal(y1, _run(engine, x, w, b, True, False, 0))
+    assert np.array_equal(y2, R.conv_wino(x2, w2, b2, True, False))
+
+
+@pytest.mark.parametrize('shape', [(1, 64, 64), (2, 96, 128)])
+def test_network_with_winograd_bit_exact_vs_order_defined_oracle(engine, shape):
+    """The whole forward with every eligible layer on the Winograd kernel (32 of the 92 layers carry 98 % of the work:
+    conv2_1 .. conv5_3 and the 25 7x7 layers) == forward_fma with the same layers restated by the C twin, bit for bit."""
+    weights = pkg('weights').synthetic_weights(0)
+    engine.set_weights(weights)
+    rng = np.random.default_rng(sum(shape) + 1)
+    imgs = rng.integers(0, 256, shape + (3,), dtype=np.uint8)
+    engine.set_option('conv_algo', 2)
+    try:
+        plan, wino, _ = forward_plan(engine, lambda: engine.forward_u8(imgs), with_wino=True)
+        paf, heat = engine.get_maps()
+    finally:
+        engine.set_option('conv_algo', 0)
+    assert {'conv2_1', 'conv3_2', 'conv4_2', 'conv5_1_CPM', 'Mconv1_stage2', 'Mconv5_stage6'} <= wino and 'conv1_2' not in wino, wino
+    x = np.concatenate([P.preprocess(im) for im in imgs])
+    rpaf, rheat = R.forward_fma(weights, x, splitk=plan, wino=wino)
+    assert np.array_equal(paf, rpaf), np.abs(paf - rpaf).max()
+    assert np.array_equal(heat, rheat), np.abs(heat - rheat).max()
+    # and it is the same network as the torch-CPU restatement / the direct kernels, to fp32 rounding
+    tpaf, theat = N.forward(weights, x)
+    assert np.abs(paf - tpaf).max() <= 1e-4 * max(1.0, np.abs(tpaf).max())
+    assert np.abs(heat - theat).max() <= 1e-4 * max(1.0, np.abs(theat).max())
+
+
+@pytest.mark.parametrize('name', ['e2e_person', 'e2e_people', 'e2e_dinner'])
+def test_config1_reference_images_with_winograd(native, name):
+    """BASELINE config 1 with every eligible layer on the Winograd kernel: what the reference's own PoseDetector returned on its
+    own images (pose_detector.py:484-517) -- identical peak indices and poses, scores to 1e-4."""
+    PD = pkg('pose_detector')
+    g = load_e2e(name)
+    det = PD.PoseDetector(weights=g['weights'], device=0)
+    det.engine.set_option('conv_algo', 2)
+    poses, scores = det(g['img'])
+    peaks = det.engine.peaks(0)
+    det.engine.close()
+    assert peaks.shape == g['all_peaks'].shape
+    assert np.array_equal(peaks[:, [0, 1, 2, 4]], g['all_peaks'][:, [0, 1, 2, 4]])
+    assert float(np.abs(peaks[:, 3] - g['all_peaks'][:, 3]).max()) <= 1e-4
+    assert np.asarray(poses).shape == g['poses'].shape and np.array_equal(np.asarray(poses), g['poses'])
+    assert float(np.abs(np.asarray(scores) - g['scores']).max()) <= 1e-4
+
+
+def test_batch_32_winograd_agrees_with_single_images(native):
+    """Batch 32 at 368x368 (Winograd by launch size) vs the same images one at a time (direct kernels, split-K): same people,
+    identical peak indices, scores to 1e-5 -- the two paths differ by fp32 rounding only."""
+    W = pkg('weights')
+    eng = native.Engine(0, max_batch=32, max_h=368, max_w=368)
+    w = W.synthetic_weights(0); eng.set_weights(w)
+    cal = np.random.default_rng(1234).integers(0, 256, (1, 368, 368, 3), dtype=np.uint8)
+    eng.forward_u8(cal); paf, heat = eng.get_maps()
+    w = W.calibrate_head(w, paf[0], heat[0]); eng.set_weights({k: w[k] for k in ('Mconv7_stage6_L1', 'Mconv7_stage6_L2')})
+    imgs = np.random.default_rng(3).integers(0, 256, (32, 368, 368, 3), dtype=np.uint8)
+    eng.set_option('conv_algo', 1)
+    eng.profile_enable(True); eng.detect_batch(imgs, 320, 320); prof = eng.profile(); eng.profile_enable(False)
+    assert len(R.wino_layers(prof)) >= 30, sorted(R.wino_layers(prof))
+    rec = eng.results().copy()
+    peaks32 = [eng.peaks(i).copy() for i in (0, 13, 31)]
+    eng.set_option('conv_algo', 0)
+    for j, i in enumerate((0, 13, 31)):
+        eng.detect_batch(imgs[i:i + 1], 320, 320)
+        r1 = eng.results()
+        p1 = eng.peaks(0)
+        assert r1['n_people'][0] == rec['n_people'][i] and r1['n_peaks'][0] == rec['n_peaks'][i]
+        assert np.array_equal(p1[:, [0, 1, 2, 4]], peaks32[j][:, [0, 1, 2, 4]])
+        assert np.abs(p1[:, 3] - peaks32[j][:, 3]).max() <= 1e-5
+        n = int(r1['n_people'][0])
+        assert np.array_equal(r1['poses'][0][:n], rec['poses'][i][:n])
+        assert np.abs(r1['scores'][0][:n] - rec['scores'][i][:n]).max() <= 1e-5
+    eng.close()

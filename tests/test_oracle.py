@@ -87,3 +87,30 @@ def test_order_defined_conv_oracle_matches_torch_and_is_deterministic():
         ref = N.conv2d_ref(x, w, b, relu=True, pool=pool)
         assert y.shape == ref.shape and np.abs(y - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
         assert np.array_equal(y, R.conv_fma(x, w, b, relu=True, pool=pool))
+
+
+def test_winograd_conv_oracle_is_the_same_convolution():
+    """oracle/conv_fma_ref.c::conv_wino_ref (twin of the Winograd F(2x2, 3x3) HIP kernel, bit-checked on the GPU): the 3x3 form
+    and the 7x7 form (four 3x3 sub-kernels in the frequency domain + 13 direct taps) equal the float64 convolution to fp32
+    rounding -- odd sizes, images smaller than the kernel, pooling -- and exactly on data where every product and sum is exact."""
+    import torch
+    from oracle import conv_fma_ref as R
+    rng = np.random.default_rng(4)
+    for (B, cin, H, W, cout, k, relu, pool) in [(2, 32, 9, 11, 7, 3, True, False), (1, 64, 8, 10, 3, 3, True, True), (1, 32, 6, 7, 40, 7, False, False),
+                                                (1, 40, 13, 5, 9, 7, True, False), (1, 32, 2, 3, 5, 7, True, False)]:
+        x = rng.standard_normal((B, cin, H, W)).astype('f')
+        w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype('f')
+        b = rng.standard_normal(cout).astype('f')
+        y = R.conv_wino(x, w, b, relu=relu, pool=pool)
+        t = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=k // 2)
+        t = torch.relu(t) if relu else t
+        t = torch.nn.functional.max_pool2d(t, 2, 2) if pool else t
+        assert y.shape == tuple(t.shape) and np.abs(y - t.numpy()).max() <= 1e-5 * max(1.0, float(t.abs().max()))
+        assert np.array_equal(y, R.conv_wino(x, w, b, relu=relu, pool=pool))
+    # small integers, weights that are multiples of 4: G g G^T, every transform and every product is exact -> equality
+    x = rng.integers(-3, 4, (1, 32, 10, 12)).astype('f')
+    for k in (3, 7):
+        w = (4 * rng.integers(-2, 3, (6, 32, k, k))).astype('f')
+        b = rng.integers(-5, 6, 6).astype('f')
+        t = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=k // 2).numpy()
+        assert np.array_equal(R.conv_wino(x, w, b), t.astype('f'))

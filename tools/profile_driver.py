@@ -24,6 +24,7 @@ ap.add_argument('--k3', type=int, default=-1)
 ap.add_argument('--gen', type=int, default=0, help='kernel generation (0 = library default)')
 ap.add_argument('--profile-json', default=None)
 ap.add_argument('--precision', type=int, default=0, help='1 = bf16x3 kernels where a v6 kernel would run')
+ap.add_argument('--algo', type=int, default=0, help='conv_algo option: 1 = Winograd F(2x2,3x3) for the 3x3 / 7x7 layers of large launches')
 a = ap.parse_args()
 native = importlib.import_module(PKG + '.native')
 weights_mod = importlib.import_module(PKG + '.weights')
@@ -42,6 +43,8 @@ if a.gen:
     eng.set_option('kernel_gen', a.gen)
 if a.precision:
     eng.set_option('precision', a.precision)
+if a.algo:
+    eng.set_option('conv_algo', a.algo)
 imgs = np.random.default_rng(1).integers(0, 256, (B, S, S, 3), dtype=np.uint8)
 if a.profile_json:
     eng.profile_enable(True)
