@@ -36,6 +36,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = 'chainer_realtime_multi-person_pose_estimation_amd'
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+WINO7_EXECUTED_FRACTION = 116.0 / 196.0      # conv_wino_kernel<7>: (4 x 16 + 13 x 4) / (49 x 4) products per output tile
+WINO3_EXECUTED_FRACTION = 16.0 / 36.0
 FLOP_PER_FRAME = 271868013568          # 2 x MACs of the 92 convs at 368 x 368
 DOMINANT_LAYERS = ('Mconv2_', 'Mconv3_', 'Mconv4_', 'Mconv5_')   # 7x7 128->128, 20 launches per step
 
@@ -48,12 +50,16 @@ def pmc_traffic(kernel_name):
     import glob
     import re
     m = re.match(r'conv(\d)x\d(_v\d)?_t(\d+)x(\d+)_n(\d+)', kernel_name)
+    mw = re.match(r'conv_wino_f2x2_(\d)x\d', kernel_name)
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_summary.json')))
-    if not m or not files:
+    if not (m or mw) or not files:
         return None, None
-    sig = 'conv_mfma%s_kernel<%s, %s, %s, %s,' % (m.group(2) or '', m.group(1), m.group(3), m.group(4), m.group(5))
-    if m.group(2) == '_v6':          # conv_mfma_v6_kernel<KS, MT, POOL>: 17 x 32 consecutive pixels of a 46-column slab
-        sig = 'conv_mfma_v6_kernel<%s, %s, 0>' % (m.group(1), m.group(3))
+    if mw:                              # conv_wino_kernel<KS, POOL>
+        sig = 'conv_wino_kernel<%s, 0>' % mw.group(1)
+    else:
+        sig = 'conv_mfma%s_kernel<%s, %s, %s, %s,' % (m.group(2) or '', m.group(1), m.group(3), m.group(4), m.group(5))
+        if m.group(2) == '_v6':          # conv_mfma_v6_kernel<KS, MT, POOL>: 17 x 32 consecutive pixels of a 46-column slab
+            sig = 'conv_mfma_v6_kernel<%s, %s, 0>' % (m.group(1), m.group(3))
     try:
         d = json.load(open(files[-1]))
         for k, e in d['kernels'].items():
@@ -152,7 +158,7 @@ def cpu_baseline(weights, imgs, map_hw, budget_s=20.0, max_threads=32):
                        % (frames, warm, threads, os.cpu_count() or 1, dt)}, results)
 
 
-def keypoint_match(eng, rec, results, weights_for_match, imgs_for_match):
+def keypoint_match(eng, rec, results, weights_for_match, imgs_for_match, wino_labels=()):
     """The second half of the metric: the GPU path's key points against the oracle's on the frames the CPU baseline
     processed (same images, same weights).  Target (BASELINE.json): integer peak indices identical, scores within 1e-4.
     The two networks differ by ~1e-6 (summation order), so a peak exactly at a tie / threshold could legitimately flip."""
@@ -173,14 +179,15 @@ def keypoint_match(eng, rec, results, weights_for_match, imgs_for_match):
             poses_same += 1
             if k:
                 d_person = max(d_person, float(np.abs(g_scores - o_scores).max()))
-    # one full-size frame through the order-defined fp32 oracle (plain C, the kernels' summation order): bit-exact maps
+    # one full-size frame through the order-defined fp32 oracle (plain C, the kernels' arithmetic: the direct FMA chains, and the
+    # Winograd twin for the layers the batch ran on the Winograd kernel): bit-exact maps
     exact = None
     try:
         from oracle import conv_fma_ref, postprocess_ref
         t0 = time.perf_counter()
         paf, heat = eng.get_maps()
-        epaf, eheat = conv_fma_ref.forward_fma(weights_for_match, postprocess_ref.preprocess(imgs_for_match[0]))
-        exact = {'frames': 1, 'paf_and_heat_maps_bit_identical': bool(np.array_equal(paf[0], epaf[0]) and np.array_equal(heat[0], eheat[0])),
+        epaf, eheat = conv_fma_ref.forward_fma(weights_for_match, postprocess_ref.preprocess(imgs_for_match[0]), wino=set(wino_labels))
+        exact = {'frames': 1, 'layers_as_winograd': len(set(wino_labels)), 'paf_and_heat_maps_bit_identical': bool(np.array_equal(paf[0], epaf[0]) and np.array_equal(heat[0], eheat[0])),
                  'oracle_seconds': time.perf_counter() - t0}
     except Exception as e:          # the checker must never break the measurement
         exact = {'error': repr(e)}
@@ -351,7 +358,17 @@ def main():
                         'flop_per_launch': flop, 'avg_launch_ms': avg_ms, 'launches_timed': launches,
                         'achieved_128ch_layers_only': sub_ach,
                         'note': 'all launches of the 7x7 conv kernel at 46x46 (both branch groups per launch, B=%d): algorithmic '
-                                'FLOP (mean per launch) / mean launch duration, HIP events on the launch stream' % B}
+                                'FLOP of the 7x7 convolution (2 * 49 * cin * cout per output pixel; mean per launch) / mean launch '
+                                'duration, HIP events on the launch stream' % B}
+                if dom_name.startswith('conv_wino'):
+                    # the Winograd kernel executes fewer multiplies than the convolution it computes: 4 sub-kernels x 16 + 13 direct
+                    # taps x 4 = 116 matrix products per 2x2 output tile and channel pair instead of 7 * 7 * 4 = 196
+                    ex = WINO7_EXECUTED_FRACTION if dom_name.endswith('7x7') else WINO3_EXECUTED_FRACTION
+                    roof['executed_flop_fraction'] = ex
+                    roof['mfma_utilisation'] = ach * ex / FP32_MFMA_PEAK_TFLOPS
+                    roof['note'] += ('.  The kernel is fp32 Winograd F(2x2,3x3): it ISSUES %.3f of the algorithmic FLOP to the matrix '
+                                     'cores, so `frac` (algorithmic, as the contract defines it) can exceed 1; `mfma_utilisation` = '
+                                     'issued MFMA FLOP / time / peak is the hardware-side fraction' % ex)
             conv_ms = sum(p['total_ms'] for p in prof_all if p['kernel'].startswith('conv'))
             pp_ms = sum(p['total_ms'] for p in prof_all if p['kernel'].startswith('pp_'))
             out['kernel_time_ms_per_step'] = {'conv': conv_ms, 'postprocess': pp_ms, 'note': 'one extra untimed step with every launch instrumented'}
@@ -368,7 +385,8 @@ def main():
             rec = eng.results()                                                                             # for keypoint_match
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'], oracle_results = cpu_baseline(weights, imgs, (map_s, map_s), a.cpu_budget)
-            out['keypoint_match'] = keypoint_match(eng, rec, oracle_results, weights, imgs)
+            out['keypoint_match'] = keypoint_match(eng, rec, oracle_results, weights, imgs,
+                                                   {p_['layer'] for p_ in prof_all if p_['kernel'].startswith('conv_wino')})
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out))

@@ -269,8 +269,9 @@ struct pmx_ctx {
     int opt_kp_flip_x = 0;           // pmx_keypoints: mirror the resized heat maps left-right before the peaks (hand_detector.py:46-47)
     int tab_flip = 0;
     int opt_keep_smoothed = 0, opt_stop_stage = 6, opt_kernel_gen = 6;
-    int opt_conv_algo = 0;           // 1: Winograd F(2x2,3x3) fp32 kernel for the 3x3 layers of large launches (defined arithmetic, its own
-                                     // rounding: ~1e-6 of the map scale away from the direct kernels); 0: direct kernels everywhere
+    int opt_conv_algo = 1;           // 1 (default): Winograd F(2x2,3x3) fp32 kernel for the 3x3 / 7x7 layers of launches that fill the chip
+                                     // (>= 2 blocks per CU: batches); 0: direct kernels everywhere; 2: Winograd on every eligible layer
+                                     // (tests).  Both are fp32 with a defined order and a C twin; they differ by fp32 rounding (~1e-6)
     int opt_precision = 0;           // 0: fp32 MFMA everywhere (the path whose results are specified); 1: bf16x3 kernels where a
                                      // v6 kernel would run (fp32-grade accuracy at 2.67x the matrix rate, NOT the fp32 FMA chain)
     int opt_fuse_conv1 = 1;          // conv1_1 recomputed on conv1_2's halo tile, one launch (conv1_fused_kernel); identical bits

@@ -169,6 +169,7 @@ def test_v6_network_equals_v5_network_bitwise(engine):
     eng.set_weights(w)
     img = np.random.default_rng(7).integers(0, 256, (32, 368, 368, 3), dtype=np.uint8)
     eng.set_option('ksplit', 1)             # one K order everywhere (the v5 strip launches of generation 5 could be split)
+    eng.set_option('conv_algo', 0)          # ... and the direct kernels at every launch size (batch 32 would take the Winograd kernel)
     eng.set_option('kernel_gen', 5)
     eng.forward_u8(img)
     p5, h5 = eng.get_maps()

@@ -131,6 +131,7 @@ def test_end_to_end_pose_detector(native, weights):
     q2, t2 = det(img2)
     assert np.array_equal(p2, q2) and np.allclose(s2, t2, rtol=0, atol=1e-5)
     det.engine.set_option('ksplit', 1)
+    det.engine.set_option('conv_algo', 0)
     (p1, s1), (p2, s2) = det.detect_batch([img, img2])
     q1, t1 = det(img)
     q2, t2 = det(img2)

@@ -48,9 +48,13 @@ def test_full_batch32_is_deterministic_and_clean(big):
     assert r1['n_peaks'].min() > 20 and r1['n_people'].sum() > 32, 'synthetic workload should exercise the post-process'
 
 
-def test_batch_independence_and_permutation(big):
+@pytest.mark.parametrize('algo', [0, 2])
+def test_batch_independence_and_permutation(big, algo):
     eng, imgs = big
-    eng.set_option('ksplit', 1)      # bitwise batch-size independence is a property of the UNSPLIT kernels (one K order)
+    # bitwise batch-size independence is a property of ONE summation order: unsplit kernels, and one algorithm at every launch size
+    # (0: the direct kernels everywhere; 2: the Winograd kernel on every eligible layer, direct elsewhere)
+    eng.set_option('ksplit', 1)
+    eng.set_option('conv_algo', algo)
     full = _run(eng, imgs)
     perm = np.random.default_rng(0).permutation(32)
     permuted = _run(eng, imgs[perm])
@@ -62,8 +66,11 @@ def test_batch_independence_and_permutation(big):
         assert _same(one, full[i:i + 1]), 'image %d alone differs from the same image inside the batch' % i
     sub = _run(eng, imgs[8:16])
     assert _same(sub, full[8:16])
-    # default configuration: single images are split over K (defined, different summation tree): same people, scores to 1e-5
+    # default configuration: single images are split over K and batches take the Winograd kernel (defined, different summation
+    # trees): same people, scores to 1e-5
     eng.set_option('ksplit', 0)
+    eng.set_option('conv_algo', 1)
+    full = _run(eng, imgs)
     for i in (0, 13, 31):
         one = _run(eng, imgs[i:i + 1])[0]
         ref = full[i]
@@ -77,6 +84,7 @@ def test_sharded_equals_single_rank(big):
     eng, imgs = big
     d = pkg('dist')
     eng.set_option('ksplit', 1)
+    eng.set_option('conv_algo', 0)
     full = _run(eng, imgs)
     for world in (2, 4, 8):
         parts = []
@@ -85,6 +93,13 @@ def test_sharded_equals_single_rank(big):
             parts.append(_run(eng, imgs[lo:hi]))
         assert _same(np.concatenate(parts), full)
     eng.set_option('ksplit', 0)
+    eng.set_option('conv_algo', 1)
+    # default configuration (kernel choice by launch size: shards of 4 images run other kernels than the batch of 32): same people,
+    # identical poses, scores to 1e-5
+    full = _run(eng, imgs)
+    parts = np.concatenate([_run(eng, imgs[lo:lo + 4]) for lo in range(0, 32, 4)])
+    assert all(np.array_equal(parts[f], full[f]) for f in ('n_people', 'n_peaks', 'status', 'poses'))
+    assert np.abs(parts['scores'] - full['scores']).max() <= 1e-5
 
 
 def test_maps_are_a_pure_function_of_the_image(big):
