@@ -1304,84 +1304,122 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[f][i] = 0.f;
 
+    // ---- pass 1, software pipeline.  A (chunk, sub-kernel) step is two PHASES of 8 frequencies x 4 k8-steps x 4 MFMAs: phase 0 runs
+    // the frequencies 0..7 (rows 0, 1 of V, U half 0) while the threads transform rows 2, 3 of the same window into U half 1; phase 1
+    // runs the frequencies 8..15 while they transform rows 0, 1 of the NEXT step's window into U half 0 (when that step starts a new
+    // chunk, the raw halo is replaced first: registers -> LDS, one extra barrier).  Every LDS / VALU instruction of the transform
+    // sits in a fixed slot between two MFMAs (36 of the 64 slots of a phase), so the matrix pipe never waits for it; one barrier per
+    // phase.  Weight fragments: ring of 16 steps, loaded 8 steps (32 MFMAs, ~2000 cycles) ahead across phase, sub-kernel and chunk
+    // boundaries (left alone, the compiler sinks the loads to one step ahead and the single wave per SIMD stalls on L2).
     float4 hreg[C::NHF];
 #pragma unroll
     for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r]);
     const int a_off = li * C::LDU + kh * 4;
-    // weight fragments: ring of 4 planes, loaded two planes (32 MFMAs, ~2000 cycles) ahead, across sub-kernel and chunk boundaries
-    f32x4 bw[4][4];
+    f32x4 bw[16];
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+    for (int st8 = 0; st8 < 8; ++st8)                 // steps 0..7 of the first phase: frequencies 0, 1 (x 4 k8-steps) of plane 0
+        bw[st8] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off + (st8 & 3) * 32, (unsigned)(st8 >> 2) * freq_b, 0));
+    halo_store(hreg);
+    __syncthreads();
+    if (nch > 1) {
 #pragma unroll
-        for (int st = 0; st < 4; ++st)
-            bw[f][st] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off + st * 32, (unsigned)f * freq_b, 0));
+        for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + C::CKW);
+    }
+    {   // rows 0, 1 of the first window (not overlapped)
+        f32x4 wv4[2][4];
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx) {
+            const f32x4 d0 = *reinterpret_cast<const f32x4*>(&s_raw[t_raw + (0 * C::HW + jx) * C::LDR]);
+            const f32x4 d1 = *reinterpret_cast<const f32x4*>(&s_raw[t_raw + (1 * C::HW + jx) * C::LDR]);
+            const f32x4 d2 = *reinterpret_cast<const f32x4*>(&s_raw[t_raw + (2 * C::HW + jx) * C::LDR]);
+            wv4[0][jx] = d0 - d2;
+            wv4[1][jx] = d1 + d2;
+        }
+#pragma unroll
+        for (int il = 0; il < 2; ++il) {
+            *reinterpret_cast<f32x4*>(&s_u[(4 * il + 0) * 32 * C::LDU + t_u]) = wv4[il][0] - wv4[il][2];
+            *reinterpret_cast<f32x4*>(&s_u[(4 * il + 1) * 32 * C::LDU + t_u]) = wv4[il][1] + wv4[il][2];
+            *reinterpret_cast<f32x4*>(&s_u[(4 * il + 2) * 32 * C::LDU + t_u]) = wv4[il][2] - wv4[il][1];
+            *reinterpret_cast<f32x4*>(&s_u[(4 * il + 3) * 32 * C::LDU + t_u]) = wv4[il][1] - wv4[il][3];
+        }
+    }
+    __syncthreads();
 
     for (int ch = 0; ch < nch; ++ch) {
-        if (ch) __syncthreads();                   // the previous chunk's MFMAs are done with U (and its transforms with the raw halo)
-        halo_store(hreg);
-        __syncthreads();
+        const bool more = ch + 1 < nch;
         const unsigned chunk_b = (unsigned)ch * panel_b;
-        const unsigned next_b = (unsigned)(ch + 1 < nch ? ch + 1 : ch) * panel_b;
+        const unsigned next_b = (unsigned)(more ? ch + 1 : ch) * panel_b;
 #pragma unroll 1
         for (int sub = 0; sub < C::NSUB; ++sub) {
-            if (sub) __syncthreads();              // the previous sub-kernel's MFMAs are done with U
-            // ---- input transform V = B^T d B of this thread's (tile, 4 channels): column by column, then the rows
-            {
-                const int src = t_raw + ((3 * (sub >> 1)) * C::HW + 3 * (sub & 1)) * C::LDR;
-                f32x4 wv4[4][4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x4 d[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) d[i] = *reinterpret_cast<const f32x4*>(&s_raw[src + (i * C::HW + j) * C::LDR]);
-                    wv4[0][j] = d[0] - d[2];
-                    wv4[1][j] = d[1] + d[2];
-                    wv4[2][j] = d[2] - d[1];
-                    wv4[3][j] = d[1] - d[3];
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const f32x4 v0 = wv4[i][0] - wv4[i][2];
-                    const f32x4 v1 = wv4[i][1] + wv4[i][2];
-                    const f32x4 v2 = wv4[i][2] - wv4[i][1];
-                    const f32x4 v3 = wv4[i][1] - wv4[i][3];
-                    *reinterpret_cast<f32x4*>(&s_u[(4 * i + 0) * 32 * C::LDU + t_u]) = v0;
-                    *reinterpret_cast<f32x4*>(&s_u[(4 * i + 1) * 32 * C::LDU + t_u]) = v1;
-                    *reinterpret_cast<f32x4*>(&s_u[(4 * i + 2) * 32 * C::LDU + t_u]) = v2;
-                    *reinterpret_cast<f32x4*>(&s_u[(4 * i + 3) * 32 * C::LDU + t_u]) = v3;
-                }
-            }
-            __syncthreads();
             const bool last_sub = sub == C::NSUB - 1;
-            if (last_sub) {     // next chunk's raw halo: global -> registers, lands under this phase's MFMAs
-                const int cn = ch + 1 < nch ? ch + 1 : ch;
+            const int sub_n = last_sub ? 0 : sub + 1;
+            const unsigned plane_b = chunk_b + (unsigned)(sub * 16) * freq_b;                       // plane sub * 16 + 0 of this chunk
+            const unsigned nplane_b = (last_sub ? next_b : chunk_b) + (unsigned)(sub_n * 16) * freq_b;     // plane 0 of the next step
+            const int src_cur = t_raw + ((3 * (sub >> 1)) * C::HW + 3 * (sub & 1)) * C::LDR;
+            const int src_nxt = t_raw + ((3 * (sub_n >> 1)) * C::HW + 3 * (sub_n & 1)) * C::LDR;
 #pragma unroll
-                for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + cn * C::CKW);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // ---- 16 frequencies x 4 k8-steps x 4 MFMAs; one weight load and one A read per 4 MFMAs, pinned between them
-            const unsigned plane_b = chunk_b + (unsigned)(sub * 16) * freq_b;                                  // plane sub * 16 + 0 of this chunk
-            const unsigned wrap_b = last_sub ? next_b : chunk_b + (unsigned)((sub + 1) * 16) * freq_b;        // plane 0 of what follows
-            f32x4 av[2];
-            av[0] = *reinterpret_cast<const f32x4*>(&s_u[a_off]);
+            for (int r = 0; r < 2; ++r) {
+                // side work of this phase: rows (2, 3) of the current window (r = 0) / rows (0, 1) of the next one (r = 1)
+                const int q = r ^ 1;                                        // V row pair produced
+                const int src = (r == 0 ? src_cur : src_nxt) + q * C::HW * C::LDR;      // d rows q .. q + 2
+                float* const udst = s_u + (q * 8) * 32 * C::LDU + t_u;
+                f32x4 dd[3][4], wv[2][4], vv;
+                f32x4 av[4];
+                av[0] = *reinterpret_cast<const f32x4*>(&s_u[(r * 8) * 32 * C::LDU + a_off]);
+                av[1] = *reinterpret_cast<const f32x4*>(&s_u[(r * 8) * 32 * C::LDU + a_off + 8]);
 #pragma unroll
-            for (int f = 0; f < 16; ++f) {
-                const unsigned so = f + 2 < 16 ? plane_b + (unsigned)(f + 2) * freq_b : wrap_b + (unsigned)(f + 2 - 16) * freq_b;
-#pragma unroll
-                for (int st = 0; st < 4; ++st) {
+                for (int s = 0; s < 32; ++s) {                              // step = (frequency r * 8 + s / 4, k8-step s % 4)
+                    const int f = r * 8 + (s >> 2), st = s & 3;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st & 1][e], bw[f & 3][st][e], acc[f], 0, 0, 0);
-                        if (e == 0) {
-                            bw[(f + 2) & 3][st] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off + st * 32, so, 0));
+                        acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 3][e], bw[s & 15][e], acc[f], 0, 0, 0);
+                        if (e == 0) {                                       // weights of step s + 8
+                            const int sn = s + 8;
+                            unsigned so;
+                            if (sn < 32) so = plane_b + (unsigned)(r * 8 + (sn >> 2)) * freq_b;
+                            else if (r == 0) so = plane_b + (unsigned)(8 + ((sn - 32) >> 2)) * freq_b;
+                            else so = nplane_b + (unsigned)((sn - 32) >> 2) * freq_b;
+                            bw[sn & 15] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off + (sn & 3) * 32, so, 0));
                             __builtin_amdgcn_sched_barrier(0);
-                        } else if (e == 1 && !(f == 15 && st == 3)) {
-                            const int fn = st == 3 ? f + 1 : f, sn = (st + 1) & 3;
-                            av[(st + 1) & 1] = *reinterpret_cast<const f32x4*>(&s_u[fn * 32 * C::LDU + a_off + sn * 8]);
-                            __builtin_amdgcn_sched_barrier(0);
+                        } else if (e == 1) {                                // A fragment of step s + 2
+                            if (s + 2 < 32) {
+                                const int fn = r * 8 + ((s + 2) >> 2), sn = (s + 2) & 3;
+                                av[(s + 2) & 3] = *reinterpret_cast<const f32x4*>(&s_u[fn * 32 * C::LDU + a_off + sn * 8]);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        } else {                                            // transform slot t
+                            const int t = 2 * s + (e - 2);
+                            if (t == 0) {
+                                if (r == 1 && last_sub && more) {           // the next window is in the next chunk: replace the raw halo
+                                    halo_store(hreg);
+                                    __syncthreads();
+                                    const int cn = ch + 2 < nch ? ch + 2 : ch + 1;
+#pragma unroll
+                                    for (int rr = 0; rr < C::NHF; ++rr) hreg[rr] = *reinterpret_cast<const float4*>(in_b + h_goff[rr] + cn * C::CKW);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                            } else if (t >= 2 && t < 14) {                  // 12 reads: d rows q .. q + 2, column by column
+                                const int jx = (t - 2) / 3, ri = (t - 2) % 3;
+                                dd[ri][jx] = *reinterpret_cast<const f32x4*>(&s_raw[src + (ri * C::HW + jx) * C::LDR]);
+                                __builtin_amdgcn_sched_barrier(0);
+                            } else if (t >= 16 && t < 24) {                 // B^T d: q = 0: (d0 - d2, d1 + d2); q = 1: (d2 - d1, d1 - d3)
+                                const int jx = (t - 16) >> 1, wi = (t - 16) & 1;
+                                if (q == 0) wv[wi][jx] = wi == 0 ? dd[0][jx] - dd[2][jx] : dd[1][jx] + dd[2][jx];
+                                else wv[wi][jx] = wi == 0 ? dd[1][jx] - dd[0][jx] : dd[0][jx] - dd[2][jx];
+                                __builtin_amdgcn_sched_barrier(0);
+                            } else if (t >= 24 && t < 40) {                 // (.) B, one column per two slots: compute, store
+                                const int pidx = (t - 24) >> 1, il = pidx >> 2, jv = pidx & 3;
+                                if (((t - 24) & 1) == 0) {
+                                    vv = jv == 0 ? wv[il][0] - wv[il][2] : jv == 1 ? wv[il][1] + wv[il][2] : jv == 2 ? wv[il][2] - wv[il][1] : wv[il][1] - wv[il][3];
+                                } else {
+                                    *reinterpret_cast<f32x4*>(&udst[(4 * il + jv) * 32 * C::LDU]) = vv;
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                         }
                     }
                 }
+                __syncthreads();            // U half q is complete, U half r is free
             }
         }
     }
