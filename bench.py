@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = 'chainer_realtime_multi-person_pose_estimation_amd'
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-WINO7_EXECUTED_FRACTION = 116.0 / 196.0      # conv_wino_kernel<7>: (4 x 16 + 13 x 4) / (49 x 4) products per output tile
+WINO7_EXECUTED_FRACTION = 100.0 / 196.0      # conv_wino_kernel<7>: (4 x 16 + 4 x 8 + 4) / (49 x 4) products per output tile
 WINO3_EXECUTED_FRACTION = 16.0 / 36.0
 FLOP_PER_FRAME = 271868013568          # 2 x MACs of the 92 convs at 368 x 368
 DOMINANT_LAYERS = ('Mconv2_', 'Mconv3_', 'Mconv4_', 'Mconv5_')   # 7x7 128->128, 20 launches per step
@@ -361,8 +361,9 @@ def main():
                                 'FLOP of the 7x7 convolution (2 * 49 * cin * cout per output pixel; mean per launch) / mean launch '
                                 'duration, HIP events on the launch stream' % B}
                 if dom_name.startswith('conv_wino'):
-                    # the Winograd kernel executes fewer multiplies than the convolution it computes: 4 sub-kernels x 16 + 13 direct
-                    # taps x 4 = 116 matrix products per 2x2 output tile and channel pair instead of 7 * 7 * 4 = 196
+                    # the Winograd kernel executes fewer multiplies than the convolution it computes: 4 sub-kernels x 16 (taps 0..5 x
+                    # 0..5) + 4 one-dimensional sub-kernels x 8 (row 6, column 6) + 4 (tap (6, 6)) = 100 matrix products per 2x2
+                    # output tile and channel pair instead of 7 * 7 * 4 = 196
                     ex = WINO7_EXECUTED_FRACTION if dom_name.endswith('7x7') else WINO3_EXECUTED_FRACTION
                     roof['executed_flop_fraction'] = ex
                     roof['mfma_utilisation'] = ach * ex / FP32_MFMA_PEAK_TFLOPS

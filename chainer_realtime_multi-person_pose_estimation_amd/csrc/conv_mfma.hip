@@ -1225,9 +1225,6 @@ struct WinoCfg {
     static constexpr int NHF = (NPX * (CKW / 4) + 255) / 256;
     static_assert(KS == 3 || KS == 7, "Winograd kernel: 3x3 or 7x7");
 };
-// direct taps of the 7x7 variant, in the order they are chained: row 6 left to right, then column 6 top to bottom
-__device__ constexpr int wino7_tap_ky(int t) { return t < 7 ? 6 : t - 7; }
-__device__ constexpr int wino7_tap_kx(int t) { return t < 7 ? t : 6; }
 
 template <int KS, int POOL>
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
@@ -1241,8 +1238,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     const bool g1 = blockIdx.z != 0;
     ConvGroupArgs G;
     G.in = g1 ? a.g[1].in : a.g[0].in;
-    G.w = g1 ? a.g[1].w : a.g[0].w;              // transformed weights [sub-kernel][freq 16][chunk32][cout_pad][32]
-    G.w2 = g1 ? a.g[1].w2 : a.g[0].w2;           // direct pack [tap][chunk16][cout_pad][16] (KS = 7)
+    G.w = g1 ? a.g[1].w : a.g[0].w;              // transformed weights [plane][chunk32][cout_pad][32] (pmx_api.hip::pack_wino)
     G.bias = g1 ? a.g[1].bias : a.g[0].bias;
     G.out = g1 ? a.g[1].out : a.g[0].out;
     G.cout = g1 ? a.g[1].cout : a.g[0].cout;
@@ -1439,64 +1435,197 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     }
 
     if (C::NDIR > 0) {
-        // ---- second pass over the chunks: the direct taps, chained onto y.  Step q = tap * 4 + k8-step: one weight load per step
-        // (from the direct pack, two steps ahead), four pixel planes x 4 MFMAs per step, one A read per plane (two planes ahead)
-        constexpr int NQ = C::NDIR * 4;
-        const __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G.w2), 0, 0x7fffffff, 0x00020000);
-        const unsigned b2_off = (unsigned)((n * 16 + kh * 4) * 4);
-        const unsigned p16_b = (unsigned)a.cout_pad * 16u * 4u;            // bytes of one (tap, chunk16) panel
-        const unsigned tap2_b = p16_b * (unsigned)(2 * nch);               // bytes between taps
-        auto q_soff = [&](int q, int ch) -> unsigned {                     // q compile-time after unrolling
-            const int t = q >> 2, st = q & 3;
-            const int tap = wino7_tap_ky(t) * 7 + wino7_tap_kx(t);
-            return (unsigned)tap * tap2_b + (unsigned)(2 * ch + (st >> 1)) * p16_b + (unsigned)((st & 1) * 32);
+        // ---- pass 2 (7x7): the 13 taps of row 6 and column 6.  Row 6 = two 1x3 sub-kernels (kx 0..2, 3..5) as 1-D F(2,3) along x:
+        // per output row i of the tile 4 horizontal frequencies -> 8 planes (i * 4 + f), both sub-kernels summed in the same planes;
+        // column 6 = two 3x1 sub-kernels (ky 0..2, 3..5) as 1-D F(2,3) along y: 8 planes (j * 4 + f); tap (6, 6) direct into the four
+        // pixel planes.  2 * 8 + 2 * 8 + 4 = 36 products per tile and channel pair instead of 13 * 4 = 52.  Weight planes (same
+        // [plane][chunk32][cout_pad][32] array as pass 1): 64 + sub * 4 + f (row 6), 72 + sub * 4 + f (column 6), 80 (tap (6, 6)).
+        // Pass 2a per chunk: D phase (16 steps x 4 MFMAs from the raw halo; the threads transform row-6 sub-kernel 0 meanwhile), H0 and
+        // H1 phases (16 steps x 8 MFMAs; during H0 sub-kernel 1 is transformed, during H1 the raw halo of the next chunk replaces this
+        // one); then y += A^T-transform of the row planes.  Pass 2b per chunk: V0, V1 phases; then y += transform of the column planes.
+        constexpr int PH = 64, PV = 72, PD = 80;
+        f32x16 e8[8];
+        f32x4 bwr[8], bd[4], av[4];
+        auto zero8 = [&]() {
+#pragma unroll
+            for (int pl = 0; pl < 8; ++pl)
+#pragma unroll
+                for (int r16 = 0; r16 < 16; ++r16) e8[pl][r16] = 0.f;
         };
+        auto wload = [&](int plane, unsigned chb, int st) -> f32x4 {
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off + st * 32, chb + (unsigned)plane * freq_b, 0));
+        };
+        // 1-D transform of this thread's (tile, 4 channels): two lines (output rows i for the row class, output columns j for the
+        // column class) of 4 samples each -> (d0 - d2, d1 + d2, d2 - d1, d1 - d3), slot by slot
+        f32x4 dd[2][4], vv[2][4];
+        auto side1d = [&](int t, int base, int line_stride, int samp_stride, float* udst) {     // t compile-time
+            if (t >= 2 && t < 10) {
+                const int l = (t - 2) >> 2, c = (t - 2) & 3;
+                dd[l][c] = *reinterpret_cast<const f32x4*>(&s_raw[base + l * line_stride + c * samp_stride]);
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (t >= 12 && t < 20) {
+                const int l = (t - 12) >> 2, f = (t - 12) & 3;
+                vv[l][f] = f == 0 ? dd[l][0] - dd[l][2] : f == 1 ? dd[l][1] + dd[l][2] : f == 2 ? dd[l][2] - dd[l][1] : dd[l][1] - dd[l][3];
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (t >= 20 && t < 28) {
+                const int l = (t - 20) >> 2, f = (t - 20) & 3;
+                *reinterpret_cast<f32x4*>(&udst[(l * 4 + f) * 32 * C::LDU]) = vv[l][f];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // one 8-plane phase: 16 steps s = f * 4 + st, per step the two lines l = 0, 1 x 4 MFMAs; A fragments one step ahead, weights
+        // four steps ahead (ring of 8; `wnext(s)` loads step s of whatever phase follows), side slots m = 2, 3, 6, 7 of every step
+        auto phase8 = [&](const float* ub, int wplane, unsigned chb, auto&& wnext, auto&& side) {
+            av[0] = *reinterpret_cast<const f32x4*>(&ub[a_off]);
+            av[1] = *reinterpret_cast<const f32x4*>(&ub[4 * 32 * C::LDU + a_off]);
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {
+                const int f = s2 >> 2, st = s2 & 3;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int l = m >> 2, e = m & 3;
+                    e8[l * 4 + f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(s2 & 1) * 2 + l][e], bwr[s2 & 7][e], e8[l * 4 + f], 0, 0, 0);
+                    if (m == 0) {
+                        if (s2 + 4 < 16) bwr[(s2 + 4) & 7] = wload(wplane + ((s2 + 4) >> 2), chb, (s2 + 4) & 3);
+                        else wnext(s2 + 4 - 16);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if ((m == 1 || m == 5) && s2 + 1 < 16) {
+                        const int ln = m == 1 ? 0 : 1, fn = (s2 + 1) >> 2, sn = (s2 + 1) & 3;
+                        av[((s2 + 1) & 1) * 2 + ln] = *reinterpret_cast<const f32x4*>(&ub[(ln * 4 + fn) * 32 * C::LDU + a_off + sn * 8]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if (m == 2 || m == 3 || m == 6 || m == 7) {
+                        side(4 * s2 + (m < 4 ? m - 2 : m - 4));
+                    }
+                }
+            }
+        };
+        float* const u0 = s_u + t_u;
+        float* const u1 = s_u + 8 * 32 * C::LDU + t_u;
+        const int a2_off = ((2 * (li >> 3)) * C::HW + 2 * (li & 7)) * C::LDR + kh * 4;
+
+        // ================= pass 2a: tap (6, 6) + row 6 =================
+        zero8();
         __syncthreads();                            // pass 1 is done with the raw halo / U
 #pragma unroll
         for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r]);
-        f32x4 b2[4];
-        b2[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w2rsrc, b2_off, q_soff(0, 0), 0));
-        b2[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w2rsrc, b2_off, q_soff(1, 0), 0));
-        // this lane's tile: pixel plane p = 2 * i + j sits at halo (2 ty + i + ky, 2 tx + j + kx)
-        const int a2_off = ((2 * (li >> 3)) * C::HW + 2 * (li & 7)) * C::LDR + kh * 4;
-        auto a2_addr = [&](int u) -> int {          // unit u = q * 4 + p (compile-time) -> LDS element offset relative to a2_off
-            const int q = u >> 2, p = u & 3, t = q >> 2, st = q & 3;
-            return ((wino7_tap_ky(t) + (p >> 1)) * C::HW + wino7_tap_kx(t) + (p & 1)) * C::LDR + st * 8;
-        };
+#pragma unroll
+        for (int st = 0; st < 4; ++st) bd[st] = wload(PD, 0u, st);
+        halo_store(hreg);
+        __syncthreads();
+        if (nch > 1) {
+#pragma unroll
+            for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + C::CKW);
+        }
         for (int ch = 0; ch < nch; ++ch) {
-            if (ch) __syncthreads();
-            halo_store(hreg);
-            __syncthreads();
+            const bool more = ch + 1 < nch;
+            const unsigned chb = (unsigned)ch * panel_b, nxb = (unsigned)(more ? ch + 1 : ch) * panel_b;
+            // ---- D phase: step q = st * 4 + p; side: row-6 sub-kernel 0 -> U half 0; weights of H0's first four steps
             {
-                const int cn = ch + 1 < nch ? ch + 1 : ch;
+                f32x4 ad[4];
+                ad[0] = *reinterpret_cast<const f32x4*>(&s_raw[a2_off + ((6 + 0) * C::HW + 6 + 0) * C::LDR]);
+                ad[1] = *reinterpret_cast<const f32x4*>(&s_raw[a2_off + ((6 + 0) * C::HW + 6 + 1) * C::LDR]);
 #pragma unroll
-                for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + cn * C::CKW);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            const int chn = ch + 1 < nch ? ch + 1 : ch;
-            f32x4 av2[4];
-            av2[0] = *reinterpret_cast<const f32x4*>(&s_raw[a2_off + a2_addr(0)]);
-            av2[1] = *reinterpret_cast<const f32x4*>(&s_raw[a2_off + a2_addr(1)]);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const unsigned so = q + 2 < NQ ? q_soff(q + 2, ch) : q_soff(q + 2 - NQ, chn);
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int u = q * 4 + p;
+                for (int q = 0; q < 16; ++q) {
+                    const int st = q >> 2, pp = q & 3;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        y[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av2[u & 3][e], b2[q & 3][e], y[p], 0, 0, 0);
-                        if (e == 0 && p == 0) {
-                            b2[(q + 2) & 3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w2rsrc, b2_off, so, 0));
-                            __builtin_amdgcn_sched_barrier(0);
-                        } else if (e == 1 && u + 2 < NQ * 4) {
-                            av2[(u + 2) & 3] = *reinterpret_cast<const f32x4*>(&s_raw[a2_off + a2_addr(u + 2)]);
-                            __builtin_amdgcn_sched_barrier(0);
+                        y[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[q & 3][e], bd[st][e], y[pp], 0, 0, 0);
+                        if (e == 0) {
+                            if (q < 4) { bwr[q] = wload(PH + 0, chb, q); __builtin_amdgcn_sched_barrier(0); }
+                        } else if (e == 1) {
+                            if (q + 2 < 16) {
+                                const int qn = q + 2, pn = qn & 3, sn = qn >> 2;
+                                ad[qn & 3] = *reinterpret_cast<const f32x4*>(&s_raw[a2_off + ((6 + (pn >> 1)) * C::HW + 6 + (pn & 1)) * C::LDR + sn * 8]);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        } else {
+                            side1d(2 * q + (e - 2), t_raw + (6 * C::HW + 0) * C::LDR, C::HW * C::LDR, C::LDR, u0);
                         }
                     }
                 }
             }
+            __syncthreads();                        // U half 0 = row-6 sub-kernel 0
+            // ---- H0: side = sub-kernel 1 (kx 3..5) -> U half 1; afterwards H1's first weights
+            phase8(s_u, PH + 0, chb,
+                   [&](int s2n) { bwr[(s2n + 16) & 7] = wload(PH + 4 + (s2n >> 2), chb, s2n & 3); },
+                   [&](int t) { side1d(t, t_raw + (6 * C::HW + 3) * C::LDR, C::HW * C::LDR, C::LDR, u1); });
+            __syncthreads();                        // U half 1 = row-6 sub-kernel 1
+            // ---- H1: side = the next chunk's raw halo; afterwards the next chunk's tap-(6,6) weights
+            phase8(s_u + 8 * 32 * C::LDU, PH + 4, chb,
+                   [&](int s2n) { bd[s2n] = wload(PD, nxb, s2n); },
+                   [&](int t) {
+                       if (t == 0) {
+                           if (more) {
+                               halo_store(hreg);
+                               __syncthreads();
+                               const int cn = ch + 2 < nch ? ch + 2 : ch + 1;
+#pragma unroll
+                               for (int rr = 0; rr < C::NHF; ++rr) hreg[rr] = *reinterpret_cast<const float4*>(in_b + h_goff[rr] + cn * C::CKW);
+                           }
+                           __builtin_amdgcn_sched_barrier(0);
+                       }
+                   });
         }
+        // y += A^T-transform of the row planes: e8[i * 4 + f]
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2) {
+                y[i2 * 2 + 0][reg] = y[i2 * 2 + 0][reg] + ((e8[i2 * 4 + 0][reg] + e8[i2 * 4 + 1][reg]) + e8[i2 * 4 + 2][reg]);
+                y[i2 * 2 + 1][reg] = y[i2 * 2 + 1][reg] + ((e8[i2 * 4 + 1][reg] - e8[i2 * 4 + 2][reg]) - e8[i2 * 4 + 3][reg]);
+            }
+
+        // ================= pass 2b: column 6 =================
+        zero8();
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r]);
+#pragma unroll
+        for (int s2n = 0; s2n < 4; ++s2n) bwr[s2n] = wload(PV + 0, 0u, s2n);
+        halo_store(hreg);
+        __syncthreads();
+        if (nch > 1) {
+#pragma unroll
+            for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + C::CKW);
+        }
+#pragma unroll
+        for (int t = 0; t < 28; ++t) side1d(t, t_raw + (0 * C::HW + 6) * C::LDR, C::LDR, C::HW * C::LDR, u0);      // column-6 sub-kernel 0 of chunk 0
+        __syncthreads();
+        for (int ch = 0; ch < nch; ++ch) {
+            const bool more = ch + 1 < nch;
+            const unsigned chb = (unsigned)ch * panel_b, nxb = (unsigned)(more ? ch + 1 : ch) * panel_b;
+            // ---- V0: side = sub-kernel 1 (ky 3..5) -> U half 1
+            phase8(s_u, PV + 0, chb,
+                   [&](int s2n) { bwr[(s2n + 16) & 7] = wload(PV + 4 + (s2n >> 2), chb, s2n & 3); },
+                   [&](int t) { side1d(t, t_raw + (3 * C::HW + 6) * C::LDR, C::LDR, C::HW * C::LDR, u1); });
+            __syncthreads();
+            // ---- V1: side = next chunk's raw halo, then its sub-kernel 0 -> U half 0
+            phase8(s_u + 8 * 32 * C::LDU, PV + 4, chb,
+                   [&](int s2n) { bwr[(s2n + 16) & 7] = wload(PV + 0 + (s2n >> 2), nxb, s2n & 3); },
+                   [&](int t) {
+                       if (t == 0) {
+                           if (more) {
+                               halo_store(hreg);
+                               __syncthreads();
+                               const int cn = ch + 2 < nch ? ch + 2 : ch + 1;
+#pragma unroll
+                               for (int rr = 0; rr < C::NHF; ++rr) hreg[rr] = *reinterpret_cast<const float4*>(in_b + h_goff[rr] + cn * C::CKW);
+                           }
+                           __builtin_amdgcn_sched_barrier(0);
+                       } else {
+                           side1d(t, t_raw + (0 * C::HW + 6) * C::LDR, C::LDR, C::HW * C::LDR, u0);
+                       }
+                   });
+            __syncthreads();
+        }
+        // y += A^T-transform of the column planes: e8[j * 4 + f]
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+                y[0 * 2 + j2][reg] = y[0 * 2 + j2][reg] + ((e8[j2 * 4 + 0][reg] + e8[j2 * 4 + 1][reg]) + e8[j2 * 4 + 2][reg]);
+                y[1 * 2 + j2][reg] = y[1 * 2 + j2][reg] + ((e8[j2 * 4 + 1][reg] - e8[j2 * 4 + 2][reg]) - e8[j2 * 4 + 3][reg]);
+            }
     }
 
     // ---- bias, ReLU, (pool), store
@@ -2405,7 +2534,6 @@ static int launch_wino(const ConvArgs& a0, int groups, hipStream_t stream)
     PMX_CHECK(!POOL || (a.H % 2 == 0 && a.W % 2 == 0), PMX_ERR_INVALID, "conv: pooled layer needs even H, W");
     PMX_CHECK(a.cout_pad % 128 == 0, PMX_ERR_INVALID, "conv wino: cout_pad %d not a multiple of 128", a.cout_pad);
     PMX_CHECK((long long)a.H * a.W * a.lda < (1ll << 31), PMX_ERR_INVALID, "conv: image too large for 32-bit offsets");
-    PMX_CHECK(KS == 3 || (a.g[0].w2 && (groups == 1 || a.g[1].w2)), PMX_ERR_INVALID, "conv wino 7x7: direct pack missing");
     a.tiles_x = (a.W + C::TW - 1) / C::TW;
     a.tiles_y = (a.H + C::TH - 1) / C::TH;
     auto kern = conv_wino_kernel<KS, POOL>;

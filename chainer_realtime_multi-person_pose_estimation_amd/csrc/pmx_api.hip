@@ -134,30 +134,39 @@ static inline float bf16_f(uint16_t h)
 // packed fp32 weights [tap][chunk][cout_pad][16] -> bf16x3 [tap][chunk][plane][cout_pad][16]
 // Winograd F(2x2, 3x3) weights: U = G g G^T per (cout, cin), G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]], evaluated in double and
 // rounded once to fp32 (oracle/conv_fma_ref.c::conv_wino_ref does the same); layout [plane = sub-kernel * 16 + 4i + j][chunk of 32
-// cin][cout_pad][32].  ks = 3: one sub-kernel; ks = 7: four, sub-kernel (sy, sx) = taps (3 sy .. 3 sy + 2, 3 sx .. 3 sx + 2) -- row 6
-// and column 6 of the 7x7 kernel stay direct (the kernel reads them from the direct pack)
+// cin][cout_pad][32].  ks = 3: one sub-kernel; ks = 7: four, sub-kernel (sy, sx) = taps (3 sy .. 3 sy + 2, 3 sx .. 3 sx + 2); row 6 and
+// column 6 of the 7x7 kernel are two 1x3 / two 3x1 sub-kernels with the 1-D transform G g (planes 64.., 72..), tap (6, 6) is plane 80
 static bool wino_eligible(int ks, int cin_pad, int cout_pad) { return (ks == 3 || ks == 7) && cin_pad % 32 == 0 && cout_pad % 128 == 0; }
 static void pack_wino(const std::vector<float>& wp, int ks, int nch16, int cout_pad, std::vector<float>& out)
 {
     static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     const int cin_pad = nch16 * CK, nch32 = cin_pad / 32, nsub = ks == 3 ? 1 : 4;
-    out.assign((size_t)nsub * 16 * nch32 * cout_pad * 32, 0.f);
-    for (int sub = 0; sub < nsub; ++sub)
-        for (int n = 0; n < cout_pad; ++n)
-            for (int ci = 0; ci < cin_pad; ++ci) {
-                double g[3][3], gg[4][3];
-                for (int t = 0; t < 9; ++t) {
-                    const int tap = (3 * (sub >> 1) + t / 3) * ks + 3 * (sub & 1) + t % 3;
-                    g[t / 3][t % 3] = wp[(((size_t)tap * nch16 + ci / CK) * cout_pad + n) * CK + ci % CK];
-                }
+    const int nplanes = ks == 3 ? 16 : 81;      // 7x7: 64 (four 3x3 sub-kernels) + 8 (row 6: two 1x3, G g) + 8 (column 6: two 3x1) + 1 (tap (6, 6))
+    out.assign((size_t)nplanes * nch32 * cout_pad * 32, 0.f);
+    auto tapw = [&](int ky, int kx, int n, int ci) -> double {
+        return wp[(((size_t)(ky * ks + kx) * nch16 + ci / CK) * cout_pad + n) * CK + ci % CK];
+    };
+    auto put = [&](int plane, int n, int ci, double v) { out[(((size_t)plane * nch32 + ci / 32) * cout_pad + n) * 32 + ci % 32] = (float)v; };
+    for (int n = 0; n < cout_pad; ++n)
+        for (int ci = 0; ci < cin_pad; ++ci) {
+            for (int sub = 0; sub < nsub; ++sub) {
+                double gg[4][3];
                 for (int i = 0; i < 4; ++i)
-                    for (int kx = 0; kx < 3; ++kx) gg[i][kx] = (Gm[i][0] * g[0][kx] + Gm[i][1] * g[1][kx]) + Gm[i][2] * g[2][kx];
+                    for (int kx = 0; kx < 3; ++kx)
+                        gg[i][kx] = (Gm[i][0] * tapw(3 * (sub >> 1) + 0, 3 * (sub & 1) + kx, n, ci) + Gm[i][1] * tapw(3 * (sub >> 1) + 1, 3 * (sub & 1) + kx, n, ci)) +
+                                    Gm[i][2] * tapw(3 * (sub >> 1) + 2, 3 * (sub & 1) + kx, n, ci);
                 for (int i = 0; i < 4; ++i)
-                    for (int j = 0; j < 4; ++j) {
-                        const double u = (gg[i][0] * Gm[j][0] + gg[i][1] * Gm[j][1]) + gg[i][2] * Gm[j][2];
-                        out[((((size_t)(sub * 16 + 4 * i + j)) * nch32 + ci / 32) * cout_pad + n) * 32 + ci % 32] = (float)u;
-                    }
+                    for (int j = 0; j < 4; ++j) put(sub * 16 + 4 * i + j, n, ci, (gg[i][0] * Gm[j][0] + gg[i][1] * Gm[j][1]) + gg[i][2] * Gm[j][2]);
             }
+            if (ks == 7) {
+                for (int sub = 0; sub < 2; ++sub)
+                    for (int f = 0; f < 4; ++f) {
+                        put(64 + sub * 4 + f, n, ci, (Gm[f][0] * tapw(6, 3 * sub + 0, n, ci) + Gm[f][1] * tapw(6, 3 * sub + 1, n, ci)) + Gm[f][2] * tapw(6, 3 * sub + 2, n, ci));
+                        put(72 + sub * 4 + f, n, ci, (Gm[f][0] * tapw(3 * sub + 0, 6, n, ci) + Gm[f][1] * tapw(3 * sub + 1, 6, n, ci)) + Gm[f][2] * tapw(3 * sub + 2, 6, n, ci));
+                    }
+                put(80, n, ci, tapw(6, 6, n, ci));
+            }
+        }
 }
 
 static void pack_bf16x3(const std::vector<float>& wp, int T, int nch, int cout_pad, std::vector<uint16_t>& out)

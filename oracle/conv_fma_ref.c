@@ -67,8 +67,9 @@ void conv_fma_ref(const float* x, const float* w, const float* bias, float* y, i
  *   16 frequency-wise sequential fmaf chains over (32-channel chunk -> sub-kernel -> 8-channel step -> e in 0..3: k = e, then e + 4);
  *   Y = A^T M A in fp32: t0j = (m0j + m1j) + m2j, t1j = (m1j - m2j) - m3j, y_i0 = (t_i0 + t_i1) + t_i2, y_i1 = (t_i1 - t_i2) - t_i3;
  *   ks = 7: sub-kernel (sy, sx) = taps (3 sy .. 3 sy + 2, 3 sx .. 3 sx + 2) on the window shifted by (3 sy, 3 sx), all four summed in the
- *   frequency domain; the other 13 taps (row 6 left to right, then column 6 top to bottom) are chained DIRECTLY onto each y, per
- *   32-channel chunk -> tap -> 8-channel step -> k, after the output transform;
+ *   frequency domain; after the output transform, tap (6, 6) is chained directly onto each y (chunk -> 8-channel step -> k), row 6 is two
+ *   1x3 sub-kernels as 1-D F(2,3) along x (weights G g in double -> fp32; per output row four chains over chunk -> sub-kernel -> channel;
+ *   y[i][0] += (m0 + m1) + m2, y[i][1] += (m1 - m2) - m3), then column 6 the same along y;
  *   max-pool (3x3 only) = max of the tile's four outputs (before the bias, like the kernel), + bias, ReLU.
  * The window of output tile (ty, tx), sub-kernel (sy, sx), covers input rows 2 ty - pad + 3 sy .. + 3 (columns alike), zeros outside. */
 #include <stdlib.h>
@@ -146,23 +147,62 @@ void conv_wino_ref(const float* x, const float* w, const float* bias, float* y, 
                     }
                     yv[0][0] = (t0[0] + t0[1]) + t0[2]; yv[0][1] = (t0[1] - t0[2]) - t0[3];
                     yv[1][0] = (t1[0] + t1[1]) + t1[2]; yv[1][1] = (t1[1] - t1[2]) - t1[3];
-                    for (int c32 = 0; c32 < cin && ndir; c32 += 32)
-                        for (int t = 0; t < ndir; ++t) {
-                            const int ky = t < 7 ? 6 : t - 7, kx = t < 7 ? t : 6;
-                            for (int c8 = c32; c8 < c32 + 32; c8 += 8)
-                                for (int e = 0; e < 4; ++e)
-                                    for (int hi = 0; hi < 2; ++hi) {
-                                        const int c = c8 + e + 4 * hi;
-                                        if (c >= cin) continue;
-                                        const float wv = w[(((size_t)n * cin + c) * ks + ky) * ks + kx];
-                                        for (int i = 0; i < 2; ++i)
-                                            for (int j = 0; j < 2; ++j) {
-                                                const int iy = 2 * ty + i + ky - pad, ix = 2 * tx + j + kx - pad;
-                                                const float xv = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((size_t)b * cin + c) * H + iy) * W + ix] : 0.f;
-                                                yv[i][j] = fmaf(xv, wv, yv[i][j]);
-                                            }
+                    if (ndir) {
+                        /* pass 2a: tap (6, 6) chained directly onto y; row 6 as two 1x3 sub-kernels, 1-D F(2,3) along x: per output row
+                         * i four frequency chains hm[i][f] over (chunk -> sub-kernel -> channel); then y[i][.] += A^T hm[i] */
+                        float hm[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, vm[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#define XIN(iy_, ix_, c_) (((iy_) >= 0 && (iy_) < H && (ix_) >= 0 && (ix_) < W) ? x[(((size_t)b * cin + (c_)) * H + (iy_)) * W + (ix_)] : 0.f)
+#define CH_LOOP(c32_) for (int c8 = (c32_); c8 < (c32_) + 32; c8 += 8) for (int e = 0; e < 4; ++e) for (int hi = 0; hi < 2; ++hi)
+                        for (int c32 = 0; c32 < cin; c32 += 32) {
+                            CH_LOOP(c32) {
+                                const int c = c8 + e + 4 * hi;
+                                if (c >= cin) continue;
+                                const float wv = w[(((size_t)n * cin + c) * ks + 6) * ks + 6];
+                                for (int i = 0; i < 2; ++i)
+                                    for (int j = 0; j < 2; ++j) yv[i][j] = fmaf(XIN(2 * ty + i + 6 - pad, 2 * tx + j + 6 - pad, c), wv, yv[i][j]);
+                            }
+                            for (int sub = 0; sub < 2; ++sub)
+                                CH_LOOP(c32) {
+                                    const int c = c8 + e + 4 * hi;
+                                    if (c >= cin) continue;
+                                    const float* g = w + (((size_t)n * cin + c) * ks + 6) * ks + 3 * sub;
+                                    float u[4];
+                                    for (int f = 0; f < 4; ++f) u[f] = (float)((Gm[f][0] * (double)g[0] + Gm[f][1] * (double)g[1]) + Gm[f][2] * (double)g[2]);
+                                    for (int i = 0; i < 2; ++i) {
+                                        float d[4];
+                                        for (int k = 0; k < 4; ++k) d[k] = XIN(2 * ty + i + 6 - pad, 2 * tx + 3 * sub + k - pad, c);
+                                        const float v4[4] = {d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]};
+                                        for (int f = 0; f < 4; ++f) hm[i][f] = fmaf(v4[f], u[f], hm[i][f]);
                                     }
+                                }
                         }
+                        for (int i = 0; i < 2; ++i) {
+                            yv[i][0] = yv[i][0] + ((hm[i][0] + hm[i][1]) + hm[i][2]);
+                            yv[i][1] = yv[i][1] + ((hm[i][1] - hm[i][2]) - hm[i][3]);
+                        }
+                        /* pass 2b: column 6 as two 3x1 sub-kernels, 1-D F(2,3) along y: per output column j four chains vm[j][f] */
+                        for (int c32 = 0; c32 < cin; c32 += 32)
+                            for (int sub = 0; sub < 2; ++sub)
+                                CH_LOOP(c32) {
+                                    const int c = c8 + e + 4 * hi;
+                                    if (c >= cin) continue;
+                                    const float* g = w + (((size_t)n * cin + c) * ks + 3 * sub) * ks + 6;
+                                    float u[4];
+                                    for (int f = 0; f < 4; ++f) u[f] = (float)((Gm[f][0] * (double)g[0] + Gm[f][1] * (double)g[ks]) + Gm[f][2] * (double)g[2 * ks]);
+                                    for (int j = 0; j < 2; ++j) {
+                                        float d[4];
+                                        for (int k = 0; k < 4; ++k) d[k] = XIN(2 * ty + 3 * sub + k - pad, 2 * tx + j + 6 - pad, c);
+                                        const float v4[4] = {d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]};
+                                        for (int f = 0; f < 4; ++f) vm[j][f] = fmaf(v4[f], u[f], vm[j][f]);
+                                    }
+                                }
+                        for (int j = 0; j < 2; ++j) {
+                            yv[0][j] = yv[0][j] + ((vm[j][0] + vm[j][1]) + vm[j][2]);
+                            yv[1][j] = yv[1][j] + ((vm[j][1] - vm[j][2]) - vm[j][3]);
+                        }
+#undef XIN
+#undef CH_LOOP
+                    }
                     if (pool) {
                         if (ty < Ho && tx < Wo) {
                             float best = yv[0][0];
