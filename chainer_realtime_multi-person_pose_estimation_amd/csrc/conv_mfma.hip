@@ -1386,10 +1386,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                         } else {                                            // transform slot t
                             const int t = 2 * s + (e - 2);
                             if (t == 0) {
-                                if (r == 1 && last_sub && more) {           // the next window is in the next chunk: replace the raw halo
+                                // the next window is in the next chunk: replace the raw halo.  Chunks are staged round-robin over the
+                                // passes (0 .. nch-1, then 0 .. again for pass 2a, 2b): the registers always hold the chunk after next
+                                if (r == 1 && last_sub && (more || C::NDIR > 0)) {
                                     halo_store(hreg);
                                     __syncthreads();
-                                    const int cn = ch + 2 < nch ? ch + 2 : ch + 1;
+                                    int cn = ch + 2;
+                                    if (cn >= nch) cn -= nch;
+                                    if (cn >= nch) cn -= nch;
 #pragma unroll
                                     for (int rr = 0; rr < C::NHF; ++rr) hreg[rr] = *reinterpret_cast<const float4*>(in_b + h_goff[rr] + cn * C::CKW);
                                 }
@@ -1504,18 +1508,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
         const int a2_off = ((2 * (li >> 3)) * C::HW + 2 * (li & 7)) * C::LDR + kh * 4;
 
         // ================= pass 2a: tap (6, 6) + row 6 =================
-        zero8();
-        __syncthreads();                            // pass 1 is done with the raw halo / U
-#pragma unroll
-        for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r]);
+        zero8();                                    // (pass 1's last phase already staged the raw halo of chunk 0 again)
 #pragma unroll
         for (int st = 0; st < 4; ++st) bd[st] = wload(PD, 0u, st);
-        halo_store(hreg);
-        __syncthreads();
-        if (nch > 1) {
-#pragma unroll
-            for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + C::CKW);
-        }
         for (int ch = 0; ch < nch; ++ch) {
             const bool more = ch + 1 < nch;
             const unsigned chb = (unsigned)ch * panel_b, nxb = (unsigned)(more ? ch + 1 : ch) * panel_b;
@@ -1552,20 +1547,29 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
             __syncthreads();                        // U half 1 = row-6 sub-kernel 1
             // ---- H1: side = the next chunk's raw halo; afterwards the next chunk's tap-(6,6) weights
             phase8(s_u + 8 * 32 * C::LDU, PH + 4, chb,
-                   [&](int s2n) { bd[s2n] = wload(PD, nxb, s2n); },
+                   [&](int s2n) {
+                       bd[s2n] = wload(PD, nxb, s2n);
+                       bwr[(s2n + 16) & 7] = wload(PV + 0, 0u, s2n);              // pass 2b's first weights (used after the last chunk)
+                   },
                    [&](int t) {
                        if (t == 0) {
-                           if (more) {
-                               halo_store(hreg);
-                               __syncthreads();
-                               const int cn = ch + 2 < nch ? ch + 2 : ch + 1;
+                           halo_store(hreg);                                        // next chunk, or chunk 0 again for pass 2b
+                           __syncthreads();
+                           int cn = ch + 2;
+                           if (cn >= nch) cn -= nch;
+                           if (cn >= nch) cn -= nch;
 #pragma unroll
-                               for (int rr = 0; rr < C::NHF; ++rr) hreg[rr] = *reinterpret_cast<const float4*>(in_b + h_goff[rr] + cn * C::CKW);
-                           }
+                           for (int rr = 0; rr < C::NHF; ++rr) hreg[rr] = *reinterpret_cast<const float4*>(in_b + h_goff[rr] + cn * C::CKW);
                            __builtin_amdgcn_sched_barrier(0);
+                       } else {
+                           // column-6 sub-kernel 0 of the staged chunk -> U half 0 (free: H1 reads half 1).  Needed after the last chunk
+                           // (chunk 0 is staged again: pass 2b starts from it); otherwise unused and overwritten by the next D phase --
+                           // unconditional, because a branch per slot would cut the schedule into pieces
+                           side1d(t, t_raw + (0 * C::HW + 6) * C::LDR, C::LDR, C::HW * C::LDR, u0);
                        }
                    });
         }
+        __syncthreads();                            // U half 0 = column-6 sub-kernel 0 of chunk 0
         // y += A^T-transform of the row planes: e8[i * 4 + f]
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg)
@@ -1577,20 +1581,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
 
         // ================= pass 2b: column 6 =================
         zero8();
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r]);
-#pragma unroll
-        for (int s2n = 0; s2n < 4; ++s2n) bwr[s2n] = wload(PV + 0, 0u, s2n);
-        halo_store(hreg);
-        __syncthreads();
-        if (nch > 1) {
-#pragma unroll
-            for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + C::CKW);
-        }
-#pragma unroll
-        for (int t = 0; t < 28; ++t) side1d(t, t_raw + (0 * C::HW + 6) * C::LDR, C::LDR, C::HW * C::LDR, u0);      // column-6 sub-kernel 0 of chunk 0
-        __syncthreads();
         for (int ch = 0; ch < nch; ++ch) {
             const bool more = ch + 1 < nch;
             const unsigned chb = (unsigned)ch * panel_b, nxb = (unsigned)(more ? ch + 1 : ch) * panel_b;
