@@ -281,6 +281,7 @@ struct pmx_ctx {
     int opt_conv_algo = 1;           // 1 (default): Winograd F(2x2,3x3) fp32 kernel for the 3x3 / 7x7 layers of launches that fill the chip
                                      // (>= 2 blocks per CU: batches); 0: direct kernels everywhere; 2: Winograd on every eligible layer
                                      // (tests).  Both are fp32 with a defined order and a C twin; they differ by fp32 rounding (~1e-6)
+    int opt_wino_min_fill = 50;      // conv_algo 1: percent of ceil(blocks / CUs) * CUs block slots a launch must fill to take the Winograd kernel
     int opt_precision = 0;           // 0: fp32 MFMA everywhere (the path whose results are specified); 1: bf16x3 kernels where a
                                      // v6 kernel would run (fp32-grade accuracy at 2.67x the matrix rate, NOT the fp32 FMA chain)
     int opt_fuse_conv1 = 1;          // conv1_1 recomputed on conv1_2's halo tile, one launch (conv1_fused_kernel); identical bits
@@ -540,6 +541,7 @@ extern "C" int pmx_set_option(pmx_ctx* c, const char* key, int value)
     else if (!strcmp(key, "fuse_conv1")) c->opt_fuse_conv1 = value;
     else if (!strcmp(key, "precision")) c->opt_precision = value;
     else if (!strcmp(key, "conv_algo")) c->opt_conv_algo = value;
+    else if (!strcmp(key, "wino_min_fill")) c->opt_wino_min_fill = value;
     else if (!strcmp(key, "ksplit")) c->opt_ksplit = value;
     else if (!strcmp(key, "ksplit_plan")) c->opt_ksplit = value > 0 ? -value : 0;     // decimal digits = chunks per slice, e.g. 3221
     else if (!strcmp(key, "conv_min_lds")) conv_set_min_lds(value);
@@ -651,8 +653,12 @@ static bool wino_use(const pmx_ctx* c, int ks, int cin_pad, int cout_pad, int im
 {
     if (c->opt_conv_algo < 1 || c->opt_precision != 0 || c->opt_force[ks] >= 0 || !wino_eligible(ks, cin_pad, cout_pad)) return false;
     if (c->opt_conv_algo == 2) return true;       // tests: every eligible 3x3 layer, whatever the launch size
+    // one equal-sized block per CU at a time: the launch takes ceil(blocks / CUs) rounds whatever the last round holds, so what
+    // decides is how full the rounds are (measured, tools/wino_batch_sweep.py: at 0.56 the Winograd kernel already beats the direct
+    // kernels + split-K -- 144 blocks of a 7x7 layer at batch 4, 288 at batch 8 -- at 0.42 it does not; thresholds 0.45 - 0.56 measure alike)
     const long long blocks = (long long)((H + 7) / 8) * ((W + 15) / 16) * images * (cout_pad / 128);
-    return blocks >= 2ll * conv_num_cus();
+    const long long ncu = conv_num_cus(), rounds = (blocks + ncu - 1) / ncu;
+    return blocks * 100 >= (long long)c->opt_wino_min_fill * rounds * ncu;
 }
 
 // one launch of 1 or 2 groups (same geometry); in/out pointers are already offset to the group's channels

@@ -87,14 +87,22 @@ def _cat_weights(W):
     return Wp
 
 
+class LaunchPlan(dict):
+    """{layer label: K slices} of the launches that were split, plus `.wino` = labels of the layers that ran on the Winograd kernel."""
+    wino = frozenset()
+
+
 def splitk_plan(profile):
-    """{layer label: chunks of every K slice} from an engine profile of the SAME forward (native.Engine.profile(); the kernel
-    label carries "/k3-2-2-1" where the launch was split).  Labels are the layer names without the _L1 / _L2 branch suffix."""
-    plan = {}
+    """Launch plan of one forward from an engine profile of the SAME forward (native.Engine.profile()): {layer label: chunks of
+    every K slice} (the kernel label carries "/k3-2-2-1" where the launch was split) and, as attribute `.wino`, the layers that
+    ran on the Winograd kernel (the kernel choice depends on the launch size).  Labels are the layer names without the _L1 / _L2
+    branch suffix.  forward_fma(weights, x, splitk=plan) restates exactly that forward."""
+    plan = LaunchPlan()
     for e in profile:
         k = e['kernel']
         if '/k' in k:
             plan[e['layer']] = [int(v) for v in k.rsplit('/k', 1)[1].split('-')]
+    plan.wino = frozenset(wino_layers(profile))
     return plan
 
 
@@ -108,6 +116,8 @@ def forward_fma(weights, x, splitk=None, wino=()):
     x: (B, 3, H, W) float32 as produced by preprocess; returns (paf (B,38,h,w), heat (B,19,h,w)) of the last stage.
     splitk: {layer label: K slices} of the launch plan the kernels used (splitk_plan); None = no launch was split (large
     batches).  wino: labels of the layers that ran as Winograd F(2x2, 3x3) (wino_layers)."""
+    if not wino:
+        wino = getattr(splitk, 'wino', ())
     splitk = splitk or {}
 
     def conv(name, h, relu=True, pool=False, cat=False):

@@ -61,16 +61,20 @@ def test_winograd_is_not_used_where_it_does_not_apply(engine):
         assert np.array_equal(_run(engine, x, w, b, True, False, 2), _run(engine, x, w, b, True, False, 0)), (cin, cout, k)
 
 
-def test_winograd_large_launch_selection(engine):
-    """conv_algo = 1 takes a layer only when the launch has at least two blocks per CU; the result is the twin's either way."""
-    x, w, b = _data(5, 1, 32, 16, 16, 128, 3)
-    assert np.array_equal(_run(engine, x, w, b, True, False, 1), _run(engine, x, w, b, True, False, 0))      # 4 blocks: direct
-    x, w, b = _data(6, 24, 32, 46, 46, 128, 3)                                                                # 18 * 24 = 432 blocks... still direct
-    y1 = _run(engine, x, w, b, True, False, 1)
-    x2, w2, b2 = _data(7, 32, 32, 46, 46, 128, 3)                                                             # 576 blocks: Winograd
-    y2 = _run(engine, x2, w2, b2, True, False, 1)
-    assert np.array_equal(y1, _run(engine, x, w, b, True, False, 0))
-    assert np.array_equal(y2, R.conv_wino(x2, w2, b2, True, False))
+def test_winograd_launch_selection_by_round_fill(engine):
+    """conv_algo = 1 takes a layer when its blocks fill at least half of the CU rounds they need (one equal block per CU at a time:
+    a round costs the same however full it is); the result is the respective twin's either way."""
+    ncu = 256
+    engine.set_option('ksplit', 1)                                          # the direct launches unsplit: one twin call each
+    for B, wino in [(1, False), (5, False), (7, False), (8, True), (15, True), (32, True)]:
+        blocks = 18 * B                                                     # 46x46 map, 128 output channels
+        rounds = -(-blocks // ncu)
+        assert (blocks * 100 >= 50 * rounds * ncu) == wino, (B, blocks)     # the rule, restated
+        x, w, b = _data(B, B, 32, 46, 46, 128, 3)
+        y = _run(engine, x, w, b, True, False, 1)
+        ref = R.conv_wino(x, w, b, True, False) if wino else R.conv_fma(x, w, b, True, False)
+        assert np.array_equal(y, ref), (B, blocks, wino)
+    engine.set_option('ksplit', 0)
 
 
 @pytest.mark.parametrize('shape', [(1, 64, 64), (2, 96, 128)])
