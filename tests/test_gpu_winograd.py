@@ -147,3 +147,30 @@ def test_batch_32_winograd_agrees_with_single_images(native):
         assert np.array_equal(r1['poses'][0][:n], rec['poses'][i][:n])
         assert np.abs(r1['scores'][0][:n] - rec['scores'][i][:n]).max() <= 1e-5
     eng.close()
+
+
+@pytest.mark.parametrize('name', ['net_posenet_64x96', 'net_posenet_184x248', 'net_facenet_64x64', 'net_handnet_72x56'])
+def test_reference_chain_goldens_with_winograd(native, name):
+    """The goldens written by the reference's own CocoPoseNet / FaceNet / HandNet.__call__ (models/*.py) with every eligible layer
+    on the Winograd kernel: maps within 1e-4 (the bar of test_gpu_reference_goldens.py, which runs the default kernel choice)."""
+    import os
+    from conftest import GOLDEN
+    from test_reference_network import _x
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    arch = name.split('_')[1]
+    h, w = [int(v) for v in z['hw']]
+    img, _ = _x(arch, int(z['seed']), h, w)
+    eng = native.Engine(0, max_batch=1, max_h=h, max_w=w, arch=arch)
+    eng.set_weights(pkg('weights').synthetic_weights(int(z['seed']), arch) if arch != 'posenet' else pkg('weights').synthetic_weights(int(z['seed'])))
+    eng.set_option('conv_algo', 2)
+    eng.profile_enable(True); eng.forward_u8(img); prof = eng.profile(); eng.profile_enable(False)
+    assert len(R.wino_layers(prof)) >= 10, sorted(R.wino_layers(prof))
+    maps = eng.get_maps()
+    eng.close()
+
+    def rel(a, b):
+        return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+    if arch == 'posenet':
+        assert rel(maps[0], z['paf']) < 1e-4 and rel(maps[1], z['heat']) < 1e-4
+    else:
+        assert rel(maps, z['heat']) < 1e-4
