@@ -1238,7 +1238,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     const bool g1 = blockIdx.z != 0;
     ConvGroupArgs G;
     G.in = g1 ? a.g[1].in : a.g[0].in;
-    G.w = g1 ? a.g[1].w : a.g[0].w;              // transformed weights [plane][chunk32][cout_pad][32] (pmx_api.hip::pack_wino)
+    G.w = g1 ? a.g[1].w : a.g[0].w;              // transformed weights [plane][chunk32][k8-step][cout_pad][8] (pmx_api.hip::pack_wino)
     G.bias = g1 ? a.g[1].bias : a.g[0].bias;
     G.out = g1 ? a.g[1].out : a.g[0].out;
     G.cout = g1 ? a.g[1].cout : a.g[0].cout;
@@ -1290,7 +1290,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     const int t_u = tt * C::LDU + tc * 4;
 
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G.w), 0, 0x7fffffff, 0x00020000);
-    const unsigned b_off = (unsigned)((n * C::CKW + kh * 4) * 4);
+    // weight panels are [plane][chunk32][k8-step 4][cout_pad][8]: the 64 lanes of one fragment load (32 channels x 2 halves x 16 B)
+    // read 1 KB of contiguous, fully used cache lines (with the channel-major [cout_pad][32] layout each load touched 32 lines and used a
+    // quarter of each, relying on the 32 KB L1 to keep them for the next three k8-steps -- it did not: weight loads cost 7.5 %)
+    const unsigned b_off = (unsigned)((n * 8 + kh * 4) * 4);
+    const unsigned st_b = (unsigned)a.cout_pad * 8u * 4u;                  // bytes between the k8-steps of a panel
     const unsigned panel_b = (unsigned)a.cout_pad * C::CKW * 4u;          // bytes of one (plane, chunk) panel
     const unsigned freq_b = panel_b * (unsigned)nch;                       // bytes between planes (sub-kernel * 16 + frequency)
 
@@ -1314,7 +1318,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     f32x4 bw[16];
 #pragma unroll
     for (int st8 = 0; st8 < 8; ++st8)                 // steps 0..7 of the first phase: frequencies 0, 1 (x 4 k8-steps) of plane 0
-        bw[st8] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off + (st8 & 3) * 32, (unsigned)(st8 >> 2) * freq_b, 0));
+        bw[st8] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off, (unsigned)(st8 >> 2) * freq_b + (unsigned)(st8 & 3) * st_b, 0));
     halo_store(hreg);
     __syncthreads();
     if (nch > 1) {
@@ -1375,7 +1379,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                             if (sn < 32) so = plane_b + (unsigned)(r * 8 + (sn >> 2)) * freq_b;
                             else if (r == 0) so = plane_b + (unsigned)(8 + ((sn - 32) >> 2)) * freq_b;
                             else so = nplane_b + (unsigned)((sn - 32) >> 2) * freq_b;
-                            bw[sn & 15] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off + (sn & 3) * 32, so, 0));
+                            bw[sn & 15] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off, so + (unsigned)(sn & 3) * st_b, 0));
                             __builtin_amdgcn_sched_barrier(0);
                         } else if (e == 1) {                                // A fragment of step s + 2
                             if (s + 2 < 32) {
@@ -1457,7 +1461,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                 for (int r16 = 0; r16 < 16; ++r16) e8[pl][r16] = 0.f;
         };
         auto wload = [&](int plane, unsigned chb, int st) -> f32x4 {
-            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off + st * 32, chb + (unsigned)plane * freq_b, 0));
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off, chb + (unsigned)plane * freq_b + (unsigned)st * st_b, 0));
         };
         // 1-D transform of this thread's (tile, 4 channels): two lines (output rows i for the row class, output columns j for the
         // column class) of 4 samples each -> (d0 - d2, d1 + d2, d2 - d1, d1 - d3), slot by slot

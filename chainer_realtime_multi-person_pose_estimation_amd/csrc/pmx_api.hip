@@ -134,7 +134,7 @@ static inline float bf16_f(uint16_t h)
 // packed fp32 weights [tap][chunk][cout_pad][16] -> bf16x3 [tap][chunk][plane][cout_pad][16]
 // Winograd F(2x2, 3x3) weights: U = G g G^T per (cout, cin), G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]], evaluated in double and
 // rounded once to fp32 (oracle/conv_fma_ref.c::conv_wino_ref does the same); layout [plane = sub-kernel * 16 + 4i + j][chunk of 32
-// cin][cout_pad][32].  ks = 3: one sub-kernel; ks = 7: four, sub-kernel (sy, sx) = taps (3 sy .. 3 sy + 2, 3 sx .. 3 sx + 2); row 6 and
+// cin][k8-step 4][cout_pad][8].  ks = 3: one sub-kernel; ks = 7: four, sub-kernel (sy, sx) = taps (3 sy .. 3 sy + 2, 3 sx .. 3 sx + 2); row 6 and
 // column 6 of the 7x7 kernel are two 1x3 / two 3x1 sub-kernels with the 1-D transform G g (planes 64.., 72..), tap (6, 6) is plane 80
 static bool wino_eligible(int ks, int cin_pad, int cout_pad) { return (ks == 3 || ks == 7) && cin_pad % 32 == 0 && cout_pad % 128 == 0; }
 static void pack_wino(const std::vector<float>& wp, int ks, int nch16, int cout_pad, std::vector<float>& out)
@@ -146,7 +146,9 @@ static void pack_wino(const std::vector<float>& wp, int ks, int nch16, int cout_
     auto tapw = [&](int ky, int kx, int n, int ci) -> double {
         return wp[(((size_t)(ky * ks + kx) * nch16 + ci / CK) * cout_pad + n) * CK + ci % CK];
     };
-    auto put = [&](int plane, int n, int ci, double v) { out[(((size_t)plane * nch32 + ci / 32) * cout_pad + n) * 32 + ci % 32] = (float)v; };
+    auto put = [&](int plane, int n, int ci, double v) {      // [plane][chunk32][k8-step][cout_pad][8]
+        out[((((size_t)plane * nch32 + ci / 32) * 4 + (ci % 32) / 8) * cout_pad + n) * 8 + ci % 8] = (float)v;
+    };
     for (int n = 0; n < cout_pad; ++n)
         for (int ci = 0; ci < cin_pad; ++ci) {
             for (int sub = 0; sub < nsub; ++sub) {

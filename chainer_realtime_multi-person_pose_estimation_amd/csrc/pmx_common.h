@@ -112,7 +112,7 @@ bool conv_pair_supported(int cin, int cmid, int cout_pad);
 // conv1_1 (3 -> 64) recomputed on the halo + conv1_2 (64 -> 64 [+ pool]) in one launch: a.g[0] = conv1_2 (in = padded network input),
 // a.g[1].w / .bias = conv1_1's packed weights / bias
 int conv1_fused_launch(const ConvArgs& a, hipStream_t stream);
-// Winograd F(2x2, 3x3): a.nch = cin / 32, a.g[].w = transformed weights [sub-kernel][freq 16][chunk32][cout_pad][32] (G g G^T, host);
+// Winograd F(2x2, 3x3): a.nch = cin / 32, a.g[].w = transformed weights [plane][chunk32][k8-step][cout_pad][8] (G g G^T, host);
 // ks = 7: four 3x3 sub-kernels (taps 0..5 x 0..5) + 13 direct taps from a.g[].w2 (the direct pack)
 int conv_wino_launch(const ConvArgs& a, int ks, int groups, hipStream_t stream);
 // K slices for a launch of `variant` (S = 1: no split); forced > 0 asks for that many (near-)even slices
