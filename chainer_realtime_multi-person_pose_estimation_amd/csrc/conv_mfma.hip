@@ -1226,22 +1226,28 @@ struct WinoCfg {
     static_assert(KS == 3 || KS == 7, "Winograd kernel: 3x3 or 7x7");
 };
 
-template <int KS, int POOL>
+template <int KS, int POOL, int UNIT>
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
 {
     using C = WinoCfg<KS>;
     static_assert(!(POOL && KS != 3), "pooling only with the 3x3 variant");
+    static_assert(!UNIT || KS == 7, "unit mode: 7x7 only");
+    // UNIT (single images: 36 blocks of a 46x46 7x7 layer cannot fill 256 CUs): blockIdx.z = unit * groups + group, and a block runs
+    // ONE unit of the work -- unit u < nu1: pass 1 over the chunks [u g, u g + g) (g = a.kbounds); unit nu1: pass 2a; unit nu1 + 1: pass
+    // 2b -- and writes its untransformed share of y (no bias / ReLU) to slab `unit`; conv_splitk_reduce_kernel adds the slabs in unit order
     extern __shared__ float4 smem4[];
     float* const s_raw = reinterpret_cast<float*>(smem4);
     float* const s_u = s_raw + C::RAW_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
-    const bool g1 = blockIdx.z != 0;
+    const int unit = UNIT ? (int)blockIdx.z / a.ngroups : 0;
+    const bool g1 = (UNIT ? (int)blockIdx.z % a.ngroups : (int)blockIdx.z) != 0;
     ConvGroupArgs G;
     G.in = g1 ? a.g[1].in : a.g[0].in;
     G.w = g1 ? a.g[1].w : a.g[0].w;              // transformed weights [plane][chunk32][k8-step][cout_pad][8] (pmx_api.hip::pack_wino)
     G.bias = g1 ? a.g[1].bias : a.g[0].bias;
     G.out = g1 ? a.g[1].out : a.g[0].out;
     G.cout = g1 ? a.g[1].cout : a.g[0].cout;
+    if (UNIT) G.out += (size_t)unit * (size_t)a.slab_stride;
     const int H = a.H, W = a.W;
     int tile;
     {
@@ -1259,6 +1265,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     float bias = G.bias[n];
     asm volatile("" : "+v"(bias));
     const int nch = a.nch;                        // chunks of 32 input channels
+    const int ug = UNIT ? (int)a.kbounds : nch;   // chunks per pass-1 unit
+    const int nu1 = UNIT ? (nch + ug - 1) / ug : 1;
+    const int c0 = UNIT ? min(unit, nu1 - 1) * ug : 0;                     // pass-1 chunk range of this block
+    const int c1 = UNIT ? min(nch, c0 + ug) : nch;
+    const bool do_p1 = !UNIT || unit < nu1, do_p2a = !UNIT || unit == nu1, do_p2b = !UNIT || unit == nu1 + 1;
 
     // raw halo staging slots (the LDS offset is recomputed at the write)
     int h_goff[C::NHF];
@@ -1312,18 +1323,19 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     // phase.  Weight fragments: ring of 16 steps, loaded 8 steps (32 MFMAs, ~2000 cycles) ahead across phase, sub-kernel and chunk
     // boundaries (left alone, the compiler sinks the loads to one step ahead and the single wave per SIMD stalls on L2).
     float4 hreg[C::NHF];
-#pragma unroll
-    for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r]);
     const int a_off = li * C::LDU + kh * 4;
     f32x4 bw[16];
+    if (do_p1) {
+#pragma unroll
+    for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + c0 * C::CKW);
 #pragma unroll
     for (int st8 = 0; st8 < 8; ++st8)                 // steps 0..7 of the first phase: frequencies 0, 1 (x 4 k8-steps) of plane 0
-        bw[st8] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off, (unsigned)(st8 >> 2) * freq_b + (unsigned)(st8 & 3) * st_b, 0));
+        bw[st8] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off, (unsigned)c0 * panel_b + (unsigned)(st8 >> 2) * freq_b + (unsigned)(st8 & 3) * st_b, 0));
     halo_store(hreg);
     __syncthreads();
-    if (nch > 1) {
+    if (c1 - c0 > 1) {
 #pragma unroll
-        for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + C::CKW);
+        for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + (c0 + 1) * C::CKW);
     }
     {   // rows 0, 1 of the first window (not overlapped)
         f32x4 wv4[2][4];
@@ -1345,8 +1357,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     }
     __syncthreads();
 
-    for (int ch = 0; ch < nch; ++ch) {
-        const bool more = ch + 1 < nch;
+    for (int ch = c0; ch < c1; ++ch) {
+        const bool more = ch + 1 < c1;
         const unsigned chunk_b = (unsigned)ch * panel_b;
         const unsigned next_b = (unsigned)(more ? ch + 1 : ch) * panel_b;
 #pragma unroll 1
@@ -1392,10 +1404,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                             if (t == 0) {
                                 // the next window is in the next chunk: replace the raw halo.  Chunks are staged round-robin over the
                                 // passes (0 .. nch-1, then 0 .. again for pass 2a, 2b): the registers always hold the chunk after next
-                                if (r == 1 && last_sub && (more || C::NDIR > 0)) {
+                                if (r == 1 && last_sub && (more || (C::NDIR > 0 && !UNIT))) {
                                     halo_store(hreg);
                                     __syncthreads();
                                     int cn = ch + 2;
+                                    if (UNIT) cn = cn < c1 ? cn : c1 - 1;
                                     if (cn >= nch) cn -= nch;
                                     if (cn >= nch) cn -= nch;
 #pragma unroll
@@ -1427,6 +1440,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
             }
         }
     }
+
+    }   // do_p1
 
     // ---- output transform Y = A^T M A per (tile, channel): y[2 * i + j] = pixel (i, j) of the tile
     f32x16 y[4];
@@ -1512,9 +1527,20 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
         const int a2_off = ((2 * (li >> 3)) * C::HW + 2 * (li & 7)) * C::LDR + kh * 4;
 
         // ================= pass 2a: tap (6, 6) + row 6 =================
+        if (do_p2a) {
         zero8();                                    // (pass 1's last phase already staged the raw halo of chunk 0 again)
 #pragma unroll
         for (int st = 0; st < 4; ++st) bd[st] = wload(PD, 0u, st);
+        if (UNIT) {                                 // standalone: stage chunk 0, keep chunk 1 in the registers
+#pragma unroll
+            for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r]);
+            halo_store(hreg);
+            __syncthreads();
+            if (nch > 1) {
+#pragma unroll
+                for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + C::CKW);
+            }
+        }
         for (int ch = 0; ch < nch; ++ch) {
             const bool more = ch + 1 < nch;
             const unsigned chb = (unsigned)ch * panel_b, nxb = (unsigned)(more ? ch + 1 : ch) * panel_b;
@@ -1583,8 +1609,26 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                 y[i2 * 2 + 1][reg] = y[i2 * 2 + 1][reg] + ((e8[i2 * 4 + 1][reg] - e8[i2 * 4 + 2][reg]) - e8[i2 * 4 + 3][reg]);
             }
 
+        }   // do_p2a
+
         // ================= pass 2b: column 6 =================
+        if (do_p2b) {
         zero8();
+        if (UNIT) {                                 // standalone: stage chunk 0, first weights, sub-kernel 0 of chunk 0 (not overlapped)
+#pragma unroll
+            for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r]);
+#pragma unroll
+            for (int s2n = 0; s2n < 4; ++s2n) bwr[s2n] = wload(PV + 0, 0u, s2n);
+            halo_store(hreg);
+            __syncthreads();
+            if (nch > 1) {
+#pragma unroll
+                for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + C::CKW);
+            }
+#pragma unroll
+            for (int t = 0; t < 28; ++t) side1d(t, t_raw + (0 * C::HW + 6) * C::LDR, C::LDR, C::HW * C::LDR, u0);
+            __syncthreads();
+        }
         for (int ch = 0; ch < nch; ++ch) {
             const bool more = ch + 1 < nch;
             const unsigned chb = (unsigned)ch * panel_b, nxb = (unsigned)(more ? ch + 1 : ch) * panel_b;
@@ -1620,6 +1664,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                 y[0 * 2 + j2][reg] = y[0 * 2 + j2][reg] + ((e8[j2 * 4 + 0][reg] + e8[j2 * 4 + 1][reg]) + e8[j2 * 4 + 2][reg]);
                 y[1 * 2 + j2][reg] = y[1 * 2 + j2][reg] + ((e8[j2 * 4 + 1][reg] - e8[j2 * 4 + 2][reg]) - e8[j2 * 4 + 3][reg]);
             }
+        }   // do_p2b
     }
 
     // ---- bias, ReLU, (pool), store
@@ -2519,7 +2564,7 @@ int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream)
     return PMX_ERR_INVALID;
 }
 
-template <int KS, int POOL>
+template <int KS, int POOL, int UNIT = 0>
 static int launch_wino(const ConvArgs& a0, int groups, hipStream_t stream)
 {
     using C = WinoCfg<KS>;
@@ -2530,18 +2575,21 @@ static int launch_wino(const ConvArgs& a0, int groups, hipStream_t stream)
     PMX_CHECK((long long)a.H * a.W * a.lda < (1ll << 31), PMX_ERR_INVALID, "conv: image too large for 32-bit offsets");
     a.tiles_x = (a.W + C::TW - 1) / C::TW;
     a.tiles_y = (a.H + C::TH - 1) / C::TH;
-    auto kern = conv_wino_kernel<KS, POOL>;
+    auto kern = conv_wino_kernel<KS, POOL, UNIT>;
     static bool attr_set[PMX_MAX_DEVICES] = {};
     if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(kern), attr_set)) return rc;
-    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / 128), (unsigned)groups);
+    if (UNIT) { a.ngroups = groups; PMX_CHECK(a.ksplit >= 3 && a.ksplit <= 8 && a.kbounds >= 1, PMX_ERR_INVALID, "conv wino: bad unit plan"); }
+    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / 128), (unsigned)(groups * (UNIT ? a.ksplit : 1)));
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, a);
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
 
 // a.nch = input channels / 32 (chunks of the Winograd kernel), a.g[].w = transformed weights (a.g[].w2 = direct pack, ks = 7)
+// a.ksplit > 1 (7x7 only): unit mode -- a.ksplit = ceil(nch / g) + 2 slabs at a.g[].out + unit * a.slab_stride, g = a.kbounds
 int conv_wino_launch(const ConvArgs& a, int ks, int groups, hipStream_t stream)
 {
+    if (ks == 7 && a.ksplit > 1) return launch_wino<7, 0, 1>(a, groups, stream);
     if (ks == 7) return launch_wino<7, 0>(a, groups, stream);
     return a.pool ? launch_wino<3, 1>(a, groups, stream) : launch_wino<3, 0>(a, groups, stream);
 }

@@ -649,12 +649,65 @@ static int launch_conv(pmx_ctx* c, const ConvArgs& a0, int groups, int v, const 
     return conv_splitk_reduce(r, groups, c->stream);
 }
 
+// Unit mode of the 7x7 Winograd kernel (single images): S = ceil(nch / g) + 2 units per (tile, group) -- pass 1 over g chunks each, pass
+// 2a, pass 2b -- as separate blocks writing slabs, combined in unit order by the split-K combine kernel (bias, ReLU there)
+static int launch_wino_units(pmx_ctx* c, const ConvArgs& a0, int groups, int g)
+{
+    const int S = (a0.nch + g - 1) / g + 2;
+    PMX_CHECK(S >= 3 && S <= 8, PMX_ERR_INVALID, "winograd units: %d slabs", S);
+    PMX_CHECK(a0.cout_pad <= SK_ZERO_BIAS, PMX_ERR_INVALID, "split-K: cout_pad %d too large", a0.cout_pad);
+    const size_t slab = (size_t)a0.B * a0.H * a0.W * a0.cout_pad;
+    const size_t need = slab * S * groups;
+    if (need > c->sk_floats) {
+        PMX_HIP(hipStreamSynchronize(c->stream));
+        if (c->sk_scratch) (void)hipFree(c->sk_scratch);
+        c->sk_scratch = nullptr; c->sk_floats = 0;
+        PMX_HIP(hipMalloc((void**)&c->sk_scratch, need * sizeof(float)));
+        c->sk_floats = need;
+    }
+    if (!c->sk_zero_bias) {
+        PMX_HIP(hipMalloc((void**)&c->sk_zero_bias, SK_ZERO_BIAS * sizeof(float)));
+        PMX_HIP(hipMemsetAsync(c->sk_zero_bias, 0, SK_ZERO_BIAS * sizeof(float), c->stream));
+    }
+    ConvArgs a = a0;
+    SplitKReduceArgs r;
+    memset(&r, 0, sizeof r);
+    for (int gi = 0; gi < groups; ++gi) {
+        float* base = c->sk_scratch + (size_t)gi * S * slab;
+        r.slabs[gi] = base; r.bias[gi] = a0.g[gi].bias; r.out[gi] = a0.g[gi].out; r.cout[gi] = a0.g[gi].cout;
+        a.g[gi].out = base; a.g[gi].bias = c->sk_zero_bias; a.g[gi].cout = a0.cout_pad;
+    }
+    a.ldc = a0.cout_pad; a.relu = 0; a.pool = 0; a.ksplit = S; a.slab_stride = (long long)slab; a.kbounds = (unsigned long long)g;
+    r.slab_stride = (long long)slab; r.ksplit = S; r.B = a0.B; r.H = a0.H; r.W = a0.W; r.ld_slab = a0.cout_pad; r.ldc = a0.ldc;
+    r.relu = a0.relu; r.pool = 0;
+    int rc = conv_wino_launch(a, 7, groups, c->stream);
+    if (rc) return rc;
+    return conv_splitk_reduce(r, groups, c->stream);
+}
+
+// chunks per pass-1 unit of the unit mode (0 = the mode does not apply): 7x7 layers whose plain Winograd launch would leave most CUs
+// idle (single images), when all units together still fit one round of the CUs
+static int wino_units_g(const pmx_ctx* c, int ks, int cin_pad, int cout_pad, int cout, int ldc, int images, int H, int W)
+{
+    if (ks != 7 || c->opt_precision != 0 || c->opt_force[7] >= 0 || c->opt_ksplit == 1) return 0;
+    if (!(ks == 7 && cin_pad % 32 == 0 && cout_pad % 128 == 0) || cout % 4 != 0 || ldc % 4 != 0) return 0;
+    const int nch = cin_pad / 32;
+    const int g = nch <= 4 ? 1 : (nch + 3) / 4;
+    const int S = (nch + g - 1) / g + 2;
+    if (S > 8) return 0;
+    if (c->opt_conv_algo == 3) return g;           // tests: wherever it applies
+    if (c->opt_conv_algo != 1) return 0;
+    const long long blocks = (long long)((H + 7) / 8) * ((W + 15) / 16) * images * (cout_pad / 128);
+    return blocks * S <= (long long)conv_num_cus() + conv_num_cus() / 8 ? g : 0;
+}
+
 // Winograd takes a 3x3 layer when the option asks for it, the fp32 path is selected, and the launch fills the chip a few times over
 // (one 8 x 16 x 128 block per CU at a time; small launches stay on the direct kernels and their split-K plans)
 static bool wino_use(const pmx_ctx* c, int ks, int cin_pad, int cout_pad, int images, int H, int W)
 {
     if (c->opt_conv_algo < 1 || c->opt_precision != 0 || c->opt_force[ks] >= 0 || !wino_eligible(ks, cin_pad, cout_pad)) return false;
-    if (c->opt_conv_algo == 2) return true;       // tests: every eligible 3x3 layer, whatever the launch size
+    if (c->opt_conv_algo == 2) return true;       // tests: every eligible 3x3 / 7x7 layer, whatever the launch size
+    if (c->opt_conv_algo == 3) return false;      // tests: unit mode on the 7x7 layers, direct kernels elsewhere
     // one equal-sized block per CU at a time: the launch takes ceil(blocks / CUs) rounds whatever the last round holds, so what
     // decides is how full the rounds are (measured, tools/wino_batch_sweep.py: at 0.56 the Winograd kernel already beats the direct
     // kernels + split-K -- 144 blocks of a 7x7 layer at batch 4, 288 at batch 8 -- at 0.42 it does not; thresholds 0.45 - 0.56 measure alike)
@@ -689,7 +742,20 @@ static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float
     }
     int rc;
     const bool prof_this = c->prof_on == 1 || (c->prof_on == 2 && L0.ks == 7);
-    if (wino_use(c, L0.ks, L0.cin_pad, L0.cout_pad, B * groups, H, W) && L0.d_ww && (groups == 1 || c->layers[li1].d_ww)) {
+    const bool wino_ok = L0.d_ww && (groups == 1 || (c->layers[li1].d_ww && c->layers[li1].cout == L0.cout));
+    const bool wino_plain = wino_ok && wino_use(c, L0.ks, L0.cin_pad, L0.cout_pad, B * groups, H, W);
+    if (const int ug = (wino_ok && !wino_plain) ? wino_units_g(c, L0.ks, L0.cin_pad, L0.cout_pad, L0.cout, ldc, B * groups, H, W) : 0) {
+        a.nch = L0.cin_pad / 32;
+        a.g[0].w = L0.d_ww;
+        if (groups == 2) a.g[1].w = c->layers[li1].d_ww;
+        if (prof_this) {
+            const double bytes = 4.0 * B * H * W * ((double)L0.cin * groups + (double)L0.cout * groups);
+            if ((rc = prof_begin(c, std::string(label) + "|conv_wino_f2x2_7x7/u" + std::to_string(ug), flops, bytes))) return rc;
+        }
+        if ((rc = launch_wino_units(c, a, groups, ug))) return rc;
+        return prof_this ? prof_end(c) : PMX_OK;
+    }
+    if (wino_plain) {
         a.nch = L0.cin_pad / 32;
         a.g[0].w = L0.d_ww; a.g[0].w2 = L0.d_w;
         if (groups == 2) { a.g[1].w = c->layers[li1].d_ww; a.g[1].w2 = c->layers[li1].d_w; }
@@ -1754,7 +1820,16 @@ extern "C" int pmx_conv2d(pmx_ctx* c, const float* x, const float* w, const floa
         PMX_HIP(hipMemcpy(d_ww, ww.data(), ww.size() * sizeof(float), hipMemcpyHostToDevice));
         a.g[0].w = d_ww; a.g[0].w2 = d_w; a.nch = cin_pad / 32;
     }
+    const int ug = wino ? 0 : wino_units_g(c, ks, cin_pad, cpad, cout, cout, B, H, W);
+    if (ug) {
+        std::vector<float> ww;
+        pack_wino(wp, ks, cin_pad / CK, cpad, ww);
+        PMX_HIP(hipMalloc((void**)&d_ww, ww.size() * sizeof(float)));
+        PMX_HIP(hipMemcpy(d_ww, ww.data(), ww.size() * sizeof(float), hipMemcpyHostToDevice));
+        a.g[0].w = d_ww; a.nch = cin_pad / 32;
+    }
     auto launch_conv = [&](pmx_ctx* cc, const ConvArgs& aa, int gg, int vv, const SplitPlan& pp) {
+        if (ug) return launch_wino_units(cc, aa, gg, ug);
         return wino ? conv_wino_launch(aa, ks, gg, cc->stream) : ::launch_conv(cc, aa, gg, vv, pp);
     };
     if (!rc) rc = launch_conv(c, a, 1, v_run, plan);

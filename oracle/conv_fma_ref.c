@@ -74,7 +74,7 @@ void conv_fma_ref(const float* x, const float* w, const float* bias, float* y, i
  * The window of output tile (ty, tx), sub-kernel (sy, sx), covers input rows 2 ty - pad + 3 sy .. + 3 (columns alike), zeros outside. */
 #include <stdlib.h>
 void conv_wino_ref(const float* x, const float* w, const float* bias, float* y, int B, int cin, int H, int W, int cout, int ks,
-                   int relu, int pool)
+                   int relu, int pool, int unit_g)
 {
     static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     const int pad = ks / 2, nsub = ks == 3 ? 1 : 4, ndir = ks == 3 ? 0 : 13;
@@ -127,9 +127,15 @@ void conv_wino_ref(const float* x, const float* w, const float* bias, float* y, 
         for (int n = 0; n < cout; ++n)
             for (int ty = 0; ty < TY; ++ty)
                 for (int tx = 0; tx < TX; ++tx) {
+                    /* unit_g > 0 (unit mode of the kernel, single images): pass 1 in units of unit_g chunks, each with its own chains (from
+                     * 0) and its own output transform; pass 2a and pass 2b as units starting from 0; the units are added in order */
+                    float yv[2][2], ysum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+                    const int ustep = unit_g > 0 ? 32 * unit_g : ((cin + 31) / 32) * 32;
+                    int nunit = 0;
+                    for (int cu = 0; cu < cin; cu += ustep, ++nunit) {
                     float m[16];
                     for (int f = 0; f < 16; ++f) m[f] = 0.f;
-                    for (int c32 = 0; c32 < cin; c32 += 32)
+                    for (int c32 = cu; c32 < cin && c32 < cu + ustep; c32 += 32)
                         for (int sub = 0; sub < nsub; ++sub)
                             for (int c8 = c32; c8 < c32 + 32; c8 += 8)
                                 for (int e = 0; e < 4; ++e)
@@ -140,13 +146,18 @@ void conv_wino_ref(const float* x, const float* w, const float* bias, float* y, 
                                         const float* u = U + (((size_t)n * cin + c) * nsub + sub) * 16;
                                         for (int f = 0; f < 16; ++f) m[f] = fmaf(v[f], u[f], m[f]);
                                     }
-                    float t0[4], t1[4], yv[2][2];
+                    float t0[4], t1[4];
                     for (int j = 0; j < 4; ++j) {
                         t0[j] = (m[j] + m[4 + j]) + m[8 + j];
                         t1[j] = (m[4 + j] - m[8 + j]) - m[12 + j];
                     }
                     yv[0][0] = (t0[0] + t0[1]) + t0[2]; yv[0][1] = (t0[1] - t0[2]) - t0[3];
                     yv[1][0] = (t1[0] + t1[1]) + t1[2]; yv[1][1] = (t1[1] - t1[2]) - t1[3];
+                    if (unit_g > 0)
+                        for (int i = 0; i < 2; ++i)
+                            for (int j = 0; j < 2; ++j) ysum[i][j] = nunit == 0 ? yv[i][j] : ysum[i][j] + yv[i][j];
+                    }
+                    if (unit_g > 0) yv[0][0] = yv[0][1] = yv[1][0] = yv[1][1] = 0.f;        /* pass 2a starts its own unit */
                     if (ndir) {
                         /* pass 2a: tap (6, 6) chained directly onto y; row 6 as two 1x3 sub-kernels, 1-D F(2,3) along x: per output row
                          * i four frequency chains hm[i][f] over (chunk -> sub-kernel -> channel); then y[i][.] += A^T hm[i] */
@@ -180,6 +191,9 @@ void conv_wino_ref(const float* x, const float* w, const float* bias, float* y, 
                             yv[i][0] = yv[i][0] + ((hm[i][0] + hm[i][1]) + hm[i][2]);
                             yv[i][1] = yv[i][1] + ((hm[i][1] - hm[i][2]) - hm[i][3]);
                         }
+                        if (unit_g > 0)         /* unit "pass 2a" is complete; pass 2b starts from 0 */
+                            for (int i = 0; i < 2; ++i)
+                                for (int j = 0; j < 2; ++j) { ysum[i][j] = ysum[i][j] + yv[i][j]; yv[i][j] = 0.f; }
                         /* pass 2b: column 6 as two 3x1 sub-kernels, 1-D F(2,3) along y: per output column j four chains vm[j][f] */
                         for (int c32 = 0; c32 < cin; c32 += 32)
                             for (int sub = 0; sub < 2; ++sub)
@@ -200,6 +214,9 @@ void conv_wino_ref(const float* x, const float* w, const float* bias, float* y, 
                             yv[0][j] = yv[0][j] + ((vm[j][0] + vm[j][1]) + vm[j][2]);
                             yv[1][j] = yv[1][j] + ((vm[j][1] - vm[j][2]) - vm[j][3]);
                         }
+                        if (unit_g > 0)
+                            for (int i = 0; i < 2; ++i)
+                                for (int j = 0; j < 2; ++j) yv[i][j] = ysum[i][j] + yv[i][j];
 #undef XIN
 #undef CH_LOOP
                     }

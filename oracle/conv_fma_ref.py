@@ -52,15 +52,16 @@ def conv_fma(x, w, b, relu=False, pool=False, splitk=1):
     return y
 
 
-def conv_wino(x, w, b, relu=False, pool=False):
+def conv_wino(x, w, b, relu=False, pool=False, unit_g=0):
     """The Winograd F(2x2, 3x3) kernel's arithmetic (csrc/conv_mfma.hip::conv_wino_kernel, option "conv_algo"): same shapes as
     conv_fma, 3x3 or 7x7 (four 3x3 sub-kernels in the frequency domain + 13 direct taps).  Defined order, but not the direct
-    kernels' chain: the two agree to ~1e-6 of the map scale."""
+    kernels' chain: the two agree to ~1e-6 of the map scale.  unit_g > 0 (7x7): the kernel's unit mode for single images -- pass 1 in
+    units of unit_g 32-channel chunks, pass 2a, pass 2b, each summed from 0 and added in that order (kernel label ".../u<g>")."""
     global _lib
     if _lib is None:
         conv_fma(np.zeros((1, 1, 1, 1), 'f'), np.zeros((1, 1, 1, 1), 'f'), np.zeros(1, 'f'))
     _lib.conv_wino_ref.restype = None
-    _lib.conv_wino_ref.argtypes = [C.c_void_p] * 4 + [C.c_int] * 8
+    _lib.conv_wino_ref.argtypes = [C.c_void_p] * 4 + [C.c_int] * 9
     x = np.ascontiguousarray(x, np.float32)
     w = np.ascontiguousarray(w, np.float32)
     b = np.ascontiguousarray(b, np.float32)
@@ -68,7 +69,7 @@ def conv_wino(x, w, b, relu=False, pool=False):
     cout, _, ks, _ = w.shape
     assert ks in (3, 7) and not (pool and ks == 7)
     y = np.empty((B, cout, H // 2 if pool else H, W // 2 if pool else W), np.float32)
-    _lib.conv_wino_ref(x.ctypes.data, w.ctypes.data, b.ctypes.data, y.ctypes.data, B, cin, H, W, cout, ks, int(relu), int(pool))
+    _lib.conv_wino_ref(x.ctypes.data, w.ctypes.data, b.ctypes.data, y.ctypes.data, B, cin, H, W, cout, ks, int(relu), int(pool), int(unit_g))
     return y
 
 
@@ -88,8 +89,10 @@ def _cat_weights(W):
 
 
 class LaunchPlan(dict):
-    """{layer label: K slices} of the launches that were split, plus `.wino` = labels of the layers that ran on the Winograd kernel."""
+    """{layer label: K slices} of the launches that were split, plus `.wino` = labels of the layers that ran on the Winograd kernel
+    and `.wino_units` = {label: chunks per pass-1 unit} of those that ran in its unit mode."""
     wino = frozenset()
+    wino_units = {}
 
 
 def splitk_plan(profile):
@@ -103,6 +106,7 @@ def splitk_plan(profile):
         if '/k' in k:
             plan[e['layer']] = [int(v) for v in k.rsplit('/k', 1)[1].split('-')]
     plan.wino = frozenset(wino_layers(profile))
+    plan.wino_units = {e['layer']: int(e['kernel'].rsplit('/u', 1)[1]) for e in profile if e['kernel'].startswith('conv_wino') and '/u' in e['kernel']}
     return plan
 
 
@@ -118,13 +122,14 @@ def forward_fma(weights, x, splitk=None, wino=()):
     batches).  wino: labels of the layers that ran as Winograd F(2x2, 3x3) (wino_layers)."""
     if not wino:
         wino = getattr(splitk, 'wino', ())
+    units = getattr(splitk, 'wino_units', {})
     splitk = splitk or {}
 
     def conv(name, h, relu=True, pool=False, cat=False):
         W, b = weights[name]
         label = name[:-3] if name.endswith(('_L1', '_L2')) else name
         if label in wino:
-            return conv_wino(h, _cat_weights(W) if cat else W, b, relu=relu, pool=pool)
+            return conv_wino(h, _cat_weights(W) if cat else W, b, relu=relu, pool=pool, unit_g=units.get(label, 0))
         return conv_fma(h, _cat_weights(W) if cat else W, b, relu=relu, pool=pool, splitk=splitk.get(label, 1))
     h = conv('conv1_1', x); h = conv('conv1_2', h, pool=True)
     h = conv('conv2_1', h); h = conv('conv2_2', h, pool=True)

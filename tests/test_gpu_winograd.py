@@ -174,3 +174,34 @@ def test_reference_chain_goldens_with_winograd(native, name):
         assert rel(maps[0], z['paf']) < 1e-4 and rel(maps[1], z['heat']) < 1e-4
     else:
         assert rel(maps, z['heat']) < 1e-4
+
+
+@pytest.mark.parametrize('B,cin,H,W,cout,relu', [(1, 128, 46, 46, 128, True), (1, 192, 46, 46, 128, True), (2, 64, 20, 30, 256, False),
+                                                  (1, 96, 9, 11, 100, True)])
+def test_winograd_unit_mode_bit_exact_vs_c_twin(engine, B, cin, H, W, cout, relu):
+    """Unit mode of the 7x7 Winograd kernel (single images; conv_algo 3 forces it): pass 1 in units of g chunks, pass 2a, pass 2b as
+    separate blocks writing slabs that the combine kernel adds in unit order == the twin's unit_g form, bit for bit."""
+    x, w, b = _data(cin + H, B, cin, H, W, cout, 7)
+    nch = (cin + 31) // 32
+    g = 1 if nch <= 4 else (nch + 3) // 4
+    y = _run(engine, x, w, b, relu, False, 3)
+    ref = R.conv_wino(x, w, b, relu, False, unit_g=g)
+    assert np.array_equal(y, ref), (np.abs(y - ref).max(), int((y != ref).sum()))
+    t = N.conv2d_ref(x, w, b, relu=relu, pool=False)
+    assert np.abs(y - t).max() <= TOL * max(1.0, np.abs(t).max())
+
+
+def test_single_image_368_default_plan_bit_exact(native):
+    """One 368x368 image with default options: the 46x46 7x7 layers run the Winograd kernel in unit mode, conv2_x / conv3_x the plain
+    Winograd kernel, the rest the direct kernels (split-K where planned) -- and forward_fma with the plan read from the profile
+    reproduces the maps bit for bit."""
+    weights = pkg('weights').synthetic_weights(0)
+    eng = native.Engine(0, max_batch=1, max_h=368, max_w=368)
+    eng.set_weights(weights)
+    img = np.random.default_rng(21).integers(0, 256, (1, 368, 368, 3), dtype=np.uint8)
+    plan, _ = forward_plan(eng, lambda: eng.forward_u8(img))
+    paf, heat = eng.get_maps()
+    eng.close()
+    assert len(plan.wino_units) >= 20 and 'conv2_2' in plan.wino and 'conv2_2' not in plan.wino_units, (plan.wino_units, sorted(plan.wino))
+    rpaf, rheat = R.forward_fma(weights, P.preprocess(img[0]), splitk=plan)
+    assert np.array_equal(paf, rpaf) and np.array_equal(heat, rheat), (np.abs(paf - rpaf).max(), np.abs(heat - rheat).max())
