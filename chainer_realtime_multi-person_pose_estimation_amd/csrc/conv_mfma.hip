@@ -1231,10 +1231,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
 {
     using C = WinoCfg<KS>;
     static_assert(!(POOL && KS != 3), "pooling only with the 3x3 variant");
-    static_assert(!UNIT || KS == 7, "unit mode: 7x7 only");
+    static_assert(!(UNIT && POOL), "unit mode: the combine kernel pools");
     // UNIT (single images: 36 blocks of a 46x46 7x7 layer cannot fill 256 CUs): blockIdx.z = unit * groups + group, and a block runs
-    // ONE unit of the work -- unit u < nu1: pass 1 over the chunks [u g, u g + g) (g = a.kbounds); unit nu1: pass 2a; unit nu1 + 1: pass
-    // 2b -- and writes its untransformed share of y (no bias / ReLU) to slab `unit`; conv_splitk_reduce_kernel adds the slabs in unit order
+    // ONE unit of the work -- unit u < nu1: pass 1 over the chunks [u g, u g + g) (g = a.kbounds); 7x7: unit nu1: pass 2a; unit nu1 + 1:
+    // pass 2b -- and writes its untransformed share of y (no bias / ReLU) to slab `unit`; conv_splitk_reduce_kernel adds the slabs in unit order
     extern __shared__ float4 smem4[];
     float* const s_raw = reinterpret_cast<float*>(smem4);
     float* const s_u = s_raw + C::RAW_ELEMS;
@@ -2578,7 +2578,7 @@ static int launch_wino(const ConvArgs& a0, int groups, hipStream_t stream)
     auto kern = conv_wino_kernel<KS, POOL, UNIT>;
     static bool attr_set[PMX_MAX_DEVICES] = {};
     if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(kern), attr_set)) return rc;
-    if (UNIT) { a.ngroups = groups; PMX_CHECK(a.ksplit >= 3 && a.ksplit <= 8 && a.kbounds >= 1, PMX_ERR_INVALID, "conv wino: bad unit plan"); }
+    if (UNIT) { a.ngroups = groups; PMX_CHECK(a.ksplit >= 2 && a.ksplit <= 8 && a.kbounds >= 1, PMX_ERR_INVALID, "conv wino: bad unit plan"); }
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / 128), (unsigned)(groups * (UNIT ? a.ksplit : 1)));
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, a);
     PMX_HIP(hipGetLastError());
@@ -2586,10 +2586,10 @@ static int launch_wino(const ConvArgs& a0, int groups, hipStream_t stream)
 }
 
 // a.nch = input channels / 32 (chunks of the Winograd kernel), a.g[].w = transformed weights (a.g[].w2 = direct pack, ks = 7)
-// a.ksplit > 1 (7x7 only): unit mode -- a.ksplit = ceil(nch / g) + 2 slabs at a.g[].out + unit * a.slab_stride, g = a.kbounds
+// a.ksplit > 1: unit mode -- a.ksplit = ceil(nch / g) (+ 2 for 7x7) slabs at a.g[].out + unit * a.slab_stride, g = a.kbounds
 int conv_wino_launch(const ConvArgs& a, int ks, int groups, hipStream_t stream)
 {
-    if (ks == 7 && a.ksplit > 1) return launch_wino<7, 0, 1>(a, groups, stream);
+    if (a.ksplit > 1) return ks == 7 ? launch_wino<7, 0, 1>(a, groups, stream) : launch_wino<3, 0, 1>(a, groups, stream);
     if (ks == 7) return launch_wino<7, 0>(a, groups, stream);
     return a.pool ? launch_wino<3, 1>(a, groups, stream) : launch_wino<3, 0>(a, groups, stream);
 }

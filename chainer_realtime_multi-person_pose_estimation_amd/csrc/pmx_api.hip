@@ -649,12 +649,13 @@ static int launch_conv(pmx_ctx* c, const ConvArgs& a0, int groups, int v, const 
     return conv_splitk_reduce(r, groups, c->stream);
 }
 
-// Unit mode of the 7x7 Winograd kernel (single images): S = ceil(nch / g) + 2 units per (tile, group) -- pass 1 over g chunks each, pass
-// 2a, pass 2b -- as separate blocks writing slabs, combined in unit order by the split-K combine kernel (bias, ReLU there)
-static int launch_wino_units(pmx_ctx* c, const ConvArgs& a0, int groups, int g)
+// Unit mode of the Winograd kernel (single images): a (tile, group) is cut into S units -- pass 1 over g chunks each (ceil(nch / g) units)
+// and, for 7x7, pass 2a and pass 2b -- that run as separate blocks writing slabs, combined in unit order by the split-K combine kernel
+// (bias, ReLU, pool there)
+static int launch_wino_units(pmx_ctx* c, const ConvArgs& a0, int ks, int groups, int g)
 {
-    const int S = (a0.nch + g - 1) / g + 2;
-    PMX_CHECK(S >= 3 && S <= 8, PMX_ERR_INVALID, "winograd units: %d slabs", S);
+    const int S = (a0.nch + g - 1) / g + (ks == 7 ? 2 : 0);
+    PMX_CHECK(S >= 2 && S <= 8, PMX_ERR_INVALID, "winograd units: %d slabs", S);
     PMX_CHECK(a0.cout_pad <= SK_ZERO_BIAS, PMX_ERR_INVALID, "split-K: cout_pad %d too large", a0.cout_pad);
     const size_t slab = (size_t)a0.B * a0.H * a0.W * a0.cout_pad;
     const size_t need = slab * S * groups;
@@ -679,26 +680,28 @@ static int launch_wino_units(pmx_ctx* c, const ConvArgs& a0, int groups, int g)
     }
     a.ldc = a0.cout_pad; a.relu = 0; a.pool = 0; a.ksplit = S; a.slab_stride = (long long)slab; a.kbounds = (unsigned long long)g;
     r.slab_stride = (long long)slab; r.ksplit = S; r.B = a0.B; r.H = a0.H; r.W = a0.W; r.ld_slab = a0.cout_pad; r.ldc = a0.ldc;
-    r.relu = a0.relu; r.pool = 0;
-    int rc = conv_wino_launch(a, 7, groups, c->stream);
+    r.relu = a0.relu; r.pool = a0.pool;
+    int rc = conv_wino_launch(a, ks, groups, c->stream);
     if (rc) return rc;
     return conv_splitk_reduce(r, groups, c->stream);
 }
 
-// chunks per pass-1 unit of the unit mode (0 = the mode does not apply): 7x7 layers whose plain Winograd launch would leave most CUs
-// idle (single images), when all units together still fit one round of the CUs
+// chunks per pass-1 unit of the unit mode (0 = the mode does not apply): layers whose plain Winograd launch would leave most CUs idle
+// (single images), cut into as many units as still fit ONE round of the CUs (at most 8 slabs), at least two pass-1 units
 static int wino_units_g(const pmx_ctx* c, int ks, int cin_pad, int cout_pad, int cout, int ldc, int images, int H, int W)
 {
-    if (ks != 7 || c->opt_precision != 0 || c->opt_force[7] >= 0 || c->opt_ksplit == 1) return 0;
-    if (!(ks == 7 && cin_pad % 32 == 0 && cout_pad % 128 == 0) || cout % 4 != 0 || ldc % 4 != 0) return 0;
-    const int nch = cin_pad / 32;
-    const int g = nch <= 4 ? 1 : (nch + 3) / 4;
-    const int S = (nch + g - 1) / g + 2;
-    if (S > 8) return 0;
-    if (c->opt_conv_algo == 3) return g;           // tests: wherever it applies
-    if (c->opt_conv_algo != 1) return 0;
+    // (a forced split-K option -- never, n slices, an explicit plan -- is a statement about the direct kernels: no unit mode then)
+    if (c->opt_precision != 0 || c->opt_force[ks] >= 0 || c->opt_ksplit != 0 || !wino_eligible(ks, cin_pad, cout_pad)) return 0;
+    if (cout % 4 != 0 || ldc % 4 != 0) return 0;
+    if (c->opt_conv_algo != 1 && c->opt_conv_algo != 3) return 0;
+    const int nch = cin_pad / 32, extra = ks == 7 ? 2 : 0;
     const long long blocks = (long long)((H + 7) / 8) * ((W + 15) / 16) * images * (cout_pad / 128);
-    return blocks * S <= (long long)conv_num_cus() + conv_num_cus() / 8 ? g : 0;
+    long long smax = c->opt_conv_algo == 3 ? 8 : conv_num_cus() / blocks;      // conv_algo 3 (tests): wherever it applies
+    if (smax > 8) smax = 8;
+    const int nu1_max = (int)smax - extra;
+    if (nu1_max < 2 || nch < 2) return 0;
+    const int g = (nch + nu1_max - 1) / nu1_max;
+    return (nch + g - 1) / g >= 2 ? g : 0;
 }
 
 // Winograd takes a 3x3 layer when the option asks for it, the fp32 path is selected, and the launch fills the chip a few times over
@@ -750,9 +753,9 @@ static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float
         if (groups == 2) a.g[1].w = c->layers[li1].d_ww;
         if (prof_this) {
             const double bytes = 4.0 * B * H * W * ((double)L0.cin * groups + (double)L0.cout * groups);
-            if ((rc = prof_begin(c, std::string(label) + "|conv_wino_f2x2_7x7/u" + std::to_string(ug), flops, bytes))) return rc;
+            if ((rc = prof_begin(c, std::string(label) + (L0.ks == 7 ? "|conv_wino_f2x2_7x7/u" : "|conv_wino_f2x2_3x3/u") + std::to_string(ug), flops, bytes))) return rc;
         }
-        if ((rc = launch_wino_units(c, a, groups, ug))) return rc;
+        if ((rc = launch_wino_units(c, a, L0.ks, groups, ug))) return rc;
         return prof_this ? prof_end(c) : PMX_OK;
     }
     if (wino_plain) {
@@ -1829,7 +1832,7 @@ extern "C" int pmx_conv2d(pmx_ctx* c, const float* x, const float* w, const floa
         a.g[0].w = d_ww; a.nch = cin_pad / 32;
     }
     auto launch_conv = [&](pmx_ctx* cc, const ConvArgs& aa, int gg, int vv, const SplitPlan& pp) {
-        if (ug) return launch_wino_units(cc, aa, gg, ug);
+        if (ug) return launch_wino_units(cc, aa, ks, gg, ug);
         return wino ? conv_wino_launch(aa, ks, gg, cc->stream) : ::launch_conv(cc, aa, gg, vv, pp);
     };
     if (!rc) rc = launch_conv(c, a, 1, v_run, plan);

@@ -157,7 +157,8 @@ void conv_wino_ref(const float* x, const float* w, const float* bias, float* y, 
                         for (int i = 0; i < 2; ++i)
                             for (int j = 0; j < 2; ++j) ysum[i][j] = nunit == 0 ? yv[i][j] : ysum[i][j] + yv[i][j];
                     }
-                    if (unit_g > 0) yv[0][0] = yv[0][1] = yv[1][0] = yv[1][1] = 0.f;        /* pass 2a starts its own unit */
+                    if (unit_g > 0 && ndir) yv[0][0] = yv[0][1] = yv[1][0] = yv[1][1] = 0.f;        /* pass 2a starts its own unit */
+                    if (unit_g > 0 && !ndir) { yv[0][0] = ysum[0][0]; yv[0][1] = ysum[0][1]; yv[1][0] = ysum[1][0]; yv[1][1] = ysum[1][1]; }
                     if (ndir) {
                         /* pass 2a: tap (6, 6) chained directly onto y; row 6 as two 1x3 sub-kernels, 1-D F(2,3) along x: per output row
                          * i four frequency chains hm[i][f] over (chunk -> sub-kernel -> channel); then y[i][.] += A^T hm[i] */

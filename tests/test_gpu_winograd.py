@@ -176,18 +176,22 @@ def test_reference_chain_goldens_with_winograd(native, name):
         assert rel(maps, z['heat']) < 1e-4
 
 
-@pytest.mark.parametrize('B,cin,H,W,cout,relu', [(1, 128, 46, 46, 128, True), (1, 192, 46, 46, 128, True), (2, 64, 20, 30, 256, False),
-                                                  (1, 96, 9, 11, 100, True)])
-def test_winograd_unit_mode_bit_exact_vs_c_twin(engine, B, cin, H, W, cout, relu):
+@pytest.mark.parametrize('B,cin,H,W,cout,k,relu,pool', [(1, 128, 46, 46, 128, 7, True, False), (1, 192, 46, 46, 128, 7, True, False),
+                                                         (2, 64, 20, 30, 256, 7, False, False), (1, 96, 9, 11, 100, 7, True, False),
+                                                         (1, 512, 46, 46, 512, 3, True, False), (1, 256, 46, 46, 128, 3, True, False),
+                                                         (2, 96, 14, 18, 132, 3, False, True)])
+def test_winograd_unit_mode_bit_exact_vs_c_twin(engine, B, cin, H, W, cout, k, relu, pool):
     """Unit mode of the 7x7 Winograd kernel (single images; conv_algo 3 forces it): pass 1 in units of g chunks, pass 2a, pass 2b as
     separate blocks writing slabs that the combine kernel adds in unit order == the twin's unit_g form, bit for bit."""
-    x, w, b = _data(cin + H, B, cin, H, W, cout, 7)
+    x, w, b = _data(cin + H, B, cin, H, W, cout, k)
     nch = (cin + 31) // 32
-    g = 1 if nch <= 4 else (nch + 3) // 4
-    y = _run(engine, x, w, b, relu, False, 3)
-    ref = R.conv_wino(x, w, b, relu, False, unit_g=g)
+    nu1_max = 8 - (2 if k == 7 else 0)                  # conv_algo 3: up to 8 slabs (pmx_api.hip::wino_units_g)
+    g = -(-nch // nu1_max)
+    y = _run(engine, x, w, b, relu, pool, 3)
+    ref = R.conv_wino(x, w, b, relu, pool, unit_g=g)
     assert np.array_equal(y, ref), (np.abs(y - ref).max(), int((y != ref).sum()))
-    t = N.conv2d_ref(x, w, b, relu=relu, pool=False)
+    assert not np.array_equal(y, R.conv_wino(x, w, b, relu, pool)), 'unit mode did not run'
+    t = N.conv2d_ref(x, w, b, relu=relu, pool=pool)
     assert np.abs(y - t).max() <= TOL * max(1.0, np.abs(t).max())
 
 
@@ -202,6 +206,7 @@ def test_single_image_368_default_plan_bit_exact(native):
     plan, _ = forward_plan(eng, lambda: eng.forward_u8(img))
     paf, heat = eng.get_maps()
     eng.close()
-    assert len(plan.wino_units) >= 20 and 'conv2_2' in plan.wino and 'conv2_2' not in plan.wino_units, (plan.wino_units, sorted(plan.wino))
+    assert len(plan.wino_units) >= 24 and 'conv4_2' in plan.wino_units and 'conv2_2' in plan.wino and 'conv2_2' not in plan.wino_units, \
+        (plan.wino_units, sorted(plan.wino))
     rpaf, rheat = R.forward_fma(weights, P.preprocess(img[0]), splitk=plan)
     assert np.array_equal(paf, rpaf) and np.array_equal(heat, rheat), (np.abs(paf - rpaf).max(), np.abs(heat - rheat).max())
