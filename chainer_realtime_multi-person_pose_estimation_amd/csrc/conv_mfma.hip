@@ -1233,8 +1233,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     static_assert(!(POOL && KS != 3), "pooling only with the 3x3 variant");
     static_assert(!(UNIT && POOL), "unit mode: the combine kernel pools");
     // UNIT (single images: 36 blocks of a 46x46 7x7 layer cannot fill 256 CUs): blockIdx.z = unit * groups + group, and a block runs
-    // ONE unit of the work -- unit u < nu1: pass 1 over the chunks [u g, u g + g) (g = a.kbounds); 7x7: unit nu1: pass 2a; unit nu1 + 1:
-    // pass 2b -- and writes its untransformed share of y (no bias / ReLU) to slab `unit`; conv_splitk_reduce_kernel adds the slabs in unit order
+    // ONE unit of the work -- unit u < nu1: pass 1 over the chunks [u g, u g + g) (g = a.kbounds); 7x7: unit nu1: row 6 (pass 2a without
+    // tap (6, 6)); unit nu1 + 1: column 6 (pass 2b); unit nu1 + 2: tap (6, 6) -- and writes its untransformed share of y (no bias / ReLU) to slab `unit`; conv_splitk_reduce_kernel adds the slabs in unit order
     extern __shared__ float4 smem4[];
     float* const s_raw = reinterpret_cast<float*>(smem4);
     float* const s_u = s_raw + C::RAW_ELEMS;
@@ -1270,6 +1270,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     const int c0 = UNIT ? min(unit, nu1 - 1) * ug : 0;                     // pass-1 chunk range of this block
     const int c1 = UNIT ? min(nch, c0 + ug) : nch;
     const bool do_p1 = !UNIT || unit < nu1, do_p2a = !UNIT || unit == nu1, do_p2b = !UNIT || unit == nu1 + 1;
+    const bool do_pd = UNIT && unit == nu1 + 2;   // unit mode: tap (6, 6) is a unit of its own (in pass 2a otherwise)
 
     // raw halo staging slots (the LDS offset is recomputed at the write)
     int h_goff[C::NHF];
@@ -1554,7 +1555,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                     const int st = q >> 2, pp = q & 3;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        y[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[q & 3][e], bd[st][e], y[pp], 0, 0, 0);
+                        if (!UNIT) y[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[q & 3][e], bd[st][e], y[pp], 0, 0, 0);
                         if (e == 0) {
                             if (q < 4) { bwr[q] = wload(PH + 0, chb, q); __builtin_amdgcn_sched_barrier(0); }
                         } else if (e == 1) {
@@ -1665,6 +1666,34 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                 y[1 * 2 + j2][reg] = y[1 * 2 + j2][reg] + ((e8[j2 * 4 + 1][reg] - e8[j2 * 4 + 2][reg]) - e8[j2 * 4 + 3][reg]);
             }
         }   // do_p2b
+
+        if (do_pd) {
+            // ================= unit mode: tap (6, 6) over all chunks, straight from the raw halo =================
+            f32x4 bdn[4];
+#pragma unroll
+            for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r]);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) bd[st] = wload(PD, 0u, st);
+            for (int ch = 0; ch < nch; ++ch) {
+                if (ch) __syncthreads();
+                halo_store(hreg);
+                __syncthreads();
+                const int cn = ch + 1 < nch ? ch + 1 : ch;
+#pragma unroll
+                for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + cn * C::CKW);
+#pragma unroll
+                for (int st = 0; st < 4; ++st) bdn[st] = wload(PD, (unsigned)cn * panel_b, st);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int st = q >> 2, pp = q & 3;
+                    const f32x4 ad = *reinterpret_cast<const f32x4*>(&s_raw[a2_off + ((6 + (pp >> 1)) * C::HW + 6 + (pp & 1)) * C::LDR + st * 8]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[e], bd[st][e], y[pp], 0, 0, 0);
+                }
+#pragma unroll
+                for (int st = 0; st < 4; ++st) bd[st] = bdn[st];
+            }
+        }
     }
 
     // ---- bias, ReLU, (pool), store
@@ -2586,7 +2615,7 @@ static int launch_wino(const ConvArgs& a0, int groups, hipStream_t stream)
 }
 
 // a.nch = input channels / 32 (chunks of the Winograd kernel), a.g[].w = transformed weights (a.g[].w2 = direct pack, ks = 7)
-// a.ksplit > 1: unit mode -- a.ksplit = ceil(nch / g) (+ 2 for 7x7) slabs at a.g[].out + unit * a.slab_stride, g = a.kbounds
+// a.ksplit > 1: unit mode -- a.ksplit = ceil(nch / g) (+ 3 for 7x7: row 6, column 6, tap (6, 6)) slabs at a.g[].out + unit * a.slab_stride, g = a.kbounds
 int conv_wino_launch(const ConvArgs& a, int ks, int groups, hipStream_t stream)
 {
     if (a.ksplit > 1) return ks == 7 ? launch_wino<7, 0, 1>(a, groups, stream) : launch_wino<3, 0, 1>(a, groups, stream);

@@ -650,11 +650,11 @@ static int launch_conv(pmx_ctx* c, const ConvArgs& a0, int groups, int v, const 
 }
 
 // Unit mode of the Winograd kernel (single images): a (tile, group) is cut into S units -- pass 1 over g chunks each (ceil(nch / g) units)
-// and, for 7x7, pass 2a and pass 2b -- that run as separate blocks writing slabs, combined in unit order by the split-K combine kernel
+// and, for 7x7, row 6, column 6 and tap (6, 6) -- that run as separate blocks writing slabs, combined in unit order by the split-K combine kernel
 // (bias, ReLU, pool there)
 static int launch_wino_units(pmx_ctx* c, const ConvArgs& a0, int ks, int groups, int g)
 {
-    const int S = (a0.nch + g - 1) / g + (ks == 7 ? 2 : 0);
+    const int S = (a0.nch + g - 1) / g + (ks == 7 ? 3 : 0);
     PMX_CHECK(S >= 2 && S <= 8, PMX_ERR_INVALID, "winograd units: %d slabs", S);
     PMX_CHECK(a0.cout_pad <= SK_ZERO_BIAS, PMX_ERR_INVALID, "split-K: cout_pad %d too large", a0.cout_pad);
     const size_t slab = (size_t)a0.B * a0.H * a0.W * a0.cout_pad;
@@ -694,7 +694,7 @@ static int wino_units_g(const pmx_ctx* c, int ks, int cin_pad, int cout_pad, int
     if (c->opt_precision != 0 || c->opt_force[ks] >= 0 || c->opt_ksplit != 0 || !wino_eligible(ks, cin_pad, cout_pad)) return 0;
     if (cout % 4 != 0 || ldc % 4 != 0) return 0;
     if (c->opt_conv_algo != 1 && c->opt_conv_algo != 3) return 0;
-    const int nch = cin_pad / 32, extra = ks == 7 ? 2 : 0;
+    const int nch = cin_pad / 32, extra = ks == 7 ? 3 : 0;     // 7x7: + row 6, column 6, tap (6, 6)
     const long long blocks = (long long)((H + 7) / 8) * ((W + 15) / 16) * images * (cout_pad / 128);
     long long smax = c->opt_conv_algo == 3 ? 8 : conv_num_cus() / blocks;      // conv_algo 3 (tests): wherever it applies
     if (smax > 8) smax = 8;

@@ -128,7 +128,8 @@ void conv_wino_ref(const float* x, const float* w, const float* bias, float* y, 
             for (int ty = 0; ty < TY; ++ty)
                 for (int tx = 0; tx < TX; ++tx) {
                     /* unit_g > 0 (unit mode of the kernel, single images): pass 1 in units of unit_g chunks, each with its own chains (from
-                     * 0) and its own output transform; pass 2a and pass 2b as units starting from 0; the units are added in order */
+                     * 0) and its own output transform; row 6, column 6 and tap (6, 6) as units starting from 0; the units are added in
+                     * that order */
                     float yv[2][2], ysum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
                     const int ustep = unit_g > 0 ? 32 * unit_g : ((cin + 31) / 32) * 32;
                     int nunit = 0;
@@ -165,13 +166,18 @@ void conv_wino_ref(const float* x, const float* w, const float* bias, float* y, 
                         float hm[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, vm[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #define XIN(iy_, ix_, c_) (((iy_) >= 0 && (iy_) < H && (ix_) >= 0 && (ix_) < W) ? x[(((size_t)b * cin + (c_)) * H + (iy_)) * W + (ix_)] : 0.f)
 #define CH_LOOP(c32_) for (int c8 = (c32_); c8 < (c32_) + 32; c8 += 8) for (int e = 0; e < 4; ++e) for (int hi = 0; hi < 2; ++hi)
+                        float yd[2][2] = {{0.f, 0.f}, {0.f, 0.f}};     /* unit mode: tap (6, 6) is a unit of its own, added last */
                         for (int c32 = 0; c32 < cin; c32 += 32) {
                             CH_LOOP(c32) {
                                 const int c = c8 + e + 4 * hi;
                                 if (c >= cin) continue;
                                 const float wv = w[(((size_t)n * cin + c) * ks + 6) * ks + 6];
                                 for (int i = 0; i < 2; ++i)
-                                    for (int j = 0; j < 2; ++j) yv[i][j] = fmaf(XIN(2 * ty + i + 6 - pad, 2 * tx + j + 6 - pad, c), wv, yv[i][j]);
+                                    for (int j = 0; j < 2; ++j) {
+                                        const float xv = XIN(2 * ty + i + 6 - pad, 2 * tx + j + 6 - pad, c);
+                                        if (unit_g > 0) yd[i][j] = fmaf(xv, wv, yd[i][j]);
+                                        else yv[i][j] = fmaf(xv, wv, yv[i][j]);
+                                    }
                             }
                             for (int sub = 0; sub < 2; ++sub)
                                 CH_LOOP(c32) {
@@ -217,7 +223,7 @@ void conv_wino_ref(const float* x, const float* w, const float* bias, float* y, 
                         }
                         if (unit_g > 0)
                             for (int i = 0; i < 2; ++i)
-                                for (int j = 0; j < 2; ++j) yv[i][j] = ysum[i][j] + yv[i][j];
+                                for (int j = 0; j < 2; ++j) yv[i][j] = (ysum[i][j] + yv[i][j]) + yd[i][j];
 #undef XIN
 #undef CH_LOOP
                     }

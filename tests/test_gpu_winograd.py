@@ -185,7 +185,7 @@ def test_winograd_unit_mode_bit_exact_vs_c_twin(engine, B, cin, H, W, cout, k, r
     separate blocks writing slabs that the combine kernel adds in unit order == the twin's unit_g form, bit for bit."""
     x, w, b = _data(cin + H, B, cin, H, W, cout, k)
     nch = (cin + 31) // 32
-    nu1_max = 8 - (2 if k == 7 else 0)                  # conv_algo 3: up to 8 slabs (pmx_api.hip::wino_units_g)
+    nu1_max = 8 - (3 if k == 7 else 0)                  # conv_algo 3: up to 8 slabs (pmx_api.hip::wino_units_g)
     g = -(-nch // nu1_max)
     y = _run(engine, x, w, b, relu, pool, 3)
     ref = R.conv_wino(x, w, b, relu, pool, unit_g=g)
