@@ -54,8 +54,8 @@ def pmc_traffic(kernel_name):
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_summary.json')))
     if not (m or mw) or not files:
         return None, None
-    if mw:                              # conv_wino_kernel<KS, POOL>
-        sig = 'conv_wino_kernel<%s, 0>' % mw.group(1)
+    if mw:
+        sig = 'conv_wino_kernel<%s, 0, 0>' % mw.group(1)          # <KS, POOL, UNIT>
     else:
         sig = 'conv_mfma%s_kernel<%s, %s, %s, %s,' % (m.group(2) or '', m.group(1), m.group(3), m.group(4), m.group(5))
         if m.group(2) == '_v6':          # conv_mfma_v6_kernel<KS, MT, POOL>: 17 x 32 consecutive pixels of a 46-column slab
