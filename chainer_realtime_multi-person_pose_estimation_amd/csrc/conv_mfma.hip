@@ -2614,7 +2614,7 @@ static int launch_wino(const ConvArgs& a0, int groups, hipStream_t stream)
     return PMX_OK;
 }
 
-// a.nch = input channels / 32 (chunks of the Winograd kernel), a.g[].w = transformed weights (a.g[].w2 = direct pack, ks = 7)
+// a.nch = input channels / 32 (chunks of the Winograd kernel), a.g[].w = transformed weights (pmx_api.hip::pack_wino)
 // a.ksplit > 1: unit mode -- a.ksplit = ceil(nch / g) (+ 3 for 7x7: row 6, column 6, tap (6, 6)) slabs at a.g[].out + unit * a.slab_stride, g = a.kbounds
 int conv_wino_launch(const ConvArgs& a, int ks, int groups, hipStream_t stream)
 {

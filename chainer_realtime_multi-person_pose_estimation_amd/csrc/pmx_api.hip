@@ -760,8 +760,8 @@ static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float
     }
     if (wino_plain) {
         a.nch = L0.cin_pad / 32;
-        a.g[0].w = L0.d_ww; a.g[0].w2 = L0.d_w;
-        if (groups == 2) { a.g[1].w = c->layers[li1].d_ww; a.g[1].w2 = c->layers[li1].d_w; }
+        a.g[0].w = L0.d_ww;
+        if (groups == 2) a.g[1].w = c->layers[li1].d_ww;
         if (prof_this) {
             const double bytes = 4.0 * B * H * W * ((double)L0.cin * groups + (double)L0.cout * groups / (pool ? 4 : 1));
             if ((rc = prof_begin(c, std::string(label) + (L0.ks == 7 ? "|conv_wino_f2x2_7x7" : "|conv_wino_f2x2_3x3"), flops, bytes))) return rc;
@@ -1821,7 +1821,7 @@ extern "C" int pmx_conv2d(pmx_ctx* c, const float* x, const float* w, const floa
         pack_wino(wp, ks, cin_pad / CK, cpad, ww);
         PMX_HIP(hipMalloc((void**)&d_ww, ww.size() * sizeof(float)));
         PMX_HIP(hipMemcpy(d_ww, ww.data(), ww.size() * sizeof(float), hipMemcpyHostToDevice));
-        a.g[0].w = d_ww; a.g[0].w2 = d_w; a.nch = cin_pad / 32;
+        a.g[0].w = d_ww; a.nch = cin_pad / 32;
     }
     const int ug = wino ? 0 : wino_units_g(c, ks, cin_pad, cpad, cout, cout, B, H, W);
     if (ug) {

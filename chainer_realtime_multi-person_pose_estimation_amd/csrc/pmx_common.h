@@ -60,7 +60,6 @@ struct ConvGroupArgs {
     float* out;         // NHWC, already offset to the group's first output channel
     int cout;           // real output channels (<= cout_pad)
     int pad_;
-    const float* w2;    // Winograd 7x7 kernel only: the direct pack (as `w` of the direct kernels) for its 13 direct taps; `w` = transformed
 };
 struct ConvArgs {
     ConvGroupArgs g[2];
@@ -113,7 +112,7 @@ bool conv_pair_supported(int cin, int cmid, int cout_pad);
 // a.g[1].w / .bias = conv1_1's packed weights / bias
 int conv1_fused_launch(const ConvArgs& a, hipStream_t stream);
 // Winograd F(2x2, 3x3): a.nch = cin / 32, a.g[].w = transformed weights [plane][chunk32][k8-step][cout_pad][8] (G g G^T, host);
-// ks = 7: four 3x3 sub-kernels (taps 0..5 x 0..5) + 13 direct taps from a.g[].w2 (the direct pack)
+// ks = 7: planes 0..63 = four 3x3 sub-kernels (taps 0..5 x 0..5), 64..71 row 6, 72..79 column 6 (1-D G g), 80 = tap (6, 6)
 int conv_wino_launch(const ConvArgs& a, int ks, int groups, hipStream_t stream);
 // K slices for a launch of `variant` (S = 1: no split); forced > 0 asks for that many (near-)even slices
 SplitPlan conv_pick_ksplit(int variant, int H, int W, int B, int groups, int cout_pad, int nch, int pool, int forced);
