@@ -1198,28 +1198,31 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_small_kernel(const ConvArg
     conv_epilogue<C, TW>(acc, biasv, a, G.out, G.cout, bimg, y0, x0, n0, wm, wn, li, kh);
 }
 
-// ---- Winograd F(2x2, 3x3) for large launches (fp32, option "conv_algo") ----------------------------------------------------------
+// ---- Winograd F(2x2, 3x3) (fp32, option "conv_algo") ------------------------------------------------------------------
 // Y = A^T [ (G g G^T) (.) (B^T d B) ] A: a 2 x 2 output tile from a 4 x 4 input window costs 16 multiplies per channel pair instead of
 // 36 -> 2.25x less matrix work; the transforms are additions only (B^T, A^T) or done once on the host (G g G^T, in double, rounded
 // to fp32).  Block = 32 Winograd tiles (4 rows x 8 columns of 2 x 2 = an 8 x 16 pixel output tile) x 128 output channels; wave w owns
 // 32 channels and all 16 "frequencies": 16 accumulator tiles of 32 (Winograd tiles) x 32 (channels) = 256 AGPRs, one block per CU.
-// Per 32-channel chunk: raw halo -> LDS, every thread transforms one (tile, 4 channels) item (32 additions) into
-// U[frequency][tile][channel] in LDS, then 16 frequencies x 4 k8-steps x 4 MFMAs per wave with the transformed weights streamed
-// from L2 two frequencies ahead (the loads are pinned between the MFMAs; left alone the compiler sinks them to one step ahead and the
-// single wave per SIMD stalls on L2).  Epilogue: A^T M A per lane (the 16 frequencies of a (tile, channel) sit in one lane's
-// registers), bias, ReLU, 2x2 max-pool = max over the tile's four outputs.
-// KS = 7 (the 7x7 layers of stages 2-6): the taps (0..5, 0..5) are four 3x3 sub-kernels, each a Winograd product on its own
-// shifted window, all four accumulated in the SAME frequency-domain accumulators (the output transform is linear); the remaining 13
-// taps (row 6, column 6) run as direct MFMAs into the four per-pixel planes of the tile after the output transform (second pass over
-// the chunks).  16 x 4 + 13 x 4 = 116 products per tile and channel pair instead of 196.
-// The arithmetic is DEFINED -- transform additions in a fixed order, one sequential FMA chain per frequency over (chunk, sub-kernel,
-// k8-step, k), then the direct taps chained onto the transformed sums -- and oracle/conv_fma_ref.c::conv_wino_ref restates it; it
-// is not the direct kernels' chain (results agree to Winograd's fp32 rounding, ~1e-6 of the map scale).
+// Everything runs as PHASES of 8 planes x 4 k8-steps x 4 MFMAs per wave: while a phase multiplies the 8 planes in one half of the
+// U[plane][tile][channel] LDS buffer, every thread transforms its (tile, 4 channels) item of the raw halo for the next phase into the
+// other half, one LDS / VALU instruction per slot between two MFMAs; the transformed weights stream from L2 in a register ring 32 MFMAs
+// ahead (pinned with sched_barrier: left alone the compiler sinks the loads to one step ahead and the single wave per SIMD stalls on
+// L2); one s_barrier per phase.  Epilogue: A^T M A per lane (the 16 frequencies of a (tile, channel) sit in one lane's registers),
+// bias, ReLU, 2x2 max-pool = max over the tile's four outputs.
+// KS = 7 (the 7x7 layers of stages 2-6), 100 instead of 196 products per tile and channel pair: pass 1 -- the taps (0..5, 0..5) are four
+// 3x3 sub-kernels, each a Winograd product on its own shifted window, all four accumulated in the SAME frequency-domain accumulators
+// (the output transform is linear: 4 x 16); pass 2a -- row 6 as two 1x3 sub-kernels, 1-D F(2,3) along x (2 x 8), and tap (6, 6) direct
+// (4); pass 2b -- column 6 as two 3x1 sub-kernels along y (2 x 8).  The raw halo of a 32-channel chunk is staged once per pass, round-robin.
+// UNIT = 1 (single images): a block runs one unit (pass 1 over a chunk range / row 6 / column 6 / tap (6, 6)) and writes its share of y to
+// a slab; conv_splitk_reduce_kernel adds the slabs in unit order.
+// The arithmetic is DEFINED -- transform additions in a fixed order, one sequential FMA chain per plane over (chunk, sub-kernel, k8-step,
+// k), output transforms in a fixed order, units added in order -- and oracle/conv_fma_ref.c::conv_wino_ref restates it bit for bit; it
+// is not the direct kernels' chain (results agree to fp32 rounding, ~1e-6 of the map scale).
 template <int KS>
 struct WinoCfg {
     static constexpr int TH = 8, TW = 16, PADK = KS / 2, HH = TH + KS - 1, HW = TW + KS - 1, NPX = HH * HW, CKW = 32, LDR = CKW + 4, LDU = CKW + 4;
     static constexpr int NSUB = KS == 3 ? 1 : 4;                       // 3x3 sub-kernels done as Winograd products
-    static constexpr int NDIR = KS == 3 ? 0 : 13;                      // taps done directly (KS = 7: row 6, column 6)
+    static constexpr int NDIR = KS == 3 ? 0 : 13;                      // taps outside the 3x3 sub-kernels (KS = 7: row 6, column 6 -> pass 2)
     static constexpr int RAW_ELEMS = NPX * LDR, U_ELEMS = 16 * 32 * LDU;
     static constexpr int LDS_BYTES = (RAW_ELEMS + U_ELEMS) * 4;
     static constexpr int NHF = (NPX * (CKW / 4) + 255) / 256;

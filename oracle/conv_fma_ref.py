@@ -54,7 +54,7 @@ def conv_fma(x, w, b, relu=False, pool=False, splitk=1):
 
 def conv_wino(x, w, b, relu=False, pool=False, unit_g=0):
     """The Winograd F(2x2, 3x3) kernel's arithmetic (csrc/conv_mfma.hip::conv_wino_kernel, option "conv_algo"): same shapes as
-    conv_fma, 3x3 or 7x7 (four 3x3 sub-kernels in the frequency domain + 13 direct taps).  Defined order, but not the direct
+    conv_fma, 3x3 or 7x7 (four 3x3 sub-kernels in the frequency domain + row 6 / column 6 as 1-D sub-kernels + tap (6, 6)).  Defined order, but not the direct
     kernels' chain: the two agree to ~1e-6 of the map scale.  unit_g > 0 (7x7): the kernel's unit mode for single images -- pass 1 in
     units of unit_g 32-channel chunks, pass 2a, pass 2b, each summed from 0 and added in that order (kernel label ".../u<g>")."""
     global _lib

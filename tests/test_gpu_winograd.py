@@ -1,7 +1,7 @@
 """GPU: the Winograd F(2x2, 3x3) fp32 kernel (csrc/conv_mfma.hip::conv_wino_kernel, option "conv_algo": 1 = the 3x3 / 7x7
 layers of launches that fill the chip, 2 = every eligible layer) -- the replacement for L.Convolution2D on those layers
 (models/CocoPoseNet.py:28-129).  Bars: bit-identical to its plain-C twin (oracle/conv_fma_ref.c::conv_wino_ref: transforms,
-frequency-wise FMA chains and direct taps in the kernel's order); within fp32 rounding of the float64 convolution; the whole
+plane-wise FMA chains and output transforms in the kernel's order); within fp32 rounding of the float64 convolution; the whole
 network and the reference's end-to-end goldens (identical peak indices / poses, scores to 1e-4) also hold with it."""
 import numpy as np
 import pytest
@@ -37,7 +37,7 @@ def _data(seed, B, cin, H, W, cout, k):
     (1, 96, 17, 33, 256, 3, True, False),       # odd H and W (half-used Winograd tiles), two 128-channel blocks
     (2, 32, 9, 15, 130, 3, True, False),        # cout not a multiple of 128 (padded to 256)
     (1, 64, 46, 46, 128, 3, True, False),       # the feature-map size of the network
-    (2, 32, 19, 21, 128, 7, True, False),       # 7x7: four 3x3 sub-kernels + 13 direct taps
+    (2, 32, 19, 21, 128, 7, True, False),       # 7x7: four 3x3 sub-kernels + row 6 / column 6 (1-D) + tap (6, 6)
     (1, 64, 46, 46, 128, 7, True, False),
     (1, 96, 9, 40, 100, 7, False, False),
     (1, 32, 3, 5, 128, 7, True, False),         # image smaller than the kernel: every window crosses the border
