@@ -114,3 +114,28 @@ def test_winograd_conv_oracle_is_the_same_convolution():
         b = rng.integers(-5, 6, 6).astype('f')
         t = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=k // 2).numpy()
         assert np.array_equal(R.conv_wino(x, w, b), t.astype('f'))
+
+
+def test_launch_plan_from_profile_labels():
+    """oracle/conv_fma_ref.py::splitk_plan reads the launch plan the kernels report in their profile labels: K slices of split direct
+    launches ("/k3-2-2-1"), layers on the Winograd kernel, and those in its unit mode ("/u<g>") -- what forward_fma needs to restate a
+    forward bit for bit; and the unit form of the Winograd twin is the same convolution."""
+    import torch
+    from oracle import conv_fma_ref as R
+    prof = [{'layer': 'conv1_1+conv1_2', 'kernel': 'conv1_fused_t8x16_n64'}, {'layer': 'conv2_2', 'kernel': 'conv_wino_f2x2_3x3'},
+            {'layer': 'conv4_2', 'kernel': 'conv_wino_f2x2_3x3/u6'}, {'layer': 'conv4_4_CPM', 'kernel': 'conv3x3_v5_t8x8_n64/k3-3-2'},
+            {'layer': 'Mconv2_stage3', 'kernel': 'conv_wino_f2x2_7x7/u1'}, {'layer': 'Mconv1_stage2', 'kernel': 'conv7x7_v5_t8x8_n64/k5-3-3-1'},
+            {'layer': 'pp_peaks', 'kernel': 'pp_peaks'}]
+    plan = R.splitk_plan(prof)
+    assert dict(plan) == {'conv4_4_CPM': [3, 3, 2], 'Mconv1_stage2': [5, 3, 3, 1]}
+    assert plan.wino == {'conv2_2', 'conv4_2', 'Mconv2_stage3'} and plan.wino_units == {'conv4_2': 6, 'Mconv2_stage3': 1}
+    assert R.wino_layers(prof) == plan.wino
+    rng = np.random.default_rng(9)
+    for (cin, k, g) in [(128, 7, 1), (192, 7, 2), (96, 3, 1), (160, 3, 2)]:
+        x = rng.standard_normal((1, cin, 9, 10)).astype('f')
+        w = (rng.standard_normal((6, cin, k, k)) / np.sqrt(cin * k * k)).astype('f')
+        b = rng.standard_normal(6).astype('f')
+        y = R.conv_wino(x, w, b, relu=True, unit_g=g)
+        t = torch.relu(torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=k // 2)).numpy()
+        assert np.abs(y - t).max() <= 1e-5 * max(1.0, np.abs(t).max())
+        assert not np.array_equal(y, R.conv_wino(x, w, b, relu=True)), 'the unit form is a different summation'
