@@ -283,6 +283,8 @@ struct pmx_ctx {
     int opt_conv_algo = 1;           // 1 (default): Winograd F(2x2,3x3) fp32 kernel for the 3x3 / 7x7 layers of launches that fill the chip
                                      // (>= 2 blocks per CU: batches); 0: direct kernels everywhere; 2: Winograd on every eligible layer
                                      // (tests).  Both are fp32 with a defined order and a C twin; they differ by fp32 rounding (~1e-6)
+    int opt_wino_unit_eff = 80;      // unit mode: in-round efficiency of the 7x7 unit blocks relative to the plain kernel, percent (cost model;
+                                     // measured with tools/wino_batch_sweep.py: 75 - 90 alike, 60 loses batch 4 and 8, 105 loses batch 16+)
     int opt_wino_min_fill = 50;      // conv_algo 1: percent of ceil(blocks / CUs) * CUs block slots a launch must fill to take the Winograd kernel
     int opt_precision = 0;           // 0: fp32 MFMA everywhere (the path whose results are specified); 1: bf16x3 kernels where a
                                      // v6 kernel would run (fp32-grade accuracy at 2.67x the matrix rate, NOT the fp32 FMA chain)
@@ -544,6 +546,7 @@ extern "C" int pmx_set_option(pmx_ctx* c, const char* key, int value)
     else if (!strcmp(key, "precision")) c->opt_precision = value;
     else if (!strcmp(key, "conv_algo")) c->opt_conv_algo = value;
     else if (!strcmp(key, "wino_min_fill")) c->opt_wino_min_fill = value;
+    else if (!strcmp(key, "wino_unit_eff")) c->opt_wino_unit_eff = value;
     else if (!strcmp(key, "ksplit")) c->opt_ksplit = value;
     else if (!strcmp(key, "ksplit_plan")) c->opt_ksplit = value > 0 ? -value : 0;     // decimal digits = chunks per slice, e.g. 3221
     else if (!strcmp(key, "conv_min_lds")) conv_set_min_lds(value);
@@ -686,37 +689,37 @@ static int launch_wino_units(pmx_ctx* c, const ConvArgs& a0, int ks, int groups,
     return conv_splitk_reduce(r, groups, c->stream);
 }
 
-// chunks per pass-1 unit of the unit mode (0 = the mode does not apply): layers whose plain Winograd launch would leave most CUs idle
-// (single images), cut into as many units as still fit ONE round of the CUs (at most 8 slabs), at least two pass-1 units
-static int wino_units_g(const pmx_ctx* c, int ks, int cin_pad, int cout_pad, int cout, int ldc, int images, int H, int W)
+// Which form a 3x3 / 7x7 layer takes: 0 = direct kernels (+ split-K), 1 = the Winograd kernel, 2 = the Winograd kernel in unit mode
+// (*unit_g = chunks per pass-1 unit).  Blocks are equal and run one per CU, so the plain kernel costs ceil(blocks / CUs) rounds however
+// full the last one is; the unit mode costs the same work at finer grain (no round quantisation, ~0.8 of the plain kernel's in-round
+// efficiency) plus the slab traffic of the combine kernel; the direct kernels win when neither fills the chip
+// (tools/wino_batch_sweep.py).  A forced split-K option (never, n slices, an explicit plan) is a statement about the direct kernels:
+// no unit mode then.
+static int wino_mode(const pmx_ctx* c, int ks, int cin_pad, int cout_pad, int cout, int ldc, int images, int H, int W, int* unit_g)
 {
-    // (a forced split-K option -- never, n slices, an explicit plan -- is a statement about the direct kernels: no unit mode then)
-    if (c->opt_precision != 0 || c->opt_force[ks] >= 0 || c->opt_ksplit != 0 || !wino_eligible(ks, cin_pad, cout_pad)) return 0;
-    if (cout % 4 != 0 || ldc % 4 != 0) return 0;
-    if (c->opt_conv_algo != 1 && c->opt_conv_algo != 3) return 0;
+    *unit_g = 0;
+    if (c->opt_conv_algo < 1 || c->opt_precision != 0 || c->opt_force[ks] >= 0 || !wino_eligible(ks, cin_pad, cout_pad)) return 0;
+    if (c->opt_conv_algo == 2) return 1;          // tests: the plain kernel on every eligible layer
     const int nch = cin_pad / 32, extra = ks == 7 ? 3 : 0;     // 7x7: + row 6, column 6, tap (6, 6)
-    const long long blocks = (long long)((H + 7) / 8) * ((W + 15) / 16) * images * (cout_pad / 128);
-    long long smax = c->opt_conv_algo == 3 ? 8 : conv_num_cus() / blocks;      // conv_algo 3 (tests): wherever it applies
-    if (smax > 8) smax = 8;
-    const int nu1_max = (int)smax - extra;
-    if (nu1_max < 2 || nch < 2) return 0;
-    const int g = (nch + nu1_max - 1) / nu1_max;
-    return (nch + g - 1) / g >= 2 ? g : 0;
-}
-
-// Winograd takes a 3x3 layer when the option asks for it, the fp32 path is selected, and the launch fills the chip a few times over
-// (one 8 x 16 x 128 block per CU at a time; small launches stay on the direct kernels and their split-K plans)
-static bool wino_use(const pmx_ctx* c, int ks, int cin_pad, int cout_pad, int images, int H, int W)
-{
-    if (c->opt_conv_algo < 1 || c->opt_precision != 0 || c->opt_force[ks] >= 0 || !wino_eligible(ks, cin_pad, cout_pad)) return false;
-    if (c->opt_conv_algo == 2) return true;       // tests: every eligible 3x3 / 7x7 layer, whatever the launch size
-    if (c->opt_conv_algo == 3) return false;      // tests: unit mode on the 7x7 layers, direct kernels elsewhere
-    // one equal-sized block per CU at a time: the launch takes ceil(blocks / CUs) rounds whatever the last round holds, so what
-    // decides is how full the rounds are (measured, tools/wino_batch_sweep.py: at 0.56 the Winograd kernel already beats the direct
-    // kernels + split-K -- 144 blocks of a 7x7 layer at batch 4, 288 at batch 8 -- at 0.42 it does not; thresholds 0.45 - 0.56 measure alike)
+    int g = 0, S = 0;
+    if (c->opt_ksplit == 0 && cout % 4 == 0 && ldc % 4 == 0 && nch >= 2) {       // unit plan: as many units as 8 slabs allow
+        const int nu1_max = 8 - extra;
+        g = (nch + nu1_max - 1) / nu1_max;
+        const int nu1 = (nch + g - 1) / g;
+        if (nu1 >= 2) S = nu1 + extra; else g = 0;
+    }
+    if (c->opt_conv_algo == 3) { *unit_g = g; return g ? 2 : 0; }               // tests: unit mode wherever it applies
     const long long blocks = (long long)((H + 7) / 8) * ((W + 15) / 16) * images * (cout_pad / 128);
     const long long ncu = conv_num_cus(), rounds = (blocks + ncu - 1) / ncu;
-    return blocks * 100 >= (long long)c->opt_wino_min_fill * rounds * ncu;
+    if (g) {
+        const double t_block = nch * (ks == 7 ? 52e-6 : 18.5e-6);                 // one plain block (measured), seconds
+        // (3x3 units are short -- 256 MFMAs per chunk against ~10 us of block prologue / epilogue: 3/4 of the 7x7 figure)
+        const double eff = c->opt_wino_unit_eff / 100.0 * (ks == 7 ? 1.0 : 0.75);
+        const double est_unit = (double)blocks / (ncu * eff) +
+                                (double)blocks * (S + 1) * 65536.0 / 3.0e12 / t_block + 0.03;      // in rounds of the plain kernel
+        if (est_unit < (double)rounds) { *unit_g = g; return 2; }
+    }
+    return blocks * 100 >= (long long)c->opt_wino_min_fill * rounds * ncu ? 1 : 0;
 }
 
 // one launch of 1 or 2 groups (same geometry); in/out pointers are already offset to the group's channels
@@ -746,8 +749,10 @@ static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float
     int rc;
     const bool prof_this = c->prof_on == 1 || (c->prof_on == 2 && L0.ks == 7);
     const bool wino_ok = L0.d_ww && (groups == 1 || (c->layers[li1].d_ww && c->layers[li1].cout == L0.cout));
-    const bool wino_plain = wino_ok && wino_use(c, L0.ks, L0.cin_pad, L0.cout_pad, B * groups, H, W);
-    if (const int ug = (wino_ok && !wino_plain) ? wino_units_g(c, L0.ks, L0.cin_pad, L0.cout_pad, L0.cout, ldc, B * groups, H, W) : 0) {
+    int ug = 0;
+    const int wmode = wino_ok ? wino_mode(c, L0.ks, L0.cin_pad, L0.cout_pad, L0.cout, ldc, B * groups, H, W, &ug) : 0;
+    const bool wino_plain = wmode == 1;
+    if (wmode == 2) {
         a.nch = L0.cin_pad / 32;
         a.g[0].w = L0.d_ww;
         if (groups == 2) a.g[1].w = c->layers[li1].d_ww;
@@ -1815,7 +1820,9 @@ extern "C" int pmx_conv2d(pmx_ctx* c, const float* x, const float* w, const floa
     SplitPlan plan = conv_pick_ksplit(v_run, H, W, B, 1, cpad, cin_pad / CK, pool, c->opt_ksplit);
     if (cout % 4 != 0) plan.S = 1;
     float* d_ww = nullptr;
-    const bool wino = wino_use(c, ks, cin_pad, cpad, B, H, W);
+    int ug = 0;
+    const int wmode = wino_mode(c, ks, cin_pad, cpad, cout, cout, B, H, W, &ug);
+    const bool wino = wmode == 1;
     if (wino) {
         std::vector<float> ww;
         pack_wino(wp, ks, cin_pad / CK, cpad, ww);
@@ -1823,7 +1830,6 @@ extern "C" int pmx_conv2d(pmx_ctx* c, const float* x, const float* w, const floa
         PMX_HIP(hipMemcpy(d_ww, ww.data(), ww.size() * sizeof(float), hipMemcpyHostToDevice));
         a.g[0].w = d_ww; a.nch = cin_pad / 32;
     }
-    const int ug = wino ? 0 : wino_units_g(c, ks, cin_pad, cpad, cout, cout, B, H, W);
     if (ug) {
         std::vector<float> ww;
         pack_wino(wp, ks, cin_pad / CK, cpad, ww);

@@ -101,9 +101,9 @@ int pmx_synchronize(pmx_ctx* ctx);                    /* cuda.get_device_from_id
  *                              of smaller ones) use the Winograd F(2x2, 3x3) kernel -- 16 instead of 36 products per 2x2 output tile
  *                              and channel pair for a 3x3 layer; a 7x7 layer = four 3x3 sub-kernels summed in the transformed domain
  *                              + four 1-D F(2,3) sub-kernels for row 6 / column 6 + one direct tap, 100 instead of 196 -- the other
- *                              launches the direct kernels with split-K, except that the 46x46 layers of a single image run the
- *                              Winograd kernel in UNIT mode (a tile's passes / chunk groups as separate blocks writing slabs + the
- *                              split-K combine kernel).  0: direct kernels everywhere.  2: Winograd on every eligible layer; 3: unit
+ *                              launches the direct kernels with split-K, except that launches whose rounds would stay mostly
+ *                              empty (the 46x46 layers of 1 - 4 and 8 images) run the Winograd kernel in UNIT mode (a tile's passes /
+ *                              chunk groups as separate blocks writing slabs + the split-K combine kernel; cost model, "wino_unit_eff").  0: direct kernels everywhere.  2: Winograd on every eligible layer; 3: unit
  *                              mode wherever it applies (tests).  Both algorithms are fp32 fused-multiply-add
  *                              chains in a defined order with a plain-C twin (oracle/conv_fma_ref.c); they differ from each other by
  *                              fp32 rounding (~1e-6 of the map scale; the Winograd form is the closer one to float64)

@@ -25,7 +25,8 @@ def run(B):
 
 
 FILLS = (45, 50, 56, 62, 70, 80)
-print('ms per forward; rule = conv_algo 1 with wino_min_fill = ' + ' / '.join(str(f) for f in FILLS))
+EFFS = (1, 60, 80, 100)         # wino_unit_eff: 1 = unit mode practically never
+print('ms per forward; rule = conv_algo 1 with wino_min_fill = ' + ' / '.join(str(f) for f in FILLS) + '; units = conv_algo 1 with wino_unit_eff = ' + ' / '.join(str(f) for f in EFFS))
 for B in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32):
     eng.set_option('conv_algo', 0); d = run(B)
     eng.set_option('conv_algo', 2); w = run(B)
@@ -34,4 +35,8 @@ for B in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32):
     for f in FILLS:
         eng.set_option('wino_min_fill', f); r.append(run(B))
     eng.set_option('wino_min_fill', 50)
-    print('B=%2d  direct %6.2f  winograd-all %6.2f  rule %s' % (B, d, w, ' / '.join('%6.2f' % v for v in r)), flush=True)
+    u = []
+    for e in EFFS:
+        eng.set_option('wino_unit_eff', e); u.append(run(B))
+    eng.set_option('wino_unit_eff', 80)
+    print('B=%2d  direct %6.2f  winograd-all %6.2f  rule %s  units %s' % (B, d, w, ' / '.join('%6.2f' % v for v in r), ' / '.join('%6.2f' % v for v in u)), flush=True)
