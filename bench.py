@@ -381,6 +381,7 @@ def main():
         if world == 1 and not a.no_extras:
             out['value_incl_h2d'] = upload_inclusive(eng, torch, dev, imgs, a.steps, map_s)
             out['single_image'] = single_image(eng, d_imgs, S, map_s)
+            out['direct_kernels_only'] = direct_only(eng, torch, d_imgs, B, S, map_s, a.steps)
             out['bf16x3'] = bf16x3_mode(eng, torch, dev, d_imgs, B, S, map_s, a.steps)
             eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(B, S, S), map_h=map_s, map_w=map_s)     # restore the batch state
             rec = eng.results()                                                                             # for keypoint_match
@@ -430,6 +431,35 @@ def upload_inclusive(eng, torch, dev, imgs, steps, map_s):
             'upload_bytes_per_step': int(imgs.nbytes),
             'how': 'pinned host batch -> HBM on a copy stream, upload of batch k+1 overlapped with the compute of batch k; '
                    'first upload exposed and counted'}
+
+
+def direct_only(eng, torch, d_imgs, B, S, map_s, steps):
+    """The same K steps with option "conv_algo" = 0: every convolution on the direct fp32-MFMA kernels (no Winograd) -- the number
+    to hold against the fp32-MFMA roofline of the direct convolution (157.3 TFLOP/s <-> 578 frames/s), and the single-image call."""
+    eng.set_option('conv_algo', 0)
+    try:
+        for _ in range(2):
+            eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(B, S, S), map_h=map_s, map_w=map_s); eng.results()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(B, S, S), map_h=map_s, map_w=map_s); eng.results()
+        eng.synchronize()
+        dt = time.perf_counter() - t0
+        for _ in range(5):
+            eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(1, S, S), map_h=map_s, map_w=map_s); eng.results()
+        t1 = time.perf_counter()
+        for _ in range(30):
+            eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(1, S, S), map_h=map_s, map_w=map_s); eng.results()
+        dt1 = (time.perf_counter() - t1) / 30
+    finally:
+        eng.set_option('conv_algo', 1)
+    fps = B * steps / dt
+    return {'value': fps, 'unit': 'frames/s', 'ms_per_step': dt / steps * 1e3, 'steps': steps, 'single_image_ms_per_call': dt1 * 1e3,
+            'achieved_tflops_whole_net': FLOP_PER_FRAME * (S * S / (368.0 * 368.0)) * fps / 1e12,
+            'frac_of_fp32_mfma_peak_whole_net': FLOP_PER_FRAME * (S * S / (368.0 * 368.0)) * fps / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+            'note': 'option conv_algo = 0: direct fp32-MFMA convolution everywhere (the headline uses the fp32 Winograd F(2x2,3x3) kernel for the '
+                    '3x3 / 7x7 layers: same dtype, same results to fp32 rounding, fewer multiplies)'}
 
 
 def bf16x3_mode(eng, torch, dev, d_imgs, B, S, map_s, steps, frames=256):
