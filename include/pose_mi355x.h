@@ -96,17 +96,20 @@ int pmx_synchronize(pmx_ctx* ctx);                    /* cuda.get_device_from_id
  *   "kernel_gen" 1 | 5 | 6     conv kernel generation: 1 = LDS-staged weights (v1) everywhere, 5 = v5 for 3x3 / 7x7,
  *                              6 = default (v6 / conv1_1 kernel where they apply, else v5); all compute identical bits
  *   "force_variant_k1|k3|k7"   force one entry of the conv variant table for that kernel size (-1 = automatic)
- *   "conv_algo" 1 | 0 | 2      fp32 algorithm of the 3x3 / 7x7 layers.  1 (default): launches whose blocks fill at least half of the
- *                              CU rounds they take ("wino_min_fill" percent, default 50: batches of 4 and more, and the large-map layers
- *                              of smaller ones) use the Winograd F(2x2, 3x3) kernel -- 16 instead of 36 products per 2x2 output tile
- *                              and channel pair for a 3x3 layer; a 7x7 layer = four 3x3 sub-kernels summed in the transformed domain
- *                              + four 1-D F(2,3) sub-kernels for row 6 / column 6 + one direct tap, 100 instead of 196 -- the other
- *                              launches the direct kernels with split-K, except that launches whose rounds would stay mostly
- *                              empty (the 46x46 layers of 1 - 4 and 8 images) run the Winograd kernel in UNIT mode (a tile's passes /
- *                              chunk groups as separate blocks writing slabs + the split-K combine kernel; cost model, "wino_unit_eff").  0: direct kernels everywhere.  2: Winograd on every eligible layer; 3: unit
- *                              mode wherever it applies (tests).  Both algorithms are fp32 fused-multiply-add
- *                              chains in a defined order with a plain-C twin (oracle/conv_fma_ref.c); they differ from each other by
- *                              fp32 rounding (~1e-6 of the map scale; the Winograd form is the closer one to float64)
+ *   "conv_algo" 1 | 0 | 2 | 3  fp32 algorithm of the 3x3 / 7x7 layers.  The Winograd F(2x2, 3x3) kernel needs 16 instead of 36 products per
+ *                              2x2 output tile and channel pair for a 3x3 layer; a 7x7 layer = four 3x3 sub-kernels summed in the
+ *                              transformed domain + four 1-D F(2,3) sub-kernels for row 6 / column 6 + one direct tap: 100 instead
+ *                              of 196.  Its blocks are equal and run one per CU, so a launch costs whole CU rounds.
+ *                              1 (default): by launch size (pmx_api.hip::wino_mode) -- the Winograd kernel when the blocks fill at
+ *                              least half of their rounds (batches); its UNIT mode (a tile's passes / chunk groups as separate
+ *                              blocks writing slabs + the split-K combine kernel) when a cost model says the rounds would stay
+ *                              mostly empty (the 46x46 layers of 1 - 4 and 8 images); else the direct kernels with split-K.
+ *                              0: direct kernels everywhere.  2: the Winograd kernel on every eligible layer; 3: unit mode wherever
+ *                              it applies (tests).  All forms are fp32 fused-multiply-add chains in a defined order with a plain-C
+ *                              twin (oracle/conv_fma_ref.c); the Winograd forms differ from the direct chain by fp32 rounding (~1e-6
+ *                              of the map scale; they are the closer ones to float64)
+ *   "wino_min_fill" percent    tuning (default 50): share of the block slots of its CU rounds a launch must fill to take the Winograd kernel
+ *   "wino_unit_eff" percent    tuning (default 80): in-round efficiency assumed for unit-mode blocks in the selection cost model
  *   "precision" 0 | 1          0 (default): every convolution is the fp32 FMA chain the parity tests specify.  1: the 3x3 / 7x7
  *                              layers that run on the one-block-per-CU kernels use the bf16 matrix cores with every fp32 value
  *                              split into three bf16 terms (six products, fp32 accumulate): fp32-grade accuracy, 2.67x the
