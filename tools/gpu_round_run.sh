@@ -23,5 +23,8 @@ cd /tmp
 cd $R
 (timeout 300 python tools/power_probe.py) > $O/power_probe.txt 2>&1
 (timeout 400 python tools/splitk_tune.py --batches 1 2 3 4 6) > $O/splitk_tune.txt 2>&1
+(timeout 300 python tools/wino_check.py --json $O/wino_check.json) > $O/wino_check.txt 2>&1
+(timeout 300 python tools/wino_batch_sweep.py) > $O/wino_batch_sweep.txt 2>&1
+(timeout 300 python tools/soak.py --steps 300) > $O/soak.txt 2>&1
 (timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')") > $O/smoke.log 2>&1
 tail -1 $O/smoke.log; tail -3 $O/pytest_gpu.log; tail -2 $O/drv_old.log $O/drv_new.log; tail -1 $O/bench.log; du -sh $O
