@@ -1218,6 +1218,29 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_small_kernel(const ConvArg
 // The arithmetic is DEFINED -- transform additions in a fixed order, one sequential FMA chain per plane over (chunk, sub-kernel, k8-step,
 // k), output transforms in a fixed order, units added in order -- and oracle/conv_fma_ref.c::conv_wino_ref restates it bit for bit; it
 // is not the direct kernels' chain (results agree to fp32 rounding, ~1e-6 of the map scale).
+// float4 add / subtract as two packed-fp32 instructions (v_pk_add_f32, the subtrahend negated by the source modifier: same rounding as
+// v_sub_f32); the scheduler-pinned one-op-per-slot transform code otherwise compiles to four scalar VALU instructions per float4
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_add2(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ f32x2 pk_sub2(f32x2 a, f32x2 b)
+{
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x4 pk_add4(f32x4 a, f32x4 b)
+{
+    const f32x2 lo = pk_add2(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1));
+    const f32x2 hi = pk_add2(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+__device__ __forceinline__ f32x4 pk_sub4(f32x4 a, f32x4 b)
+{
+    const f32x2 lo = pk_sub2(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1));
+    const f32x2 hi = pk_sub2(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+
 template <int KS>
 struct WinoCfg {
     static constexpr int TH = 8, TW = 16, PADK = KS / 2, HH = TH + KS - 1, HW = TW + KS - 1, NPX = HH * HW, CKW = 32, LDR = CKW + 4, LDU = CKW + 4;
@@ -1425,13 +1448,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                                 __builtin_amdgcn_sched_barrier(0);
                             } else if (t >= 16 && t < 24) {                 // B^T d: q = 0: (d0 - d2, d1 + d2); q = 1: (d2 - d1, d1 - d3)
                                 const int jx = (t - 16) >> 1, wi = (t - 16) & 1;
-                                if (q == 0) wv[wi][jx] = wi == 0 ? dd[0][jx] - dd[2][jx] : dd[1][jx] + dd[2][jx];
-                                else wv[wi][jx] = wi == 0 ? dd[1][jx] - dd[0][jx] : dd[0][jx] - dd[2][jx];
+                                if (q == 0) wv[wi][jx] = wi == 0 ? pk_sub4(dd[0][jx], dd[2][jx]) : pk_add4(dd[1][jx], dd[2][jx]);
+                                else wv[wi][jx] = wi == 0 ? pk_sub4(dd[1][jx], dd[0][jx]) : pk_sub4(dd[0][jx], dd[2][jx]);
                                 __builtin_amdgcn_sched_barrier(0);
                             } else if (t >= 24 && t < 40) {                 // (.) B, one column per two slots: compute, store
                                 const int pidx = (t - 24) >> 1, il = pidx >> 2, jv = pidx & 3;
                                 if (((t - 24) & 1) == 0) {
-                                    vv = jv == 0 ? wv[il][0] - wv[il][2] : jv == 1 ? wv[il][1] + wv[il][2] : jv == 2 ? wv[il][2] - wv[il][1] : wv[il][1] - wv[il][3];
+                                    vv = jv == 0 ? pk_sub4(wv[il][0], wv[il][2]) : jv == 1 ? pk_add4(wv[il][1], wv[il][2]) : jv == 2 ? pk_sub4(wv[il][2], wv[il][1]) : pk_sub4(wv[il][1], wv[il][3]);
                                 } else {
                                     *reinterpret_cast<f32x4*>(&udst[(4 * il + jv) * 32 * C::LDU]) = vv;
                                 }
@@ -1492,7 +1515,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                 __builtin_amdgcn_sched_barrier(0);
             } else if (t >= 12 && t < 20) {
                 const int l = (t - 12) >> 2, f = (t - 12) & 3;
-                vv[l][f] = f == 0 ? dd[l][0] - dd[l][2] : f == 1 ? dd[l][1] + dd[l][2] : f == 2 ? dd[l][2] - dd[l][1] : dd[l][1] - dd[l][3];
+                vv[l][f] = f == 0 ? pk_sub4(dd[l][0], dd[l][2]) : f == 1 ? pk_add4(dd[l][1], dd[l][2]) : f == 2 ? pk_sub4(dd[l][2], dd[l][1]) : pk_sub4(dd[l][1], dd[l][3]);
                 __builtin_amdgcn_sched_barrier(0);
             } else if (t >= 20 && t < 28) {
                 const int l = (t - 20) >> 2, f = (t - 20) & 3;
