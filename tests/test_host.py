@@ -140,3 +140,19 @@ def test_draw_person_pose_and_image_io(tmp_path):
     p = str(tmp_path / 'x.png')
     PD.imwrite_bgr(p, out)
     assert np.array_equal(PD.imread_bgr(p), out)
+
+
+def test_every_option_key_is_documented_in_the_header():
+    """include/pose_mi355x.h documents every key pmx_set_option accepts (the boundary a maintainer reads)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, 'chainer_realtime_multi-person_pose_estimation_amd', 'csrc', 'pmx_api.hip')).read()
+    i = src.index('extern "C" int pmx_set_option')
+    body = src[i:src.index('\n}\n', i)]
+    keys = re.findall(r'strcmp\(key, "([a-z0-9_]+)"\)', body)
+    assert len(keys) >= 15
+    hdr = open(os.path.join(root, 'include', 'pose_mi355x.h')).read()
+    for k in keys:
+        documented = ('"%s"' % k) in hdr or (k.startswith('force_variant_k') and '"force_variant_k1|k3|k7"' in hdr)
+        assert documented, 'option "%s" is not described in include/pose_mi355x.h' % k
