@@ -1241,21 +1241,31 @@ __device__ __forceinline__ f32x4 pk_sub4(f32x4 a, f32x4 b)
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
 
-template <int KS>
+// GEOM 0: a block = 4 x 8 Winograd tiles = an 8 x 16 pixel output rectangle (any map size).
+// GEOM 1 ("runs", 46-pixel-wide maps = the 46 x 46 maps of a 368 x 368 input): a block = 32 CONSECUTIVE Winograd tiles in row-major order
+// of the 23-tile-wide grid of one image (at most 3 tile rows): a 46 x 46 map is 529 tiles = 16 full blocks + 17 tiles instead of 18
+// rectangles (8.9 % padding), and the 16 full blocks of 32 images x 2 branch groups are exactly 4 rounds of 256 CUs; the part-filled last
+// block of every image runs in unit mode (pmx_api.hip::run_conv).  Raw halo = the 6 + KS - 1 input rows the three tile rows touch x all
+// 46 + KS - 1 columns (7x7: 12 x 52 pixels x 32 channels = 90 KB next to the 74 KB of U: 256 bytes short of the 160 KB LDS).
+template <int KS, int GEOM>
 struct WinoCfg {
-    static constexpr int TH = 8, TW = 16, PADK = KS / 2, HH = TH + KS - 1, HW = TW + KS - 1, NPX = HH * HW, CKW = 32, LDR = CKW + 4, LDU = CKW + 4;
+    static constexpr int TH = 8, TW = 16, PADK = KS / 2, CKW = 32, LDR = CKW + 4, LDU = CKW + 4;
+    static constexpr int RUN_TX = PMX_WINO_RUN_TX, RUN_W = 2 * RUN_TX;
+    static constexpr int HH = GEOM ? 6 + KS - 1 : TH + KS - 1, HW = GEOM ? RUN_W + KS - 1 : TW + KS - 1, NPX = HH * HW;
     static constexpr int NSUB = KS == 3 ? 1 : 4;                       // 3x3 sub-kernels done as Winograd products
     static constexpr int NDIR = KS == 3 ? 0 : 13;                      // taps outside the 3x3 sub-kernels (KS = 7: row 6, column 6 -> pass 2)
     static constexpr int RAW_ELEMS = NPX * LDR, U_ELEMS = 16 * 32 * LDU;
     static constexpr int LDS_BYTES = (RAW_ELEMS + U_ELEMS) * 4;
     static constexpr int NHF = (NPX * (CKW / 4) + 255) / 256;
     static_assert(KS == 3 || KS == 7, "Winograd kernel: 3x3 or 7x7");
+    static_assert(LDS_BYTES <= 160 * 1024, "Winograd kernel: LDS");
 };
 
-template <int KS, int POOL, int UNIT>
+template <int KS, int POOL, int UNIT, int GEOM>
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
 {
-    using C = WinoCfg<KS>;
+    using C = WinoCfg<KS, GEOM>;
+    static_assert(!(GEOM && POOL), "run geometry: no pooled variant");
     static_assert(!(POOL && KS != 3), "pooling only with the 3x3 variant");
     static_assert(!(UNIT && POOL), "unit mode: the combine kernel pools");
     // UNIT (single images: 36 blocks of a 46x46 7x7 layer cannot fill 256 CUs): blockIdx.z = unit * groups + group, and a block runs
@@ -1281,10 +1291,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    // GEOM 1: block jl of this launch = the 32 consecutive Winograd tiles [t0, t0 + 32) of image bimg (row-major over 23 tile columns),
+    // tile rows r0 .. r0 + 2; raw halo row 0 / column 0 = image row 2 r0 - PADK / column -PADK
+    const int tiles_per_img = GEOM ? a.run_nb : a.tiles_x * a.tiles_y;
     const int bimg = tile / tiles_per_img;
     const int trem = tile - bimg * tiles_per_img;
-    const int y0 = (trem / a.tiles_x) * C::TH, x0 = (trem % a.tiles_x) * C::TW;
+    const int t0 = GEOM ? (a.run_j0 + trem) * PMX_WINO_RUN_TILES : 0;
+    const int r0 = GEOM ? t0 / C::RUN_TX : 0;
+    const int ntiles = C::RUN_TX * ((a.H + 1) >> 1);
+    const int y0 = GEOM ? 2 * r0 : (trem / a.tiles_x) * C::TH, x0 = GEOM ? 0 : (trem % a.tiles_x) * C::TW;
     const int n0 = blockIdx.y * 128;
     const int n = n0 + wave * 32 + li;
     const float* in_b = G.in + (size_t)bimg * H * W * a.lda;
@@ -1298,33 +1313,68 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     const bool do_p1 = !UNIT || unit < nu1, do_p2a = !UNIT || unit == nu1, do_p2b = !UNIT || unit == nu1 + 1;
     const bool do_pd = UNIT && unit == nu1 + 2;   // unit mode: tap (6, 6) is a unit of its own (in pass 2a otherwise)
 
-    // raw halo staging slots (the LDS offset is recomputed at the write)
-    int h_goff[C::NHF];
+    // raw halo staging: slot r of a thread = pixel (tid >> 3) + 32 r of the halo, channels 4 (tid & 7) .. + 3 of the chunk.
+    // GEOM 0: global offsets and an in-image mask per slot in registers (the LDS offset is recomputed at the write).
+    // GEOM 1 (20 slots for 7x7): nothing per slot is kept -- the loads go through a buffer resource that spans exactly this image, so
+    // rows above / below the map fall out of its range and return 0; columns left / right of it get an out-of-range offset
+    int h_goff[GEOM ? 1 : C::NHF];
     unsigned h_ok = 0;
+    if (!GEOM) {
 #pragma unroll
-    for (int r = 0; r < C::NHF; ++r) {
-        const int f = tid + r * 256;
-        const bool slot = f < C::NPX * (C::CKW / 4);
-        const int hp = slot ? f / (C::CKW / 4) : 0, c4 = f % (C::CKW / 4);
-        const int hy = hp / C::HW, hx = hp - hy * C::HW;
-        const int gy = y0 + hy - C::PADK, gx = x0 + hx - C::PADK;
-        const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-        const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-        h_goff[r] = (cy * W + cx) * a.lda + c4 * 4;
-        h_ok |= (slot && inb) ? (1u << r) : 0u;
+        for (int r = 0; r < (GEOM ? 0 : C::NHF); ++r) {
+            const int f = tid + r * 256;
+            const bool slot = f < C::NPX * (C::CKW / 4);
+            const int hp = slot ? f / (C::CKW / 4) : 0, c4 = f % (C::CKW / 4);
+            const int hy = hp / C::HW, hx = hp - hy * C::HW;
+            const int gy = y0 + hy - C::PADK, gx = x0 + hx - C::PADK;
+            const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+            h_goff[r] = (cy * W + cx) * a.lda + c4 * 4;
+            h_ok |= (slot && inb) ? (1u << r) : 0u;
+        }
     }
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, GEOM ? (unsigned)(H * W * a.lda) * 4u : 0u, 0x00020000);
+    const int hbase_b = (((y0 - C::PADK) * W - C::PADK) * a.lda + (tid & 7) * 4) * 4;     // byte offset of halo pixel (0, 0), may be negative
+    const int lda_b = a.lda * 4;
+    auto halo_load = [&](float4 (&hv)[C::NHF], int chunk) {
+        if constexpr (GEOM != 0) {
+#pragma unroll
+            for (int r = 0; r < C::NHF; ++r) {
+                const unsigned hp = (unsigned)(tid >> 3) + 32u * r;
+                const unsigned hy = hp / (unsigned)C::HW, hx = hp - hy * (unsigned)C::HW;
+                // halo pixel (hy, hx) = image pixel (y0 - PADK + hy, hx - PADK): hp - (KS - 1) hy pixels after halo pixel (0, 0) in the image
+                int off = hbase_b + (int)(hp - (unsigned)(KS - 1) * hy) * lda_b + chunk * (C::CKW * 4);
+                if (hx - (unsigned)C::PADK >= (unsigned)C::RUN_W) off = -1;
+                hv[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, 0));
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < C::NHF; ++r) hv[r] = *reinterpret_cast<const float4*>(in_b + h_goff[GEOM ? 0 : r] + chunk * C::CKW);
+        }
+    };
     auto halo_store = [&](const float4 (&hv)[C::NHF]) {
 #pragma unroll
         for (int r = 0; r < C::NHF; ++r) {
             const int f = tid + r * 256;
             float4 v = hv[r];
-            if (!((h_ok >> r) & 1)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < C::NPX * (C::CKW / 4)) *reinterpret_cast<float4*>(&s_raw[(f >> 3) * C::LDR + (f & 7) * 4]) = v;
+            if (!GEOM && !((h_ok >> r) & 1)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            // (only the last slot can fall behind the halo; spelled out because the compiler does not bound tid by the block size)
+            if (r * 256 + 255 < C::NPX * (C::CKW / 4) || f < C::NPX * (C::CKW / 4)) *reinterpret_cast<float4*>(&s_raw[(f >> 3) * C::LDR + (f & 7) * 4]) = v;
         }
     };
-    // transform item of this thread: Winograd tile tt (4 x 8 grid), channels 4 * tc .. + 3 of the chunk
+    // position of Winograd tile m of the block in the raw halo (top-left pixel of sub-kernel 0's 4 x 4 window), in pixels.
+    // GEOM 0: 4 x 8 grid; GEOM 1: tile t0 + m of the row-major run (tiles past the end of the map repeat the last one; never stored)
+    auto tile_px = [&](int m) -> int {
+        if (GEOM) {
+            const int t = min(t0 + m, ntiles - 1);
+            const int ty = t / C::RUN_TX;
+            return (2 * (ty - r0)) * C::HW + 2 * (t - ty * C::RUN_TX);
+        }
+        return (2 * (m >> 3)) * C::HW + 2 * (m & 7);
+    };
+    // transform item of this thread: Winograd tile tt, channels 4 * tc .. + 3 of the chunk
     const int tt = tid >> 3, tc = tid & 7;
-    const int t_raw = ((2 * (tt >> 3)) * C::HW + 2 * (tt & 7)) * C::LDR + tc * 4;        // top-left pixel of sub-kernel 0's 4 x 4 window
+    const int t_raw = tile_px(tt) * C::LDR + tc * 4;
     const int t_u = tt * C::LDU + tc * 4;
 
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G.w), 0, 0x7fffffff, 0x00020000);
@@ -1353,16 +1403,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     const int a_off = li * C::LDU + kh * 4;
     f32x4 bw[16];
     if (do_p1) {
-#pragma unroll
-    for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + c0 * C::CKW);
+    halo_load(hreg, c0);
 #pragma unroll
     for (int st8 = 0; st8 < 8; ++st8)                 // steps 0..7 of the first phase: frequencies 0, 1 (x 4 k8-steps) of plane 0
         bw[st8] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off, (unsigned)c0 * panel_b + (unsigned)(st8 >> 2) * freq_b + (unsigned)(st8 & 3) * st_b, 0));
     halo_store(hreg);
     __syncthreads();
     if (c1 - c0 > 1) {
-#pragma unroll
-        for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + (c0 + 1) * C::CKW);
+        halo_load(hreg, c0 + 1);
     }
     {   // rows 0, 1 of the first window (not overlapped)
         f32x4 wv4[2][4];
@@ -1438,8 +1486,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                                     if (UNIT) cn = cn < c1 ? cn : c1 - 1;
                                     if (cn >= nch) cn -= nch;
                                     if (cn >= nch) cn -= nch;
-#pragma unroll
-                                    for (int rr = 0; rr < C::NHF; ++rr) hreg[rr] = *reinterpret_cast<const float4*>(in_b + h_goff[rr] + cn * C::CKW);
+                                    halo_load(hreg, cn);
                                 }
                                 __builtin_amdgcn_sched_barrier(0);
                             } else if (t >= 2 && t < 14) {                  // 12 reads: d rows q .. q + 2, column by column
@@ -1551,7 +1598,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
         };
         float* const u0 = s_u + t_u;
         float* const u1 = s_u + 8 * 32 * C::LDU + t_u;
-        const int a2_off = ((2 * (li >> 3)) * C::HW + 2 * (li & 7)) * C::LDR + kh * 4;
+        const int a2_off = tile_px(li) * C::LDR + kh * 4;
 
         // ================= pass 2a: tap (6, 6) + row 6 =================
         if (do_p2a) {
@@ -1559,13 +1606,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
 #pragma unroll
         for (int st = 0; st < 4; ++st) bd[st] = wload(PD, 0u, st);
         if (UNIT) {                                 // standalone: stage chunk 0, keep chunk 1 in the registers
-#pragma unroll
-            for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r]);
+            halo_load(hreg, 0);
             halo_store(hreg);
             __syncthreads();
             if (nch > 1) {
-#pragma unroll
-                for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + C::CKW);
+                halo_load(hreg, 1);
             }
         }
         for (int ch = 0; ch < nch; ++ch) {
@@ -1615,8 +1660,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                            int cn = ch + 2;
                            if (cn >= nch) cn -= nch;
                            if (cn >= nch) cn -= nch;
-#pragma unroll
-                           for (int rr = 0; rr < C::NHF; ++rr) hreg[rr] = *reinterpret_cast<const float4*>(in_b + h_goff[rr] + cn * C::CKW);
+                           halo_load(hreg, cn);
                            __builtin_amdgcn_sched_barrier(0);
                        } else {
                            // column-6 sub-kernel 0 of the staged chunk -> U half 0 (free: H1 reads half 1).  Needed after the last chunk
@@ -1642,15 +1686,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
         if (do_p2b) {
         zero8();
         if (UNIT) {                                 // standalone: stage chunk 0, first weights, sub-kernel 0 of chunk 0 (not overlapped)
-#pragma unroll
-            for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r]);
+            halo_load(hreg, 0);
 #pragma unroll
             for (int s2n = 0; s2n < 4; ++s2n) bwr[s2n] = wload(PV + 0, 0u, s2n);
             halo_store(hreg);
             __syncthreads();
             if (nch > 1) {
-#pragma unroll
-                for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + C::CKW);
+                halo_load(hreg, 1);
             }
 #pragma unroll
             for (int t = 0; t < 28; ++t) side1d(t, t_raw + (0 * C::HW + 6) * C::LDR, C::LDR, C::HW * C::LDR, u0);
@@ -1673,8 +1715,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                                halo_store(hreg);
                                __syncthreads();
                                const int cn = ch + 2 < nch ? ch + 2 : ch + 1;
-#pragma unroll
-                               for (int rr = 0; rr < C::NHF; ++rr) hreg[rr] = *reinterpret_cast<const float4*>(in_b + h_goff[rr] + cn * C::CKW);
+                               halo_load(hreg, cn);
                            }
                            __builtin_amdgcn_sched_barrier(0);
                        } else {
@@ -1696,8 +1737,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
         if (do_pd) {
             // ================= unit mode: tap (6, 6) over all chunks, straight from the raw halo =================
             f32x4 bdn[4];
-#pragma unroll
-            for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r]);
+            halo_load(hreg, 0);
 #pragma unroll
             for (int st = 0; st < 4; ++st) bd[st] = wload(PD, 0u, st);
             for (int ch = 0; ch < nch; ++ch) {
@@ -1705,8 +1745,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                 halo_store(hreg);
                 __syncthreads();
                 const int cn = ch + 1 < nch ? ch + 1 : ch;
-#pragma unroll
-                for (int r = 0; r < C::NHF; ++r) hreg[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r] + cn * C::CKW);
+                halo_load(hreg, cn);
 #pragma unroll
                 for (int st = 0; st < 4; ++st) bdn[st] = wload(PD, (unsigned)cn * panel_b, st);
 #pragma unroll
@@ -1729,9 +1768,21 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int mr = (reg & 3) + 8 * (reg >> 2) + 4 * kh;          // Winograd tile of this register row
-        const int ty = mr >> 3, tx = mr & 7;
         float y00 = y[0][reg], y01 = y[1][reg], y10 = y[2][reg], y11 = y[3][reg];
-        const int gy = y0 + 2 * ty, gx = x0 + 2 * tx;
+        if (UNIT && GEOM) {
+            // unit mode of a run (the part-filled last block of an image): compact slab [image][block of the launch][tile][pixel][cout_pad];
+            // conv_wino_tail_reduce_kernel adds the units in order and drops the tiles past the end of the map
+            float* oc = G.out + (((size_t)(bimg * a.run_nb + trem) * 32 + mr) * 4) * a.ldc + n;
+            oc[0] = y00; oc[a.ldc] = y01; oc[2 * a.ldc] = y10; oc[3 * a.ldc] = y11;
+            continue;
+        }
+        int gy, gx;
+        if (GEOM) {
+            const int t = t0 + mr, ty = t / C::RUN_TX;                // tiles past the end of the map land on rows >= H
+            gy = 2 * ty; gx = 2 * (t - ty * C::RUN_TX);
+        } else {
+            gy = y0 + 2 * (mr >> 3); gx = x0 + 2 * (mr & 7);
+        }
         if (POOL) {
             float v = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)) + bias;
             if (a.relu) v = fmaxf(v, 0.f);
@@ -2622,7 +2673,7 @@ int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream)
 template <int KS, int POOL, int UNIT = 0>
 static int launch_wino(const ConvArgs& a0, int groups, hipStream_t stream)
 {
-    using C = WinoCfg<KS>;
+    using C = WinoCfg<KS, 0>;
     ConvArgs a = a0;
     PMX_CHECK(!!a.pool == !!POOL, PMX_ERR_INVALID, "conv wino: pool mismatch");
     PMX_CHECK(!POOL || (a.H % 2 == 0 && a.W % 2 == 0), PMX_ERR_INVALID, "conv: pooled layer needs even H, W");
@@ -2630,7 +2681,8 @@ static int launch_wino(const ConvArgs& a0, int groups, hipStream_t stream)
     PMX_CHECK((long long)a.H * a.W * a.lda < (1ll << 31), PMX_ERR_INVALID, "conv: image too large for 32-bit offsets");
     a.tiles_x = (a.W + C::TW - 1) / C::TW;
     a.tiles_y = (a.H + C::TH - 1) / C::TH;
-    auto kern = conv_wino_kernel<KS, POOL, UNIT>;
+    a.run_j0 = a.run_nb = 0;
+    auto kern = conv_wino_kernel<KS, POOL, UNIT, 0>;
     static bool attr_set[PMX_MAX_DEVICES] = {};
     if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(kern), attr_set)) return rc;
     if (UNIT) { a.ngroups = groups; PMX_CHECK(a.ksplit >= 2 && a.ksplit <= 8 && a.kbounds >= 1, PMX_ERR_INVALID, "conv wino: bad unit plan"); }
@@ -2647,4 +2699,77 @@ int conv_wino_launch(const ConvArgs& a, int ks, int groups, hipStream_t stream)
     if (a.ksplit > 1) return ks == 7 ? launch_wino<7, 0, 1>(a, groups, stream) : launch_wino<3, 0, 1>(a, groups, stream);
     if (ks == 7) return launch_wino<7, 0>(a, groups, stream);
     return a.pool ? launch_wino<3, 1>(a, groups, stream) : launch_wino<3, 0>(a, groups, stream);
+}
+
+// run geometry (46-pixel-wide maps): the blocks [a.run_j0, a.run_j0 + a.run_nb) of every image, 32 consecutive Winograd tiles each
+template <int KS, int UNIT>
+static int launch_wino_run(const ConvArgs& a0, int groups, hipStream_t stream)
+{
+    using C = WinoCfg<KS, 1>;
+    ConvArgs a = a0;
+    PMX_CHECK(!a.pool && a.W == C::RUN_W, PMX_ERR_INVALID, "conv wino runs: %d-pixel-wide maps without pooling only (W %d, pool %d)", C::RUN_W, a.W, a.pool);
+    PMX_CHECK(a.cout_pad % 128 == 0, PMX_ERR_INVALID, "conv wino: cout_pad %d not a multiple of 128", a.cout_pad);
+    PMX_CHECK((long long)a.H * a.W * a.lda * 4 < (1ll << 31), PMX_ERR_INVALID, "conv: image too large for 32-bit offsets");
+    const int nblk = (C::RUN_TX * ((a.H + 1) / 2) + PMX_WINO_RUN_TILES - 1) / PMX_WINO_RUN_TILES;
+    PMX_CHECK(a.run_j0 >= 0 && a.run_nb >= 1 && a.run_j0 + a.run_nb <= nblk, PMX_ERR_INVALID, "conv wino runs: blocks [%d, %d) of %d", a.run_j0, a.run_j0 + a.run_nb, nblk);
+    a.tiles_x = a.tiles_y = 0;
+    auto kern = conv_wino_kernel<KS, 0, UNIT, 1>;
+    static bool attr_set[PMX_MAX_DEVICES] = {};
+    if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(kern), attr_set)) return rc;
+    if (UNIT) { a.ngroups = groups; PMX_CHECK(a.ksplit >= 2 && a.ksplit <= 8 && a.kbounds >= 1, PMX_ERR_INVALID, "conv wino: bad unit plan"); }
+    dim3 grid((unsigned)(a.run_nb * a.B), (unsigned)(a.cout_pad / 128), (unsigned)(groups * (UNIT ? a.ksplit : 1)));
+    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, a);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+int conv_wino_run_launch(const ConvArgs& a, int ks, int groups, hipStream_t stream)
+{
+    if (a.ksplit > 1) return ks == 7 ? launch_wino_run<7, 1>(a, groups, stream) : launch_wino_run<3, 1>(a, groups, stream);
+    return ks == 7 ? launch_wino_run<7, 0>(a, groups, stream) : launch_wino_run<3, 0>(a, groups, stream);
+}
+
+// ---- combine of the unit-mode slabs of a block range of the run geometry (see WinoTailReduceArgs) -------------------------------------------
+// One thread per (image, block, tile, pixel of the tile, 4 output channels): slabs added in unit order (left to right), then bias, ReLU --
+// the arithmetic of conv_splitk_reduce_kernel on the compact slab layout of conv_wino_kernel<KS, 0, 1, 1>.
+__global__ __launch_bounds__(256) void conv_wino_tail_reduce_kernel(const WinoTailReduceArgs r)
+{
+    const int g = blockIdx.z;
+    const float* slabs = g ? r.slabs[1] : r.slabs[0];
+    const float* bias = g ? r.bias[1] : r.bias[0];
+    float* out = g ? r.out[1] : r.out[0];
+    const int cout = g ? r.cout[1] : r.cout[0];
+    const int c4n = cout >> 2;
+    const long long total = (long long)r.B * r.run_nb * (PMX_WINO_RUN_TILES * 4) * c4n;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % c4n) * 4;
+    const long long q = i / c4n;                        // ((image * run_nb + block) * 32 + tile) * 4 + pixel
+    const int k = (int)(q & 3), m = (int)((q >> 2) & (PMX_WINO_RUN_TILES - 1));
+    const long long bj = q >> 7;
+    const int jl = (int)(bj % r.run_nb), b = (int)(bj / r.run_nb);
+    const int t = (r.run_j0 + jl) * PMX_WINO_RUN_TILES + m, ty = t / PMX_WINO_RUN_TX, tx = t - ty * PMX_WINO_RUN_TX;
+    const int gy = 2 * ty + (k >> 1), gx = 2 * tx + (k & 1);
+    if (gy >= r.H || gx >= r.W) return;                 // tiles past the end of the map, the odd last row
+    const float* src = slabs + q * r.ld_slab + c;
+    float4 acc = *reinterpret_cast<const float4*>(src);
+    for (int s = 1; s < r.S; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (long long)s * r.slab_stride);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const float4 bv = *reinterpret_cast<const float4*>(bias + c);
+    acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w;
+    if (r.relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+    *reinterpret_cast<float4*>(out + (((long long)b * r.H + gy) * r.W + gx) * r.ldc + c) = acc;
+}
+
+int conv_wino_tail_reduce(const WinoTailReduceArgs& r, int groups, hipStream_t stream)
+{
+    PMX_CHECK(r.cout[0] % 4 == 0 && (groups < 2 || r.cout[1] == r.cout[0]) && r.ldc % 4 == 0 && r.ld_slab % 4 == 0, PMX_ERR_INVALID,
+              "winograd tail reduce: channel counts / strides must be multiples of 4");
+    static_assert(PMX_WINO_RUN_TILES == 32, "tile index bits");
+    const long long total = (long long)r.B * r.run_nb * (PMX_WINO_RUN_TILES * 4) * (r.cout[0] / 4);
+    hipLaunchKernelGGL(conv_wino_tail_reduce_kernel, dim3((unsigned)((total + 255) / 256), 1, (unsigned)groups), dim3(256), 0, stream, r);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
 }

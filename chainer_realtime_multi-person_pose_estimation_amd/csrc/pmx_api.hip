@@ -286,6 +286,11 @@ struct pmx_ctx {
     int opt_wino_unit_eff = 80;      // unit mode: in-round efficiency of the 7x7 unit blocks relative to the plain kernel, percent (cost model;
                                      // measured with tools/wino_batch_sweep.py: 75 - 90 alike, 60 loses batch 4 and 8, 105 loses batch 16+)
     int opt_wino_min_fill = 50;      // conv_algo 1: percent of ceil(blocks / CUs) * CUs block slots a launch must fill to take the Winograd kernel
+    int opt_wino_geom = -1;          // Winograd block geometry on 46-pixel-wide maps: -1 / 1 runs of 32 consecutive tiles, 0 the 8 x 16 pixel rectangles
+                                     // of every other map size (same bits either way)
+    int opt_wino_tail = -1;          // run geometry: the part-filled last block of every image in unit mode (K units + combine) -- -1 by the cost
+                                     // model (conv_algo 1), 0 never, 1 wherever a unit plan exists.  Changes the summation of those tiles (C twin: unit_from)
+    int opt_wino_tail_g = 0;         // tuning: chunks per pass-1 unit of the tail (0 = automatic)
     int opt_precision = 0;           // 0: fp32 MFMA everywhere (the path whose results are specified); 1: bf16x3 kernels where a
                                      // v6 kernel would run (fp32-grade accuracy at 2.67x the matrix rate, NOT the fp32 FMA chain)
     int opt_fuse_conv1 = 1;          // conv1_1 recomputed on conv1_2's halo tile, one launch (conv1_fused_kernel); identical bits
@@ -547,6 +552,9 @@ extern "C" int pmx_set_option(pmx_ctx* c, const char* key, int value)
     else if (!strcmp(key, "conv_algo")) c->opt_conv_algo = value;
     else if (!strcmp(key, "wino_min_fill")) c->opt_wino_min_fill = value;
     else if (!strcmp(key, "wino_unit_eff")) c->opt_wino_unit_eff = value;
+    else if (!strcmp(key, "wino_geom")) c->opt_wino_geom = value;
+    else if (!strcmp(key, "wino_tail")) c->opt_wino_tail = value;
+    else if (!strcmp(key, "wino_tail_g")) c->opt_wino_tail_g = value;
     else if (!strcmp(key, "ksplit")) c->opt_ksplit = value;
     else if (!strcmp(key, "ksplit_plan")) c->opt_ksplit = value > 0 ? -value : 0;     // decimal digits = chunks per slice, e.g. 3221
     else if (!strcmp(key, "conv_min_lds")) conv_set_min_lds(value);
@@ -689,17 +697,62 @@ static int launch_wino_units(pmx_ctx* c, const ConvArgs& a0, int ks, int groups,
     return conv_splitk_reduce(r, groups, c->stream);
 }
 
+// Run geometry of the Winograd kernel (46-pixel-wide maps): the full blocks [0, nfull) of every image as one plain launch; the part-filled
+// last block of every image in unit mode (S units of g pass-1 chunks (+ row 6, column 6, tap (6, 6)) writing compact slabs) + the combine
+// kernel.  B = 32 at 46 x 46: 16 x 32 x 2 = 1024 full blocks = exactly 4 rounds of the 256 CUs, then 64 x 7 short unit blocks, instead of
+// 5 rounds of 18 x 32 x 2 rectangles.  tail_g = 0: every block (also the part-filled one) in the plain launch.
+static int launch_wino_run(pmx_ctx* c, const ConvArgs& a0, int ks, int groups, int tail_g)
+{
+    const int ntiles = PMX_WINO_RUN_TX * ((a0.H + 1) / 2), nblk = (ntiles + PMX_WINO_RUN_TILES - 1) / PMX_WINO_RUN_TILES, nfull = ntiles / PMX_WINO_RUN_TILES;
+    ConvArgs a = a0;
+    a.ksplit = 1; a.slab_stride = 0; a.run_j0 = 0; a.run_nb = tail_g ? nfull : nblk;
+    int rc = conv_wino_run_launch(a, ks, groups, c->stream);
+    if (rc || !tail_g) return rc;
+    PMX_CHECK(nfull >= 1 && nfull < nblk, PMX_ERR_INVALID, "winograd tail: no part-filled block (%d tiles)", ntiles);
+    const int S = (a0.nch + tail_g - 1) / tail_g + (ks == 7 ? 3 : 0);
+    PMX_CHECK(S >= 2 && S <= 8, PMX_ERR_INVALID, "winograd tail: %d slabs", S);
+    PMX_CHECK(a0.cout_pad <= SK_ZERO_BIAS, PMX_ERR_INVALID, "split-K: cout_pad %d too large", a0.cout_pad);
+    const size_t slab = (size_t)a0.B * PMX_WINO_RUN_TILES * 4 * a0.cout_pad;      // one block per image: [image][tile][pixel][cout_pad]
+    const size_t need = slab * S * groups;
+    if (need > c->sk_floats) {
+        PMX_HIP(hipStreamSynchronize(c->stream));
+        if (c->sk_scratch) (void)hipFree(c->sk_scratch);
+        c->sk_scratch = nullptr; c->sk_floats = 0;
+        PMX_HIP(hipMalloc((void**)&c->sk_scratch, need * sizeof(float)));
+        c->sk_floats = need;
+    }
+    if (!c->sk_zero_bias) {
+        PMX_HIP(hipMalloc((void**)&c->sk_zero_bias, SK_ZERO_BIAS * sizeof(float)));
+        PMX_HIP(hipMemsetAsync(c->sk_zero_bias, 0, SK_ZERO_BIAS * sizeof(float), c->stream));
+    }
+    WinoTailReduceArgs r;
+    memset(&r, 0, sizeof r);
+    for (int gi = 0; gi < groups; ++gi) {
+        float* base = c->sk_scratch + (size_t)gi * S * slab;
+        r.slabs[gi] = base; r.bias[gi] = a0.g[gi].bias; r.out[gi] = a0.g[gi].out; r.cout[gi] = a0.g[gi].cout;
+        a.g[gi].out = base; a.g[gi].bias = c->sk_zero_bias; a.g[gi].cout = a0.cout_pad;
+    }
+    a.ldc = a0.cout_pad; a.relu = 0; a.pool = 0; a.ksplit = S; a.slab_stride = (long long)slab; a.kbounds = (unsigned long long)tail_g;
+    a.run_j0 = nfull; a.run_nb = 1;
+    r.slab_stride = (long long)slab; r.S = S; r.B = a0.B; r.H = a0.H; r.W = a0.W; r.ld_slab = a0.cout_pad; r.ldc = a0.ldc;
+    r.relu = a0.relu; r.run_j0 = nfull; r.run_nb = 1;
+    if ((rc = conv_wino_run_launch(a, ks, groups, c->stream))) return rc;
+    return conv_wino_tail_reduce(r, groups, c->stream);
+}
+
 // Which form a 3x3 / 7x7 layer takes: 0 = direct kernels (+ split-K), 1 = the Winograd kernel, 2 = the Winograd kernel in unit mode
 // (*unit_g = chunks per pass-1 unit).  Blocks are equal and run one per CU, so the plain kernel costs ceil(blocks / CUs) rounds however
 // full the last one is; the unit mode costs the same work at finer grain (no round quantisation, ~0.8 of the plain kernel's in-round
 // efficiency) plus the slab traffic of the combine kernel; the direct kernels win when neither fills the chip
 // (tools/wino_batch_sweep.py).  A forced split-K option (never, n slices, an explicit plan) is a statement about the direct kernels:
 // no unit mode then.
-static int wino_mode(const pmx_ctx* c, int ks, int cin_pad, int cout_pad, int cout, int ldc, int images, int H, int W, int* unit_g)
+// *run = 1: mode 1 in the run geometry (46-pixel-wide maps, no pool); *tail_g > 0: its part-filled last blocks in unit mode, g chunks per
+// pass-1 unit (launch_wino_run)
+static int wino_mode(const pmx_ctx* c, int ks, int cin_pad, int cout_pad, int cout, int ldc, int images, int H, int W, int pool, int* unit_g,
+                     int* run, int* tail_g)
 {
-    *unit_g = 0;
+    *unit_g = 0; *run = 0; *tail_g = 0;
     if (c->opt_conv_algo < 1 || c->opt_precision != 0 || c->opt_force[ks] >= 0 || !wino_eligible(ks, cin_pad, cout_pad)) return 0;
-    if (c->opt_conv_algo == 2) return 1;          // tests: the plain kernel on every eligible layer
     const int nch = cin_pad / 32, extra = ks == 7 ? 3 : 0;     // 7x7: + row 6, column 6, tap (6, 6)
     int g = 0, S = 0;
     if (c->opt_ksplit == 0 && cout % 4 == 0 && ldc % 4 == 0 && nch >= 2) {       // unit plan: as many units as 8 slabs allow
@@ -708,18 +761,43 @@ static int wino_mode(const pmx_ctx* c, int ks, int cin_pad, int cout_pad, int co
         const int nu1 = (nch + g - 1) / g;
         if (nu1 >= 2) S = nu1 + extra; else g = 0;
     }
+    const long long ncu = conv_num_cus(), nb = cout_pad / 128;
+    // run geometry: blocks of 32 consecutive tiles; the part-filled last block of an image (if any) can run as S unit blocks
+    const bool geom_run = W == PMX_WINO_RUN_TX * 2 && !pool && c->opt_wino_geom != 0;
+    const int ntiles = PMX_WINO_RUN_TX * ((H + 1) / 2), nblk = (ntiles + PMX_WINO_RUN_TILES - 1) / PMX_WINO_RUN_TILES, nfull = ntiles / PMX_WINO_RUN_TILES;
+    const bool tail_ok = geom_run && g > 0 && nfull >= 1 && nfull < nblk && c->opt_wino_tail != 0;
+    if (c->opt_conv_algo == 2) {                  // tests: the plain kernel on every eligible layer (the tail in units only when asked for)
+        *run = geom_run;
+        if (tail_ok && c->opt_wino_tail == 1) *tail_g = g;
+        return 1;
+    }
     if (c->opt_conv_algo == 3) { *unit_g = g; return g ? 2 : 0; }               // tests: unit mode wherever it applies
-    const long long blocks = (long long)((H + 7) / 8) * ((W + 15) / 16) * images * (cout_pad / 128);
-    const long long ncu = conv_num_cus(), rounds = (blocks + ncu - 1) / ncu;
+    // cost of the plain kernel in rounds of one block per CU (equal blocks: a round costs the same however full it is)
+    const long long blocks = geom_run ? (long long)nblk * images * nb : (long long)((H + 7) / 8) * ((W + 15) / 16) * images * nb;
+    const long long rounds = (blocks + ncu - 1) / ncu;
+    double plain_cost = (double)rounds;
+    int tg = 0;
+    if (tail_ok) {
+        // unit blocks of the tail: the longest unit (g pass-1 chunks of 1024 (7x7) / 256 (3x3) MFMAs per wave, or row 6 / column 6 of all
+        // chunks at 256 per chunk) relative to a whole block, + ~10 us of block prologue / epilogue / slab store per unit round
+        const double mf_block = nch * (ks == 7 ? 1600.0 : 256.0), mf_unit = ks == 7 ? fmax(g * 1024.0, nch * 256.0) : g * 256.0;
+        const double t_block = nch * (ks == 7 ? 52e-6 : 18.5e-6);
+        const long long main_rounds = ((long long)nfull * images * nb + ncu - 1) / ncu, tail_rounds = ((long long)images * nb * S + ncu - 1) / ncu;
+        const double cost = (double)main_rounds + tail_rounds * (mf_unit / mf_block + 10e-6 / t_block) + 8e-6 / t_block;      // + two more launches
+        if (c->opt_wino_tail == 1 || cost < plain_cost) { plain_cost = cost; tg = g; }
+        if (tg && c->opt_wino_tail_g > 0 && c->opt_wino_tail_g <= nch && (nch + c->opt_wino_tail_g - 1) / c->opt_wino_tail_g + extra >= 2) tg = c->opt_wino_tail_g;
+    }
     if (g) {
         const double t_block = nch * (ks == 7 ? 52e-6 : 18.5e-6);                 // one plain block (measured), seconds
         // (3x3 units are short -- 256 MFMAs per chunk against ~10 us of block prologue / epilogue: 3/4 of the 7x7 figure)
         const double eff = c->opt_wino_unit_eff / 100.0 * (ks == 7 ? 1.0 : 0.75);
-        const double est_unit = (double)blocks / (ncu * eff) +
-                                (double)blocks * (S + 1) * 65536.0 / 3.0e12 / t_block + 0.03;      // in rounds of the plain kernel
-        if (est_unit < (double)rounds) { *unit_g = g; return 2; }
+        const long long ublocks = (long long)((H + 7) / 8) * ((W + 15) / 16) * images * nb;       // unit mode keeps the rectangles
+        const double est_unit = (double)ublocks / (ncu * eff) +
+                                (double)ublocks * (S + 1) * 65536.0 / 3.0e12 / t_block + 0.03;      // in rounds of the plain kernel
+        if (est_unit < plain_cost) { *unit_g = g; return 2; }
     }
-    return blocks * 100 >= (long long)c->opt_wino_min_fill * rounds * ncu ? 1 : 0;
+    if (blocks * 100 >= (long long)c->opt_wino_min_fill * rounds * ncu) { *run = geom_run; *tail_g = tg; return 1; }
+    return 0;
 }
 
 // one launch of 1 or 2 groups (same geometry); in/out pointers are already offset to the group's channels
@@ -749,8 +827,8 @@ static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float
     int rc;
     const bool prof_this = c->prof_on == 1 || (c->prof_on == 2 && L0.ks == 7);
     const bool wino_ok = L0.d_ww && (groups == 1 || (c->layers[li1].d_ww && c->layers[li1].cout == L0.cout));
-    int ug = 0;
-    const int wmode = wino_ok ? wino_mode(c, L0.ks, L0.cin_pad, L0.cout_pad, L0.cout, ldc, B * groups, H, W, &ug) : 0;
+    int ug = 0, wrun = 0, wtail = 0;
+    const int wmode = wino_ok ? wino_mode(c, L0.ks, L0.cin_pad, L0.cout_pad, L0.cout, ldc, B * groups, H, W, pool, &ug, &wrun, &wtail) : 0;
     const bool wino_plain = wmode == 1;
     if (wmode == 2) {
         a.nch = L0.cin_pad / 32;
@@ -769,9 +847,13 @@ static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float
         if (groups == 2) a.g[1].w = c->layers[li1].d_ww;
         if (prof_this) {
             const double bytes = 4.0 * B * H * W * ((double)L0.cin * groups + (double)L0.cout * groups / (pool ? 4 : 1));
-            if ((rc = prof_begin(c, std::string(label) + (L0.ks == 7 ? "|conv_wino_f2x2_7x7" : "|conv_wino_f2x2_3x3"), flops, bytes))) return rc;
+            // "r": run geometry; "/t<g>": its part-filled last blocks in unit mode, g chunks per pass-1 unit (part of the arithmetic)
+            std::string kn = L0.ks == 7 ? "|conv_wino_f2x2_7x7" : "|conv_wino_f2x2_3x3";
+            if (wrun) kn += "r";
+            if (wtail) kn += "/t" + std::to_string(wtail);
+            if ((rc = prof_begin(c, std::string(label) + kn, flops, bytes))) return rc;
         }
-        if ((rc = conv_wino_launch(a, L0.ks, groups, c->stream))) return rc;
+        if ((rc = wrun ? launch_wino_run(c, a, L0.ks, groups, wtail) : conv_wino_launch(a, L0.ks, groups, c->stream))) return rc;
         return prof_this ? prof_end(c) : PMX_OK;
     }
     SplitPlan plan = conv_pick_ksplit(v, H, W, B, groups, L0.cout_pad, L0.nch, pool, c->opt_ksplit);
@@ -1820,8 +1902,8 @@ extern "C" int pmx_conv2d(pmx_ctx* c, const float* x, const float* w, const floa
     SplitPlan plan = conv_pick_ksplit(v_run, H, W, B, 1, cpad, cin_pad / CK, pool, c->opt_ksplit);
     if (cout % 4 != 0) plan.S = 1;
     float* d_ww = nullptr;
-    int ug = 0;
-    const int wmode = wino_mode(c, ks, cin_pad, cpad, cout, cout, B, H, W, &ug);
+    int ug = 0, wrun = 0, wtail = 0;
+    const int wmode = wino_mode(c, ks, cin_pad, cpad, cout, cout, B, H, W, pool, &ug, &wrun, &wtail);
     const bool wino = wmode == 1;
     if (wino) {
         std::vector<float> ww;
@@ -1839,6 +1921,7 @@ extern "C" int pmx_conv2d(pmx_ctx* c, const float* x, const float* w, const floa
     }
     auto launch_conv = [&](pmx_ctx* cc, const ConvArgs& aa, int gg, int vv, const SplitPlan& pp) {
         if (ug) return launch_wino_units(cc, aa, ks, gg, ug);
+        if (wino && wrun) return launch_wino_run(cc, aa, ks, gg, wtail);
         return wino ? conv_wino_launch(aa, ks, gg, cc->stream) : ::launch_conv(cc, aa, gg, vv, pp);
     };
     if (!rc) rc = launch_conv(c, a, 1, v_run, plan);

@@ -77,7 +77,26 @@ struct ConvArgs {
     int ngroups;             // 1 | 2 (split-K launches only)
     long long slab_stride;   // floats between the partial-sum slabs of one group (0 when ksplit == 1)
     unsigned long long kbounds;   // byte s = first chunk of slice s (s = 0 .. ksplit - 1); slice s ends where s + 1 starts / at nch
+    // Winograd kernel, run geometry (46-pixel-wide maps): a block owns 32 consecutive Winograd tiles (row-major over the 23 x ceil(H / 2)
+    // tile grid of one image); this launch covers the blocks [run_j0, run_j0 + run_nb) of every image
+    int run_j0, run_nb;
 };
+// Winograd run geometry: tile columns of a 46-pixel-wide map / tiles per block
+#define PMX_WINO_RUN_TX 23
+#define PMX_WINO_RUN_TILES 32
+// combine of the unit-mode slabs of a block range (the part-filled last block of every image): out = slab_0 + slab_1 + ... (unit order),
+// + bias, ReLU; compact slabs [unit][image][block - run_j0][tile 32][pixel 4][ld_slab]
+struct WinoTailReduceArgs {
+    const float* slabs[2];
+    const float* bias[2];
+    float* out[2];           // NHWC, channel stride ldc, already offset to the group's first output channel
+    int cout[2];
+    long long slab_stride;   // floats between the unit slabs of one group
+    int S, B, H, W, ld_slab, ldc, relu, run_j0, run_nb;
+};
+int conv_wino_tail_reduce(const WinoTailReduceArgs& r, int groups, hipStream_t stream);
+// launch of the run-geometry Winograd kernel (a.W == 46, no pool); a.ksplit > 1: unit mode writing compact slabs (see WinoTailReduceArgs)
+int conv_wino_run_launch(const ConvArgs& a, int ks, int groups, hipStream_t stream);
 struct SplitPlan { int S; unsigned long long bounds; int sizes[8]; };
 struct SplitKReduceArgs {
     const float* slabs[2];   // per group: ksplit slabs of B x H x W x ld_slab floats

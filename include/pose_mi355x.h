@@ -110,6 +110,14 @@ int pmx_synchronize(pmx_ctx* ctx);                    /* cuda.get_device_from_id
  *                              of the map scale; they are the closer ones to float64)
  *   "wino_min_fill" percent    tuning (default 50): share of the block slots of its CU rounds a launch must fill to take the Winograd kernel
  *   "wino_unit_eff" percent    tuning (default 80): in-round efficiency assumed for unit-mode blocks in the selection cost model
+ *   "wino_geom" -1 | 0 | 1     block geometry of the plain Winograd kernel on 46-pixel-wide maps (the 46 x 46 maps of a 368 x 368 input):
+ *                              -1 / 1 (default) = runs of 32 consecutive Winograd tiles (529 tiles = 16.5 blocks per map), 0 = the
+ *                              8 x 16 pixel rectangles every other map size uses (18 per map).  Same bits either way
+ *   "wino_tail" -1 | 0 | 1     run geometry: the part-filled last block of every image as K units + a combine kernel (the 16 full
+ *                              blocks of 32 images x 2 branches are exactly 4 rounds of 256 CUs): -1 (default) by the cost model,
+ *                              0 never, 1 wherever a unit plan exists.  The tiles of that block (row-major index >= 32 * full blocks)
+ *                              are then summed unit by unit (C twin: `unit_from`); profile label "...r/t<chunks per unit>"
+ *   "wino_tail_g" n            tuning: chunks per pass-1 unit of those tails (0 = automatic)
  *   "precision" 0 | 1          0 (default): every convolution is the fp32 FMA chain the parity tests specify.  1: the 3x3 / 7x7
  *                              layers that run on the one-block-per-CU kernels use the bf16 matrix cores with every fp32 value
  *                              split into three bf16 terms (six products, fp32 accumulate): fp32-grade accuracy, 2.67x the

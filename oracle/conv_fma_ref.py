@@ -52,16 +52,24 @@ def conv_fma(x, w, b, relu=False, pool=False, splitk=1):
     return y
 
 
-def conv_wino(x, w, b, relu=False, pool=False, unit_g=0):
+def wino_run_unit_from(H, W):
+    """First Winograd tile (row-major index) of the part-filled last block of an image in the kernel's run geometry: blocks of 32
+    consecutive tiles of the ceil(H / 2) x ceil(W / 2) grid (csrc/conv_mfma.hip: GEOM 1, 46-pixel-wide maps)."""
+    return ((H + 1) // 2) * ((W + 1) // 2) // 32 * 32
+
+
+def conv_wino(x, w, b, relu=False, pool=False, unit_g=0, unit_from=0):
     """The Winograd F(2x2, 3x3) kernel's arithmetic (csrc/conv_mfma.hip::conv_wino_kernel, option "conv_algo"): same shapes as
     conv_fma, 3x3 or 7x7 (four 3x3 sub-kernels in the frequency domain + row 6 / column 6 as 1-D sub-kernels + tap (6, 6)).  Defined order, but not the direct
     kernels' chain: the two agree to ~1e-6 of the map scale.  unit_g > 0 (7x7): the kernel's unit mode for single images -- pass 1 in
-    units of unit_g 32-channel chunks, pass 2a, pass 2b, each summed from 0 and added in that order (kernel label ".../u<g>")."""
+    units of unit_g 32-channel chunks, pass 2a, pass 2b, each summed from 0 and added in that order (kernel label ".../u<g>").
+    unit_from: only the tiles with row-major index >= unit_from are summed that way (the part-filled last block of every image in the
+    run geometry, kernel label "...r/t<g>": unit_from = wino_run_unit_from(H, W))."""
     global _lib
     if _lib is None:
         conv_fma(np.zeros((1, 1, 1, 1), 'f'), np.zeros((1, 1, 1, 1), 'f'), np.zeros(1, 'f'))
-    _lib.conv_wino_ref.restype = None
-    _lib.conv_wino_ref.argtypes = [C.c_void_p] * 4 + [C.c_int] * 9
+    _lib.conv_wino_ref2.restype = None
+    _lib.conv_wino_ref2.argtypes = [C.c_void_p] * 4 + [C.c_int] * 10
     x = np.ascontiguousarray(x, np.float32)
     w = np.ascontiguousarray(w, np.float32)
     b = np.ascontiguousarray(b, np.float32)
@@ -69,7 +77,8 @@ def conv_wino(x, w, b, relu=False, pool=False, unit_g=0):
     cout, _, ks, _ = w.shape
     assert ks in (3, 7) and not (pool and ks == 7)
     y = np.empty((B, cout, H // 2 if pool else H, W // 2 if pool else W), np.float32)
-    _lib.conv_wino_ref(x.ctypes.data, w.ctypes.data, b.ctypes.data, y.ctypes.data, B, cin, H, W, cout, ks, int(relu), int(pool), int(unit_g))
+    _lib.conv_wino_ref2(x.ctypes.data, w.ctypes.data, b.ctypes.data, y.ctypes.data, B, cin, H, W, cout, ks, int(relu), int(pool), int(unit_g),
+                        int(unit_from))
     return y
 
 
@@ -90,9 +99,11 @@ def _cat_weights(W):
 
 class LaunchPlan(dict):
     """{layer label: K slices} of the launches that were split, plus `.wino` = labels of the layers that ran on the Winograd kernel
-    and `.wino_units` = {label: chunks per pass-1 unit} of those that ran in its unit mode."""
+    and `.wino_units` = {label: chunks per pass-1 unit} of those that ran in its unit mode, `.wino_tails` = {label: chunks per pass-1
+    unit} of those that ran the part-filled last block of every image in unit mode (run geometry, label "...r/t<g>")."""
     wino = frozenset()
     wino_units = {}
+    wino_tails = {}
 
 
 def splitk_plan(profile):
@@ -107,6 +118,7 @@ def splitk_plan(profile):
             plan[e['layer']] = [int(v) for v in k.rsplit('/k', 1)[1].split('-')]
     plan.wino = frozenset(wino_layers(profile))
     plan.wino_units = {e['layer']: int(e['kernel'].rsplit('/u', 1)[1]) for e in profile if e['kernel'].startswith('conv_wino') and '/u' in e['kernel']}
+    plan.wino_tails = {e['layer']: int(e['kernel'].rsplit('/t', 1)[1]) for e in profile if e['kernel'].startswith('conv_wino') and '/t' in e['kernel']}
     return plan
 
 
@@ -123,12 +135,16 @@ def forward_fma(weights, x, splitk=None, wino=()):
     if not wino:
         wino = getattr(splitk, 'wino', ())
     units = getattr(splitk, 'wino_units', {})
+    tails = getattr(splitk, 'wino_tails', {})
     splitk = splitk or {}
 
     def conv(name, h, relu=True, pool=False, cat=False):
         W, b = weights[name]
         label = name[:-3] if name.endswith(('_L1', '_L2')) else name
         if label in wino:
+            if label in tails:
+                return conv_wino(h, _cat_weights(W) if cat else W, b, relu=relu, pool=pool, unit_g=tails[label],
+                                 unit_from=wino_run_unit_from(h.shape[2], h.shape[3]))
             return conv_wino(h, _cat_weights(W) if cat else W, b, relu=relu, pool=pool, unit_g=units.get(label, 0))
         return conv_fma(h, _cat_weights(W) if cat else W, b, relu=relu, pool=pool, splitk=splitk.get(label, 1))
     h = conv('conv1_1', x); h = conv('conv1_2', h, pool=True)

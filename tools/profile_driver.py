@@ -25,6 +25,7 @@ ap.add_argument('--gen', type=int, default=0, help='kernel generation (0 = libra
 ap.add_argument('--profile-json', default=None)
 ap.add_argument('--precision', type=int, default=0, help='1 = bf16x3 kernels where a v6 kernel would run')
 ap.add_argument('--algo', type=int, default=0, help='conv_algo option: 1 = Winograd F(2x2,3x3) for the 3x3 / 7x7 layers of large launches')
+ap.add_argument('--opt', action='append', default=[], help='engine option key=value (repeatable), e.g. --opt wino_geom=0')
 a = ap.parse_args()
 native = importlib.import_module(PKG + '.native')
 weights_mod = importlib.import_module(PKG + '.weights')
@@ -45,6 +46,9 @@ if a.precision:
     eng.set_option('precision', a.precision)
 if a.algo:
     eng.set_option('conv_algo', a.algo)
+for kv in a.opt:
+    k, v = kv.split('=')
+    eng.set_option(k, int(v))
 imgs = np.random.default_rng(1).integers(0, 256, (B, S, S, 3), dtype=np.uint8)
 if a.profile_json:
     eng.profile_enable(True)
@@ -57,6 +61,6 @@ for _ in range(a.steps):
 if a.profile_json:
     import json
     json.dump({'batch': B, 'steps': a.steps, 'entries': eng.profile()}, open(a.profile_json, 'w'), indent=1)
-print('B=%d k7=%d k3=%d gen=%d: %.3f ms/step  %.3f ms/frame' % (B, a.k7, a.k3, a.gen, (time.perf_counter() - _t0) / a.steps * 1e3, (time.perf_counter() - _t0) / a.steps * 1e3 / B))
+print('B=%d k7=%d k3=%d gen=%d %s: %.3f ms/step  %.3f ms/frame' % (B, a.k7, a.k3, a.gen, ' '.join(a.opt), (time.perf_counter() - _t0) / a.steps * 1e3, (time.perf_counter() - _t0) / a.steps * 1e3 / B))
 print('people/frame %.2f peaks/frame %.1f status %d' % (rec['n_people'].mean(), rec['n_peaks'].mean(), int(np.bitwise_or.reduce(rec['status']))))
 eng.close()
