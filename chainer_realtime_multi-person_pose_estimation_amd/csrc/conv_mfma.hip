@@ -29,6 +29,7 @@
 //                    128 B contiguous per half-wave).
 //   grid             x = tiles * batch, y = cout_pad / BN, z = group (the PAF and heat-map branches of a stage
 //                    run as the two groups of one launch).
+#include <type_traits>
 #include "pmx_common.h"
 
 #include <map>
@@ -1336,31 +1337,33 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, GEOM ? (unsigned)(H * W * a.lda) * 4u : 0u, 0x00020000);
     const int hbase_b = (((y0 - C::PADK) * W - C::PADK) * a.lda + (tid & 7) * 4) * 4;     // byte offset of halo pixel (0, 0), may be negative
     const int lda_b = a.lda * 4;
-    auto halo_load = [&](float4 (&hv)[C::NHF], int chunk) {
+    auto halo_load_slot = [&](float4 (&hv)[C::NHF], int chunk, int r) {       // r is a compile-time constant at every call
         if constexpr (GEOM != 0) {
-#pragma unroll
-            for (int r = 0; r < C::NHF; ++r) {
-                const unsigned hp = (unsigned)(tid >> 3) + 32u * r;
-                const unsigned hy = hp / (unsigned)C::HW, hx = hp - hy * (unsigned)C::HW;
-                // halo pixel (hy, hx) = image pixel (y0 - PADK + hy, hx - PADK): hp - (KS - 1) hy pixels after halo pixel (0, 0) in the image
-                int off = hbase_b + (int)(hp - (unsigned)(KS - 1) * hy) * lda_b + chunk * (C::CKW * 4);
-                if (hx - (unsigned)C::PADK >= (unsigned)C::RUN_W) off = -1;
-                hv[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, 0));
-            }
+            const unsigned hp = (unsigned)(tid >> 3) + 32u * r;
+            const unsigned hy = hp / (unsigned)C::HW, hx = hp - hy * (unsigned)C::HW;
+            // halo pixel (hy, hx) = image pixel (y0 - PADK + hy, hx - PADK): hp - (KS - 1) hy pixels after halo pixel (0, 0) in the image
+            int off = hbase_b + (int)(hp - (unsigned)(KS - 1) * hy) * lda_b + chunk * (C::CKW * 4);
+            if (hx - (unsigned)C::PADK >= (unsigned)C::RUN_W) off = -1;
+            hv[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, 0));
         } else {
-#pragma unroll
-            for (int r = 0; r < C::NHF; ++r) hv[r] = *reinterpret_cast<const float4*>(in_b + h_goff[GEOM ? 0 : r] + chunk * C::CKW);
+            hv[r] = *reinterpret_cast<const float4*>(in_b + h_goff[GEOM ? 0 : r] + chunk * C::CKW);
         }
+    };
+    float* const s_raw_t = s_raw + (tid >> 3) * C::LDR + (tid & 7) * 4;       // slot r of this thread: + r * 32 * LDR floats (an immediate offset)
+    auto halo_store_slot = [&](const float4 (&hv)[C::NHF], int r) {
+        const int f = tid + r * 256;
+        float4 v = hv[r];
+        if (!GEOM && !((h_ok >> r) & 1)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        // (only the last slot can fall behind the halo; spelled out because the compiler does not bound tid by the block size)
+        if (r * 256 + 255 < C::NPX * (C::CKW / 4) || f < C::NPX * (C::CKW / 4)) *reinterpret_cast<float4*>(s_raw_t + r * (32 * C::LDR)) = v;
+    };
+    auto halo_load = [&](float4 (&hv)[C::NHF], int chunk) {
+#pragma unroll
+        for (int r = 0; r < C::NHF; ++r) halo_load_slot(hv, chunk, r);
     };
     auto halo_store = [&](const float4 (&hv)[C::NHF]) {
 #pragma unroll
-        for (int r = 0; r < C::NHF; ++r) {
-            const int f = tid + r * 256;
-            float4 v = hv[r];
-            if (!GEOM && !((h_ok >> r) & 1)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            // (only the last slot can fall behind the halo; spelled out because the compiler does not bound tid by the block size)
-            if (r * 256 + 255 < C::NPX * (C::CKW / 4) || f < C::NPX * (C::CKW / 4)) *reinterpret_cast<float4*>(&s_raw[(f >> 3) * C::LDR + (f & 7) * 4]) = v;
-        }
+        for (int r = 0; r < C::NHF; ++r) halo_store_slot(hv, r);
     };
     // position of Winograd tile m of the block in the raw halo (top-left pixel of sub-kernel 0's 4 x 4 window), in pixels.
     // GEOM 0: 4 x 8 grid; GEOM 1: tile t0 + m of the row-major run (tiles past the end of the map repeat the last one; never stored)
@@ -1432,86 +1435,102 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     }
     __syncthreads();
 
+    // one (chunk, sub-kernel) step = the two phases.  LAST (compile time): the last sub-kernel of a chunk, whose second phase transforms the
+    // first window of the NEXT chunk -- the raw halo is replaced in between, spread over the free side slots so that the matrix pipe never
+    // waits for it: phase 0 reads the old halo in slots 2..13, then one barrier (slot 14: every wave is done with the old halo) and one
+    // ds_write_b128 of the new halo per slot from slot 40 on (the barrier that ends the phase publishes it); phase 1 issues one global
+    // load of the chunk after next per slot from slot 40 on.  (Before: 10 / 20 stores + a barrier + the loads in one clump in slot 0 of
+    // phase 1, exposed: +4 % per block with the 12 x 52 halo of the run geometry.)
+    auto p1_step = [&](auto sub_c, int ch, bool more, unsigned chunk_b, unsigned next_b) {
+        constexpr int sub = decltype(sub_c)::value;
+        constexpr bool LAST = sub == C::NSUB - 1;
+        constexpr int sub_n = LAST ? 0 : sub + 1;
+        const bool repl = LAST && ((C::NDIR > 0 && !UNIT) ? true : more);      // chunks are staged round-robin over the passes (0 .. nch-1, then 0 ..
+        int cn = ch + 2;                                                        // again for pass 2a, 2b): the registers hold the chunk after next
+        if (UNIT) cn = cn < c1 ? cn : c1 - 1;
+        if (cn >= nch) cn -= nch;
+        if (cn >= nch) cn -= nch;
+        const unsigned plane_b = chunk_b + (unsigned)(sub * 16) * freq_b;                       // plane sub * 16 + 0 of this chunk
+        const unsigned nplane_b = (LAST ? next_b : chunk_b) + (unsigned)(sub_n * 16) * freq_b;     // plane 0 of the next step
+        const int src_cur = t_raw + ((3 * (sub >> 1)) * C::HW + 3 * (sub & 1)) * C::LDR;
+        const int src_nxt = t_raw + ((3 * (sub_n >> 1)) * C::HW + 3 * (sub_n & 1)) * C::LDR;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            // side work of this phase: rows (2, 3) of the current window (r = 0) / rows (0, 1) of the next one (r = 1)
+            const int q = r ^ 1;                                        // V row pair produced
+            const int src = (r == 0 ? src_cur : src_nxt) + q * C::HW * C::LDR;      // d rows q .. q + 2
+            float* const udst = s_u + (q * 8) * 32 * C::LDU + t_u;
+            f32x4 dd[3][4], wv[2][4], vv;
+            f32x4 av[4];
+            av[0] = *reinterpret_cast<const f32x4*>(&s_u[(r * 8) * 32 * C::LDU + a_off]);
+            av[1] = *reinterpret_cast<const f32x4*>(&s_u[(r * 8) * 32 * C::LDU + a_off + 8]);
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {                              // step = (frequency r * 8 + s / 4, k8-step s % 4)
+                const int f = r * 8 + (s >> 2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 3][e], bw[s & 15][e], acc[f], 0, 0, 0);
+                    if (e == 0) {                                       // weights of step s + 8
+                        const int sn = s + 8;
+                        unsigned so;
+                        if (sn < 32) so = plane_b + (unsigned)(r * 8 + (sn >> 2)) * freq_b;
+                        else if (r == 0) so = plane_b + (unsigned)(8 + ((sn - 32) >> 2)) * freq_b;
+                        else so = nplane_b + (unsigned)((sn - 32) >> 2) * freq_b;
+                        bw[sn & 15] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off, so + (unsigned)(sn & 3) * st_b, 0));
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if (e == 1) {                                // A fragment of step s + 2
+                        if (s + 2 < 32) {
+                            const int fn = r * 8 + ((s + 2) >> 2), sn = (s + 2) & 3;
+                            av[(s + 2) & 3] = *reinterpret_cast<const f32x4*>(&s_u[fn * 32 * C::LDU + a_off + sn * 8]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    } else {                                            // transform slot t
+                        const int t = 2 * s + (e - 2);
+                        if (t >= 2 && t < 14) {                         // 12 reads: d rows q .. q + 2, column by column
+                            const int jx = (t - 2) / 3, ri = (t - 2) % 3;
+                            dd[ri][jx] = *reinterpret_cast<const f32x4*>(&s_raw[src + (ri * C::HW + jx) * C::LDR]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        } else if (LAST && t == 14 && r == 0) {         // every wave has read what it needs of the old halo
+                            if (repl) __syncthreads();
+                            __builtin_amdgcn_sched_barrier(0);
+                        } else if (t >= 16 && t < 24) {                 // B^T d: q = 0: (d0 - d2, d1 + d2); q = 1: (d2 - d1, d1 - d3)
+                            const int jx = (t - 16) >> 1, wi = (t - 16) & 1;
+                            if (q == 0) wv[wi][jx] = wi == 0 ? pk_sub4(dd[0][jx], dd[2][jx]) : pk_add4(dd[1][jx], dd[2][jx]);
+                            else wv[wi][jx] = wi == 0 ? pk_sub4(dd[1][jx], dd[0][jx]) : pk_sub4(dd[0][jx], dd[2][jx]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        } else if (t >= 24 && t < 40) {                 // (.) B, one column per two slots: compute, store
+                            const int pidx = (t - 24) >> 1, il = pidx >> 2, jv = pidx & 3;
+                            if (((t - 24) & 1) == 0) {
+                                vv = jv == 0 ? pk_sub4(wv[il][0], wv[il][2]) : jv == 1 ? pk_add4(wv[il][1], wv[il][2]) : jv == 2 ? pk_sub4(wv[il][2], wv[il][1]) : pk_sub4(wv[il][1], wv[il][3]);
+                            } else {
+                                *reinterpret_cast<f32x4*>(&udst[(4 * il + jv) * 32 * C::LDU]) = vv;
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        } else if (LAST && t >= 40 && t < 40 + C::NHF) { // the halo of the next chunk -> LDS (r = 0) / of the one after it -> registers
+                            if (repl) {
+                                if (r == 0) halo_store_slot(hreg, t - 40);
+                                else halo_load_slot(hreg, cn, t - 40);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            }
+            __syncthreads();            // U half q is complete, U half r is free (LAST, r = 0: and the new raw halo is in place)
+        }
+    };
+    static_assert(40 + C::NHF <= 64, "halo slots");
     for (int ch = c0; ch < c1; ++ch) {
         const bool more = ch + 1 < c1;
         const unsigned chunk_b = (unsigned)ch * panel_b;
         const unsigned next_b = (unsigned)(more ? ch + 1 : ch) * panel_b;
-#pragma unroll 1
-        for (int sub = 0; sub < C::NSUB; ++sub) {
-            const bool last_sub = sub == C::NSUB - 1;
-            const int sub_n = last_sub ? 0 : sub + 1;
-            const unsigned plane_b = chunk_b + (unsigned)(sub * 16) * freq_b;                       // plane sub * 16 + 0 of this chunk
-            const unsigned nplane_b = (last_sub ? next_b : chunk_b) + (unsigned)(sub_n * 16) * freq_b;     // plane 0 of the next step
-            const int src_cur = t_raw + ((3 * (sub >> 1)) * C::HW + 3 * (sub & 1)) * C::LDR;
-            const int src_nxt = t_raw + ((3 * (sub_n >> 1)) * C::HW + 3 * (sub_n & 1)) * C::LDR;
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                // side work of this phase: rows (2, 3) of the current window (r = 0) / rows (0, 1) of the next one (r = 1)
-                const int q = r ^ 1;                                        // V row pair produced
-                const int src = (r == 0 ? src_cur : src_nxt) + q * C::HW * C::LDR;      // d rows q .. q + 2
-                float* const udst = s_u + (q * 8) * 32 * C::LDU + t_u;
-                f32x4 dd[3][4], wv[2][4], vv;
-                f32x4 av[4];
-                av[0] = *reinterpret_cast<const f32x4*>(&s_u[(r * 8) * 32 * C::LDU + a_off]);
-                av[1] = *reinterpret_cast<const f32x4*>(&s_u[(r * 8) * 32 * C::LDU + a_off + 8]);
-#pragma unroll
-                for (int s = 0; s < 32; ++s) {                              // step = (frequency r * 8 + s / 4, k8-step s % 4)
-                    const int f = r * 8 + (s >> 2), st = s & 3;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 3][e], bw[s & 15][e], acc[f], 0, 0, 0);
-                        if (e == 0) {                                       // weights of step s + 8
-                            const int sn = s + 8;
-                            unsigned so;
-                            if (sn < 32) so = plane_b + (unsigned)(r * 8 + (sn >> 2)) * freq_b;
-                            else if (r == 0) so = plane_b + (unsigned)(8 + ((sn - 32) >> 2)) * freq_b;
-                            else so = nplane_b + (unsigned)((sn - 32) >> 2) * freq_b;
-                            bw[sn & 15] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off, so + (unsigned)(sn & 3) * st_b, 0));
-                            __builtin_amdgcn_sched_barrier(0);
-                        } else if (e == 1) {                                // A fragment of step s + 2
-                            if (s + 2 < 32) {
-                                const int fn = r * 8 + ((s + 2) >> 2), sn = (s + 2) & 3;
-                                av[(s + 2) & 3] = *reinterpret_cast<const f32x4*>(&s_u[fn * 32 * C::LDU + a_off + sn * 8]);
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
-                        } else {                                            // transform slot t
-                            const int t = 2 * s + (e - 2);
-                            if (t == 0) {
-                                // the next window is in the next chunk: replace the raw halo.  Chunks are staged round-robin over the
-                                // passes (0 .. nch-1, then 0 .. again for pass 2a, 2b): the registers always hold the chunk after next
-                                if (r == 1 && last_sub && (more || (C::NDIR > 0 && !UNIT))) {
-                                    halo_store(hreg);
-                                    __syncthreads();
-                                    int cn = ch + 2;
-                                    if (UNIT) cn = cn < c1 ? cn : c1 - 1;
-                                    if (cn >= nch) cn -= nch;
-                                    if (cn >= nch) cn -= nch;
-                                    halo_load(hreg, cn);
-                                }
-                                __builtin_amdgcn_sched_barrier(0);
-                            } else if (t >= 2 && t < 14) {                  // 12 reads: d rows q .. q + 2, column by column
-                                const int jx = (t - 2) / 3, ri = (t - 2) % 3;
-                                dd[ri][jx] = *reinterpret_cast<const f32x4*>(&s_raw[src + (ri * C::HW + jx) * C::LDR]);
-                                __builtin_amdgcn_sched_barrier(0);
-                            } else if (t >= 16 && t < 24) {                 // B^T d: q = 0: (d0 - d2, d1 + d2); q = 1: (d2 - d1, d1 - d3)
-                                const int jx = (t - 16) >> 1, wi = (t - 16) & 1;
-                                if (q == 0) wv[wi][jx] = wi == 0 ? pk_sub4(dd[0][jx], dd[2][jx]) : pk_add4(dd[1][jx], dd[2][jx]);
-                                else wv[wi][jx] = wi == 0 ? pk_sub4(dd[1][jx], dd[0][jx]) : pk_sub4(dd[0][jx], dd[2][jx]);
-                                __builtin_amdgcn_sched_barrier(0);
-                            } else if (t >= 24 && t < 40) {                 // (.) B, one column per two slots: compute, store
-                                const int pidx = (t - 24) >> 1, il = pidx >> 2, jv = pidx & 3;
-                                if (((t - 24) & 1) == 0) {
-                                    vv = jv == 0 ? pk_sub4(wv[il][0], wv[il][2]) : jv == 1 ? pk_add4(wv[il][1], wv[il][2]) : jv == 2 ? pk_sub4(wv[il][2], wv[il][1]) : pk_sub4(wv[il][1], wv[il][3]);
-                                } else {
-                                    *reinterpret_cast<f32x4*>(&udst[(4 * il + jv) * 32 * C::LDU]) = vv;
-                                }
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
-                        }
-                    }
-                }
-                __syncthreads();            // U half q is complete, U half r is free
-            }
+        // (the sub-kernels are unrolled: a run-time loop over three of them + a peeled last one made the register allocator shuttle
+        //  accumulator tiles between the two copies with v_accvgpr_mov + s_nop 15)
+        p1_step(std::integral_constant<int, 0>{}, ch, more, chunk_b, next_b);
+        if constexpr (C::NSUB > 1) {
+            p1_step(std::integral_constant<int, 1>{}, ch, more, chunk_b, next_b);
+            p1_step(std::integral_constant<int, 2>{}, ch, more, chunk_b, next_b);
+            p1_step(std::integral_constant<int, 3>{}, ch, more, chunk_b, next_b);
         }
     }
 
@@ -1642,32 +1661,31 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                 }
             }
             __syncthreads();                        // U half 0 = row-6 sub-kernel 0
-            // ---- H0: side = sub-kernel 1 (kx 3..5) -> U half 1; afterwards H1's first weights
+            // The raw halo is replaced without ever stopping the matrix pipe and without the staging registers meeting the transform's:
+            // ---- H0: side = sub-kernel 1 (kx 3..5) -> U half 1 (the last reads of this chunk's raw halo, slots 2..27); then the halo of the
+            // next chunk (chunk 0 again after the last one: pass 2b starts from it) global -> registers, one load per slot from slot 28
+            // on; afterwards H1's first weights
+            const int cnx = more ? ch + 1 : 0;
             phase8(s_u, PH + 0, chb,
                    [&](int s2n) { bwr[(s2n + 16) & 7] = wload(PH + 4 + (s2n >> 2), chb, s2n & 3); },
-                   [&](int t) { side1d(t, t_raw + (6 * C::HW + 3) * C::LDR, C::HW * C::LDR, C::LDR, u1); });
-            __syncthreads();                        // U half 1 = row-6 sub-kernel 1
-            // ---- H1: side = the next chunk's raw halo; afterwards the next chunk's tap-(6,6) weights
+                   [&](int t) {
+                       if (t >= 28 && t < 28 + C::NHF) { halo_load_slot(hreg, cnx, t - 28); __builtin_amdgcn_sched_barrier(0); }
+                       else side1d(t, t_raw + (6 * C::HW + 3) * C::LDR, C::HW * C::LDR, C::LDR, u1);
+                   });
+            __syncthreads();                        // U half 1 = row-6 sub-kernel 1; nobody reads the old raw halo any more
+            // ---- H1: side = registers -> LDS, one ds_write_b128 per slot from slot 0 on, a barrier (slot 20), then column-6 sub-kernel 0
+            // of the new chunk -> U half 0 (free: H1 reads half 1; needed after the last chunk, otherwise unused and overwritten by the
+            // next D phase -- unconditional, because a branch per slot would cut the schedule into pieces); afterwards the next chunk's
+            // tap-(6,6) weights
             phase8(s_u + 8 * 32 * C::LDU, PH + 4, chb,
                    [&](int s2n) {
                        bd[s2n] = wload(PD, nxb, s2n);
                        bwr[(s2n + 16) & 7] = wload(PV + 0, 0u, s2n);              // pass 2b's first weights (used after the last chunk)
                    },
                    [&](int t) {
-                       if (t == 0) {
-                           halo_store(hreg);                                        // next chunk, or chunk 0 again for pass 2b
-                           __syncthreads();
-                           int cn = ch + 2;
-                           if (cn >= nch) cn -= nch;
-                           if (cn >= nch) cn -= nch;
-                           halo_load(hreg, cn);
-                           __builtin_amdgcn_sched_barrier(0);
-                       } else {
-                           // column-6 sub-kernel 0 of the staged chunk -> U half 0 (free: H1 reads half 1).  Needed after the last chunk
-                           // (chunk 0 is staged again: pass 2b starts from it); otherwise unused and overwritten by the next D phase --
-                           // unconditional, because a branch per slot would cut the schedule into pieces
-                           side1d(t, t_raw + (0 * C::HW + 6) * C::LDR, C::LDR, C::HW * C::LDR, u0);
-                       }
+                       if (t < C::NHF) { halo_store_slot(hreg, t); __builtin_amdgcn_sched_barrier(0); }
+                       else if (t == 20) { __syncthreads(); __builtin_amdgcn_sched_barrier(0); }
+                       else if (t >= 22) side1d(t - 20, t_raw + (0 * C::HW + 6) * C::LDR, C::LDR, C::HW * C::LDR, u0);
                    });
         }
         __syncthreads();                            // U half 0 = column-6 sub-kernel 0 of chunk 0
@@ -1698,32 +1716,41 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
             for (int t = 0; t < 28; ++t) side1d(t, t_raw + (0 * C::HW + 6) * C::LDR, C::LDR, C::HW * C::LDR, u0);
             __syncthreads();
         }
-        for (int ch = 0; ch < nch; ++ch) {
-            const bool more = ch + 1 < nch;
-            const unsigned chb = (unsigned)ch * panel_b, nxb = (unsigned)(more ? ch + 1 : ch) * panel_b;
-            // ---- V0: side = sub-kernel 1 (ky 3..5) -> U half 1
+        // one chunk; MORE (compile time): another chunk follows -- its raw halo replaces this one inside V0 (barrier in slot 10 after
+        // the last reads of the old halo, one ds_write_b128 per slot from slot 28 on), the halo after it is requested inside V1
+        auto p2b_chunk = [&](auto more_c, int ch) {
+            constexpr bool MORE = decltype(more_c)::value;
+            // y rests during pass 2b: pin it to the accumulator file (64 of its registers are free here) -- left in VGPRs next to the 20-slot
+            // halo it pushed the halo addresses to scratch, each reload with an s_waitcnt vmcnt(0) that also drains the weight ring
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) asm volatile("" : "+a"(y[pp]));
+            const unsigned chb = (unsigned)ch * panel_b, nxb = (unsigned)(MORE ? ch + 1 : ch) * panel_b;
+            // ---- V0: side = sub-kernel 1 (ky 3..5) -> U half 1, then the next chunk's halo global -> registers (slots 28 ..)
             phase8(s_u, PV + 0, chb,
                    [&](int s2n) { bwr[(s2n + 16) & 7] = wload(PV + 4 + (s2n >> 2), chb, s2n & 3); },
-                   [&](int t) { side1d(t, t_raw + (3 * C::HW + 6) * C::LDR, C::LDR, C::HW * C::LDR, u1); });
-            __syncthreads();
-            // ---- V1: side = next chunk's raw halo, then its sub-kernel 0 -> U half 0
-            phase8(s_u + 8 * 32 * C::LDU, PV + 4, chb,
-                   [&](int s2n) { bwr[(s2n + 16) & 7] = wload(PV + 0 + (s2n >> 2), nxb, s2n & 3); },
                    [&](int t) {
-                       if (t == 0) {
-                           if (more) {
-                               halo_store(hreg);
-                               __syncthreads();
-                               const int cn = ch + 2 < nch ? ch + 2 : ch + 1;
-                               halo_load(hreg, cn);
-                           }
-                           __builtin_amdgcn_sched_barrier(0);
-                       } else {
-                           side1d(t, t_raw + (0 * C::HW + 6) * C::LDR, C::LDR, C::HW * C::LDR, u0);
-                       }
+                       if (MORE && t >= 28 && t < 28 + C::NHF) { halo_load_slot(hreg, ch + 1, t - 28); __builtin_amdgcn_sched_barrier(0); }
+                       else side1d(t, t_raw + (3 * C::HW + 6) * C::LDR, C::LDR, C::HW * C::LDR, u1);
                    });
             __syncthreads();
-        }
+            // ---- V1: side = registers -> LDS (slots 0 ..), barrier (slot 20), the next chunk's sub-kernel 0 -> U half 0
+            if constexpr (MORE)
+                phase8(s_u + 8 * 32 * C::LDU, PV + 4, chb,
+                       [&](int s2n) { bwr[(s2n + 16) & 7] = wload(PV + 0 + (s2n >> 2), nxb, s2n & 3); },
+                       [&](int t) {
+                           if (t < C::NHF) { halo_store_slot(hreg, t); __builtin_amdgcn_sched_barrier(0); }
+                           else if (t == 20) { __syncthreads(); __builtin_amdgcn_sched_barrier(0); }
+                           else if (t >= 22) side1d(t - 20, t_raw + (0 * C::HW + 6) * C::LDR, C::LDR, C::HW * C::LDR, u0);
+                       });
+            else
+                phase8(s_u + 8 * 32 * C::LDU, PV + 4, chb,
+                       [&](int s2n) { bwr[(s2n + 16) & 7] = wload(PV + 0 + (s2n >> 2), nxb, s2n & 3); },
+                       [&](int) {});
+            __syncthreads();
+        };
+        static_assert(C::NHF <= 20 && 28 + C::NHF <= 64, "halo slots");
+        for (int ch = 0; ch < nch - 1; ++ch) p2b_chunk(std::true_type{}, ch);
+        p2b_chunk(std::false_type{}, nch - 1);
         // y += A^T-transform of the column planes: e8[j * 4 + f]
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg)
