@@ -14,11 +14,13 @@ to the host there).  Weak scaling: every rank processes its own shard of `--batc
 (BASELINE.json config "Batch 256 sharded 8 x 32"); value = all images / max-rank time.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      the dominant kernel (7x7 128->128 conv, two branch groups per launch): algorithmic FLOP per launch
-                / its average launch duration, measured live with HIP events on the stream the kernels run on
-                (per-launch event pairs inside the timed region), against the dense fp32-MFMA peak (157.3 TFLOP/s,
-                MI355X_MICROARCH.md).  `traffic` (HBM bytes/launch from PMC counters) is filled from
-                profiles/ when a counter pass exists, else null.
+  roofline      the dominant kernel (the 7x7 Winograd kernel, two branch groups per launch): FLOP per launch the kernel
+                ISSUES to the matrix cores (engine profile) / its average launch duration, measured live with HIP events
+                on the stream the kernels run on (per-launch event pairs inside the timed region), against the dense
+                fp32-MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md): `frac` <= 1.  `algorithmic_frac` = the same with the
+                FLOP of the convolution the kernel computes.  `traffic` (HBM bytes/launch from PMC counters) is filled
+                from profiles/ when a counter pass of this kernel exists, else null.  `step_roofline`: the same pair for
+                the whole step.  tools/summarize_profiles.py recomputes both from the rocprofv3 kernel stats.
   cpu_baseline  the oracle (torch-CPU fp32 restatement of the network + NumPy restatement of the reference
                 post-process, one image per call as the reference does) timed on this box's host cores, rank 0, N=1
                 only, on a bounded sample of the same workload.
@@ -36,37 +38,47 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = 'chainer_realtime_multi-person_pose_estimation_amd'
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-WINO7_EXECUTED_FRACTION = 100.0 / 196.0      # conv_wino_kernel<7>: (4 x 16 + 4 x 8 + 4) / (49 x 4) products per output tile
-WINO3_EXECUTED_FRACTION = 16.0 / 36.0
 FLOP_PER_FRAME = 271868013568          # 2 x MACs of the 92 convs at 368 x 368
 DOMINANT_LAYERS = ('Mconv2_', 'Mconv3_', 'Mconv4_', 'Mconv5_')   # 7x7 128->128, 20 launches per step
 
 
-def pmc_traffic(kernel_name):
-    """HBM bytes per launch of `kernel_name` from the newest committed PMC summary (profiles/rNN_pmc_summary.json,
+def rocprof_kernel(label):
+    """HIP kernel (as rocprofv3 --kernel-trace names it) behind an engine profile label -- the key the live HIP-event figures and
+    the committed rocprofv3 / PMC summaries share.  Labels: csrc/pmx_api.hip::run_conv."""
+    import re
+    m = re.match(r'conv_wino_f2x2_(\d)x\d(r?)(/[ut]\d+)?(:units|:combine)?$', label)
+    if m:
+        ks, run, plan, part = m.group(1), m.group(2), m.group(3) or '', m.group(4) or ''
+        if part == ':combine':
+            return 'conv_wino_tail_reduce_kernel'
+        if part == ':units':
+            return 'conv_wino_kernel<%s, 0, 1, 1>' % ks                     # <KS, POOL, UNIT, GEOM>
+        if plan.startswith('/u'):
+            return 'conv_wino_kernel<%s, 0, 1, 0>' % ks                     # (+ conv_splitk_reduce_kernel inside the same event pair)
+        return 'conv_wino_kernel<%s, 0, 0, %d>' % (ks, 1 if run else 0)     # (the pooled 3x3 layers are <3, 1, 0, 0>)
+    m = re.match(r'conv(\d)x\d(_v\d)?_t(\d+)x(\d+)_n(\d+)', label)
+    if m:
+        if m.group(2) == '_v6':          # conv_mfma_v6_kernel<KS, MT, POOL>: 17 x 32 consecutive pixels of a 46-column slab
+            return 'conv_mfma_v6_kernel<%s, %s, 0>' % (m.group(1), m.group(3))
+        return 'conv_mfma%s_kernel<%s, %s, %s, %s,' % (m.group(2) or '', m.group(1), m.group(3), m.group(4), m.group(5))
+    return label
+
+
+def pmc_traffic(kernel_sig):
+    """HBM bytes per launch of the kernel from the newest committed PMC summary (profiles/rNN_pmc_summary.json,
     written by tools/summarize_profiles.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same
     workload; (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md).  Mean over all launches of the kernel,
-    like `achieved`.  None if no summary exists."""
+    like `achieved`.  None if no summary names the kernel."""
     import glob
-    import re
-    m = re.match(r'conv(\d)x\d(_v\d)?_t(\d+)x(\d+)_n(\d+)', kernel_name)
-    mw = re.match(r'conv_wino_f2x2_(\d)x\d', kernel_name)
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_summary.json')))
-    if not (m or mw) or not files:
-        return None, None
-    if mw:
-        sig = 'conv_wino_kernel<%s, 0, 0>' % mw.group(1)          # <KS, POOL, UNIT>
-    else:
-        sig = 'conv_mfma%s_kernel<%s, %s, %s, %s,' % (m.group(2) or '', m.group(1), m.group(3), m.group(4), m.group(5))
-        if m.group(2) == '_v6':          # conv_mfma_v6_kernel<KS, MT, POOL>: 17 x 32 consecutive pixels of a 46-column slab
-            sig = 'conv_mfma_v6_kernel<%s, %s, 0>' % (m.group(1), m.group(3))
-    try:
-        d = json.load(open(files[-1]))
-        for k, e in d['kernels'].items():
-            if sig in k and 'hbm_bytes_per_launch_mean' in e.get('derived', {}):
-                return e['derived']['hbm_bytes_per_launch_mean'], os.path.basename(files[-1])
-    except Exception:
-        pass
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+            for k, e in d['kernels'].items():
+                if kernel_sig in k and 'hbm_bytes_per_launch_mean' in e.get('derived', {}):
+                    return e['derived']['hbm_bytes_per_launch_mean'], os.path.basename(f)
+        except Exception:
+            pass
     return None, None
 
 
@@ -85,6 +97,8 @@ def parse():
                     "for the single-GPU multi-rank smoke test, where all ranks share device 0)")
     ap.add_argument('--dump-records', default=None, help='rank 0 writes the gathered result records of the last step (.npy)')
     ap.add_argument('--no-extras', action='store_true', help='skip the single-image and upload-inclusive measurements')
+    ap.add_argument('--force-gather', action='store_true', help='N = 1: still create a one-rank process group and route the records '
+                    'through the RCCL gather (dist.gather_device_records), the code path of N > 1')
     return ap.parse_args()
 
 
@@ -109,21 +123,25 @@ def self_launch(a):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def usable_cores():
-    """Host cores this process may really use: affinity mask and cgroup CPU quota (containers often expose all
-    host CPUs through os.cpu_count() while the quota is far smaller)."""
-    n = os.cpu_count() or 1
+def core_limits():
+    """What bounds the host cores of this process: os.cpu_count(), the affinity mask, the cgroup CPU quota (containers often
+    expose all host CPUs through os.cpu_count() while the quota is far smaller)."""
+    lim = {'os_cpu_count': os.cpu_count() or 1, 'affinity': None, 'cgroup_quota': None}
     try:
-        n = min(n, len(os.sched_getaffinity(0)))
+        lim['affinity'] = len(os.sched_getaffinity(0))
     except Exception:
         pass
     try:
         quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
         if quota != 'max':
-            n = min(n, max(1, int(float(quota) / float(period))))
+            lim['cgroup_quota'] = max(1, int(float(quota) / float(period)))
     except Exception:
         pass
-    return max(1, n)
+    return lim
+
+
+def usable_cores():
+    return max(1, min(v for v in core_limits().values() if v))
 
 
 def cpu_baseline(weights, imgs, map_hw, budget_s=20.0, max_threads=32):
@@ -132,7 +150,10 @@ def cpu_baseline(weights, imgs, map_hw, budget_s=20.0, max_threads=32):
     Returns (cpu_baseline object, per-frame oracle results for the keypoint-match check)."""
     import torch
     from oracle import network_ref, postprocess_ref
+    lim = core_limits()
     threads = min(usable_cores(), max_threads)     # oneDNN scales poorly beyond a few tens of threads at batch 1
+    bound_by = ('the %d-thread cap of this script (oneDNN at batch 1 does not scale further)' % max_threads if threads == max_threads and usable_cores() > max_threads
+                else 'the cgroup CPU quota' if lim['cgroup_quota'] == threads else 'the affinity mask' if lim['affinity'] == threads else 'os.cpu_count()')
     torch.set_num_threads(threads)
 
     def one(i):
@@ -152,13 +173,16 @@ def cpu_baseline(weights, imgs, map_hw, budget_s=20.0, max_threads=32):
         if dt + dt / frames > budget_s or frames >= 30:
             break
     return ({'value': frames / dt, 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
+             'core_limits': lim,
              'sample': '%d frames (after 1 warm-up frame of %.1f s) of the same 368x368 synthetic workload, batch 1 per '
                        'call, torch-CPU fp32 (oneDNN) network restatement + NumPy restatement of the reference '
-                       'post-process, %d threads of %d visible cores; %.1f s'
-                       % (frames, warm, threads, os.cpu_count() or 1, dt)}, results)
+                       'post-process (both pinned bit-exactly to the verbatim reference in the authoring container; the verbatim '
+                       'code cannot travel to this box -- its own timing: BASELINE.md section 3); %d threads = %s (os.cpu_count %s, '
+                       'affinity %s, cgroup quota %s); %.1f s'
+                       % (frames, warm, threads, bound_by, lim['os_cpu_count'], lim['affinity'], lim['cgroup_quota'], dt)}, results)
 
 
-def keypoint_match(eng, rec, results, weights_for_match, imgs_for_match, wino_labels=()):
+def keypoint_match(eng, rec, results, weights_for_match, imgs_for_match, plan=None):
     """The second half of the metric: the GPU path's key points against the oracle's on the frames the CPU baseline
     processed (same images, same weights).  Target (BASELINE.json): integer peak indices identical, scores within 1e-4.
     The two networks differ by ~1e-6 (summation order), so a peak exactly at a tie / threshold could legitimately flip."""
@@ -183,12 +207,17 @@ def keypoint_match(eng, rec, results, weights_for_match, imgs_for_match, wino_la
     # Winograd twin for the layers the batch ran on the Winograd kernel): bit-exact maps
     exact = None
     try:
+        if weights_for_match is None:
+            raise StopIteration
         from oracle import conv_fma_ref, postprocess_ref
         t0 = time.perf_counter()
         paf, heat = eng.get_maps()
-        epaf, eheat = conv_fma_ref.forward_fma(weights_for_match, postprocess_ref.preprocess(imgs_for_match[0]), wino=set(wino_labels))
-        exact = {'frames': 1, 'layers_as_winograd': len(set(wino_labels)), 'paf_and_heat_maps_bit_identical': bool(np.array_equal(paf[0], epaf[0]) and np.array_equal(heat[0], eheat[0])),
+        epaf, eheat = conv_fma_ref.forward_fma(weights_for_match, postprocess_ref.preprocess(imgs_for_match[0]), splitk=plan)
+        exact = {'frames': 1, 'layers_as_winograd': len(plan.wino), 'layers_with_unit_mode_tails': len(plan.wino_tails),
+                 'paf_and_heat_maps_bit_identical': bool(np.array_equal(paf[0], epaf[0]) and np.array_equal(heat[0], eheat[0])),
                  'oracle_seconds': time.perf_counter() - t0}
+    except StopIteration:
+        exact = None
     except Exception as e:          # the checker must never break the measurement
         exact = {'error': repr(e)}
     return {'frames_compared': n, 'frames_with_identical_peak_indices': peaks_same, 'max_abs_peak_score_diff': d_peak,
@@ -199,13 +228,15 @@ def keypoint_match(eng, rec, results, weights_for_match, imgs_for_match, wino_la
 
 
 def dominant_kernel(prof):
-    """(name, total_ms, launches, total_flop) of the kernel with the largest total time (by name, as rocprofv3 groups them)."""
+    """(HIP kernel, total_ms, launches, algorithmic FLOP, issued FLOP, labels) of the kernel with the largest total time -- grouped by
+    HIP kernel, as rocprofv3 groups them (the profile labels of one kernel differ by layer plan, e.g. ".../t2" and ".../t3")."""
     by_kernel = {}
     for p_ in prof:
-        e = by_kernel.setdefault(p_['kernel'], [0.0, 0, 0.0])
+        e = by_kernel.setdefault(rocprof_kernel(p_['kernel']), [0.0, 0, 0.0, 0.0, set()])
         e[0] += p_['total_ms']; e[1] += p_['launches']; e[2] += p_['flop_per_launch'] * p_['launches']
+        e[3] += p_.get('issued_flop_per_launch', p_['flop_per_launch']) * p_['launches']; e[4].add(p_['kernel'])
     name = max(by_kernel, key=lambda k: by_kernel[k][0])
-    return (name,) + tuple(by_kernel[name])
+    return (name,) + tuple(by_kernel[name][:4]) + (sorted(by_kernel[name][4]),)
 
 
 def main():
@@ -227,7 +258,13 @@ def main():
     elif torch.cuda.device_count() <= local_rank:
         raise SystemExit('bench.py: rank %d has no GPU (%d visible)' % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_group = world > 1 or a.force_gather
+    if use_group:
+        if world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            if 'MASTER_PORT' not in os.environ:
+                import socket
+                s_ = socket.socket(); s_.bind(('127.0.0.1', 0)); os.environ['MASTER_PORT'] = str(s_.getsockname()[1]); s_.close()
         if a.backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
         else:
@@ -261,7 +298,7 @@ def main():
 
     def step(ptr=None):
         eng.detect_batch(device_ptr=d_imgs.data_ptr() if ptr is None else ptr, shape=(B, S, S), map_h=map_s, map_w=map_s)
-        if world > 1 and a.backend == 'nccl':
+        if use_group and a.backend == 'nccl':
             # RCCL gather (the only collective) straight from the device-resident records, then one D2H copy on rank 0
             t = time.perf_counter()
             eng.results_layout()                      # stream sync: the records are final
@@ -307,6 +344,15 @@ def main():
         dist.all_gather(pr, torch.tensor([per_rank[0]], dtype=torch.float64, device=coll_dev))
         per_rank = [float(v.item()) for v in pr]
 
+    # evidence that N ranks on N distinct GPUs took part: every rank reports (rank, local_rank, device name / uuid / PCI bus id)
+    me = device_identity(torch, rank, local_rank)
+    rank_info = [me]
+    if world > 1:
+        rank_info = [None] * world
+        dist.all_gather_object(rank_info, me)
+        if a.backend == 'nccl':
+            ids = [r_['uuid'] or r_['pci_bus_id'] for r_ in rank_info]
+            assert len(set(ids)) == world, 'ranks share a GPU: %s' % ids
     prof = eng.profile() if profile else []
     prof_all = []
     if profile:
@@ -339,40 +385,57 @@ def main():
         if world > 1:
             out['per_rank_frames_per_s'] = per_rank
             out['gather_ms_per_step_rank0'] = gather_ms[0] / a.steps
+        out['backend'] = ('rccl (torch.distributed "nccl")' if a.backend == 'nccl' else a.backend) if use_group else None
+        out['records_path'] = ('dist.gather_device_records (RCCL gather from the device-resident records)' if use_group and a.backend == 'nccl'
+                               else 'dist.gather_records (host records, %s)' % a.backend if world > 1 else 'pmx_get_results (one D2H copy)')
+        out['ranks_seen'] = [r_['rank'] for r_ in rank_info]
+        out['devices'] = rank_info
         roof = None
         if prof:
-            # dominant kernel = the kernel (by name, as rocprofv3 groups them) with the largest total time in the
-            # timed region: the 7x7 conv, 25 launches per step (5 x Mconv1 with 185 input channels + 20 x Mconv2-5)
-            dom_name, total_ms, launches, total_flop = dominant_kernel(prof)
+            # dominant kernel = the HIP kernel (as rocprofv3 groups them) with the largest total time in the timed region: the 7x7
+            # Winograd kernel, 25 launches per step (5 x Mconv1 with 185 input channels + 20 x Mconv2-5; at batch 32 the launch of the
+            # full 32-tile runs -- the part-filled last block of every image is a separate unit-mode launch with its own entry)
+            dom_name, total_ms, launches, total_flop, total_issued, dom_labels = dominant_kernel(prof)
             if launches:
                 avg_ms = total_ms / launches
-                flop = total_flop / launches
-                ach = total_flop / (total_ms * 1e-3) / 1e12
+                ach_alg = total_flop / (total_ms * 1e-3) / 1e12
+                ach = total_issued / (total_ms * 1e-3) / 1e12
                 traffic, traffic_src = pmc_traffic(dom_name)
-                sub = [p_ for p_ in prof if p_['kernel'] == dom_name and p_['layer'].startswith(DOMINANT_LAYERS)]
-                sub_ach = (sum(p_['flop_per_launch'] * p_['launches'] for p_ in sub) / (sum(p_['total_ms'] for p_ in sub) * 1e-3) / 1e12
+                sub = [p_ for p_ in prof if rocprof_kernel(p_['kernel']) == dom_name and p_['layer'].startswith(DOMINANT_LAYERS)]
+                sub_ach = (sum(p_['issued_flop_per_launch'] * p_['launches'] for p_ in sub) / (sum(p_['total_ms'] for p_ in sub) * 1e-3) / 1e12
                            if sub else None)
-                roof = {'kernel': dom_name, 'bound': 'mfma', 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS,
-                        'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
-                        'traffic_source': traffic_src,
-                        'flop_per_launch': flop, 'avg_launch_ms': avg_ms, 'launches_timed': launches,
-                        'achieved_128ch_layers_only': sub_ach,
-                        'note': 'all launches of the 7x7 conv kernel at 46x46 (both branch groups per launch, B=%d): algorithmic '
-                                'FLOP of the 7x7 convolution (2 * 49 * cin * cout per output pixel; mean per launch) / mean launch '
-                                'duration, HIP events on the launch stream' % B}
-                if dom_name.startswith('conv_wino'):
-                    # the Winograd kernel executes fewer multiplies than the convolution it computes: 4 sub-kernels x 16 (taps 0..5 x
-                    # 0..5) + 4 one-dimensional sub-kernels x 8 (row 6, column 6) + 4 (tap (6, 6)) = 100 matrix products per 2x2
-                    # output tile and channel pair instead of 7 * 7 * 4 = 196
-                    ex = WINO7_EXECUTED_FRACTION if dom_name.endswith('7x7') else WINO3_EXECUTED_FRACTION
-                    roof['executed_flop_fraction'] = ex
-                    roof['mfma_utilisation'] = ach * ex / FP32_MFMA_PEAK_TFLOPS
-                    roof['note'] += ('.  The kernel is fp32 Winograd F(2x2,3x3): it ISSUES %.3f of the algorithmic FLOP to the matrix '
-                                     'cores, so `frac` (algorithmic, as the contract defines it) can exceed 1; `mfma_utilisation` = '
-                                     'issued MFMA FLOP / time / peak is the hardware-side fraction' % ex)
+                roof = {'kernel': dom_name, 'profile_labels': dom_labels, 'bound': 'mfma', 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS,
+                        'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_src,
+                        'issued_flop_per_launch': total_issued / launches, 'flop_per_launch': total_flop / launches,
+                        'executed_flop_fraction': total_issued / total_flop if total_flop else None,
+                        'algorithmic_achieved': ach_alg, 'algorithmic_frac': ach_alg / FP32_MFMA_PEAK_TFLOPS,
+                        'avg_launch_ms': avg_ms, 'launches_timed': launches, 'achieved_128ch_layers_only': sub_ach,
+                        'note': 'all launches of the dominant kernel in the timed region (B=%d, both branch groups per launch), HIP events on '
+                                'the launch stream.  `achieved` / `frac` = FLOP the kernel ISSUES to the matrix cores for real outputs '
+                                '(per-launch figures from the engine profile: pmx_profile_issued) / mean launch duration / dense fp32-MFMA '
+                                'peak: <= 1 by construction.  `algorithmic_*` = the same with the FLOP of the convolution it computes '
+                                '(2 * k * k * cin * cout per output pixel); it exceeds the issued figure where the kernel is Winograd '
+                                'F(2x2,3x3) (7x7: 100 of 196 products per output tile and channel pair, 3x3: 16 of 36)' % B}
             conv_ms = sum(p['total_ms'] for p in prof_all if p['kernel'].startswith('conv'))
             pp_ms = sum(p['total_ms'] for p in prof_all if p['kernel'].startswith('pp_'))
             out['kernel_time_ms_per_step'] = {'conv': conv_ms, 'postprocess': pp_ms, 'note': 'one extra untimed step with every launch instrumented'}
+            # the same pair for the whole step: issued / algorithmic FLOP of every launch of one step (untimed, fully instrumented step
+            # gives the launch plan) over the TIMED step duration
+            step_issued = sum(p['issued_flop_per_launch'] * p['launches'] for p in prof_all)
+            step_alg = sum(p['flop_per_launch'] * p['launches'] for p in prof_all)
+            by_form = {}
+            for p in prof_all:
+                if p['flop_per_launch'] > 0:
+                    e = by_form.setdefault(rocprof_kernel(p['kernel']), [0, 0.0])
+                    e[0] += p['launches']; e[1] += p['total_ms']
+            out['step_roofline'] = {'bound': 'mfma', 'achieved': step_issued / (ms_per_step * 1e-3) / 1e12, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                    'frac': step_issued / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                    'algorithmic_achieved': step_alg / (ms_per_step * 1e-3) / 1e12,
+                                    'algorithmic_frac': step_alg / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                    'issued_flop_per_step': step_issued, 'flop_per_step': step_alg,
+                                    'launch_plan': {k: {'launches': v[0], 'ms': v[1]} for k, v in sorted(by_form.items())},
+                                    'note': 'whole step (preprocess + 92 layers + post-process + record copy): issued / algorithmic conv FLOP of '
+                                            'one step / timed ms_per_step / peak'}
             if a.dump_profile:
                 with open(a.dump_profile, 'w') as f:
                     json.dump({'batch': B, 'steps': 1, 'entries': prof_all}, f, indent=1)
@@ -387,15 +450,42 @@ def main():
             rec = eng.results()                                                                             # for keypoint_match
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'], oracle_results = cpu_baseline(weights, imgs, (map_s, map_s), a.cpu_budget)
-            out['keypoint_match'] = keypoint_match(eng, rec, oracle_results, weights, imgs,
-                                                   {p_['layer'] for p_ in prof_all if p_['kernel'].startswith('conv_wino')})
+            from oracle import conv_fma_ref
+            out['keypoint_match'] = keypoint_match(eng, rec, oracle_results, weights, imgs, conv_fma_ref.splitk_plan(prof_all))
+            if not a.no_extras:
+                # the opt-in bf16x3 mode against the same CPU oracle frames (it is compared with the fp32 path above; this is the
+                # figure the north_star tolerance applies to)
+                eng.set_option('precision', 1)
+                try:
+                    eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(B, S, S), map_h=map_s, map_w=map_s)
+                    out['bf16x3']['keypoint_match_vs_cpu_oracle'] = keypoint_match(eng, eng.results(), oracle_results, None, None)
+                finally:
+                    eng.set_option('precision', 0)
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if use_group:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def device_identity(torch, rank, local_rank):
+    pr = torch.cuda.get_device_properties(local_rank)
+    uuid = getattr(pr, 'uuid', None)
+    bus = None
+    try:
+        bus = '%04x:%02x:%02x' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+    except Exception:
+        try:        # older torch builds: ask the HIP runtime
+            import ctypes
+            buf = ctypes.create_string_buffer(64)
+            if ctypes.CDLL('libamdhip64.so').hipDeviceGetPCIBusId(buf, 64, int(local_rank)) == 0:
+                bus = buf.value.decode()
+        except Exception:
+            pass
+    return {'rank': rank, 'local_rank': local_rank, 'name': pr.name, 'uuid': str(uuid) if uuid is not None else None, 'pci_bus_id': bus,
+            'compute_units': getattr(pr, 'multi_processor_count', None)}
 
 
 def upload_inclusive(eng, torch, dev, imgs, steps, map_s):
@@ -531,9 +621,10 @@ def single_image(eng, d_imgs, S, map_s):
     one_ms = (time.perf_counter() - t1) / n * 1e3
     flop = FLOP_PER_FRAME * (S * S / (368.0 * 368.0))
     out = {'ms_per_call': one_ms, 'frames_per_s': 1e3 / one_ms, 'calls_timed': n,
-           'roofline': {'bound': 'mfma', 'achieved': flop / (one_ms * 1e-3) / 1e12, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': flop / (one_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                        'note': 'whole call (network + post-process + result copy) against the fp32-MFMA peak'}}
+           'roofline': {'bound': 'mfma', 'algorithmic_achieved': flop / (one_ms * 1e-3) / 1e12, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'algorithmic_frac': flop / (one_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                        'note': 'whole call (network + post-process + result copy), algorithmic FLOP against the fp32-MFMA peak; the issued '
+                                'fraction of the dominant kernel is in roofline_dominant_kernel'}}
     eng.profile_reset()
     eng.profile_enable(True)
     for _ in range(10):
@@ -543,11 +634,12 @@ def single_image(eng, d_imgs, S, map_s):
     eng.profile_enable(False)
     eng.profile_reset()
     if prof:
-        name, total_ms, launches, total_flop = dominant_kernel(prof)
+        name, total_ms, launches, total_flop, total_issued, labels = dominant_kernel(prof)
         if launches and total_ms > 0:
-            ach = total_flop / (total_ms * 1e-3) / 1e12
-            out['roofline_dominant_kernel'] = {'kernel': name, 'bound': 'mfma', 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS,
+            ach = total_issued / (total_ms * 1e-3) / 1e12
+            out['roofline_dominant_kernel'] = {'kernel': name, 'profile_labels': labels, 'bound': 'mfma', 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS,
                                                'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS,
+                                               'algorithmic_frac': total_flop / (total_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                                                'avg_launch_ms': total_ms / launches, 'launches_timed': launches}
         out['kernel_ms_per_call'] = sum(p['total_ms'] for p in prof) / 10
     return out

@@ -29,6 +29,8 @@
 //                    128 B contiguous per half-wave).
 //   grid             x = tiles * batch, y = cout_pad / BN, z = group (the PAF and heat-map branches of a stage
 //                    run as the two groups of one launch).
+#include <atomic>
+#include <mutex>
 #include <type_traits>
 #include "pmx_common.h"
 
@@ -2064,6 +2066,7 @@ static int launch_c3(const ConvArgs& a0, int groups, hipStream_t stream)
 
 // dynamic LDS above 64 KB must be allowed per kernel AND per device (a process may hold contexts on several GPUs)
 constexpr int PMX_MAX_DEVICES = 64;
+// (`done` is a plain flag per kernel and device: two host threads racing here both call hipFuncSetAttribute with the same value -- idempotent)
 static int conv_allow_big_lds(const void* kern, bool (&done)[PMX_MAX_DEVICES])
 {
     int dev = 0;
@@ -2148,9 +2151,9 @@ int conv_bf16x3_twin(int v)
 int conv_num_variants() { return (int)(sizeof(g_variants) / sizeof(g_variants[0])); }
 const ConvVariant& conv_variant(int idx) { return g_variants[idx]; }
 
-static int g_num_cus = 256;
-void conv_set_num_cus(int n) { if (n > 0) g_num_cus = n; }
-int conv_num_cus() { return g_num_cus; }
+static std::atomic<int> g_num_cus{256};       // process-wide (contexts on different devices of one process are expected to be the same part)
+void conv_set_num_cus(int n) { if (n > 0) g_num_cus.store(n, std::memory_order_relaxed); }
+int conv_num_cus() { return g_num_cus.load(std::memory_order_relaxed); }
 
 // gen: 1 = v1 kernels everywhere, 5 = v5 for 3x3 / 7x7, 6 (default) = v6 / c3 where they apply, else v5
 int conv_pick_variant(int ks, int cout, int H, int W, int B, int forced, int gen, int pool, int cin, int bf16x3)
@@ -2321,11 +2324,17 @@ SplitPlan conv_pick_ksplit(int variant, int H, int W, int B, int groups, int cou
                 return make(sizes);
             }
     }
-    // one answer per launch shape
+    // one answer per launch shape (process-wide: contexts of several host threads share it -- the header allows one context per
+    // thread and ctypes releases the GIL -- hence the lock; the simulation below runs outside it, two threads may both compute a
+    // missing entry, the results are equal)
     static std::map<std::vector<long>, SplitPlan> cache;
+    static std::mutex cache_mu;
     const std::vector<long> key = {variant, H, W, B, groups, cout_pad, nch, ncu};
-    auto it = cache.find(key);
-    if (it != cache.end()) return it->second;
+    {
+        std::lock_guard<std::mutex> lk(cache_mu);
+        auto it = cache.find(key);
+        if (it != cache.end()) return it->second;
+    }
     // per-wave MFMAs of one chunk in this block shape (32x32x2 MFMA = 64 cycles), microseconds at 2.4 GHz, ~91 % pipe rate
     const int mt_nt = ((v.th * v.tw + 31) / 32) * (v.bn / 32) / 4;
     const double t_chunk = (double)v.ks * v.ks * 8 * mt_nt * 64 / 2400.0 / 0.91;
@@ -2349,7 +2358,10 @@ SplitPlan conv_pick_ksplit(int variant, int H, int W, int B, int groups, int cou
             if (t < best * 0.97 - 1e-9 && (best_p.S == 1 || t < best - 1e-9)) { best = t; best_p = make(sizes); }
         }
     }
-    cache[key] = best_p;
+    {
+        std::lock_guard<std::mutex> lk(cache_mu);
+        cache[key] = best_p;
+    }
     return best_p;
 }
 

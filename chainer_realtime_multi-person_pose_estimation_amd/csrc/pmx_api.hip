@@ -220,7 +220,9 @@ struct ProfEntry {
     std::string name;
     double total_ms = 0;
     int64_t launches = 0;
-    double flops = 0, bytes = 0;   // per launch
+    double flops = 0, bytes = 0;   // per launch: algorithmic FLOP of the convolution, compulsory bytes
+    double issued = 0;             // per launch: FLOP the kernel issues to the matrix cores for real outputs (Winograd forms: 16/36, 100/196 of
+                                   // the algorithmic figure; direct kernels: all of it; tile padding is not counted)
 };
 struct ProfPending { int entry; hipEvent_t e0, e1; };
 
@@ -309,14 +311,14 @@ struct pmx_ctx {
     int prof_open = -1;
 };
 
-static int prof_begin(pmx_ctx* c, const std::string& name, double flops, double bytes)
+static int prof_begin(pmx_ctx* c, const std::string& name, double flops, double bytes, double issued = -1.0)
 {
     if (!c->prof_on) return PMX_OK;
     int idx;
     auto it = c->prof_index.find(name);
     if (it == c->prof_index.end()) {
         idx = (int)c->prof.size();
-        ProfEntry e; e.name = name; e.flops = flops; e.bytes = bytes;
+        ProfEntry e; e.name = name; e.flops = flops; e.bytes = bytes; e.issued = issued < 0 ? flops : issued;
         c->prof.push_back(e);
         c->prof_index[name] = idx;
     } else idx = it->second;
@@ -587,18 +589,10 @@ extern "C" int pmx_set_layer(pmx_ctx* c, const char* name, const float* w, const
     if (!L.d_b) PMX_HIP(hipMalloc((void**)&L.d_b, bp.size() * sizeof(float)));
     PMX_HIP(hipMemcpy(L.d_w, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice));
     PMX_HIP(hipMemcpy(L.d_b, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (ks > 1) {       // the layers the bf16x3 kernels can take (3x3 / 7x7)
-        std::vector<uint16_t> w3;
-        pack_bf16x3(wp, ks * ks, (int)cmap.size() / CK, cpad, w3);
-        if (!L.d_w3) PMX_HIP(hipMalloc(&L.d_w3, w3.size() * sizeof(uint16_t)));
-        PMX_HIP(hipMemcpy(L.d_w3, w3.data(), w3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    }
-    if (wino_eligible(ks, (int)cmap.size(), cpad)) {
-        std::vector<float> ww;
-        pack_wino(wp, ks, (int)cmap.size() / CK, cpad, ww);
-        if (!L.d_ww) PMX_HIP(hipMalloc((void**)&L.d_ww, ww.size() * sizeof(float)));
-        PMX_HIP(hipMemcpy(L.d_ww, ww.data(), ww.size() * sizeof(float), hipMemcpyHostToDevice));
-    }
+    // the bf16x3 pack (1.5x the fp32 weights) and the Winograd pack (16/9 x for 3x3, 81/49 x for 7x7) are derived from the packed fp32
+    // weights on first use (ensure_*_pack): a context that never runs those kernels neither holds nor computes them
+    if (L.d_w3) { (void)hipFree(L.d_w3); L.d_w3 = nullptr; }
+    if (L.d_ww) { (void)hipFree(L.d_ww); L.d_ww = nullptr; }
     L.set = true; L.cin = cin; L.cout = cout; L.ks = ks;
     L.cin_pad = (int)cmap.size(); L.cout_pad = cpad; L.nch = L.cin_pad / CK;
     return PMX_OK;
@@ -615,6 +609,35 @@ extern "C" int pmx_weights_missing(pmx_ctx* c, int* n)
 
 // ------------------------------------------------------------------------------------------ forward
 struct ConvIO { const float* in; int lda; float* out; int ldc; };
+
+// derived weight packs, built from the device-resident packed fp32 weights when a kernel first needs them
+static int fetch_packed(const PackedLayer& L, std::vector<float>& wp)
+{
+    wp.resize((size_t)L.ks * L.ks * L.nch * L.cout_pad * CK);
+    PMX_HIP(hipMemcpy(wp.data(), L.d_w, wp.size() * sizeof(float), hipMemcpyDeviceToHost));
+    return PMX_OK;
+}
+static int ensure_wino_pack(PackedLayer& L)
+{
+    if (L.d_ww) return PMX_OK;
+    std::vector<float> wp, ww;
+    if (int rc = fetch_packed(L, wp)) return rc;
+    pack_wino(wp, L.ks, L.nch, L.cout_pad, ww);
+    PMX_HIP(hipMalloc((void**)&L.d_ww, ww.size() * sizeof(float)));
+    PMX_HIP(hipMemcpy(L.d_ww, ww.data(), ww.size() * sizeof(float), hipMemcpyHostToDevice));
+    return PMX_OK;
+}
+static int ensure_bf16x3_pack(PackedLayer& L)
+{
+    if (L.d_w3) return PMX_OK;
+    std::vector<float> wp;
+    std::vector<uint16_t> w3;
+    if (int rc = fetch_packed(L, wp)) return rc;
+    pack_bf16x3(wp, L.ks * L.ks, L.nch, L.cout_pad, w3);
+    PMX_HIP(hipMalloc(&L.d_w3, w3.size() * sizeof(uint16_t)));
+    PMX_HIP(hipMemcpy(L.d_w3, w3.data(), w3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return PMX_OK;
+}
 
 // Launches one convolution (1 or 2 groups) whose ConvArgs describe the FINAL result (real bias, ReLU, pool, output slices).
 // With S > 1 K slices the slice blocks write raw partial sums into the context's slab scratch and conv_splitk_reduce
@@ -701,12 +724,19 @@ static int launch_wino_units(pmx_ctx* c, const ConvArgs& a0, int ks, int groups,
 // last block of every image in unit mode (S units of g pass-1 chunks (+ row 6, column 6, tap (6, 6)) writing compact slabs) + the combine
 // kernel.  B = 32 at 46 x 46: 16 x 32 x 2 = 1024 full blocks = exactly 4 rounds of the 256 CUs, then 64 x 7 short unit blocks, instead of
 // 5 rounds of 18 x 32 x 2 rectangles.  tail_g = 0: every block (also the part-filled one) in the plain launch.
-static int launch_wino_run(pmx_ctx* c, const ConvArgs& a0, int ks, int groups, int tail_g)
+struct WinoProf { std::string name; double flops, bytes, issued; };      // profile entry of the layer (null: not profiled)
+static int launch_wino_run(pmx_ctx* c, const ConvArgs& a0, int ks, int groups, int tail_g, const WinoProf* pf = nullptr)
 {
     const int ntiles = PMX_WINO_RUN_TX * ((a0.H + 1) / 2), nblk = (ntiles + PMX_WINO_RUN_TILES - 1) / PMX_WINO_RUN_TILES, nfull = ntiles / PMX_WINO_RUN_TILES;
     ConvArgs a = a0;
     a.ksplit = 1; a.slab_stride = 0; a.run_j0 = 0; a.run_nb = tail_g ? nfull : nblk;
-    int rc = conv_wino_run_launch(a, ks, groups, c->stream);
+    // profile: the three launches of a layer with a unit-mode tail are separate entries -- "<layer>|<kernel>" (the full blocks; carries
+    // their share of the FLOP), "...:units", "...:combine" -- so that each can be held against its own rocprofv3 kernel row
+    const double share = tail_g ? (double)nfull * PMX_WINO_RUN_TILES / ntiles : 1.0;
+    int rc;
+    if (pf && (rc = prof_begin(c, pf->name, pf->flops * share, pf->bytes, pf->issued * share))) return rc;
+    rc = conv_wino_run_launch(a, ks, groups, c->stream);
+    if (pf && !rc) rc = prof_end(c);
     if (rc || !tail_g) return rc;
     PMX_CHECK(nfull >= 1 && nfull < nblk, PMX_ERR_INVALID, "winograd tail: no part-filled block (%d tiles)", ntiles);
     const int S = (a0.nch + tail_g - 1) / tail_g + (ks == 7 ? 3 : 0);
@@ -736,8 +766,12 @@ static int launch_wino_run(pmx_ctx* c, const ConvArgs& a0, int ks, int groups, i
     a.run_j0 = nfull; a.run_nb = 1;
     r.slab_stride = (long long)slab; r.S = S; r.B = a0.B; r.H = a0.H; r.W = a0.W; r.ld_slab = a0.cout_pad; r.ldc = a0.ldc;
     r.relu = a0.relu; r.run_j0 = nfull; r.run_nb = 1;
+    if (pf && (rc = prof_begin(c, pf->name + ":units", pf->flops * (1.0 - share), 0.0, pf->issued * (1.0 - share)))) return rc;
     if ((rc = conv_wino_run_launch(a, ks, groups, c->stream))) return rc;
-    return conv_wino_tail_reduce(r, groups, c->stream);
+    if (pf && (rc = prof_end(c))) return rc;
+    if (pf && (rc = prof_begin(c, pf->name + ":combine", 0.0, 0.0, 0.0))) return rc;
+    if ((rc = conv_wino_tail_reduce(r, groups, c->stream))) return rc;
+    return pf ? prof_end(c) : PMX_OK;
 }
 
 // Which form a 3x3 / 7x7 layer takes: 0 = direct kernels (+ split-K), 1 = the Winograd kernel, 2 = the Winograd kernel in unit mode
@@ -746,6 +780,34 @@ static int launch_wino_run(pmx_ctx* c, const ConvArgs& a0, int ks, int groups, i
 // efficiency) plus the slab traffic of the combine kernel; the direct kernels win when neither fills the chip
 // (tools/wino_batch_sweep.py).  A forced split-K option (never, n slices, an explicit plan) is a statement about the direct kernels:
 // no unit mode then.
+// Measured block times of the Winograd kernel (MI355X, one block per CU), microseconds per 32-channel chunk of a plain block / per phase of
+// 128 MFMAs per wave, and the fixed cost of a unit block (prologue: first halo + weights exposed; epilogue: output transform, slab store)
+static const double WINO_T7_CHUNK_US = 50.0, WINO_T3_CHUNK_US = 9.3, WINO_PHASE_US = 4.0, WINO_UNIT_FIXED_US = 8.0;
+
+// Makespan (microseconds) of the unit-mode launch of `nblk` part-filled blocks (images x 128-channel blocks) cut into pass-1 units of g chunks
+// (+ row 6, column 6, tap (6, 6) for 7x7): blocks are dispatched unit by unit (blockIdx.z = unit * groups + group) to the CU that frees first
+static double wino_tail_makespan(int ks, int nch, int g, long long nblk, int ncu)
+{
+    std::vector<double> unit_us;
+    for (int c = 0; c < nch; c += g) unit_us.push_back(std::min(g, nch - c) * (ks == 7 ? 8.0 : 2.0) * WINO_PHASE_US + WINO_UNIT_FIXED_US);
+    if (ks == 7) {
+        unit_us.push_back(nch * 2.0 * WINO_PHASE_US + WINO_UNIT_FIXED_US);      // row 6
+        unit_us.push_back(nch * 2.0 * WINO_PHASE_US + WINO_UNIT_FIXED_US);      // column 6
+        unit_us.push_back(nch * 0.5 * WINO_PHASE_US + WINO_UNIT_FIXED_US);      // tap (6, 6)
+    }
+    std::vector<double> cu((size_t)ncu, 0.0);        // min-heap of the CUs' free times
+    auto cmp = [](double a, double b) { return a > b; };
+    double end = 0.0;
+    for (double t : unit_us)
+        for (long long b = 0; b < nblk; ++b) {
+            std::pop_heap(cu.begin(), cu.end(), cmp);
+            cu.back() += t;
+            end = std::max(end, cu.back());
+            std::push_heap(cu.begin(), cu.end(), cmp);
+        }
+    return end;
+}
+
 // *run = 1: mode 1 in the run geometry (46-pixel-wide maps, no pool); *tail_g > 0: its part-filled last blocks in unit mode, g chunks per
 // pass-1 unit (launch_wino_run)
 static int wino_mode(const pmx_ctx* c, int ks, int cin_pad, int cout_pad, int cout, int ldc, int images, int H, int W, int pool, int* unit_g,
@@ -778,14 +840,23 @@ static int wino_mode(const pmx_ctx* c, int ks, int cin_pad, int cout_pad, int co
     double plain_cost = (double)rounds;
     int tg = 0;
     if (tail_ok) {
-        // unit blocks of the tail: the longest unit (g pass-1 chunks of 1024 (7x7) / 256 (3x3) MFMAs per wave, or row 6 / column 6 of all
-        // chunks at 256 per chunk) relative to a whole block, + ~10 us of block prologue / epilogue / slab store per unit round
-        const double mf_block = nch * (ks == 7 ? 1600.0 : 256.0), mf_unit = ks == 7 ? fmax(g * 1024.0, nch * 256.0) : g * 256.0;
-        const double t_block = nch * (ks == 7 ? 52e-6 : 18.5e-6);
-        const long long main_rounds = ((long long)nfull * images * nb + ncu - 1) / ncu, tail_rounds = ((long long)images * nb * S + ncu - 1) / ncu;
-        const double cost = (double)main_rounds + tail_rounds * (mf_unit / mf_block + 10e-6 / t_block) + 8e-6 / t_block;      // + two more launches
-        if (c->opt_wino_tail == 1 || cost < plain_cost) { plain_cost = cost; tg = g; }
-        if (tg && c->opt_wino_tail_g > 0 && c->opt_wino_tail_g <= nch && (nch + c->opt_wino_tail_g - 1) / c->opt_wino_tail_g + extra >= 2) tg = c->opt_wino_tail_g;
+        // the full blocks as whole rounds + the tail as unit blocks (best g by a dispatch simulation) + two more launches and the combine
+        const double t_block = nch * (ks == 7 ? WINO_T7_CHUNK_US : WINO_T3_CHUNK_US);
+        const long long main_rounds = ((long long)nfull * images * nb + ncu - 1) / ncu;
+        double best = 1e30;
+        int best_g = 0;
+        for (int gg = 1; gg <= nch; ++gg) {
+            const int SS = (nch + gg - 1) / gg + extra;
+            if (SS < 2 || SS > 8 || (gg > 1 && (nch + gg - 2) / (gg - 1) + extra == SS)) continue;      // (same unit count as a smaller g: skip)
+            const double t = wino_tail_makespan(ks, nch, gg, (long long)images * nb, (int)ncu) + 2.0 * SS;   // + the combine's slab reads
+            if (t < best) { best = t; best_g = gg; }
+        }
+        if (c->opt_wino_tail_g > 0 && c->opt_wino_tail_g <= nch) {
+            const int SS = (nch + c->opt_wino_tail_g - 1) / c->opt_wino_tail_g + extra;
+            if (SS >= 2 && SS <= 8) { best_g = c->opt_wino_tail_g; best = wino_tail_makespan(ks, nch, best_g, (long long)images * nb, (int)ncu) + 2.0 * SS; }
+        }
+        const double cost = (double)main_rounds + (best + 10.0) / t_block;
+        if (best_g && (c->opt_wino_tail == 1 || cost < plain_cost)) { plain_cost = cost; tg = best_g; }
     }
     if (g) {
         const double t_block = nch * (ks == 7 ? 52e-6 : 18.5e-6);                 // one plain block (measured), seconds
@@ -817,26 +888,30 @@ static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float
     }
     a.B = B; a.H = H; a.W = W; a.lda = lda; a.ldc = ldc; a.nch = L0.nch; a.cout_pad = L0.cout_pad;
     a.relu = relu; a.pool = pool;
+    int rc;
     int v = conv_pick_variant(L0.ks, L0.cout_pad, H, W, B * groups, c->opt_force[L0.ks], c->opt_kernel_gen, pool, groups == 1 ? L0.cin : 9999,
-                              c->opt_precision == 1 && L0.d_w3 != nullptr);
-    if (c->opt_precision == 1 && conv_bf16x3_twin(v) >= 0 && L0.d_w3 && (groups == 1 || c->layers[li1].d_w3)) {
+                              c->opt_precision == 1 && L0.ks > 1);
+    if (c->opt_precision == 1 && L0.ks > 1 && conv_bf16x3_twin(v) >= 0) {
+        if ((rc = ensure_bf16x3_pack(c->layers[li0])) || (groups == 2 && (rc = ensure_bf16x3_pack(c->layers[li1])))) return rc;
         v = conv_bf16x3_twin(v);
         a.g[0].w = (const float*)L0.d_w3;
         if (groups == 2) a.g[1].w = (const float*)c->layers[li1].d_w3;
     }
-    int rc;
     const bool prof_this = c->prof_on == 1 || (c->prof_on == 2 && L0.ks == 7);
-    const bool wino_ok = L0.d_ww && (groups == 1 || (c->layers[li1].d_ww && c->layers[li1].cout == L0.cout));
+    const bool wino_ok = wino_eligible(L0.ks, L0.cin_pad, L0.cout_pad) &&
+                         (groups == 1 || (wino_eligible(c->layers[li1].ks, c->layers[li1].cin_pad, c->layers[li1].cout_pad) && c->layers[li1].cout == L0.cout));
     int ug = 0, wrun = 0, wtail = 0;
     const int wmode = wino_ok ? wino_mode(c, L0.ks, L0.cin_pad, L0.cout_pad, L0.cout, ldc, B * groups, H, W, pool, &ug, &wrun, &wtail) : 0;
     const bool wino_plain = wmode == 1;
+    if (wmode && ((rc = ensure_wino_pack(c->layers[li0])) || (groups == 2 && (rc = ensure_wino_pack(c->layers[li1]))))) return rc;
     if (wmode == 2) {
         a.nch = L0.cin_pad / 32;
         a.g[0].w = L0.d_ww;
         if (groups == 2) a.g[1].w = c->layers[li1].d_ww;
         if (prof_this) {
             const double bytes = 4.0 * B * H * W * ((double)L0.cin * groups + (double)L0.cout * groups);
-            if ((rc = prof_begin(c, std::string(label) + (L0.ks == 7 ? "|conv_wino_f2x2_7x7/u" : "|conv_wino_f2x2_3x3/u") + std::to_string(ug), flops, bytes))) return rc;
+            if ((rc = prof_begin(c, std::string(label) + (L0.ks == 7 ? "|conv_wino_f2x2_7x7/u" : "|conv_wino_f2x2_3x3/u") + std::to_string(ug), flops, bytes,
+                                 flops * (L0.ks == 7 ? 100.0 / 196.0 : 16.0 / 36.0)))) return rc;
         }
         if ((rc = launch_wino_units(c, a, L0.ks, groups, ug))) return rc;
         return prof_this ? prof_end(c) : PMX_OK;
@@ -851,7 +926,13 @@ static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float
             std::string kn = L0.ks == 7 ? "|conv_wino_f2x2_7x7" : "|conv_wino_f2x2_3x3";
             if (wrun) kn += "r";
             if (wtail) kn += "/t" + std::to_string(wtail);
-            if ((rc = prof_begin(c, std::string(label) + kn, flops, bytes))) return rc;
+            // products per 2 x 2 output tile and channel pair: 3x3: 16 of 36; 7x7: 4 x 16 + 4 x 8 + 4 = 100 of 196
+            const double issued = flops * (L0.ks == 7 ? 100.0 / 196.0 : 16.0 / 36.0);
+            if (wrun) {
+                const WinoProf pf{std::string(label) + kn, flops, bytes, issued};
+                return launch_wino_run(c, a, L0.ks, groups, wtail, &pf);
+            }
+            if ((rc = prof_begin(c, std::string(label) + kn, flops, bytes, issued))) return rc;
         }
         if ((rc = wrun ? launch_wino_run(c, a, L0.ks, groups, wtail) : conv_wino_launch(a, L0.ks, groups, c->stream))) return rc;
         return prof_this ? prof_end(c) : PMX_OK;
@@ -1349,6 +1430,28 @@ static int next_pow2(long long v)
 // (peaks: to the largest per-joint count seen; candidates: device-memory store sized to the largest accepted count; subsets:
 // doubled), reallocate the post-process buffers and run the post-process of the batch again on the same network output --
 // until every image fits.  After this the records on the device are final.
+// Re-size the post-process buffers: the new set is allocated FIRST and swapped in only when every allocation succeeded -- on failure (out
+// of memory on a crowd image, an absurd user capacity) the context keeps its old buffers and capacities and stays usable
+static int pp_realloc(pmx_ctx* c, int cap_pk, int cap_sub, int cap_cand, int cap_ppl)
+{
+    const PPBuffers old = c->pp;
+    PPBuffers fresh{};
+    fresh.cap_pk = cap_pk; fresh.cap_sub = cap_sub; fresh.cap_cand = cap_cand; fresh.cap_ppl = cap_ppl;
+    fresh.smoothed = old.smoothed;               // (owned by the context, sized separately)
+    c->pp = fresh;
+    const int rc = pp_alloc(c);
+    if (rc) {
+        pp_free(c);                              // whatever part of the new set exists
+        c->pp = old;
+        return rc;
+    }
+    const PPBuffers neu = c->pp;
+    c->pp = old;
+    pp_free(c);
+    c->pp = neu;
+    return PMX_OK;
+}
+
 static int pp_finalize(pmx_ctx* c)
 {
     if (!c->pp_valid || c->pp_final) return PMX_OK;
@@ -1387,10 +1490,8 @@ static int pp_finalize(pmx_ctx* c)
         }
         PMX_CHECK(cap_pk != c->pp.cap_pk || cap_sub != c->pp.cap_sub || cap_cand != c->pp.cap_cand || cap_ppl != c->pp.cap_ppl,
                   PMX_ERR_STATE, "post-process reports a capacity overflow (0x%x) that growing does not resolve", bits);
-        pp_free(c);
-        c->pp.cap_pk = cap_pk; c->pp.cap_sub = cap_sub; c->pp.cap_cand = cap_cand; c->pp.cap_ppl = cap_ppl;
-        int rc = pp_alloc(c);
-        if (rc) { c->pp_valid = false; return rc; }
+        int rc = pp_realloc(c, cap_pk, cap_sub, cap_cand, cap_ppl);
+        if (rc) { c->pp_valid = false; return rc; }      // (old buffers and capacities stay in place; this batch has no results)
         c->pp_regrown += 1;
         rc = pp_launch(c->pp_maps, c->tab, c->pp, B, c->pp_h, c->pp_w, c->pp_img_len, c->pp_has_scale ? c->d_scale : nullptr,
                        c->opt_keep_smoothed && c->pp.smoothed, c->stream, nullptr, nullptr);
@@ -1404,15 +1505,15 @@ extern "C" int pmx_set_capacities(pmx_ctx* c, int peaks_per_joint, int subsets, 
 {
     PMX_CHECK(c, PMX_ERR_INVALID, "null ctx");
     PMX_CHECK(peaks_per_joint >= 0 && subsets >= 0 && people >= 0 && candidates >= 0, PMX_ERR_INVALID, "pmx_set_capacities: negative capacity");
+    const int lim = 1 << 20;
+    PMX_CHECK(peaks_per_joint <= lim && subsets <= lim && people <= lim && candidates <= (1 << 24), PMX_ERR_INVALID, "pmx_set_capacities: capacity too large");
+    const int cap_pk = peaks_per_joint ? peaks_per_joint : c->pp.cap_pk, cap_sub = subsets ? subsets : c->pp.cap_sub;
+    const int cap_ppl = people ? people : c->pp.cap_ppl;
+    PMX_CHECK(cap_ppl <= cap_sub, PMX_ERR_INVALID, "pmx_set_capacities: people (%d) must not exceed subsets (%d)", cap_ppl, cap_sub);
     PMX_DEV(c);
     PMX_HIP(hipStreamSynchronize(c->stream));
-    pp_free(c);
-    if (peaks_per_joint) c->pp.cap_pk = peaks_per_joint;
-    if (subsets) c->pp.cap_sub = subsets;
-    if (people) c->pp.cap_ppl = people;
-    c->pp.cap_cand = candidates;
     c->pp_valid = false;
-    return pp_alloc(c);
+    return pp_realloc(c, cap_pk, cap_sub, candidates, cap_ppl);
 }
 
 extern "C" int pmx_get_capacities(pmx_ctx* c, int* peaks_per_joint, int* subsets, int* people, int* candidates)
@@ -1694,6 +1795,9 @@ extern "C" int pmx_get_results(pmx_ctx* c, int B, void* out, size_t out_bytes)
 extern "C" int pmx_results_device_ptr(pmx_ctx* c, void** p, size_t* bytes)
 {
     PMX_CHECK(c && p && bytes, PMX_ERR_INVALID, "null arg");
+    PMX_CHECK(c->pp_valid, PMX_ERR_STATE, "no post-process results yet");
+    if (hipSetDevice(c->device) != hipSuccess) { pmx_set_error("hipSetDevice failed"); return PMX_ERR_HIP; }
+    if (int rc = pp_finalize(c)) return rc;      // never hand out records that still carry capacity-overflow bits / a layout about to change
     *p = c->pp.results;
     *bytes = c->pp.rec_bytes;
     return PMX_OK;
@@ -1843,6 +1947,13 @@ extern "C" int pmx_profile_count(pmx_ctx* c, int* n)
     *n = (int)c->prof.size();
     return rc;
 }
+extern "C" int pmx_profile_issued(pmx_ctx* c, int i, double* issued_flop)
+{
+    PMX_CHECK(c && issued_flop && i >= 0 && i < (int)c->prof.size(), PMX_ERR_INVALID, "bad profile index");
+    *issued_flop = c->prof[i].issued;
+    return PMX_OK;
+}
+
 extern "C" int pmx_profile_entry(pmx_ctx* c, int i, char* name, int cap, double* total_ms, int64_t* launches, double* flops, double* bytes)
 {
     PMX_CHECK(c && i >= 0 && i < (int)c->prof.size(), PMX_ERR_INVALID, "bad profile index");

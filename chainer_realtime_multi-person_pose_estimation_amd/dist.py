@@ -92,8 +92,8 @@ class _DeviceBytes(object):
 
 
 def gather_device_records(engine, n_local, dst=0, group=None):
-    """RCCL gather to rank `dst` straight out of the engine's device-resident result records: no host round trip before the
-    collective, one device-to-host copy of the gathered records on the root after it.
+    """RCCL gather to rank `dst` out of the engine's device-resident result records: no host round trip before the collective (one
+    device-to-device copy into a torch-owned send buffer), one device-to-host copy of the gathered records on the root after it.
 
     `engine.results_layout()` first makes the records final (stream sync; capacity growth + re-run if an image needed it).
     The collective runs on torch's RCCL stream.  Returns the records of all ranks on `dst`, None elsewhere."""
@@ -108,12 +108,12 @@ def gather_device_records(engine, n_local, dst=0, group=None):
     counts, caps = _exchange_meta(n_local, people_cap, group, dev)
     sizes = [n * native.result_dtype(c).itemsize for n, c in zip(counts, caps)]
     nmax = max(max(sizes), 1)
-    if sizes[rank] == nmax:
-        view = torch.as_tensor(_DeviceBytes(ptr, nmax), device=dev)        # the common case: equal shards, equal capacities
-    else:
-        view = torch.zeros(nmax, dtype=torch.uint8, device=dev)
-        if sizes[rank]:
-            view[:sizes[rank]] = torch.as_tensor(_DeviceBytes(ptr, sizes[rank]), device=dev)
+    # send buffer = a torch-owned staging tensor filled by one device-to-device copy out of the engine's records (<= 1 MB per 32
+    # frames): RCCL then only ever sees allocations of torch's caching allocator (buffer registration / IPC for the xGMI transport
+    # never meets a foreign hipMalloc block), and uneven shards / capacities need no special case
+    view = torch.zeros(nmax, dtype=torch.uint8, device=dev)
+    if sizes[rank]:
+        view[:sizes[rank]].copy_(torch.as_tensor(_DeviceBytes(ptr, sizes[rank]), device=dev))
     big = torch.empty(world * nmax, dtype=torch.uint8, device=dev) if rank == dst else None
     dist.gather(view, list(big.split(nmax)) if rank == dst else None, dst=dst, group=group)
     if rank != dst:

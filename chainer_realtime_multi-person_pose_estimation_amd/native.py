@@ -154,6 +154,7 @@ def load():
         'pmx_profile_reset': (ci, [vp]),
         'pmx_profile_count': (ci, [vp, ip]),
         'pmx_profile_entry': (ci, [vp, ci, C.c_char_p, ci, dp, C.POINTER(C.c_int64), dp, dp]),
+        'pmx_profile_issued': (ci, [vp, ci, dp]),
         'pmx_conv2d': (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, dp]),
     }
     for name, (res, args) in sig.items():
@@ -228,17 +229,24 @@ class Engine(object):
         self._check(self.lib.pmx_set_stream(self._ctx, C.c_void_p(stream_ptr)))
         self._stream_ptr = stream_ptr
 
+    def state(self):
+        """Weights (host copies), options, stream and (grown) capacities of this engine -- what a larger context needs to take over."""
+        return dict(layers=dict(self._layers), options=dict(self._options), stream=self._stream_ptr, caps=self.capacities())
+
+    def load_state(self, st):
+        for name, (W, b) in st['layers'].items():
+            self.set_layer(name, W, b)
+        for k, v in st['options'].items():
+            self.set_option(k, v)
+        if st['stream']:
+            self.set_stream(st['stream'])
+        caps = st['caps']
+        if (caps['peaks_per_joint'], caps['subsets'], caps['people']) != (INIT_PEAKS_PER_JOINT, INIT_SUBSETS, INIT_PEOPLE) or caps['candidates']:
+            self.set_capacities(caps['peaks_per_joint'], caps['subsets'], caps['people'], caps['candidates'])
+
     def copy_state_to(self, other):
         """Install this engine's weights, options, stream and (grown) capacities in `other` (a larger context)."""
-        for name, (W, b) in self._layers.items():
-            other.set_layer(name, W, b)
-        for k, v in self._options.items():
-            other.set_option(k, v)
-        if self._stream_ptr:
-            other.set_stream(self._stream_ptr)
-        caps = self.capacities()
-        if (caps['peaks_per_joint'], caps['subsets'], caps['people']) != (INIT_PEAKS_PER_JOINT, INIT_SUBSETS, INIT_PEOPLE) or caps['candidates']:
-            other.set_capacities(caps['peaks_per_joint'], caps['subsets'], caps['people'], caps['candidates'])
+        other.load_state(self.state())
 
     def synchronize(self):
         self._check(self.lib.pmx_synchronize(self._ctx))
@@ -460,18 +468,21 @@ class Engine(object):
         self._check(self.lib.pmx_profile_reset(self._ctx))
 
     def profile(self):
-        """[{layer, kernel, total_ms, launches, avg_ms, flop_per_launch, bytes_per_launch}]"""
+        """[{layer, kernel, total_ms, launches, avg_ms, flop_per_launch, issued_flop_per_launch, bytes_per_launch}]: algorithmic FLOP of the
+        convolution and the FLOP the kernel issues to the matrix cores (fewer for the Winograd forms)."""
         n = C.c_int(0)
         self._check(self.lib.pmx_profile_count(self._ctx, C.byref(n)))
         out = []
         for i in range(n.value):
             name = C.create_string_buffer(128)
-            ms, fl, by = C.c_double(0), C.c_double(0), C.c_double(0)
+            ms, fl, by, iss = C.c_double(0), C.c_double(0), C.c_double(0), C.c_double(0)
             ln = C.c_int64(0)
             self._check(self.lib.pmx_profile_entry(self._ctx, i, name, 128, C.byref(ms), C.byref(ln), C.byref(fl), C.byref(by)))
+            self._check(self.lib.pmx_profile_issued(self._ctx, i, C.byref(iss)))
             layer, _, kern = name.value.decode().partition('|')
             out.append(dict(layer=layer, kernel=kern, total_ms=ms.value, launches=ln.value,
-                            avg_ms=ms.value / max(ln.value, 1), flop_per_launch=fl.value, bytes_per_launch=by.value))
+                            avg_ms=ms.value / max(ln.value, 1), flop_per_launch=fl.value, issued_flop_per_launch=iss.value,
+                            bytes_per_launch=by.value))
         return out
 
     # ---- single-layer test entry ---------------------------------------------------------------------

@@ -65,15 +65,19 @@ class PoseDetector(object):
         self._make_engine(max_batch, mh, mw)
 
     def _make_engine(self, max_batch, mh, mw):
-        old = self.engine
+        # growth keeps the engine's state: weights (also those installed through detector.engine.set_weights / set_layer), options,
+        # stream, capacities -- taken from the old context, which is destroyed BEFORE the larger one is created (the two never hold
+        # their buffers and weight packs at the same time)
+        st = None
+        if self.engine is not None:
+            st = self.engine.state()
+            self.engine.close()
+            self.engine = None
         self._cap = (max_batch, mh, mw)
         self.engine = native.Engine(self._gpu, max_batch=max_batch, max_h=mh, max_w=mw,
                                     gaussian_sigma=params['gaussian_sigma'])
-        if old is not None:
-            # growth keeps the engine's state: weights (also those installed through detector.engine.set_weights / set_layer),
-            # options, stream, capacities
-            old.copy_state_to(self.engine)
-            old.close()
+        if st is not None:
+            self.engine.load_state(st)
         elif self._weights is not None:
             self.engine.set_weights(self._weights)
         if self._precision == 'bf16x3':
@@ -85,22 +89,17 @@ class PoseDetector(object):
 
     # ---- host helpers with the reference's names and semantics -------------------------------------
     def compute_optimal_size(self, orig_img, img_size, stride=8):
-        """reference pose_detector.py:57-73 (np.round = round-half-even; long side rounded UP to `stride`)."""
-        orig_img_h, orig_img_w, _ = orig_img.shape
-        aspect = orig_img_h / orig_img_w
-        if orig_img_h < orig_img_w:
-            img_h = img_size
-            img_w = np.round(img_size / aspect).astype(int)
-            surplus = img_w % stride
-            if surplus != 0:
-                img_w += stride - surplus
-        else:
-            img_w = img_size
-            img_h = np.round(img_size * aspect).astype(int)
-            surplus = img_h % stride
-            if surplus != 0:
-                img_h += stride - surplus
-        return (int(img_w), int(img_h))
+        """Network input size (w, h) for an image: the SHORT side becomes `img_size`, the long side follows the aspect ratio
+        (round-half-even, as np.round does) and is then rounded UP to a multiple of `stride`; a square image takes the second rule
+        for its height.  Same results as reference pose_detector.py:57-73 (tests/test_oracle_vs_reference.py)."""
+        h, w = orig_img.shape[:2]
+        ratio = h / w                                        # the reference divides / multiplies by this float: keep its rounding
+
+        def long_side(exact):
+            return -(-int(np.round(exact)) // stride) * stride
+        if h < w:
+            return (long_side(img_size / ratio), int(img_size))
+        return (int(img_size), long_side(img_size * ratio))
 
     def preprocess(self, img):
         """reference pose_detector.py:426-431 (host version, for `model=` callables; the built-in network

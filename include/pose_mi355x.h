@@ -194,10 +194,13 @@ int pmx_detect_batch(pmx_ctx* ctx, const uint8_t* bgr_nhwc, int batch, int h, in
  * (out_bytes >= batch * bytes_per_record, else PMX_ERR_CAPACITY). */
 int pmx_results_layout(pmx_ctx* ctx, int* people_cap, size_t* bytes_per_record);
 int pmx_get_results(pmx_ctx* ctx, int batch, void* out, size_t out_bytes);
-/* device pointer of the record array (for RCCL gathers): call pmx_results_layout first; valid until the next post-process */
+/* device pointer of the record array (for RCCL gathers): synchronises and finalises the records like pmx_results_layout (PMX_ERR_STATE
+ * before any post-process); valid until the next post-process, capacity change or pmx_destroy */
 int pmx_results_device_ptr(pmx_ctx* ctx, void** dev_ptr, size_t* bytes_per_record);
 /* capacities: pre-size a context for crowds (or shrink them in tests to exercise the growth path); 0 keeps a value.
- * candidates: 0 = accepted candidates of a limb are kept in LDS (4096 slots), > 0 = that many slots in device memory. */
+ * candidates: 0 = accepted candidates of a limb are kept in LDS (4096 slots), > 0 = that many slots in device memory.
+ * people <= subsets, every value <= 2^20 (candidates <= 2^24), else PMX_ERR_INVALID; if the device cannot hold the new buffers the
+ * call fails with PMX_ERR_HIP and the context keeps its previous buffers and capacities. */
 int pmx_set_capacities(pmx_ctx* ctx, int peaks_per_joint, int subsets, int people, int candidates);
 int pmx_get_capacities(pmx_ctx* ctx, int* peaks_per_joint, int* subsets, int* people, int* candidates);
 
@@ -223,6 +226,9 @@ int pmx_profile_reset(pmx_ctx* ctx);
 int pmx_profile_count(pmx_ctx* ctx, int* n);
 int pmx_profile_entry(pmx_ctx* ctx, int i, char* name, int name_cap, double* total_ms,
                       int64_t* launches, double* flop_per_launch, double* bytes_per_launch);
+/* FLOP per launch the entry's kernel ISSUES to the matrix cores for real outputs: the algorithmic figure for the direct kernels,
+ * 16/36 (3x3) or 100/196 (7x7) of it for the Winograd forms -- the numerator of a roofline fraction that cannot exceed 1 */
+int pmx_profile_issued(pmx_ctx* ctx, int i, double* issued_flop_per_launch);
 
 /* ---- kernel unit-test entry (T0): one convolution layer through the product kernels -----------
  * x: float32 NCHW host (B, cin, h, w); w: OIHW; y: NCHW host (B, cout, h', w') with h' = h/2 if pool.

@@ -112,13 +112,18 @@ def splitk_plan(profile):
     ran on the Winograd kernel (the kernel choice depends on the launch size).  Labels are the layer names without the _L1 / _L2
     branch suffix.  forward_fma(weights, x, splitk=plan) restates exactly that forward."""
     plan = LaunchPlan()
+    plan.wino_units, plan.wino_tails = {}, {}
     for e in profile:
         k = e['kernel']
         if '/k' in k:
             plan[e['layer']] = [int(v) for v in k.rsplit('/k', 1)[1].split('-')]
     plan.wino = frozenset(wino_layers(profile))
-    plan.wino_units = {e['layer']: int(e['kernel'].rsplit('/u', 1)[1]) for e in profile if e['kernel'].startswith('conv_wino') and '/u' in e['kernel']}
-    plan.wino_tails = {e['layer']: int(e['kernel'].rsplit('/t', 1)[1]) for e in profile if e['kernel'].startswith('conv_wino') and '/t' in e['kernel']}
+    import re
+    for e in profile:
+        if e['kernel'].startswith('conv_wino'):
+            m = re.search(r'/([ut])(\d+)', e['kernel'])          # ".../u<g>": unit mode; "...r/t<g>[:units|:combine]": run geometry, tail in units
+            if m:
+                (plan.wino_units if m.group(1) == 'u' else plan.wino_tails)[e['layer']] = int(m.group(2))
     return plan
 
 

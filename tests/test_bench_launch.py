@@ -54,3 +54,23 @@ def test_two_ranks_equal_one_rank(tmp_path):
         # batch 4 and batch 8 may pick different conv kernels (split-K at small launches): poses exact, scores to 1e-5
         assert np.array_equal(a['poses'][i, :n[i]], b['poses'][i, :n[i]])
         assert np.allclose(a['scores'][i, :n[i]], b['scores'][i, :n[i]], rtol=0, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_one_rank_through_the_rccl_gather_equals_plain_run(tmp_path):
+    """`--force-gather`: N = 1 with a one-rank "nccl" (RCCL) process group, records routed through dist.gather_device_records -- the
+    branch every rank takes at N > 1 -- must give the records of the plain run, and the line must say which path and device it used."""
+    common = ['--gpus', '1', '--batch', '4', '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--no-profile', '--no-extras']
+    fg, fp = str(tmp_path / 'g.npy'), str(tmp_path / 'p.npy')
+    rg = _run(common + ['--force-gather', '--dump-records', fg])
+    assert rg.returncode == 0, rg.stdout[-2000:] + rg.stderr[-4000:]
+    lg = json.loads([l for l in rg.stdout.splitlines() if l.startswith('{')][-1])
+    assert 'rccl' in lg['backend'] and 'gather_device_records' in lg['records_path'] and lg['ranks_seen'] == [0]
+    assert len(lg['devices']) == 1 and (lg['devices'][0]['uuid'] or lg['devices'][0]['pci_bus_id'])
+    rp = _run(common + ['--dump-records', fp])
+    assert rp.returncode == 0, rp.stdout[-2000:] + rp.stderr[-4000:]
+    lp = json.loads([l for l in rp.stdout.splitlines() if l.startswith('{')][-1])
+    assert lp['backend'] is None and 'pmx_get_results' in lp['records_path']
+    a, b = np.load(fg), np.load(fp)
+    assert a.dtype == b.dtype and a.tobytes() == b.tobytes() and int(a['n_peaks'].sum()) > 0
+

@@ -39,8 +39,8 @@ def _worker(rank, world, port, n_items, q):
     d = importlib.import_module(PKG + '.dist')
     native = importlib.import_module(PKG + '.native')
     lo, hi = d.shard_range(n_items, rank, world)
-    # rank 1's context has grown its person capacity (crowd image): the root re-packs everything at the largest capacity
-    rec = np.zeros(hi - lo, dtype=native.result_dtype(64 if rank == 0 else 256))
+    # contexts of other ranks have grown their person capacity (crowd images): the root re-packs everything at the largest capacity
+    rec = np.zeros(hi - lo, dtype=native.result_dtype((64, 256, 128)[rank % 3]))
     for i in range(lo, hi):     # deterministic fake "results" keyed by the global image index
         rec[i - lo]['n_people'] = i % 5
         rec[i - lo]['n_peaks'] = 10 * i
@@ -70,3 +70,19 @@ def test_gather_records_world2_gloo(n_items):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_gather_records_world8_gloo_uneven_shards_mixed_capacities():
+    """The shape of BASELINE config 4 (8 ranks), with what a real run can throw at the gather: 255 images do not divide by 8 (shards
+    of 32 and 31) and the ranks' record capacities differ (64 / 256 / 128)."""
+    world, n_items = 8, 255
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_items, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    assert sorted(res) == [(r, True) for r in range(world)]

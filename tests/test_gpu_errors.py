@@ -55,6 +55,17 @@ def test_state_errors(native, small):
     rc = small.lib.pmx_precise_finish(small._ctx)
     assert rc != 0 and b'nothing accumulated' in small.lib.pmx_last_error()
     assert small.lib.pmx_set_option(small._ctx, b'no_such_option', 1) != 0
+    # capacities: people <= subsets, bounded; a refused call leaves the context as it was
+    before = small.capacities()
+    assert small.lib.pmx_set_capacities(small._ctx, 0, 2, 8, 0) == 1 and b'must not exceed' in small.lib.pmx_last_error()
+    assert small.lib.pmx_set_capacities(small._ctx, 1 << 21, 0, 0, 0) == 1
+    assert small.capacities() == before
+    # the device pointer of the records is only handed out once a post-process has produced them
+    import ctypes as C
+    p, nb = C.c_void_p(), C.c_size_t()
+    fresh = native.Engine(0, max_batch=1, max_h=64, max_w=64)
+    assert fresh.lib.pmx_results_device_ptr(fresh._ctx, C.byref(p), C.byref(nb)) == 6       # PMX_ERR_STATE
+    fresh.close()
 
 
 def test_null_arguments_do_not_crash(native):

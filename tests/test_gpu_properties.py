@@ -156,7 +156,7 @@ def test_hypothesis_capacity_growth_matches_oracle(native, seed, n, fh, fw, up, 
     except IndexError:
         ref = None
     e = native.Engine(0, max_batch=1, max_h=64, max_w=64)
-    e.set_capacities(peaks_per_joint=cap_pk, subsets=cap_sub, people=cap_ppl, candidates=cap_cand)
+    e.set_capacities(peaks_per_joint=cap_pk, subsets=cap_sub, people=min(cap_ppl, cap_sub), candidates=cap_cand)      # people <= subsets (ABI)
     e.set_maps(paf[None], heat[None])
     e.postprocess(mh, mw, img_len=mw)
     rec = e.results()[0]

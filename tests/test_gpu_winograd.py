@@ -200,9 +200,12 @@ def test_config1_reference_images_with_winograd(native, name):
     assert float(np.abs(np.asarray(scores) - g['scores']).max()) <= 1e-4
 
 
-def test_batch_32_winograd_agrees_with_single_images(native):
-    """Batch 32 at 368x368 (Winograd by launch size) vs the same images one at a time (direct kernels, split-K): same people,
-    identical peak indices, scores to 1e-5 -- the two paths differ by fp32 rounding only."""
+def test_batch_32_default_path_vs_cpu_oracle_and_single_images(native):
+    """Batch 32 at 368x368 with default options (run-geometry Winograd kernel + unit-mode tails on the 46x46 layers, plain Winograd
+    on conv2_x / conv3_x) -- ALL 32 frames against (a) the CPU oracle (torch fp32 restatement of models/CocoPoseNet.py + NumPy
+    restatement of pose_detector.py:75-265): identical peak indices and poses, scores to 1e-4 (the north_star tolerance); (b) the
+    same images one at a time (unit-mode Winograd / direct kernels + split-K): identical peaks and poses, scores to 1e-5 -- the
+    launch forms differ by fp32 rounding only."""
     W = pkg('weights')
     eng = native.Engine(0, max_batch=32, max_h=368, max_w=368)
     w = W.synthetic_weights(0); eng.set_weights(w)
@@ -210,22 +213,36 @@ def test_batch_32_winograd_agrees_with_single_images(native):
     eng.forward_u8(cal); paf, heat = eng.get_maps()
     w = W.calibrate_head(w, paf[0], heat[0]); eng.set_weights({k: w[k] for k in ('Mconv7_stage6_L1', 'Mconv7_stage6_L2')})
     imgs = np.random.default_rng(3).integers(0, 256, (32, 368, 368, 3), dtype=np.uint8)
-    eng.set_option('conv_algo', 1)
     eng.profile_enable(True); eng.detect_batch(imgs, 320, 320); prof = eng.profile(); eng.profile_enable(False)
-    assert len(R.wino_layers(prof)) >= 30, sorted(R.wino_layers(prof))
+    plan = R.splitk_plan(prof)
+    assert len(plan.wino) >= 30 and len(plan.wino_tails) >= 25, (sorted(plan.wino), plan.wino_tails)
     rec = eng.results().copy()
-    peaks32 = [eng.peaks(i).copy() for i in (0, 13, 31)]
-    eng.set_option('conv_algo', 0)
-    for j, i in enumerate((0, 13, 31)):
+    peaks32 = [eng.peaks(i).copy() for i in range(32)]
+    assert int(rec['n_people'].sum()) > 32 and int(np.bitwise_or.reduce(rec['status'])) == 0
+    worst_peak = worst_person = 0.0
+    for i in range(32):                                   # (a) the CPU oracle
+        x = P.preprocess(imgs[i])
+        opaf, oheat = N.forward(w, x)
+        o = P.postprocess_from_net_output(opaf[0], oheat[0], 320, 320)
+        op = np.asarray(o['all_peaks'], dtype=np.float64).reshape(-1, 5)
+        assert peaks32[i].shape == op.shape and np.array_equal(peaks32[i][:, [0, 1, 2, 4]], op[:, [0, 1, 2, 4]]), i
+        worst_peak = max(worst_peak, float(np.abs(peaks32[i][:, 3] - op[:, 3]).max()))
+        n = int(rec['n_people'][i])
+        oposes = np.asarray(o['poses'], dtype=np.float64).reshape(-1, 18, 3)
+        assert oposes.shape[0] == n and np.array_equal(rec['poses'][i][:n], oposes), i
+        if n:
+            worst_person = max(worst_person, float(np.abs(rec['scores'][i][:n] - np.asarray(o['scores']).reshape(-1)).max()))
+    assert worst_peak <= 1e-4 and worst_person <= 1e-4, (worst_peak, worst_person)
+    for i in range(32):                                   # (b) one image per call
         eng.detect_batch(imgs[i:i + 1], 320, 320)
         r1 = eng.results()
         p1 = eng.peaks(0)
         assert r1['n_people'][0] == rec['n_people'][i] and r1['n_peaks'][0] == rec['n_peaks'][i]
-        assert np.array_equal(p1[:, [0, 1, 2, 4]], peaks32[j][:, [0, 1, 2, 4]])
-        assert np.abs(p1[:, 3] - peaks32[j][:, 3]).max() <= 1e-5
+        assert np.array_equal(p1[:, [0, 1, 2, 4]], peaks32[i][:, [0, 1, 2, 4]])
+        assert np.abs(p1[:, 3] - peaks32[i][:, 3]).max() <= 1e-5
         n = int(r1['n_people'][0])
         assert np.array_equal(r1['poses'][0][:n], rec['poses'][i][:n])
-        assert np.abs(r1['scores'][0][:n] - rec['scores'][i][:n]).max() <= 1e-5
+        assert n == 0 or np.abs(r1['scores'][0][:n] - rec['scores'][i][:n]).max() <= 1e-5
     eng.close()
 
 

@@ -82,3 +82,23 @@ if os.path.exists(bl):
         json.dump(json.loads(lines[-1]), open(os.path.join(P, rnd + '_bench.json'), 'w'), indent=1)
 for k, e in summary['kernels'].items():
     print(k[:60], json.dumps(e['derived']))
+
+# the bench line's roofline, recomputed from the rocprofv3 kernel stats of the same command: issued / algorithmic FLOP per launch (from the
+# bench line = the engine's launch plan) over rocprofv3's average duration of that kernel
+bj, ks = os.path.join(P, rnd + '_bench.json'), os.path.join(P, rnd + '_bench_kernel_stats.csv')
+if os.path.exists(bj) and os.path.exists(ks):
+    b = json.load(open(bj))
+    roof = b.get('roofline') or {}
+    rows = [r for r in csv.DictReader(open(ks)) if roof.get('kernel') and roof['kernel'] in r['Name']]
+    if rows:
+        calls = sum(int(r['Calls']) for r in rows)
+        avg_ns = sum(float(r['TotalDurationNs']) for r in rows) / calls
+        peak = roof['peak']
+        chk = {'kernel': roof['kernel'], 'rocprofv3_calls': calls, 'rocprofv3_avg_launch_ms': avg_ns / 1e6, 'bench_avg_launch_ms': roof['avg_launch_ms'],
+               'frac_from_rocprofv3': roof['issued_flop_per_launch'] / (avg_ns * 1e-9) / 1e12 / peak, 'frac_in_bench_line': roof['frac'],
+               'algorithmic_frac_from_rocprofv3': roof['flop_per_launch'] / (avg_ns * 1e-9) / 1e12 / peak,
+               'algorithmic_frac_in_bench_line': roof.get('algorithmic_frac'),
+               'note': 'rocprofv3 --kernel-trace --stats of `python bench.py` (all its phases: the timed steps, the extras, the batch-1 calls share the '
+                       'kernel name; launches of other batch sizes pull the average down slightly)'}
+        json.dump(chk, open(os.path.join(P, rnd + '_roofline_check.json'), 'w'), indent=1)
+        print('roofline check', json.dumps(chk))
