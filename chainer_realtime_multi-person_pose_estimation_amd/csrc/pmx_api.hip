@@ -766,12 +766,15 @@ static int launch_wino_run(pmx_ctx* c, const ConvArgs& a0, int ks, int groups, i
     a.run_j0 = nfull; a.run_nb = 1;
     r.slab_stride = (long long)slab; r.S = S; r.B = a0.B; r.H = a0.H; r.W = a0.W; r.ld_slab = a0.cout_pad; r.ldc = a0.ldc;
     r.relu = a0.relu; r.run_j0 = nfull; r.run_nb = 1;
-    if (pf && (rc = prof_begin(c, pf->name + ":units", pf->flops * (1.0 - share), 0.0, pf->issued * (1.0 - share)))) return rc;
+    // (profile mode 2 -- the dominant kernel only, inside timed regions -- leaves these two short launches without events: an event pair
+    //  costs ~5 us of idle stream)
+    const bool pf_all = pf && c->prof_on == 1;
+    if (pf_all && (rc = prof_begin(c, pf->name + ":units", pf->flops * (1.0 - share), 0.0, pf->issued * (1.0 - share)))) return rc;
     if ((rc = conv_wino_run_launch(a, ks, groups, c->stream))) return rc;
-    if (pf && (rc = prof_end(c))) return rc;
-    if (pf && (rc = prof_begin(c, pf->name + ":combine", 0.0, 0.0, 0.0))) return rc;
+    if (pf_all && (rc = prof_end(c))) return rc;
+    if (pf_all && (rc = prof_begin(c, pf->name + ":combine", 0.0, 0.0, 0.0))) return rc;
     if ((rc = conv_wino_tail_reduce(r, groups, c->stream))) return rc;
-    return pf ? prof_end(c) : PMX_OK;
+    return pf_all ? prof_end(c) : PMX_OK;
 }
 
 // Which form a 3x3 / 7x7 layer takes: 0 = direct kernels (+ split-K), 1 = the Winograd kernel, 2 = the Winograd kernel in unit mode
