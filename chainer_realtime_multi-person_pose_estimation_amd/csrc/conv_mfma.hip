@@ -1268,7 +1268,6 @@ template <int KS, int POOL, int UNIT, int GEOM>
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
 {
     using C = WinoCfg<KS, GEOM>;
-    static_assert(!(GEOM && POOL), "run geometry: no pooled variant");
     static_assert(!(POOL && KS != 3), "pooling only with the 3x3 variant");
     static_assert(!(UNIT && POOL), "unit mode: the combine kernel pools");
     // UNIT (single images: 36 blocks of a 46x46 7x7 layer cannot fill 256 CUs): blockIdx.z = unit * groups + group, and a block runs
@@ -1294,15 +1293,21 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    // GEOM 1: block jl of this launch = the 32 consecutive Winograd tiles [t0, t0 + 32) of image bimg (row-major over 23 tile columns),
-    // tile rows r0 .. r0 + 2; raw halo row 0 / column 0 = image row 2 r0 - PADK / column -PADK
+    // GEOM 1: the map is cut into vertical slabs of 46 columns (23 tile columns; 46 / 92 / 184-wide maps = 1 / 2 / 4 slabs); block trem of
+    // this launch in (image, slab) bslab = the 32 consecutive Winograd tiles [t0, t0 + 32) of that slab (row-major), tile rows r0 .. r0 + 2;
+    // raw halo row 0 / column 0 = image row 2 r0 - PADK / column 46 slab - PADK (halo columns inside the map come from the neighbour slab)
     const int tiles_per_img = GEOM ? a.run_nb : a.tiles_x * a.tiles_y;
-    const int bimg = tile / tiles_per_img;
-    const int trem = tile - bimg * tiles_per_img;
+    const int bslab = tile / tiles_per_img;
+    const int trem = tile - bslab * tiles_per_img;
+    // (GEOM 1 = a single slab, the 46-wide maps of the 7x7 layers: the slab arithmetic is compiled out -- its extra scalar registers
+    //  pushed the 7x7 kernel's transition code into 30 more spill reloads per block, +3 %; GEOM 2 = any number of slabs)
+    constexpr bool SLABS = GEOM == 2;
+    const int bimg = SLABS ? bslab / a.run_nslab : bslab;
+    const int sx0 = SLABS ? (bslab - bimg * a.run_nslab) * C::RUN_W : 0;
     const int t0 = GEOM ? (a.run_j0 + trem) * PMX_WINO_RUN_TILES : 0;
     const int r0 = GEOM ? t0 / C::RUN_TX : 0;
     const int ntiles = C::RUN_TX * ((a.H + 1) >> 1);
-    const int y0 = GEOM ? 2 * r0 : (trem / a.tiles_x) * C::TH, x0 = GEOM ? 0 : (trem % a.tiles_x) * C::TW;
+    const int y0 = GEOM ? 2 * r0 : (trem / a.tiles_x) * C::TH, x0 = GEOM ? sx0 : (trem % a.tiles_x) * C::TW;
     const int n0 = blockIdx.y * 128;
     const int n = n0 + wave * 32 + li;
     const float* in_b = G.in + (size_t)bimg * H * W * a.lda;
@@ -1337,15 +1342,17 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
         }
     }
     const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, GEOM ? (unsigned)(H * W * a.lda) * 4u : 0u, 0x00020000);
-    const int hbase_b = (((y0 - C::PADK) * W - C::PADK) * a.lda + (tid & 7) * 4) * 4;     // byte offset of halo pixel (0, 0), may be negative
+    const int hbase_b = (((y0 - C::PADK) * W + x0 - C::PADK) * a.lda + (tid & 7) * 4) * 4;     // byte offset of halo pixel (0, 0), may be negative
+    const int hrow_skip = SLABS ? W - C::HW : -(KS - 1);                                     // image pixels between the end of a halo row and the next
     const int lda_b = a.lda * 4;
     auto halo_load_slot = [&](float4 (&hv)[C::NHF], int chunk, int r) {       // r is a compile-time constant at every call
         if constexpr (GEOM != 0) {
             const unsigned hp = (unsigned)(tid >> 3) + 32u * r;
             const unsigned hy = hp / (unsigned)C::HW, hx = hp - hy * (unsigned)C::HW;
-            // halo pixel (hy, hx) = image pixel (y0 - PADK + hy, hx - PADK): hp - (KS - 1) hy pixels after halo pixel (0, 0) in the image
-            int off = hbase_b + (int)(hp - (unsigned)(KS - 1) * hy) * lda_b + chunk * (C::CKW * 4);
-            if (hx - (unsigned)C::PADK >= (unsigned)C::RUN_W) off = -1;
+            // halo pixel (hy, hx) = image pixel (y0 - PADK + hy, x0 - PADK + hx): hp + (W - HW) hy pixels after halo pixel (0, 0) in the image
+            int off = hbase_b + ((int)hp + (int)hy * hrow_skip) * lda_b + chunk * (C::CKW * 4);
+            if (SLABS ? (unsigned)(x0 - C::PADK) + hx >= (unsigned)W      // (left of the map the sum wraps around: also out)
+                      : hx - (unsigned)C::PADK >= (unsigned)C::RUN_W) off = -1;
             hv[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, 0));
         } else {
             hv[r] = *reinterpret_cast<const float4*>(in_b + h_goff[GEOM ? 0 : r] + chunk * C::CKW);
@@ -1801,14 +1808,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
         if (UNIT && GEOM) {
             // unit mode of a run (the part-filled last block of an image): compact slab [image][block of the launch][tile][pixel][cout_pad];
             // conv_wino_tail_reduce_kernel adds the units in order and drops the tiles past the end of the map
-            float* oc = G.out + (((size_t)(bimg * a.run_nb + trem) * 32 + mr) * 4) * a.ldc + n;
+            float* oc = G.out + (((size_t)(bslab * a.run_nb + trem) * 32 + mr) * 4) * a.ldc + n;
             oc[0] = y00; oc[a.ldc] = y01; oc[2 * a.ldc] = y10; oc[3 * a.ldc] = y11;
             continue;
         }
         int gy, gx;
         if (GEOM) {
             const int t = t0 + mr, ty = t / C::RUN_TX;                // tiles past the end of the map land on rows >= H
-            gy = 2 * ty; gx = 2 * (t - ty * C::RUN_TX);
+            gy = 2 * ty; gx = x0 + 2 * (t - ty * C::RUN_TX);
         } else {
             gy = y0 + 2 * (mr >> 3); gx = x0 + 2 * (mr & 7);
         }
@@ -2741,31 +2748,41 @@ int conv_wino_launch(const ConvArgs& a, int ks, int groups, hipStream_t stream)
 }
 
 // run geometry (46-pixel-wide maps): the blocks [a.run_j0, a.run_j0 + a.run_nb) of every image, 32 consecutive Winograd tiles each
-template <int KS, int UNIT>
-static int launch_wino_run(const ConvArgs& a0, int groups, hipStream_t stream)
+template <int KS, int POOL, int UNIT, int GEOM>
+static int launch_wino_run_g(const ConvArgs& a0, int groups, hipStream_t stream)
 {
-    using C = WinoCfg<KS, 1>;
+    using C = WinoCfg<KS, GEOM>;
     ConvArgs a = a0;
-    PMX_CHECK(!a.pool && a.W == C::RUN_W, PMX_ERR_INVALID, "conv wino runs: %d-pixel-wide maps without pooling only (W %d, pool %d)", C::RUN_W, a.W, a.pool);
+    PMX_CHECK(!!a.pool == !!POOL && a.W % C::RUN_W == 0 && a.W > 0, PMX_ERR_INVALID, "conv wino runs: map width must be a multiple of %d (W %d)", C::RUN_W, a.W);
+    PMX_CHECK(!POOL || (a.H % 2 == 0 && a.W % 2 == 0), PMX_ERR_INVALID, "conv: pooled layer needs even H, W");
+    a.run_nslab = a.W / C::RUN_W;
     PMX_CHECK(a.cout_pad % 128 == 0, PMX_ERR_INVALID, "conv wino: cout_pad %d not a multiple of 128", a.cout_pad);
     PMX_CHECK((long long)a.H * a.W * a.lda * 4 < (1ll << 31), PMX_ERR_INVALID, "conv: image too large for 32-bit offsets");
     const int nblk = (C::RUN_TX * ((a.H + 1) / 2) + PMX_WINO_RUN_TILES - 1) / PMX_WINO_RUN_TILES;
     PMX_CHECK(a.run_j0 >= 0 && a.run_nb >= 1 && a.run_j0 + a.run_nb <= nblk, PMX_ERR_INVALID, "conv wino runs: blocks [%d, %d) of %d", a.run_j0, a.run_j0 + a.run_nb, nblk);
     a.tiles_x = a.tiles_y = 0;
-    auto kern = conv_wino_kernel<KS, 0, UNIT, 1>;
+    PMX_CHECK(GEOM == 2 || a.run_nslab == 1, PMX_ERR_INVALID, "conv wino runs: single-slab kernel on a %d-wide map", a.W);
+    auto kern = conv_wino_kernel<KS, POOL, UNIT, GEOM>;
     static bool attr_set[PMX_MAX_DEVICES] = {};
     if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(kern), attr_set)) return rc;
     if (UNIT) { a.ngroups = groups; PMX_CHECK(a.ksplit >= 2 && a.ksplit <= 8 && a.kbounds >= 1, PMX_ERR_INVALID, "conv wino: bad unit plan"); }
-    dim3 grid((unsigned)(a.run_nb * a.B), (unsigned)(a.cout_pad / 128), (unsigned)(groups * (UNIT ? a.ksplit : 1)));
+    dim3 grid((unsigned)(a.run_nb * a.B * a.run_nslab), (unsigned)(a.cout_pad / 128), (unsigned)(groups * (UNIT ? a.ksplit : 1)));
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, a);
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
 
+template <int KS, int POOL, int UNIT>
+static int launch_wino_run(const ConvArgs& a, int groups, hipStream_t stream)
+{
+    return a.W == 2 * PMX_WINO_RUN_TX ? launch_wino_run_g<KS, POOL, UNIT, 1>(a, groups, stream) : launch_wino_run_g<KS, POOL, UNIT, 2>(a, groups, stream);
+}
+
 int conv_wino_run_launch(const ConvArgs& a, int ks, int groups, hipStream_t stream)
 {
-    if (a.ksplit > 1) return ks == 7 ? launch_wino_run<7, 1>(a, groups, stream) : launch_wino_run<3, 1>(a, groups, stream);
-    return ks == 7 ? launch_wino_run<7, 0>(a, groups, stream) : launch_wino_run<3, 0>(a, groups, stream);
+    if (a.ksplit > 1) return ks == 7 ? launch_wino_run<7, 0, 1>(a, groups, stream) : launch_wino_run<3, 0, 1>(a, groups, stream);      // (the combine pools)
+    if (ks == 7) return launch_wino_run<7, 0, 0>(a, groups, stream);
+    return a.pool ? launch_wino_run<3, 1, 0>(a, groups, stream) : launch_wino_run<3, 0, 0>(a, groups, stream);
 }
 
 // ---- combine of the unit-mode slabs of a block range of the run geometry (see WinoTailReduceArgs) -------------------------------------------
@@ -2779,27 +2796,45 @@ __global__ __launch_bounds__(256) void conv_wino_tail_reduce_kernel(const WinoTa
     float* out = g ? r.out[1] : r.out[0];
     const int cout = g ? r.cout[1] : r.cout[0];
     const int c4n = cout >> 2;
-    const long long total = (long long)r.B * r.run_nb * (PMX_WINO_RUN_TILES * 4) * c4n;
+    // pooled layers: one thread per TILE (its four pixels are the pooling window), else one per pixel
+    const int ppt = r.pool ? 1 : 4;
+    const long long total = (long long)r.B * r.nslab * r.run_nb * (PMX_WINO_RUN_TILES * ppt) * c4n;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int c = (int)(i % c4n) * 4;
-    const long long q = i / c4n;                        // ((image * run_nb + block) * 32 + tile) * 4 + pixel
-    const int k = (int)(q & 3), m = (int)((q >> 2) & (PMX_WINO_RUN_TILES - 1));
-    const long long bj = q >> 7;
-    const int jl = (int)(bj % r.run_nb), b = (int)(bj / r.run_nb);
+    const long long q = i / c4n;                        // ((image-slab * run_nb + block) * 32 + tile) [* 4 + pixel]
+    const int k = r.pool ? 0 : (int)(q & 3);
+    const long long qt = r.pool ? q : q >> 2;           // (image-slab * run_nb + block) * 32 + tile
+    const int m = (int)(qt & (PMX_WINO_RUN_TILES - 1));
+    const long long bj = qt >> 5;
+    const int jl = (int)(bj % r.run_nb);
+    const long long bs = bj / r.run_nb;
+    const int b = (int)(bs / r.nslab), sx0 = (int)(bs % r.nslab) * (2 * PMX_WINO_RUN_TX);
     const int t = (r.run_j0 + jl) * PMX_WINO_RUN_TILES + m, ty = t / PMX_WINO_RUN_TX, tx = t - ty * PMX_WINO_RUN_TX;
-    const int gy = 2 * ty + (k >> 1), gx = 2 * tx + (k & 1);
-    if (gy >= r.H || gx >= r.W) return;                 // tiles past the end of the map, the odd last row
-    const float* src = slabs + q * r.ld_slab + c;
-    float4 acc = *reinterpret_cast<const float4*>(src);
-    for (int s = 1; s < r.S; ++s) {
-        const float4 v = *reinterpret_cast<const float4*>(src + (long long)s * r.slab_stride);
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    float4 best;
+    for (int kk = 0; kk < (r.pool ? 4 : 1); ++kk) {
+        const int kq = r.pool ? kk : k;
+        const float* src = slabs + (qt * 4 + kq) * r.ld_slab + c;
+        float4 acc = *reinterpret_cast<const float4*>(src);
+        for (int s = 1; s < r.S; ++s) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (long long)s * r.slab_stride);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        if (kk == 0) best = acc;
+        else { best.x = fmaxf(best.x, acc.x); best.y = fmaxf(best.y, acc.y); best.z = fmaxf(best.z, acc.z); best.w = fmaxf(best.w, acc.w); }
     }
     const float4 bv = *reinterpret_cast<const float4*>(bias + c);
-    acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w;
-    if (r.relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
-    *reinterpret_cast<float4*>(out + (((long long)b * r.H + gy) * r.W + gx) * r.ldc + c) = acc;
+    best.x += bv.x; best.y += bv.y; best.z += bv.z; best.w += bv.w;
+    if (r.relu) { best.x = fmaxf(best.x, 0.f); best.y = fmaxf(best.y, 0.f); best.z = fmaxf(best.z, 0.f); best.w = fmaxf(best.w, 0.f); }
+    if (r.pool) {
+        const int Hp = r.H >> 1, Wp = r.W >> 1, py = ty, px = (sx0 >> 1) + tx;
+        if (py >= Hp || px >= Wp) return;
+        *reinterpret_cast<float4*>(out + (((long long)b * Hp + py) * Wp + px) * r.ldc + c) = best;
+    } else {
+        const int gy = 2 * ty + (k >> 1), gx = sx0 + 2 * tx + (k & 1);
+        if (gy >= r.H || gx >= r.W) return;                 // tiles past the end of the map, the odd last row
+        *reinterpret_cast<float4*>(out + (((long long)b * r.H + gy) * r.W + gx) * r.ldc + c) = best;
+    }
 }
 
 int conv_wino_tail_reduce(const WinoTailReduceArgs& r, int groups, hipStream_t stream)
@@ -2807,7 +2842,7 @@ int conv_wino_tail_reduce(const WinoTailReduceArgs& r, int groups, hipStream_t s
     PMX_CHECK(r.cout[0] % 4 == 0 && (groups < 2 || r.cout[1] == r.cout[0]) && r.ldc % 4 == 0 && r.ld_slab % 4 == 0, PMX_ERR_INVALID,
               "winograd tail reduce: channel counts / strides must be multiples of 4");
     static_assert(PMX_WINO_RUN_TILES == 32, "tile index bits");
-    const long long total = (long long)r.B * r.run_nb * (PMX_WINO_RUN_TILES * 4) * (r.cout[0] / 4);
+    const long long total = (long long)r.B * r.nslab * r.run_nb * (PMX_WINO_RUN_TILES * (r.pool ? 1 : 4)) * (r.cout[0] / 4);
     hipLaunchKernelGGL(conv_wino_tail_reduce_kernel, dim3((unsigned)((total + 255) / 256), 1, (unsigned)groups), dim3(256), 0, stream, r);
     PMX_HIP(hipGetLastError());
     return PMX_OK;

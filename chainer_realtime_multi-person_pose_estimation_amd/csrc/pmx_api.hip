@@ -136,7 +136,6 @@ static inline float bf16_f(uint16_t h)
 // rounded once to fp32 (oracle/conv_fma_ref.c::conv_wino_ref does the same); layout [plane = sub-kernel * 16 + 4i + j][chunk of 32
 // cin][k8-step 4][cout_pad][8].  ks = 3: one sub-kernel; ks = 7: four, sub-kernel (sy, sx) = taps (3 sy .. 3 sy + 2, 3 sx .. 3 sx + 2); row 6 and
 // column 6 of the 7x7 kernel are two 1x3 / two 3x1 sub-kernels with the 1-D transform G g (planes 64.., 72..), tap (6, 6) is plane 80
-static bool wino_eligible(int ks, int cin_pad, int cout_pad) { return (ks == 3 || ks == 7) && cin_pad % 32 == 0 && cout_pad % 128 == 0; }
 static void pack_wino(const std::vector<float>& wp, int ks, int nch16, int cout_pad, std::vector<float>& out)
 {
     static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
@@ -742,7 +741,8 @@ static int launch_wino_run(pmx_ctx* c, const ConvArgs& a0, int ks, int groups, i
     const int S = (a0.nch + tail_g - 1) / tail_g + (ks == 7 ? 3 : 0);
     PMX_CHECK(S >= 2 && S <= 8, PMX_ERR_INVALID, "winograd tail: %d slabs", S);
     PMX_CHECK(a0.cout_pad <= SK_ZERO_BIAS, PMX_ERR_INVALID, "split-K: cout_pad %d too large", a0.cout_pad);
-    const size_t slab = (size_t)a0.B * PMX_WINO_RUN_TILES * 4 * a0.cout_pad;      // one block per image: [image][tile][pixel][cout_pad]
+    const int nslab = a0.W / (2 * PMX_WINO_RUN_TX);
+    const size_t slab = (size_t)a0.B * nslab * PMX_WINO_RUN_TILES * 4 * a0.cout_pad;      // one block per (image, slab): [image][slab][tile][pixel][cout_pad]
     const size_t need = slab * S * groups;
     if (need > c->sk_floats) {
         PMX_HIP(hipStreamSynchronize(c->stream));
@@ -765,7 +765,7 @@ static int launch_wino_run(pmx_ctx* c, const ConvArgs& a0, int ks, int groups, i
     a.ldc = a0.cout_pad; a.relu = 0; a.pool = 0; a.ksplit = S; a.slab_stride = (long long)slab; a.kbounds = (unsigned long long)tail_g;
     a.run_j0 = nfull; a.run_nb = 1;
     r.slab_stride = (long long)slab; r.S = S; r.B = a0.B; r.H = a0.H; r.W = a0.W; r.ld_slab = a0.cout_pad; r.ldc = a0.ldc;
-    r.relu = a0.relu; r.run_j0 = nfull; r.run_nb = 1;
+    r.relu = a0.relu; r.run_j0 = nfull; r.run_nb = 1; r.nslab = nslab; r.pool = a0.pool;
     // (profile mode 2 -- the dominant kernel only, inside timed regions -- leaves these two short launches without events: an event pair
     //  costs ~5 us of idle stream)
     const bool pf_all = pf && c->prof_on == 1;
@@ -777,101 +777,16 @@ static int launch_wino_run(pmx_ctx* c, const ConvArgs& a0, int ks, int groups, i
     return pf_all ? prof_end(c) : PMX_OK;
 }
 
-// Which form a 3x3 / 7x7 layer takes: 0 = direct kernels (+ split-K), 1 = the Winograd kernel, 2 = the Winograd kernel in unit mode
-// (*unit_g = chunks per pass-1 unit).  Blocks are equal and run one per CU, so the plain kernel costs ceil(blocks / CUs) rounds however
-// full the last one is; the unit mode costs the same work at finer grain (no round quantisation, ~0.8 of the plain kernel's in-round
-// efficiency) plus the slab traffic of the combine kernel; the direct kernels win when neither fills the chip
-// (tools/wino_batch_sweep.py).  A forced split-K option (never, n slices, an explicit plan) is a statement about the direct kernels:
-// no unit mode then.
-// Measured block times of the Winograd kernel (MI355X, one block per CU), microseconds per 32-channel chunk of a plain block / per phase of
-// 128 MFMAs per wave, and the fixed cost of a unit block (prologue: first halo + weights exposed; epilogue: output transform, slab store)
-static const double WINO_T7_CHUNK_US = 50.0, WINO_T3_CHUNK_US = 9.3, WINO_PHASE_US = 4.0, WINO_UNIT_FIXED_US = 8.0;
-
-// Makespan (microseconds) of the unit-mode launch of `nblk` part-filled blocks (images x 128-channel blocks) cut into pass-1 units of g chunks
-// (+ row 6, column 6, tap (6, 6) for 7x7): blocks are dispatched unit by unit (blockIdx.z = unit * groups + group) to the CU that frees first
-static double wino_tail_makespan(int ks, int nch, int g, long long nblk, int ncu)
-{
-    std::vector<double> unit_us;
-    for (int c = 0; c < nch; c += g) unit_us.push_back(std::min(g, nch - c) * (ks == 7 ? 8.0 : 2.0) * WINO_PHASE_US + WINO_UNIT_FIXED_US);
-    if (ks == 7) {
-        unit_us.push_back(nch * 2.0 * WINO_PHASE_US + WINO_UNIT_FIXED_US);      // row 6
-        unit_us.push_back(nch * 2.0 * WINO_PHASE_US + WINO_UNIT_FIXED_US);      // column 6
-        unit_us.push_back(nch * 0.5 * WINO_PHASE_US + WINO_UNIT_FIXED_US);      // tap (6, 6)
-    }
-    std::vector<double> cu((size_t)ncu, 0.0);        // min-heap of the CUs' free times
-    auto cmp = [](double a, double b) { return a > b; };
-    double end = 0.0;
-    for (double t : unit_us)
-        for (long long b = 0; b < nblk; ++b) {
-            std::pop_heap(cu.begin(), cu.end(), cmp);
-            cu.back() += t;
-            end = std::max(end, cu.back());
-            std::push_heap(cu.begin(), cu.end(), cmp);
-        }
-    return end;
-}
-
-// *run = 1: mode 1 in the run geometry (46-pixel-wide maps, no pool); *tail_g > 0: its part-filled last blocks in unit mode, g chunks per
-// pass-1 unit (launch_wino_run)
+// Which form a 3x3 / 7x7 layer takes (conv_select.hip): 0 = direct kernels (+ split-K), 1 = the Winograd kernel (*run: in the run geometry,
+// *tail_g > 0: its part-filled last blocks in unit mode), 2 = the Winograd kernel in unit mode (*unit_g = chunks per pass-1 unit)
 static int wino_mode(const pmx_ctx* c, int ks, int cin_pad, int cout_pad, int cout, int ldc, int images, int H, int W, int pool, int* unit_g,
                      int* run, int* tail_g)
 {
-    *unit_g = 0; *run = 0; *tail_g = 0;
-    if (c->opt_conv_algo < 1 || c->opt_precision != 0 || c->opt_force[ks] >= 0 || !wino_eligible(ks, cin_pad, cout_pad)) return 0;
-    const int nch = cin_pad / 32, extra = ks == 7 ? 3 : 0;     // 7x7: + row 6, column 6, tap (6, 6)
-    int g = 0, S = 0;
-    if (c->opt_ksplit == 0 && cout % 4 == 0 && ldc % 4 == 0 && nch >= 2) {       // unit plan: as many units as 8 slabs allow
-        const int nu1_max = 8 - extra;
-        g = (nch + nu1_max - 1) / nu1_max;
-        const int nu1 = (nch + g - 1) / g;
-        if (nu1 >= 2) S = nu1 + extra; else g = 0;
-    }
-    const long long ncu = conv_num_cus(), nb = cout_pad / 128;
-    // run geometry: blocks of 32 consecutive tiles; the part-filled last block of an image (if any) can run as S unit blocks
-    const bool geom_run = W == PMX_WINO_RUN_TX * 2 && !pool && c->opt_wino_geom != 0;
-    const int ntiles = PMX_WINO_RUN_TX * ((H + 1) / 2), nblk = (ntiles + PMX_WINO_RUN_TILES - 1) / PMX_WINO_RUN_TILES, nfull = ntiles / PMX_WINO_RUN_TILES;
-    const bool tail_ok = geom_run && g > 0 && nfull >= 1 && nfull < nblk && c->opt_wino_tail != 0;
-    if (c->opt_conv_algo == 2) {                  // tests: the plain kernel on every eligible layer (the tail in units only when asked for)
-        *run = geom_run;
-        if (tail_ok && c->opt_wino_tail == 1) *tail_g = g;
-        return 1;
-    }
-    if (c->opt_conv_algo == 3) { *unit_g = g; return g ? 2 : 0; }               // tests: unit mode wherever it applies
-    // cost of the plain kernel in rounds of one block per CU (equal blocks: a round costs the same however full it is)
-    const long long blocks = geom_run ? (long long)nblk * images * nb : (long long)((H + 7) / 8) * ((W + 15) / 16) * images * nb;
-    const long long rounds = (blocks + ncu - 1) / ncu;
-    double plain_cost = (double)rounds;
-    int tg = 0;
-    if (tail_ok) {
-        // the full blocks as whole rounds + the tail as unit blocks (best g by a dispatch simulation) + two more launches and the combine
-        const double t_block = nch * (ks == 7 ? WINO_T7_CHUNK_US : WINO_T3_CHUNK_US);
-        const long long main_rounds = ((long long)nfull * images * nb + ncu - 1) / ncu;
-        double best = 1e30;
-        int best_g = 0;
-        for (int gg = 1; gg <= nch; ++gg) {
-            const int SS = (nch + gg - 1) / gg + extra;
-            if (SS < 2 || SS > 8 || (gg > 1 && (nch + gg - 2) / (gg - 1) + extra == SS)) continue;      // (same unit count as a smaller g: skip)
-            const double t = wino_tail_makespan(ks, nch, gg, (long long)images * nb, (int)ncu) + 2.0 * SS;   // + the combine's slab reads
-            if (t < best) { best = t; best_g = gg; }
-        }
-        if (c->opt_wino_tail_g > 0 && c->opt_wino_tail_g <= nch) {
-            const int SS = (nch + c->opt_wino_tail_g - 1) / c->opt_wino_tail_g + extra;
-            if (SS >= 2 && SS <= 8) { best_g = c->opt_wino_tail_g; best = wino_tail_makespan(ks, nch, best_g, (long long)images * nb, (int)ncu) + 2.0 * SS; }
-        }
-        const double cost = (double)main_rounds + (best + 10.0) / t_block;
-        if (best_g && (c->opt_wino_tail == 1 || cost < plain_cost)) { plain_cost = cost; tg = best_g; }
-    }
-    if (g) {
-        const double t_block = nch * (ks == 7 ? 52e-6 : 18.5e-6);                 // one plain block (measured), seconds
-        // (3x3 units are short -- 256 MFMAs per chunk against ~10 us of block prologue / epilogue: 3/4 of the 7x7 figure)
-        const double eff = c->opt_wino_unit_eff / 100.0 * (ks == 7 ? 1.0 : 0.75);
-        const long long ublocks = (long long)((H + 7) / 8) * ((W + 15) / 16) * images * nb;       // unit mode keeps the rectangles
-        const double est_unit = (double)ublocks / (ncu * eff) +
-                                (double)ublocks * (S + 1) * 65536.0 / 3.0e12 / t_block + 0.03;      // in rounds of the plain kernel
-        if (est_unit < plain_cost) { *unit_g = g; return 2; }
-    }
-    if (blocks * 100 >= (long long)c->opt_wino_min_fill * rounds * ncu) { *run = geom_run; *tail_g = tg; return 1; }
-    return 0;
+    WinoSelectOpts o;
+    o.conv_algo = c->opt_conv_algo; o.precision = c->opt_precision; o.forced_variant = c->opt_force[ks]; o.ksplit = c->opt_ksplit;
+    o.wino_unit_eff = c->opt_wino_unit_eff; o.wino_min_fill = c->opt_wino_min_fill; o.wino_geom = c->opt_wino_geom; o.wino_tail = c->opt_wino_tail;
+    o.wino_tail_g = c->opt_wino_tail_g;
+    return wino_select(o, ks, cin_pad, cout_pad, cout, ldc, images, H, W, pool, unit_g, run, tail_g);
 }
 
 // one launch of 1 or 2 groups (same geometry); in/out pointers are already offset to the group's channels

@@ -80,12 +80,13 @@ struct ConvArgs {
     // Winograd kernel, run geometry (46-pixel-wide maps): a block owns 32 consecutive Winograd tiles (row-major over the 23 x ceil(H / 2)
     // tile grid of one image); this launch covers the blocks [run_j0, run_j0 + run_nb) of every image
     int run_j0, run_nb;
+    int run_nslab;           // slabs of 46 columns per image (W / 46)
 };
 // Winograd run geometry: tile columns of a 46-pixel-wide map / tiles per block
 #define PMX_WINO_RUN_TX 23
 #define PMX_WINO_RUN_TILES 32
 // combine of the unit-mode slabs of a block range (the part-filled last block of every image): out = slab_0 + slab_1 + ... (unit order),
-// + bias, ReLU; compact slabs [unit][image][block - run_j0][tile 32][pixel 4][ld_slab]
+// [2x2 max-pool], + bias, ReLU; compact slabs [unit][image][slab][block - run_j0][tile 32][pixel 4][ld_slab]
 struct WinoTailReduceArgs {
     const float* slabs[2];
     const float* bias[2];
@@ -93,10 +94,20 @@ struct WinoTailReduceArgs {
     int cout[2];
     long long slab_stride;   // floats between the unit slabs of one group
     int S, B, H, W, ld_slab, ldc, relu, run_j0, run_nb;
+    int nslab, pool;         // slabs per image; pool: 2x2 max over the tile's four pixels before the bias
 };
 int conv_wino_tail_reduce(const WinoTailReduceArgs& r, int groups, hipStream_t stream);
-// launch of the run-geometry Winograd kernel (a.W == 46, no pool); a.ksplit > 1: unit mode writing compact slabs (see WinoTailReduceArgs)
+// launch of the run-geometry Winograd kernel (a.W % 46 == 0); a.ksplit > 1: unit mode writing compact slabs (see WinoTailReduceArgs)
 int conv_wino_run_launch(const ConvArgs& a, int ks, int groups, hipStream_t stream);
+// ---- kernel selection for the 3x3 / 7x7 layers (conv_select.hip) ------------------------------------------------------------
+struct WinoSelectOpts {      // the context options the choice depends on (pmx_set_option keys of the same names)
+    int conv_algo, precision, forced_variant, ksplit, wino_unit_eff, wino_min_fill, wino_geom, wino_tail, wino_tail_g;
+};
+bool wino_eligible(int ks, int cin_pad, int cout_pad);
+// returns 0 = direct kernels (+ split-K), 1 = the Winograd kernel (*run = 1: run geometry; *tail_g > 0: chunks per pass-1 unit of its
+// part-filled last blocks, which then run in unit mode), 2 = the Winograd kernel in unit mode (*unit_g = chunks per pass-1 unit)
+int wino_select(const WinoSelectOpts& o, int ks, int cin_pad, int cout_pad, int cout, int ldc, int images, int H, int W, int pool, int* unit_g,
+                int* run, int* tail_g);
 struct SplitPlan { int S; unsigned long long bounds; int sizes[8]; };
 struct SplitKReduceArgs {
     const float* slabs[2];   // per group: ksplit slabs of B x H x W x ld_slab floats

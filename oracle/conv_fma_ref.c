@@ -73,11 +73,13 @@ void conv_fma_ref(const float* x, const float* w, const float* bias, float* y, i
  *   max-pool (3x3 only) = max of the tile's four outputs (before the bias, like the kernel), + bias, ReLU.
  * The window of output tile (ty, tx), sub-kernel (sy, sx), covers input rows 2 ty - pad + 3 sy .. + 3 (columns alike), zeros outside. */
 #include <stdlib.h>
-/* unit_g_all > 0: the tiles with row-major index ty * TX + tx >= unit_from are summed unit by unit (the kernel's unit mode: every tile of
- * a single image, unit_from = 0; or the part-filled last block of every image in the run geometry of 46-pixel-wide maps, unit_from =
- * 32 * (TY * TX / 32), profile label ".../t<g>"); all other tiles are one chain (plain kernel). */
+/* unit_g_all > 0: the tiles with row-major index >= unit_from are summed unit by unit (the kernel's unit mode: every tile of a single
+ * image, unit_from = 0; or the part-filled last block of every (image, slab) in the run geometry, profile label ".../t<g>"); all other
+ * tiles are one chain (plain kernel).  run_tx = 0: the index runs over the whole tile grid (ty * TX + tx); run_tx > 0 (run geometry: 23):
+ * the map is cut into slabs of run_tx tile columns and the index runs inside a slab (ty * run_tx + tx % run_tx; unit_from =
+ * 32 * (TY * run_tx / 32)). */
 void conv_wino_ref2(const float* x, const float* w, const float* bias, float* y, int B, int cin, int H, int W, int cout, int ks,
-                    int relu, int pool, int unit_g_all, int unit_from)
+                    int relu, int pool, int unit_g_all, int unit_from, int run_tx)
 {
     static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     const int pad = ks / 2, nsub = ks == 3 ? 1 : 4, ndir = ks == 3 ? 0 : 13;
@@ -134,7 +136,8 @@ void conv_wino_ref2(const float* x, const float* w, const float* bias, float* y,
                      * 0) and its own output transform; row 6, column 6 and tap (6, 6) as units starting from 0; the units are added in
                      * that order */
                     float yv[2][2], ysum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-                    const int unit_g = (unit_g_all > 0 && ty * TX + tx >= unit_from) ? unit_g_all : 0;
+                    const int tidx = run_tx > 0 ? ty * run_tx + tx % run_tx : ty * TX + tx;
+                    const int unit_g = (unit_g_all > 0 && tidx >= unit_from) ? unit_g_all : 0;
                     const int ustep = unit_g > 0 ? 32 * unit_g : ((cin + 31) / 32) * 32;
                     int nunit = 0;
                     for (int cu = 0; cu < cin; cu += ustep, ++nunit) {
@@ -258,5 +261,5 @@ void conv_wino_ref2(const float* x, const float* w, const float* bias, float* y,
 void conv_wino_ref(const float* x, const float* w, const float* bias, float* y, int B, int cin, int H, int W, int cout, int ks,
                    int relu, int pool, int unit_g)
 {
-    conv_wino_ref2(x, w, bias, y, B, cin, H, W, cout, ks, relu, pool, unit_g, 0);
+    conv_wino_ref2(x, w, bias, y, B, cin, H, W, cout, ks, relu, pool, unit_g, 0, 0);
 }

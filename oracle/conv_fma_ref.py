@@ -52,24 +52,30 @@ def conv_fma(x, w, b, relu=False, pool=False, splitk=1):
     return y
 
 
+RUN_TX = 23       # tile columns of a slab of the run geometry (46 pixels)
+
+
 def wino_run_unit_from(H, W):
-    """First Winograd tile (row-major index) of the part-filled last block of an image in the kernel's run geometry: blocks of 32
-    consecutive tiles of the ceil(H / 2) x ceil(W / 2) grid (csrc/conv_mfma.hip: GEOM 1, 46-pixel-wide maps)."""
-    return ((H + 1) // 2) * ((W + 1) // 2) // 32 * 32
+    """First Winograd tile (row-major index inside a slab) of the part-filled last block of an (image, slab) in the kernel's run
+    geometry: the map is cut into slabs of 46 columns and a block owns 32 consecutive tiles of the ceil(H / 2) x 23 grid of one slab
+    (csrc/conv_mfma.hip: GEOM 1, maps whose width is a multiple of 46)."""
+    assert W % (2 * RUN_TX) == 0
+    return ((H + 1) // 2) * RUN_TX // 32 * 32
 
 
-def conv_wino(x, w, b, relu=False, pool=False, unit_g=0, unit_from=0):
+def conv_wino(x, w, b, relu=False, pool=False, unit_g=0, unit_from=0, run_tx=None):
     """The Winograd F(2x2, 3x3) kernel's arithmetic (csrc/conv_mfma.hip::conv_wino_kernel, option "conv_algo"): same shapes as
     conv_fma, 3x3 or 7x7 (four 3x3 sub-kernels in the frequency domain + row 6 / column 6 as 1-D sub-kernels + tap (6, 6)).  Defined order, but not the direct
     kernels' chain: the two agree to ~1e-6 of the map scale.  unit_g > 0 (7x7): the kernel's unit mode for single images -- pass 1 in
     units of unit_g 32-channel chunks, pass 2a, pass 2b, each summed from 0 and added in that order (kernel label ".../u<g>").
-    unit_from: only the tiles with row-major index >= unit_from are summed that way (the part-filled last block of every image in the
-    run geometry, kernel label "...r/t<g>": unit_from = wino_run_unit_from(H, W))."""
+    unit_from: only the tiles with row-major index >= unit_from are summed that way (the part-filled last block of every (image, slab)
+    in the run geometry, kernel label "...r/t<g>": unit_from = wino_run_unit_from(H, W), the index then runs inside a 23-column slab:
+    run_tx, default 23 when unit_from is given on a map whose width is a multiple of 46)."""
     global _lib
     if _lib is None:
         conv_fma(np.zeros((1, 1, 1, 1), 'f'), np.zeros((1, 1, 1, 1), 'f'), np.zeros(1, 'f'))
     _lib.conv_wino_ref2.restype = None
-    _lib.conv_wino_ref2.argtypes = [C.c_void_p] * 4 + [C.c_int] * 10
+    _lib.conv_wino_ref2.argtypes = [C.c_void_p] * 4 + [C.c_int] * 11
     x = np.ascontiguousarray(x, np.float32)
     w = np.ascontiguousarray(w, np.float32)
     b = np.ascontiguousarray(b, np.float32)
@@ -77,8 +83,10 @@ def conv_wino(x, w, b, relu=False, pool=False, unit_g=0, unit_from=0):
     cout, _, ks, _ = w.shape
     assert ks in (3, 7) and not (pool and ks == 7)
     y = np.empty((B, cout, H // 2 if pool else H, W // 2 if pool else W), np.float32)
+    if run_tx is None:
+        run_tx = RUN_TX if (unit_from and W % (2 * RUN_TX) == 0) else 0
     _lib.conv_wino_ref2(x.ctypes.data, w.ctypes.data, b.ctypes.data, y.ctypes.data, B, cin, H, W, cout, ks, int(relu), int(pool), int(unit_g),
-                        int(unit_from))
+                        int(unit_from), int(run_tx))
     return y
 
 

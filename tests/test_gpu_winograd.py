@@ -77,70 +77,80 @@ def test_winograd_launch_selection_by_round_fill(engine):
     engine.set_option('ksplit', 0)
 
 
-@pytest.mark.parametrize('B,cin,H,cout,k,relu', [
-    (2, 64, 46, 128, 7, True),          # 46 x 46: 16 full runs of 32 tiles + 17 tiles
-    (1, 192, 46, 128, 7, True),         # Mconv1-shaped (6 chunks)
-    (3, 32, 20, 130, 7, False),         # 230 tiles = 7 runs + 6 tiles; cout padded to 256
-    (1, 96, 45, 256, 3, True),          # odd H: the last tile row is half used
-    (2, 64, 46, 128, 3, True),
-    (1, 32, 2, 128, 7, True),           # one part-filled run, every window crosses the border
-    (1, 64, 3, 128, 3, False),
-    (1, 64, 92, 128, 7, True)])         # taller than wide: 34 runs
-def test_winograd_run_geometry_bit_exact_vs_c_twin(engine, B, cin, H, cout, k, relu):
-    """46-pixel-wide maps take the run geometry of the Winograd kernel (blocks of 32 consecutive tiles in row-major order instead of
-    8 x 16 pixel rectangles; conv_mfma.hip GEOM 1): same arithmetic per tile, so the same bits as the rectangles and as the twin."""
-    x, w, b = _data(7 * B + cin + H + k, B, cin, H, 46, cout, k)
-    y = _run(engine, x, w, b, relu, False, 2)
+@pytest.mark.parametrize('B,cin,H,W,cout,k,relu,pool', [
+    (2, 64, 46, 46, 128, 7, True, False),          # 46 x 46: 16 full runs of 32 tiles + 17 tiles
+    (1, 192, 46, 46, 128, 7, True, False),         # Mconv1-shaped (6 chunks)
+    (3, 32, 20, 46, 130, 7, False, False),         # 230 tiles = 7 runs + 6 tiles; cout padded to 256
+    (1, 96, 45, 46, 256, 3, True, False),          # odd H: the last tile row is half used
+    (2, 64, 46, 46, 128, 3, True, False),
+    (1, 32, 2, 46, 128, 7, True, False),           # one part-filled run, every window crosses the border
+    (1, 64, 3, 46, 128, 3, False, False),
+    (1, 64, 92, 46, 128, 7, True, False),          # taller than wide: 34 runs
+    (1, 64, 30, 92, 128, 3, True, False),          # two slabs of 46 columns: halo columns come from the neighbour slab
+    (2, 32, 24, 92, 128, 3, True, True),           # ... with the fused 2x2 max-pool (conv3_4-shaped)
+    (1, 64, 14, 184, 128, 3, False, True),         # four slabs (conv2_2-shaped)
+    (1, 32, 9, 138, 128, 7, True, False)])         # three slabs, 7x7, odd H
+def test_winograd_run_geometry_bit_exact_vs_c_twin(engine, B, cin, H, W, cout, k, relu, pool):
+    """Maps whose width is a multiple of 46 take the run geometry of the Winograd kernel (vertical slabs of 46 columns, blocks of 32
+    consecutive tiles of a slab in row-major order instead of 8 x 16 pixel rectangles; conv_mfma.hip GEOM 1): same arithmetic per
+    tile, so the same bits as the rectangles and as the twin."""
+    x, w, b = _data(7 * B + cin + H + k + W, B, cin, H, W, cout, k)
+    y = _run(engine, x, w, b, relu, pool, 2)
     engine.set_option('wino_geom', 0)
     try:
-        y_rect = _run(engine, x, w, b, relu, False, 2)
+        y_rect = _run(engine, x, w, b, relu, pool, 2)
     finally:
         engine.set_option('wino_geom', -1)
-    ref = R.conv_wino(x, w, b, relu, False)
+    ref = R.conv_wino(x, w, b, relu, pool)
     assert y.shape == ref.shape and np.isfinite(y).all()
     assert np.array_equal(y, ref), (np.abs(y - ref).max(), int((y != ref).sum()))
     assert np.array_equal(y_rect, ref)
-    assert not np.array_equal(y, _run(engine, x, w, b, relu, False, 0)), 'the Winograd kernel did not run'
+    assert not np.array_equal(y, _run(engine, x, w, b, relu, pool, 0)), 'the Winograd kernel did not run'
 
 
-@pytest.mark.parametrize('B,cin,H,cout,k,relu', [
-    (2, 128, 46, 128, 7, True),         # the 7x7 layers of stages 2-6: units of 1 chunk -> 4 + row 6 + column 6 + tap (6, 6) = 7 slabs
-    (1, 192, 46, 128, 7, True),         # Mconv1: units of 2 chunks -> 6 slabs
-    (1, 64, 46, 256, 7, False),
-    (2, 256, 46, 128, 3, True),         # conv4_4: 8 chunk units
-    (1, 512, 46, 512, 3, True),         # conv4_2: 16 chunks in units of 2
-    (1, 96, 45, 132, 7, True),          # odd H, cout padded to 256
-    (1, 64, 10, 128, 3, True)])         # 115 tiles = 3 runs + 19 tiles
-def test_winograd_run_tail_in_unit_mode_bit_exact_vs_c_twin(engine, B, cin, H, cout, k, relu):
+@pytest.mark.parametrize('B,cin,H,W,cout,k,relu,pool', [
+    (2, 128, 46, 46, 128, 7, True, False),         # the 7x7 layers of stages 2-6: units of 1 chunk -> 4 + row 6 + column 6 + tap (6, 6) = 7 slabs
+    (1, 192, 46, 46, 128, 7, True, False),         # Mconv1: units of 2 chunks -> 6 slabs
+    (1, 64, 46, 46, 256, 7, False, False),
+    (2, 256, 46, 46, 128, 3, True, False),         # conv4_4: 8 chunk units
+    (1, 512, 46, 46, 512, 3, True, False),         # conv4_2: 16 chunks in units of 2
+    (1, 96, 45, 46, 132, 7, True, False),          # odd H, cout padded to 256
+    (1, 64, 10, 46, 128, 3, True, False),          # 115 tiles = 3 runs + 19 tiles
+    (2, 64, 12, 92, 128, 3, True, False),          # two slabs, 138 tiles each = 4 runs + 10 tiles
+    (1, 128, 20, 184, 128, 3, True, True)])        # four slabs, pooled: the combine kernel pools the tail tiles
+def test_winograd_run_tail_in_unit_mode_bit_exact_vs_c_twin(engine, B, cin, H, W, cout, k, relu, pool):
     """Run geometry with the part-filled last block of every image in unit mode (option wino_tail = 1; by the cost model at batch
     32): the full runs as one plain launch, the tail as K units writing compact slabs + conv_wino_tail_reduce_kernel == the twin with
     `unit_from` = first tile of that block, bit for bit; the tiles in front of it keep the plain chain."""
-    x, w, b = _data(11 * B + cin + H + k, B, cin, H, 46, cout, k)
+    x, w, b = _data(11 * B + cin + H + k + W, B, cin, H, W, cout, k)
     nch = (cin + 31) // 32
     g = -(-nch // (8 - (3 if k == 7 else 0)))
     engine.set_option('wino_tail', 1)
     try:
-        y = _run(engine, x, w, b, relu, False, 2)
+        y = _run(engine, x, w, b, relu, pool, 2)
     finally:
         engine.set_option('wino_tail', -1)
-    uf = R.wino_run_unit_from(H, 46)
+    uf = R.wino_run_unit_from(H, W)
     ntiles = 23 * ((H + 1) // 2)
     assert 0 < uf < ntiles
-    ref = R.conv_wino(x, w, b, relu, False, unit_g=g, unit_from=uf)
-    plain = R.conv_wino(x, w, b, relu, False)
+    ref = R.conv_wino(x, w, b, relu, pool, unit_g=g, unit_from=uf)
+    plain = R.conv_wino(x, w, b, relu, pool)
     assert np.array_equal(y, ref), (np.abs(y - ref).max(), int((y != ref).sum()))
     assert not np.array_equal(y, plain), 'the tail did not run in unit mode'
-    m = np.zeros((H + 1, 46), bool)                       # pixels of the tiles in front of the tail: the plain chain
-    for t in range(uf):
-        m[2 * (t // 23):2 * (t // 23) + 2, 2 * (t % 23):2 * (t % 23) + 2] = True
-    assert np.array_equal(y[..., m[:H]], plain[..., m[:H]])
-    t = N.conv2d_ref(x, w, b, relu=relu, pool=False)
+    if not pool:
+        m = np.zeros((H + 1, W), bool)                    # pixels of the tiles in front of the tails: the plain chain
+        for sl in range(W // 46):
+            for t in range(uf):
+                m[2 * (t // 23):2 * (t // 23) + 2, 46 * sl + 2 * (t % 23):46 * sl + 2 * (t % 23) + 2] = True
+        assert np.array_equal(y[..., m[:H]], plain[..., m[:H]])
+    t = N.conv2d_ref(x, w, b, relu=relu, pool=pool)
     assert np.abs(y - t).max() <= TOL * max(1.0, np.abs(t).max())
 
 
 def test_single_image_368_runs_and_tails_bit_exact(native):
     """One 368x368 image with the plain Winograd kernel forced on every eligible layer and the tails in unit mode: the 46x46 layers
-    (conv4_x, conv5_x, all 7x7 layers) take the run geometry (labels "...r/t<g>") and forward_fma with that plan reproduces the maps
+    (conv4_x, conv5_x, all 7x7 layers) and the 92- / 184-wide ones of the stem (two / four slabs) take the run geometry (labels
+    "...r/t<g>") and forward_fma with that plan reproduces the maps
     bit for bit -- the launch forms batch 32 uses by default, on one frame."""
     weights = pkg('weights').synthetic_weights(0)
     eng = native.Engine(0, max_batch=1, max_h=368, max_w=368)
@@ -152,7 +162,8 @@ def test_single_image_368_runs_and_tails_bit_exact(native):
     paf, heat = eng.get_maps()
     eng.close()
     assert plan.wino_tails.get('Mconv2_stage3') == 1 and plan.wino_tails.get('Mconv1_stage2') == 2 and plan.wino_tails.get('conv4_2') == 2 \
-        and plan.wino_tails.get('conv5_1_CPM') == 1 and 'conv3_2' not in plan.wino_tails and len(plan.wino_tails) == 32, plan.wino_tails
+        and plan.wino_tails.get('conv5_1_CPM') == 1 and plan.wino_tails.get('conv3_2') == 1 and plan.wino_tails.get('conv2_2') == 1 \
+        and len(plan.wino_tails) == 38, plan.wino_tails
     rpaf, rheat = R.forward_fma(weights, P.preprocess(img[0]), splitk=plan)
     assert np.array_equal(paf, rpaf) and np.array_equal(heat, rheat), (np.abs(paf - rpaf).max(), np.abs(heat - rheat).max())
 
