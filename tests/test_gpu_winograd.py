@@ -318,3 +318,36 @@ def test_single_image_368_default_plan_bit_exact(native):
         (plan.wino_units, sorted(plan.wino))
     rpaf, rheat = R.forward_fma(weights, P.preprocess(img[0]), splitk=plan)
     assert np.array_equal(paf, rpaf) and np.array_equal(heat, rheat), (np.abs(paf - rpaf).max(), np.abs(heat - rheat).max())
+
+
+# ---- randomised shapes for the run geometry (deterministic example set by default; PMX_FUZZ=<n> draws n fresh random examples) ----------
+import os as _os
+from hypothesis import given, settings, strategies as st, HealthCheck
+
+_FUZZ = int(_os.environ.get('PMX_FUZZ', '0'))
+
+
+@settings(max_examples=_FUZZ or 24, derandomize=not _FUZZ, deadline=None, database=None,
+          suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(seed=st.integers(0, 10 ** 6), k=st.sampled_from([3, 7]), B=st.integers(1, 3), H=st.integers(1, 60), slabs=st.integers(1, 3),
+       nch=st.integers(1, 6), cout=st.sampled_from([100, 128, 132, 256]), relu=st.booleans(), pool=st.booleans(), tail=st.booleans())
+def test_random_run_geometry_shapes_bit_exact(engine, seed, k, B, H, slabs, nch, cout, relu, pool, tail):
+    """Random maps of 1-3 slabs of 46 columns, any height (part-filled runs, single rows, odd heights), 1-6 chunks, padded output
+    channels, with / without the fused pool, tails in unit mode or in the plain launch: the run-geometry kernels (GEOM 1 / 2, their
+    unit-mode twins and conv_wino_tail_reduce_kernel) equal the plain-C twin bit for bit."""
+    W = 46 * slabs
+    pool = pool and k == 3 and H % 2 == 0
+    cin = 32 * nch
+    x, w, b = _data(seed, B, cin, H, W, cout, k)
+    engine.set_option('wino_tail', 1 if tail else 0)
+    try:
+        y = _run(engine, x, w, b, relu, pool, 2)
+    finally:
+        engine.set_option('wino_tail', -1)
+    g = -(-nch // (8 - (3 if k == 7 else 0)))
+    ntiles = 23 * ((H + 1) // 2)
+    uf = R.wino_run_unit_from(H, W)
+    tailed = tail and nch >= 2 and cout % 4 == 0 and 0 < uf < ntiles and -(-nch // g) >= 2        # the plan wino_select makes
+    ref = R.conv_wino(x, w, b, relu, pool, unit_g=g, unit_from=uf) if tailed else R.conv_wino(x, w, b, relu, pool)
+    assert y.shape == ref.shape
+    assert np.array_equal(y, ref), (k, B, cin, H, W, cout, relu, pool, tailed, float(np.abs(y - ref).max()), int((y != ref).sum()))
