@@ -29,6 +29,7 @@
 //                    128 B contiguous per half-wave).
 //   grid             x = tiles * batch, y = cout_pad / BN, z = group (the PAF and heat-map branches of a stage
 //                    run as the two groups of one launch).
+#include <hip/hip_ext.h>
 #include <atomic>
 #include <mutex>
 #include <type_traits>
@@ -2748,6 +2749,12 @@ int conv_wino_launch(const ConvArgs& a, int ks, int groups, hipStream_t stream)
 }
 
 // run geometry (46-pixel-wide maps): the blocks [a.run_j0, a.run_j0 + a.run_nb) of every image, 32 consecutive Winograd tiles each
+// Events for the NEXT run-geometry launch of this thread (profile mode 2): handed to hipExtLaunchKernelGGL, which stamps them from the
+// dispatch's own completion signal -- the kernel's execution time without the two barrier packets of hipEventRecord (~6 us of idle stream
+// per pair, 25 pairs per step inside bench.py's timed region)
+static thread_local hipEvent_t g_launch_ev0 = nullptr, g_launch_ev1 = nullptr;
+void conv_set_launch_events(hipEvent_t e0, hipEvent_t e1) { g_launch_ev0 = e0; g_launch_ev1 = e1; }
+
 template <int KS, int POOL, int UNIT, int GEOM>
 static int launch_wino_run_g(const ConvArgs& a0, int groups, hipStream_t stream)
 {
@@ -2767,7 +2774,11 @@ static int launch_wino_run_g(const ConvArgs& a0, int groups, hipStream_t stream)
     if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(kern), attr_set)) return rc;
     if (UNIT) { a.ngroups = groups; PMX_CHECK(a.ksplit >= 2 && a.ksplit <= 8 && a.kbounds >= 1, PMX_ERR_INVALID, "conv wino: bad unit plan"); }
     dim3 grid((unsigned)(a.run_nb * a.B * a.run_nslab), (unsigned)(a.cout_pad / 128), (unsigned)(groups * (UNIT ? a.ksplit : 1)));
-    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, a);
+    if (g_launch_ev0) {
+        hipExtLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, g_launch_ev0, g_launch_ev1, 0, a);
+        g_launch_ev0 = g_launch_ev1 = nullptr;
+    } else
+        hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, a);
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }

@@ -310,7 +310,7 @@ struct pmx_ctx {
     int prof_open = -1;
 };
 
-static int prof_begin(pmx_ctx* c, const std::string& name, double flops, double bytes, double issued = -1.0)
+static int prof_begin(pmx_ctx* c, const std::string& name, double flops, double bytes, double issued = -1.0, bool record = true)
 {
     if (!c->prof_on) return PMX_OK;
     int idx;
@@ -326,7 +326,7 @@ static int prof_begin(pmx_ctx* c, const std::string& name, double flops, double 
         if (!c->ev_pool.empty()) { *e = c->ev_pool.back(); c->ev_pool.pop_back(); }
         else PMX_HIP(hipEventCreate(e));
     }
-    PMX_HIP(hipEventRecord(p.e0, c->stream));
+    if (record) PMX_HIP(hipEventRecord(p.e0, c->stream));
     c->pending.push_back(p);
     c->prof_open = (int)c->pending.size() - 1;
     return PMX_OK;
@@ -733,9 +733,18 @@ static int launch_wino_run(pmx_ctx* c, const ConvArgs& a0, int ks, int groups, i
     // their share of the FLOP), "...:units", "...:combine" -- so that each can be held against its own rocprofv3 kernel row
     const double share = tail_g ? (double)nfull * PMX_WINO_RUN_TILES / ntiles : 1.0;
     int rc;
-    if (pf && (rc = prof_begin(c, pf->name, pf->flops * share, pf->bytes, pf->issued * share))) return rc;
-    rc = conv_wino_run_launch(a, ks, groups, c->stream);
-    if (pf && !rc) rc = prof_end(c);
+    if (pf && c->prof_on == 2) {
+        // inside timed regions: the dispatch stamps the two events itself (no hipEventRecord barrier packets around the launch)
+        if ((rc = prof_begin(c, pf->name, pf->flops * share, pf->bytes, pf->issued * share, /*record=*/false))) return rc;
+        conv_set_launch_events(c->pending.back().e0, c->pending.back().e1);
+        c->prof_open = -1;
+        rc = conv_wino_run_launch(a, ks, groups, c->stream);
+        conv_set_launch_events(nullptr, nullptr);
+    } else {
+        if (pf && (rc = prof_begin(c, pf->name, pf->flops * share, pf->bytes, pf->issued * share))) return rc;
+        rc = conv_wino_run_launch(a, ks, groups, c->stream);
+        if (pf && !rc) rc = prof_end(c);
+    }
     if (rc || !tail_g) return rc;
     PMX_CHECK(nfull >= 1 && nfull < nblk, PMX_ERR_INVALID, "winograd tail: no part-filled block (%d tiles)", ntiles);
     const int S = (a0.nch + tail_g - 1) / tail_g + (ks == 7 ? 3 : 0);

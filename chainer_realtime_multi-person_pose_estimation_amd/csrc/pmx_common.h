@@ -99,6 +99,8 @@ struct WinoTailReduceArgs {
 int conv_wino_tail_reduce(const WinoTailReduceArgs& r, int groups, hipStream_t stream);
 // launch of the run-geometry Winograd kernel (a.W % 46 == 0); a.ksplit > 1: unit mode writing compact slabs (see WinoTailReduceArgs)
 int conv_wino_run_launch(const ConvArgs& a, int ks, int groups, hipStream_t stream);
+// start / stop events for the next conv_wino_run_launch of this thread (stamped by the dispatch itself: hipExtLaunchKernelGGL)
+void conv_set_launch_events(hipEvent_t e0, hipEvent_t e1);
 // ---- kernel selection for the 3x3 / 7x7 layers (conv_select.hip) ------------------------------------------------------------
 struct WinoSelectOpts {      // the context options the choice depends on (pmx_set_option keys of the same names)
     int conv_algo, precision, forced_variant, ksplit, wino_unit_eff, wino_min_fill, wino_geom, wino_tail, wino_tail_g;
