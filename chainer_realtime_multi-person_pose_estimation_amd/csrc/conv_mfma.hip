@@ -2514,23 +2514,30 @@ __global__ __launch_bounds__(256) void conv1x1_pair_kernel(const PairArgs a)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[u][i] = 0.f;
     }
-    __syncthreads();
-#pragma unroll 2
-    for (int ch = 0; ch < CIN / 16; ++ch) {
-        f32x4 bw[NT1][2];
+    // weights one chunk ahead (double-buffered in registers): loaded at the top of the chunk that uses them, every chunk waited out an L2
+    // round trip -- the kernel is latency-bound (the first chunk's fragments are requested before the barrier that publishes X)
+    f32x4 bw[2][NT1][2];
+    auto load_w1 = [&](f32x4 (&dst)[NT1][2], int ch) {
 #pragma unroll
         for (int u = 0; u < NT1; ++u) {
             const unsigned off = (unsigned)(((ch * CMID + (wave * NT1 + u) * 32 + li) * 16 + kh * 4) * 4);
-            bw[u][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, off, 0u, 0));
-            bw[u][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, off + 32, 0u, 0));
+            dst[u][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, off, 0u, 0));
+            dst[u][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, off + 32, 0u, 0));
         }
+    };
+    load_w1(bw[0], 0);
+    __syncthreads();
+#pragma unroll
+    for (int ch = 0; ch < CIN / 16; ++ch) {
+        if (ch + 1 < CIN / 16) load_w1(bw[(ch + 1) & 1], ch + 1);
+        __builtin_amdgcn_sched_barrier(0);          // (left alone the compiler sinks the loads back next to their use)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const f32x4 av = *reinterpret_cast<const f32x4*>(&sX[li * LDX + ch * 16 + s * 8 + kh * 4]);
 #pragma unroll
             for (int u = 0; u < NT1; ++u)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bw[u][s][e], acc[u], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bw[ch & 1][u][s][e], acc[u], 0, 0, 0);
         }
     }
     __syncthreads();            // all waves are done with the X tile: the hidden tile may overwrite it
