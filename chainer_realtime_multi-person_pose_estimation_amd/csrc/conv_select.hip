@@ -6,6 +6,9 @@
 
 #include <math.h>
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <vector>
 
 bool wino_eligible(int ks, int cin_pad, int cout_pad) { return (ks == 3 || ks == 7) && cin_pad % 32 == 0 && cout_pad % 128 == 0; }
@@ -83,17 +86,33 @@ int wino_select(const WinoSelectOpts& o, int ks, int cin_pad, int cout_pad, int 
         // the full blocks as whole rounds + the tail as unit blocks (best g by a dispatch simulation) + two more launches and the combine
         const double t_block = nch * (ks == 7 ? WINO_T7_CHUNK_US : WINO_T3_CHUNK_US);
         const long long main_rounds = ((long long)nfull * nslab * images * nb + ncu - 1) / ncu;
+        // the best g is a pure function of (ks, nch, tail blocks, CUs, forced g): memoised -- run_conv asks for every layer of every
+        // forward, and the dispatch simulation is a heap walk over units x blocks per candidate
+        struct Key { int ks, nch, forced; long long nblk, ncu; bool operator<(const Key& k) const { return std::tie(ks, nch, forced, nblk, ncu) < std::tie(k.ks, k.nch, k.forced, k.nblk, k.ncu); } };
+        static std::mutex mu;
+        static std::map<Key, std::pair<double, int>> memo;
+        const Key key{ks, nch, o.wino_tail_g, (long long)images * nslab * nb, ncu};
         double best = 1e30;
         int best_g = 0;
-        for (int gg = 1; gg <= nch; ++gg) {
-            const int SS = (nch + gg - 1) / gg + extra;
-            if (SS < 2 || SS > 8 || (gg > 1 && (nch + gg - 2) / (gg - 1) + extra == SS)) continue;      // (same unit count as a smaller g: skip)
-            const double t = wino_tail_makespan(ks, nch, gg, (long long)images * nslab * nb, (int)ncu) + 2.0 * SS;   // + the combine's slab reads
-            if (t < best) { best = t; best_g = gg; }
+        bool hit = false;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = memo.find(key);
+            if (it != memo.end()) { best = it->second.first; best_g = it->second.second; hit = true; }
         }
-        if (o.wino_tail_g > 0 && o.wino_tail_g <= nch) {
-            const int SS = (nch + o.wino_tail_g - 1) / o.wino_tail_g + extra;
-            if (SS >= 2 && SS <= 8) { best_g = o.wino_tail_g; best = wino_tail_makespan(ks, nch, best_g, (long long)images * nslab * nb, (int)ncu) + 2.0 * SS; }
+        if (!hit) {
+            for (int gg = 1; gg <= nch; ++gg) {
+                const int SS = (nch + gg - 1) / gg + extra;
+                if (SS < 2 || SS > 8 || (gg > 1 && (nch + gg - 2) / (gg - 1) + extra == SS)) continue;      // (same unit count as a smaller g: skip)
+                const double t = wino_tail_makespan(ks, nch, gg, key.nblk, (int)ncu) + 2.0 * SS;   // + the combine's slab reads
+                if (t < best) { best = t; best_g = gg; }
+            }
+            if (o.wino_tail_g > 0 && o.wino_tail_g <= nch) {
+                const int SS = (nch + o.wino_tail_g - 1) / o.wino_tail_g + extra;
+                if (SS >= 2 && SS <= 8) { best_g = o.wino_tail_g; best = wino_tail_makespan(ks, nch, best_g, key.nblk, (int)ncu) + 2.0 * SS; }
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            memo[key] = std::make_pair(best, best_g);
         }
         const double cost = (double)main_rounds + (best + 10.0) / t_block;
         if (best_g && (o.wino_tail == 1 || cost < plain_cost)) { plain_cost = cost; tg = best_g; }

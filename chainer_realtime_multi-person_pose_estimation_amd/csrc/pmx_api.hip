@@ -5,7 +5,7 @@
 //   stage 1 (5 launches) and stages 2-6 (7 launches each); the PAF branch (L1) and the heat-map branch (L2)
 //   of a stage are the two groups (blockIdx.z) of one launch; F.concat (:168,...) is replaced by channel-slice
 //   writes into the 192-channel "cat" buffer (layout in pmx_common.h).
-#include "pmx_common.h"
+#include "pmx_ctx.h"
 
 #include <math.h>
 #include <stdarg.h>
@@ -37,9 +37,7 @@ extern "C" int pmx_device_count(int* n)
 }
 
 // -------------------------------------------------------------------------------------- layer table
-struct LayerDesc { std::string name; int cin, cout, ks; };
 
-enum NetKind { NET_POSE = 0, NET_FACE = 1, NET_HAND = 2 };     // params['archs'] (entity.py:50-54)
 static int net_out_channels(int kind) { return kind == NET_FACE ? 71 : (kind == NET_HAND ? 22 : 19); }
 
 // FaceNet / HandNet (models/FaceNet.py:12-75, models/HandNet.py): VGG-19 stem to conv5_2, conv5_3_CPM, single-branch 6-stage CPM
@@ -85,16 +83,7 @@ static std::vector<LayerDesc> make_layer_table()   // models/CocoPoseNet.py:26-1
     return t;
 }
 
-static const int CK = 16;   // channel chunk of every kernel variant
 
-struct PackedLayer {
-    bool set = false;
-    float* d_w = nullptr;
-    float* d_b = nullptr;
-    float* d_ww = nullptr;       // Winograd F(2x2,3x3) pack [freq 16][chunk32][cout_pad][32] = G g G^T (3x3 layers; option "conv_algo" = 1)
-    void* d_w3 = nullptr;        // bf16x3 pack [tap][chunk][plane hi|mid|lo][cout_pad][16] (3x3 / 7x7 layers; option "precision" = 1)
-    int cin = 0, cout = 0, ks = 0, cin_pad = 0, cout_pad = 0, nch = 0;
-};
 
 static int cout_pad_of(int cout) { return cout <= 64 ? 64 : round_up(cout, 128); }
 
@@ -214,101 +203,6 @@ static std::vector<int> concat_map_cpm(int C)
     return m;
 }
 
-// ------------------------------------------------------------------------------------------ profiler
-struct ProfEntry {
-    std::string name;
-    double total_ms = 0;
-    int64_t launches = 0;
-    double flops = 0, bytes = 0;   // per launch: algorithmic FLOP of the convolution, compulsory bytes
-    double issued = 0;             // per launch: FLOP the kernel issues to the matrix cores for real outputs (Winograd forms: 16/36, 100/196 of
-                                   // the algorithmic figure; direct kernels: all of it; tile padding is not counted)
-};
-struct ProfPending { int entry; hipEvent_t e0, e1; };
-
-// ------------------------------------------------------------------------------------------- context
-struct pmx_ctx {
-    int kind = NET_POSE;             // architecture: posenet | facenet | handnet
-    int n_heat = PMX_N_HEAT;         // heat-map channels of the last layer (19 | 71 | 22)
-    int cat_c = PMX_CAT_C;           // channels of the cat buffer (192 | 208 | 160)
-    int cat_heat = PMX_CAT_HEAT;     // first heat-map channel in the cat buffer (168 | 128 | 128)
-    // detect_precise accumulation state (pmx_precise_*)
-    int pr_h = 0, pr_w = 0, pr_scales = 0;
-    float* pr_tmp = nullptr; size_t pr_tmp_cap = 0;      // x8 up-sampled maps of one scale, NHWC-57
-    void* pr_tab = nullptr; size_t pr_tab_cap = 0;       // cubic tables of the current resize
-    double* d_kp = nullptr;          // key-point records of pmx_keypoints
-    size_t kp_cap = 0;
-    int device = 0;
-    hipStream_t stream = nullptr, own_stream = nullptr;
-    int max_batch = 0, max_h = 0, max_w = 0;
-    std::vector<LayerDesc> table;
-    std::map<std::string, int> index;
-    std::vector<PackedLayer> layers;
-    // buffers
-    float *in16 = nullptr, *act0 = nullptr, *act1 = nullptr, *cat = nullptr, *brA = nullptr, *brB = nullptr, *brT = nullptr;
-    float* nchw_tmp = nullptr;       // staging for NCHW host <-> NHWC device conversions
-    size_t nchw_tmp_bytes = 0;
-    uint8_t* u8_tmp = nullptr;
-    uint8_t* u8_src = nullptr;       // original-size images awaiting the on-device resize
-    size_t u8_src_cap = 0;
-    int* rs_tab = nullptr;           // resize tables: x (4 * dw ints) then y (4 * dh ints)
-    size_t rs_tab_cap = 0;
-    // state of the last forward / set_maps
-    bool maps_valid = false, maps_external = false;
-    int cur_B = 0, cur_fh = 0, cur_fw = 0;
-    float *ext_paf = nullptr, *ext_heat = nullptr;   // NCHW copies installed by pmx_set_maps
-    size_t ext_cap = 0;
-    // post-process
-    PPTables tab{};
-    int tab_cap = 0;
-    int tab_in_h = -1, tab_in_w = -1, tab_out_h = -1, tab_out_w = -1;
-    std::vector<double> gauss;
-    PPBuffers pp{};
-    double* d_scale = nullptr;
-    unsigned char* h_results = nullptr;         // pinned staging for pmx_get_results (pageable D2H is slow and jittery)
-    size_t h_results_bytes = 0;
-    bool pp_valid = false;
-    bool pp_final = false;                      // statuses checked: no image of the last post-process overflowed a capacity
-    int pp_B = 0, pp_h = 0, pp_w = 0;
-    // arguments of the last post-process, kept for the grow-and-re-run
-    PPMaps pp_maps{};
-    double pp_img_len = 0;
-    bool pp_has_scale = false;
-    int pp_regrown = 0;                         // number of capacity growths so far (diagnostics)
-    size_t smoothed_cap = 0;
-    // options
-    int opt_force[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // by ksize
-    int opt_gpu_branch_peaks = 0;    // reference GPU-branch peak extraction (non-golden variant)
-    int opt_kp_flip_x = 0;           // pmx_keypoints: mirror the resized heat maps left-right before the peaks (hand_detector.py:46-47)
-    int tab_flip = 0;
-    int opt_keep_smoothed = 0, opt_stop_stage = 6, opt_kernel_gen = 6;
-    int opt_conv_algo = 1;           // 1 (default): Winograd F(2x2,3x3) fp32 kernel for the 3x3 / 7x7 layers of launches that fill the chip
-                                     // (>= 2 blocks per CU: batches); 0: direct kernels everywhere; 2: Winograd on every eligible layer
-                                     // (tests).  Both are fp32 with a defined order and a C twin; they differ by fp32 rounding (~1e-6)
-    int opt_wino_unit_eff = 80;      // unit mode: in-round efficiency of the 7x7 unit blocks relative to the plain kernel, percent (cost model;
-                                     // measured with tools/wino_batch_sweep.py: 75 - 90 alike, 60 loses batch 4 and 8, 105 loses batch 16+)
-    int opt_wino_min_fill = 50;      // conv_algo 1: percent of ceil(blocks / CUs) * CUs block slots a launch must fill to take the Winograd kernel
-    int opt_wino_geom = -1;          // Winograd block geometry on 46-pixel-wide maps: -1 / 1 runs of 32 consecutive tiles, 0 the 8 x 16 pixel rectangles
-                                     // of every other map size (same bits either way)
-    int opt_wino_tail = -1;          // run geometry: the part-filled last block of every image in unit mode (K units + combine) -- -1 by the cost
-                                     // model (conv_algo 1), 0 never, 1 wherever a unit plan exists.  Changes the summation of those tiles (C twin: unit_from)
-    int opt_wino_tail_g = 0;         // tuning: chunks per pass-1 unit of the tail (0 = automatic)
-    int opt_precision = 0;           // 0: fp32 MFMA everywhere (the path whose results are specified); 1: bf16x3 kernels where a
-                                     // v6 kernel would run (fp32-grade accuracy at 2.67x the matrix rate, NOT the fp32 FMA chain)
-    int opt_fuse_conv1 = 1;          // conv1_1 recomputed on conv1_2's halo tile, one launch (conv1_fused_kernel); identical bits
-    int opt_fuse_pairs = 1;          // the two 1x1 layers that end every stage run as one launch (conv1x1_pair_kernel)
-    int opt_ksplit = 0;              // 0: automatic split-K for small launches; n > 0: force n K slices where split-K applies
-    // split-K scratch: partial-sum slabs of the current launch + a zero bias vector for the slice blocks
-    float* sk_scratch = nullptr; size_t sk_floats = 0;
-    float* sk_zero_bias = nullptr;
-    // timing / profiling
-    hipEvent_t t0 = nullptr, t1 = nullptr;
-    int prof_on = 0;                 // 0 off | 1 every launch | 2 only the 7x7 convolutions (the dominant kernel: fewest events in a timed region)
-    std::vector<ProfEntry> prof;
-    std::map<std::string, int> prof_index;
-    std::vector<ProfPending> pending;
-    std::vector<hipEvent_t> ev_pool;   // recycled events (creating two per launch inside the timed region costs ~0.5 %)
-    int prof_open = -1;
-};
 
 static int prof_begin(pmx_ctx* c, const std::string& name, double flops, double bytes, double issued = -1.0, bool record = true)
 {
@@ -360,7 +254,6 @@ static void pp_prof_cb(void* vc, const char* name, int begin)
     else (void)prof_end(c);
 }
 
-#define PMX_DEV(c) PMX_HIP(hipSetDevice((c)->device))
 
 template <typename T>
 static int dev_alloc(T** p, size_t count)
@@ -622,8 +515,15 @@ static int ensure_wino_pack(PackedLayer& L)
     std::vector<float> wp, ww;
     if (int rc = fetch_packed(L, wp)) return rc;
     pack_wino(wp, L.ks, L.nch, L.cout_pad, ww);
-    PMX_HIP(hipMalloc((void**)&L.d_ww, ww.size() * sizeof(float)));
-    PMX_HIP(hipMemcpy(L.d_ww, ww.data(), ww.size() * sizeof(float), hipMemcpyHostToDevice));
+    // (the pack becomes visible only once it is complete: a failed copy must not leave a non-null pointer to garbage behind)
+    float* d = nullptr;
+    PMX_HIP(hipMalloc((void**)&d, ww.size() * sizeof(float)));
+    if (hipMemcpy(d, ww.data(), ww.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        pmx_set_error("winograd weight pack: host-to-device copy failed: %s", hipGetErrorString(hipGetLastError()));
+        return PMX_ERR_HIP;
+    }
+    L.d_ww = d;
     return PMX_OK;
 }
 static int ensure_bf16x3_pack(PackedLayer& L)
@@ -633,8 +533,14 @@ static int ensure_bf16x3_pack(PackedLayer& L)
     std::vector<uint16_t> w3;
     if (int rc = fetch_packed(L, wp)) return rc;
     pack_bf16x3(wp, L.ks * L.ks, L.nch, L.cout_pad, w3);
-    PMX_HIP(hipMalloc(&L.d_w3, w3.size() * sizeof(uint16_t)));
-    PMX_HIP(hipMemcpy(L.d_w3, w3.data(), w3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    void* d = nullptr;
+    PMX_HIP(hipMalloc(&d, w3.size() * sizeof(uint16_t)));
+    if (hipMemcpy(d, w3.data(), w3.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        pmx_set_error("bf16x3 weight pack: host-to-device copy failed: %s", hipGetErrorString(hipGetLastError()));
+        return PMX_ERR_HIP;
+    }
+    L.d_w3 = d;
     return PMX_OK;
 }
 
@@ -740,6 +646,11 @@ static int launch_wino_run(pmx_ctx* c, const ConvArgs& a0, int ks, int groups, i
         c->prof_open = -1;
         rc = conv_wino_run_launch(a, ks, groups, c->stream);
         conv_set_launch_events(nullptr, nullptr);
+        if (rc) {       // nothing was dispatched, so nothing will ever stamp the pair: take it back (prof_collect would fail on it for good)
+            c->ev_pool.push_back(c->pending.back().e0);
+            c->ev_pool.push_back(c->pending.back().e1);
+            c->pending.pop_back();
+        }
     } else {
         if (pf && (rc = prof_begin(c, pf->name, pf->flops * share, pf->bytes, pf->issued * share))) return rc;
         rc = conv_wino_run_launch(a, ks, groups, c->stream);
@@ -992,7 +903,7 @@ static int forward_cpm(pmx_ctx* c, int B, int H, int W)
     return PMX_OK;
 }
 
-static int forward_from_in16(pmx_ctx* c, int B, int H, int W)
+int pmx_forward_from_in16(pmx_ctx* c, int B, int H, int W)
 {
     if (c->kind != NET_POSE) return forward_cpm(c, B, H, W);
     auto id = [&](const char* n) { return c->index.at(n); };
@@ -1075,7 +986,7 @@ extern "C" int pmx_forward_u8(pmx_ctx* c, const uint8_t* img, int B, int H, int 
     if (c->prof_on == 1 && (rc = prof_begin(c, "prep_u8|prep_u8", 0, (double)B * H * W * (3 + 64)))) return rc;
     if ((rc = launch_prep_u8(d, c->in16, B, H, W, c->kind == NET_POSE ? 255.0f : 256.0f, c->stream))) return rc;
     if ((rc = prof_end(c))) return rc;
-    return forward_from_in16(c, B, H, W);
+    return pmx_forward_from_in16(c, B, H, W);
 }
 
 extern "C" int pmx_forward_f32(pmx_ctx* c, const float* x, int B, int H, int W, int on_device)
@@ -1089,7 +1000,7 @@ extern "C" int pmx_forward_f32(pmx_ctx* c, const float* x, int B, int H, int W, 
         d = c->nchw_tmp;
     }
     if ((rc = launch_prep_f32(d, c->in16, B, H, W, c->stream))) return rc;
-    return forward_from_in16(c, B, H, W);
+    return pmx_forward_from_in16(c, B, H, W);
 }
 
 // OpenCV INTER_LINEAR uint8 tables for one axis: [idx0 | idx1 | coef0 | coef1], each `dst` ints.
@@ -1250,7 +1161,7 @@ static void make_grid(int in, int out, std::vector<int>& i0, std::vector<int>& i
     }
 }
 
-static int ensure_tables(pmx_ctx* c, int in_h, int in_w, int out_h, int out_w, int flip_x = 0)
+int pmx_ensure_tables(pmx_ctx* c, int in_h, int in_w, int out_h, int out_w, int flip_x)
 {
     if (c->tab_in_h == in_h && c->tab_in_w == in_w && c->tab_out_h == out_h && c->tab_out_w == out_w && c->tab_flip == flip_x) return PMX_OK;
     const int cap = out_h > out_w ? out_h : out_w;
@@ -1308,7 +1219,7 @@ extern "C" int pmx_postprocess(pmx_ctx* c, int B, int map_h, int map_w, double i
     PMX_CHECK(map_h >= 1 && map_w >= 1 && (long long)map_h * map_w < (1ll << 31), PMX_ERR_INVALID, "pmx_postprocess: bad map size");
     PMX_DEV(c);
     int rc;
-    if ((rc = ensure_tables(c, c->cur_fh, c->cur_fw, map_h, map_w))) return rc;
+    if ((rc = pmx_ensure_tables(c, c->cur_fh, c->cur_fw, map_h, map_w))) return rc;
     const long long fhw = (long long)c->cur_fh * c->cur_fw;
     PPMaps m;
     if (c->maps_external) {          // NCHW copies installed by pmx_set_maps
@@ -1415,6 +1326,9 @@ static int pp_finalize(pmx_ctx* c)
             }
             cap_ppl = next_pow2(need);
         }
+        // invariant pmx_set_capacities enforces (people <= subsets): keep it through growth, so that a grown state can be replayed
+        // through pmx_set_capacities (Engine.state() / load_state() when a PoseDetector re-creates its context)
+        if (cap_sub < cap_ppl) cap_sub = cap_ppl;
         PMX_CHECK(cap_pk != c->pp.cap_pk || cap_sub != c->pp.cap_sub || cap_cand != c->pp.cap_cand || cap_ppl != c->pp.cap_ppl,
                   PMX_ERR_STATE, "post-process reports a capacity overflow (0x%x) that growing does not resolve", bits);
         int rc = pp_realloc(c, cap_pk, cap_sub, cap_cand, cap_ppl);
@@ -1450,218 +1364,6 @@ extern "C" int pmx_get_capacities(pmx_ctx* c, int* peaks_per_joint, int* subsets
     if (subsets) *subsets = c->pp.cap_sub;
     if (people) *people = c->pp.cap_ppl;
     if (candidates) *candidates = c->pp.cap_cand;
-    return PMX_OK;
-}
-
-// ---------------------------------------------------------------------------------------- detect_precise on the device
-// OpenCV bicubic tables for one axis (A = -0.75): idx[k][d] (clamped, replicate border) and coef[k][d] float32, k = 0..3.
-// Same float32 expression order as pose_detector.py::_cubic_taps / oracle/precise_ref.py::_coeffs.
-#pragma clang fp contract(off)
-static void make_cubic_table(int dst, int src, int* idx, float* coef)
-{
-    const double scale = 1.0 / ((double)dst / (double)src);
-    const float A = -0.75f;
-    for (int d = 0; d < dst; ++d) {
-        const float f = (float)(((double)d + 0.5) * scale - 0.5);
-        const int s = (int)floorf(f);
-        const float x = f - (float)s;
-        const float x1 = x + 1.0f, xm = 1.0f - x;
-        float c0 = A * x1;  c0 = c0 - 5.0f * A;  c0 = c0 * x1;  c0 = c0 + 8.0f * A;  c0 = c0 * x1;  c0 = c0 - 4.0f * A;
-        float c1 = (A + 2.0f) * x;  c1 = c1 - (A + 3.0f);  c1 = c1 * x;  c1 = c1 * x;  c1 = c1 + 1.0f;
-        float c2 = (A + 2.0f) * xm;  c2 = c2 - (A + 3.0f);  c2 = c2 * xm;  c2 = c2 * xm;  c2 = c2 + 1.0f;
-        float c3 = 1.0f - c0;  c3 = c3 - c1;  c3 = c3 - c2;
-        const float cs[4] = {c0, c1, c2, c3};
-        for (int k = 0; k < 4; ++k) {
-            int i = s - 1 + k;
-            i = i < 0 ? 0 : (i > src - 1 ? src - 1 : i);
-            idx[k * dst + d] = i;
-            coef[k * dst + d] = cs[k];
-        }
-    }
-}
-
-// uploads [xi | yi | xc | yc] (or fixed-point coefficients when `fixed`) for a (sh, sw) -> (dh, dw) cubic resize
-static int upload_cubic_tables(pmx_ctx* c, int sh, int sw, int dh, int dw, bool fixed, int** xi, void** xc, int** yi, void** yc)
-{
-    const size_t n = (size_t)4 * (dw + dh);
-    const size_t bytes = n * 2 * sizeof(int);
-    if (bytes > c->pr_tab_cap) {
-        PMX_HIP(hipStreamSynchronize(c->stream));
-        if (c->pr_tab) (void)hipFree(c->pr_tab);
-        c->pr_tab = nullptr;
-        PMX_HIP(hipMalloc(&c->pr_tab, bytes));
-        c->pr_tab_cap = bytes;
-    }
-    std::vector<int> hi(n);
-    std::vector<float> hc(n);
-    make_cubic_table(dw, sw, hi.data(), hc.data());
-    make_cubic_table(dh, sh, hi.data() + 4 * dw, hc.data() + 4 * dw);
-    PMX_HIP(hipStreamSynchronize(c->stream));     // previous resize may still read the table buffer
-    int* d_i = (int*)c->pr_tab;
-    PMX_HIP(hipMemcpy(d_i, hi.data(), n * sizeof(int), hipMemcpyHostToDevice));
-    if (fixed) {
-        std::vector<int> ha(n);
-        for (size_t k = 0; k < n; ++k) {
-            long v = lrintf(hc[k] * 2048.0f);      // saturate_cast<short>(coef * INTER_RESIZE_COEF_SCALE)
-            ha[k] = (int)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
-        }
-        PMX_HIP(hipMemcpy(d_i + n, ha.data(), n * sizeof(int), hipMemcpyHostToDevice));
-    } else {
-        PMX_HIP(hipMemcpy(d_i + n, hc.data(), n * sizeof(float), hipMemcpyHostToDevice));
-    }
-    *xi = d_i; *yi = d_i + 4 * dw;
-    *xc = (void*)(d_i + n); *yc = (void*)((int*)(d_i + n) + 4 * dw);
-    return PMX_OK;
-}
-
-// detect_precise (pose_detector.py:433-470) accumulated on the device.  begin: zero the per-channel sums at the original size.
-extern "C" int pmx_precise_begin(pmx_ctx* c, int orig_h, int orig_w)
-{
-    PMX_CHECK(c && c->kind == NET_POSE, PMX_ERR_INVALID, "pmx_precise_begin: posenet context required");
-    PMX_CHECK(orig_h >= 1 && orig_w >= 1, PMX_ERR_INVALID, "pmx_precise_begin: bad size");
-    PMX_DEV(c);
-    const size_t need = (size_t)orig_h * orig_w;
-    if (need > c->ext_cap) {
-        PMX_HIP(hipStreamSynchronize(c->stream));
-        if (c->ext_paf) (void)hipFree(c->ext_paf);
-        if (c->ext_heat) (void)hipFree(c->ext_heat);
-        c->ext_paf = c->ext_heat = nullptr;
-        PMX_HIP(hipMalloc((void**)&c->ext_paf, need * PMX_N_PAF * 4));
-        PMX_HIP(hipMalloc((void**)&c->ext_heat, need * PMX_N_HEAT * 4));
-        c->ext_cap = need;
-    }
-    PMX_HIP(hipMemsetAsync(c->ext_paf, 0, need * PMX_N_PAF * 4, c->stream));
-    PMX_HIP(hipMemsetAsync(c->ext_heat, 0, need * PMX_N_HEAT * 4, c->stream));
-    c->pr_h = orig_h; c->pr_w = orig_w; c->pr_scales = 0;
-    c->maps_valid = false;
-    return PMX_OK;
-}
-
-// one scale of the loop at :441-467: cubic resize of the uint8 image to (scaled_h, scaled_w) (:443), pad to a multiple of 8
-// with (104, 117, 123) (:445), forward (:451), x8 cubic up-sampling of both outputs (:461,465), crop of the padding
-// (:462,466), cubic resize to the original size and accumulation (:463,467).  `img`: host uint8 orig_h x orig_w x 3.
-extern "C" int pmx_precise_add_scale(pmx_ctx* c, const uint8_t* img, int scaled_h, int scaled_w)
-{
-    PMX_CHECK(c && img && c->pr_h > 0, PMX_ERR_STATE, "pmx_precise_add_scale: call pmx_precise_begin first");
-    PMX_CHECK(scaled_h >= 1 && scaled_w >= 1, PMX_ERR_INVALID, "bad size");
-    PMX_DEV(c);
-    const int oh = c->pr_h, ow = c->pr_w;
-    const int ph = round_up(scaled_h, 8), pw = round_up(scaled_w, 8);
-    PMX_CHECK((size_t)ph * pw <= (size_t)c->max_h * c->max_w && c->max_batch >= 1, PMX_ERR_CAPACITY,
-              "pmx_precise_add_scale: padded size %d x %d exceeds the context capacity %d x %d", ph, pw, c->max_h, c->max_w);
-    int missing = 0;
-    for (auto& l : c->layers) missing += l.set ? 0 : 1;
-    PMX_CHECK(missing == 0, PMX_ERR_WEIGHTS, "pmx_precise_add_scale: %d layers have no weights", missing);
-    int rc;
-    // original image -> device
-    const size_t nsrc = (size_t)oh * ow * 3;
-    if (nsrc > c->u8_src_cap) {
-        PMX_HIP(hipStreamSynchronize(c->stream));
-        if (c->u8_src) (void)hipFree(c->u8_src);
-        c->u8_src = nullptr;
-        PMX_HIP(hipMalloc((void**)&c->u8_src, nsrc));
-        c->u8_src_cap = nsrc;
-    }
-    PMX_HIP(hipMemcpyAsync(c->u8_src, img, nsrc, hipMemcpyHostToDevice, c->stream));
-    int *xi, *yi; void *xc, *yc;
-    // (1) uint8 cubic resize into the padded image
-    if ((rc = launch_fill_bgr(c->u8_tmp, (long long)ph * pw, 104, 117, 123, c->stream))) return rc;
-    if (scaled_h == oh && scaled_w == ow) {
-        PMX_HIP(hipMemcpy2DAsync(c->u8_tmp, (size_t)pw * 3, c->u8_src, (size_t)ow * 3, (size_t)ow * 3, oh, hipMemcpyDeviceToDevice, c->stream));
-    } else {
-        if ((rc = upload_cubic_tables(c, oh, ow, scaled_h, scaled_w, true, &xi, &xc, &yi, &yc))) return rc;
-        if ((rc = launch_resize_cubic_u8(c->u8_src, ow, c->u8_tmp, scaled_h, scaled_w, pw, xi, (const int*)xc, yi, (const int*)yc, c->stream))) return rc;
-    }
-    // (2) network
-    if ((rc = launch_prep_u8(c->u8_tmp, c->in16, 1, ph, pw, 255.0f, c->stream))) return rc;
-    if ((rc = forward_from_in16(c, 1, ph, pw))) return rc;
-    const int fh = ph / 8, fw = pw / 8;
-    // (3) x8 cubic up-sampling of PAF (38) and heat (19) channels into NHWC-57
-    const size_t ntmp = (size_t)ph * pw * 57;
-    if (ntmp > c->pr_tmp_cap) {
-        PMX_HIP(hipStreamSynchronize(c->stream));
-        if (c->pr_tmp) (void)hipFree(c->pr_tmp);
-        c->pr_tmp = nullptr;
-        PMX_HIP(hipMalloc((void**)&c->pr_tmp, ntmp * sizeof(float)));
-        c->pr_tmp_cap = ntmp;
-    }
-    if ((rc = upload_cubic_tables(c, fh, fw, ph, pw, false, &xi, &xc, &yi, &yc))) return rc;
-    const long long sy = (long long)fw * PMX_CAT_C, sx = PMX_CAT_C;
-    // PAF and heat are separate arrays in the reference (two cv2.resize calls); here two launches into one NHWC-57 buffer
-    // would need a strided destination, so each map set gets its own dense NHWC temp region: [ph*pw*38 | ph*pw*19]
-    float* t_paf = c->pr_tmp;
-    float* t_heat = c->pr_tmp + (size_t)ph * pw * PMX_N_PAF;
-    if ((rc = launch_resize_cubic_f32(c->cat + PMX_CAT_PAF, sy, sx, 1, PMX_N_PAF, t_paf, ph, pw, xi, (const float*)xc, yi, (const float*)yc, 0, 0, c->stream))) return rc;
-    if ((rc = launch_resize_cubic_f32(c->cat + PMX_CAT_HEAT, sy, sx, 1, PMX_N_HEAT, t_heat, ph, pw, xi, (const float*)xc, yi, (const float*)yc, 0, 0, c->stream))) return rc;
-    // (4) crop the padding (source extent scaled_h x scaled_w of the padded maps) and cubic resize to the original size, accumulating
-    if ((rc = upload_cubic_tables(c, scaled_h, scaled_w, oh, ow, false, &xi, &xc, &yi, &yc))) return rc;
-    if ((rc = launch_resize_cubic_f32(t_paf, (long long)pw * PMX_N_PAF, PMX_N_PAF, 1, PMX_N_PAF, c->ext_paf, oh, ow, xi, (const float*)xc, yi,
-                                      (const float*)yc, 1, 0, c->stream))) return rc;
-    if ((rc = launch_resize_cubic_f32(t_heat, (long long)pw * PMX_N_HEAT, PMX_N_HEAT, 1, PMX_N_HEAT, c->ext_heat, oh, ow, xi, (const float*)xc, yi,
-                                      (const float*)yc, 1, 0, c->stream))) return rc;
-    c->pr_scales += 1;
-    c->maps_valid = false;       // the cat buffer holds one scale only; the averaged maps become valid in pmx_precise_finish
-    return PMX_OK;
-}
-
-// :469-470: divide the sums by the number of scales and install them as the maps of a batch of one at the original size
-extern "C" int pmx_precise_finish(pmx_ctx* c)
-{
-    PMX_CHECK(c && c->pr_h > 0 && c->pr_scales > 0, PMX_ERR_STATE, "pmx_precise_finish: nothing accumulated");
-    PMX_DEV(c);
-    int rc;
-    const long long n = (long long)c->pr_h * c->pr_w;
-    if ((rc = launch_scale_f32(c->ext_paf, n * PMX_N_PAF, (float)c->pr_scales, c->stream))) return rc;
-    if ((rc = launch_scale_f32(c->ext_heat, n * PMX_N_HEAT, (float)c->pr_scales, c->stream))) return rc;
-    c->maps_valid = true; c->maps_external = true;
-    c->cur_B = 1; c->cur_fh = c->pr_h; c->cur_fw = c->pr_w;
-    c->pp_valid = false;
-    c->pr_scales = 0;
-    return PMX_OK;
-}
-
-// FaceDetector / HandDetector.__call__ post-process (face_detector.py:37-38,58-68; hand_detector.py:41,68-78):
-// F.resize_images(hs[-1], (out_h, out_w)) + gaussian_filter + per-channel arg-max over the n_heat - 1 key-point channels.
-// out: batch x (n_heat - 1) x 4 float64 rows (x, y, confidence, valid); valid = 0 where the reference appends None.
-extern "C" int pmx_keypoints(pmx_ctx* c, int B, int out_h, int out_w, double thresh, double* out)
-{
-    PMX_CHECK(c && out, PMX_ERR_INVALID, "null arg");
-    PMX_CHECK(c->kind != NET_POSE, PMX_ERR_STATE, "pmx_keypoints: facenet / handnet only");
-    PMX_CHECK(c->maps_valid && B == c->cur_B, PMX_ERR_STATE, "pmx_keypoints: no network output for batch %d", B);
-    PMX_CHECK(out_h >= 1 && out_w >= 1 && (long long)out_h * out_w < (1ll << 31), PMX_ERR_INVALID, "pmx_keypoints: bad size");
-    PMX_DEV(c);
-    int rc;
-    if ((rc = ensure_tables(c, c->cur_fh, c->cur_fw, out_h, out_w, c->opt_kp_flip_x))) return rc;
-    const int n_ch = c->n_heat - 1;
-    const long long fhw = (long long)c->cur_fh * c->cur_fw;
-    PPMaps m;
-    if (c->maps_external) {
-        m.heat = c->ext_heat; m.paf = nullptr; m.sx = 1; m.sy = c->cur_fw; m.sc = fhw; m.sbh = c->n_heat * fhw; m.sbp = 0;
-    } else {
-        m.heat = c->cat + c->cat_heat; m.paf = nullptr; m.sc = 1; m.sx = c->cat_c; m.sy = (long long)c->cur_fw * c->cat_c;
-        m.sbh = fhw * c->cat_c; m.sbp = 0;
-    }
-    m.fh = c->cur_fh; m.fw = c->cur_fw;
-    const size_t need = (size_t)B * n_ch * out_h * out_w;
-    if (need > c->smoothed_cap) {
-        PMX_HIP(hipStreamSynchronize(c->stream));
-        if (c->pp.smoothed) (void)hipFree(c->pp.smoothed);
-        c->pp.smoothed = nullptr;
-        PMX_HIP(hipMalloc((void**)&c->pp.smoothed, need * sizeof(float)));
-        c->smoothed_cap = need;
-    }
-    const size_t nkp = (size_t)B * n_ch * 4;
-    if (nkp > c->kp_cap) {
-        PMX_HIP(hipStreamSynchronize(c->stream));
-        if (c->d_kp) (void)hipFree(c->d_kp);
-        c->d_kp = nullptr;
-        PMX_HIP(hipMalloc((void**)&c->d_kp, nkp * sizeof(double)));
-        c->kp_cap = nkp;
-    }
-    if ((rc = pp_keypoints_launch(m, c->tab, c->pp, B, n_ch, out_h, out_w, thresh, c->d_kp, c->stream))) return rc;
-    PMX_HIP(hipMemcpyAsync(out, c->d_kp, nkp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    PMX_HIP(hipStreamSynchronize(c->stream));
-    c->pp_valid = true; c->pp_final = true; c->pp_B = B; c->pp_h = out_h; c->pp_w = out_w;
     return PMX_OK;
 }
 

@@ -1,0 +1,125 @@
+// pmx_ctx.h -- the context behind the opaque `pmx_ctx*` of the C ABI and the few internal entry points the translation units of the
+// ABI share (pmx_api.hip: context, weights, forward plan, post-process, results; pmx_precise.hip: detect_precise and the key-point nets).
+#pragma once
+#include "pmx_common.h"
+
+#include <map>
+#include <string>
+#include <vector>
+
+struct LayerDesc { std::string name; int cin, cout, ks; };
+
+enum NetKind { NET_POSE = 0, NET_FACE = 1, NET_HAND = 2 };     // params['archs'] (entity.py:50-54)
+
+static const int CK = 16;   // channel chunk of every kernel variant
+
+struct PackedLayer {
+    bool set = false;
+    float* d_w = nullptr;
+    float* d_b = nullptr;
+    float* d_ww = nullptr;       // Winograd F(2x2,3x3) pack [freq 16][chunk32][cout_pad][32] = G g G^T (3x3 layers; option "conv_algo" = 1)
+    void* d_w3 = nullptr;        // bf16x3 pack [tap][chunk][plane hi|mid|lo][cout_pad][16] (3x3 / 7x7 layers; option "precision" = 1)
+    int cin = 0, cout = 0, ks = 0, cin_pad = 0, cout_pad = 0, nch = 0;
+};
+
+// ------------------------------------------------------------------------------------------ profiler
+struct ProfEntry {
+    std::string name;
+    double total_ms = 0;
+    int64_t launches = 0;
+    double flops = 0, bytes = 0;   // per launch: algorithmic FLOP of the convolution, compulsory bytes
+    double issued = 0;             // per launch: FLOP the kernel issues to the matrix cores for real outputs (Winograd forms: 16/36, 100/196 of
+                                   // the algorithmic figure; direct kernels: all of it; tile padding is not counted)
+};
+struct ProfPending { int entry; hipEvent_t e0, e1; };
+
+// ------------------------------------------------------------------------------------------- context
+struct pmx_ctx {
+    int kind = NET_POSE;             // architecture: posenet | facenet | handnet
+    int n_heat = PMX_N_HEAT;         // heat-map channels of the last layer (19 | 71 | 22)
+    int cat_c = PMX_CAT_C;           // channels of the cat buffer (192 | 208 | 160)
+    int cat_heat = PMX_CAT_HEAT;     // first heat-map channel in the cat buffer (168 | 128 | 128)
+    // detect_precise accumulation state (pmx_precise_*)
+    int pr_h = 0, pr_w = 0, pr_scales = 0;
+    float* pr_tmp = nullptr; size_t pr_tmp_cap = 0;      // x8 up-sampled maps of one scale, NHWC-57
+    void* pr_tab = nullptr; size_t pr_tab_cap = 0;       // cubic tables of the current resize
+    double* d_kp = nullptr;          // key-point records of pmx_keypoints
+    size_t kp_cap = 0;
+    int device = 0;
+    hipStream_t stream = nullptr, own_stream = nullptr;
+    int max_batch = 0, max_h = 0, max_w = 0;
+    std::vector<LayerDesc> table;
+    std::map<std::string, int> index;
+    std::vector<PackedLayer> layers;
+    // buffers
+    float *in16 = nullptr, *act0 = nullptr, *act1 = nullptr, *cat = nullptr, *brA = nullptr, *brB = nullptr, *brT = nullptr;
+    float* nchw_tmp = nullptr;       // staging for NCHW host <-> NHWC device conversions
+    size_t nchw_tmp_bytes = 0;
+    uint8_t* u8_tmp = nullptr;
+    uint8_t* u8_src = nullptr;       // original-size images awaiting the on-device resize
+    size_t u8_src_cap = 0;
+    int* rs_tab = nullptr;           // resize tables: x (4 * dw ints) then y (4 * dh ints)
+    size_t rs_tab_cap = 0;
+    // state of the last forward / set_maps
+    bool maps_valid = false, maps_external = false;
+    int cur_B = 0, cur_fh = 0, cur_fw = 0;
+    float *ext_paf = nullptr, *ext_heat = nullptr;   // NCHW copies installed by pmx_set_maps
+    size_t ext_cap = 0;
+    // post-process
+    PPTables tab{};
+    int tab_cap = 0;
+    int tab_in_h = -1, tab_in_w = -1, tab_out_h = -1, tab_out_w = -1;
+    std::vector<double> gauss;
+    PPBuffers pp{};
+    double* d_scale = nullptr;
+    unsigned char* h_results = nullptr;         // pinned staging for pmx_get_results (pageable D2H is slow and jittery)
+    size_t h_results_bytes = 0;
+    bool pp_valid = false;
+    bool pp_final = false;                      // statuses checked: no image of the last post-process overflowed a capacity
+    int pp_B = 0, pp_h = 0, pp_w = 0;
+    // arguments of the last post-process, kept for the grow-and-re-run
+    PPMaps pp_maps{};
+    double pp_img_len = 0;
+    bool pp_has_scale = false;
+    int pp_regrown = 0;                         // number of capacity growths so far (diagnostics)
+    size_t smoothed_cap = 0;
+    // options
+    int opt_force[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // by ksize
+    int opt_gpu_branch_peaks = 0;    // reference GPU-branch peak extraction (non-golden variant)
+    int opt_kp_flip_x = 0;           // pmx_keypoints: mirror the resized heat maps left-right before the peaks (hand_detector.py:46-47)
+    int tab_flip = 0;
+    int opt_keep_smoothed = 0, opt_stop_stage = 6, opt_kernel_gen = 6;
+    int opt_conv_algo = 1;           // 1 (default): Winograd F(2x2,3x3) fp32 kernel for the 3x3 / 7x7 layers of launches that fill the chip
+                                     // (>= 2 blocks per CU: batches); 0: direct kernels everywhere; 2: Winograd on every eligible layer
+                                     // (tests).  Both are fp32 with a defined order and a C twin; they differ by fp32 rounding (~1e-6)
+    int opt_wino_unit_eff = 80;      // unit mode: in-round efficiency of the 7x7 unit blocks relative to the plain kernel, percent (cost model;
+                                     // measured with tools/wino_batch_sweep.py: 75 - 90 alike, 60 loses batch 4 and 8, 105 loses batch 16+)
+    int opt_wino_min_fill = 50;      // conv_algo 1: percent of ceil(blocks / CUs) * CUs block slots a launch must fill to take the Winograd kernel
+    int opt_wino_geom = -1;          // Winograd block geometry on 46-pixel-wide maps: -1 / 1 runs of 32 consecutive tiles, 0 the 8 x 16 pixel rectangles
+                                     // of every other map size (same bits either way)
+    int opt_wino_tail = -1;          // run geometry: the part-filled last block of every image in unit mode (K units + combine) -- -1 by the cost
+                                     // model (conv_algo 1), 0 never, 1 wherever a unit plan exists.  Changes the summation of those tiles (C twin: unit_from)
+    int opt_wino_tail_g = 0;         // tuning: chunks per pass-1 unit of the tail (0 = automatic)
+    int opt_precision = 0;           // 0: fp32 MFMA everywhere (the path whose results are specified); 1: bf16x3 kernels where a
+                                     // v6 kernel would run (fp32-grade accuracy at 2.67x the matrix rate, NOT the fp32 FMA chain)
+    int opt_fuse_conv1 = 1;          // conv1_1 recomputed on conv1_2's halo tile, one launch (conv1_fused_kernel); identical bits
+    int opt_fuse_pairs = 1;          // the two 1x1 layers that end every stage run as one launch (conv1x1_pair_kernel)
+    int opt_ksplit = 0;              // 0: automatic split-K for small launches; n > 0: force n K slices where split-K applies
+    // split-K scratch: partial-sum slabs of the current launch + a zero bias vector for the slice blocks
+    float* sk_scratch = nullptr; size_t sk_floats = 0;
+    float* sk_zero_bias = nullptr;
+    // timing / profiling
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    int prof_on = 0;                 // 0 off | 1 every launch | 2 only the 7x7 convolutions (the dominant kernel: fewest events in a timed region)
+    std::vector<ProfEntry> prof;
+    std::map<std::string, int> prof_index;
+    std::vector<ProfPending> pending;
+    std::vector<hipEvent_t> ev_pool;   // recycled events (creating two per launch inside the timed region costs ~0.5 %)
+    int prof_open = -1;
+};
+
+#define PMX_DEV(c) PMX_HIP(hipSetDevice((c)->device))
+
+// pmx_api.hip
+int pmx_forward_from_in16(pmx_ctx* c, int B, int H, int W);      // the network on the padded float input already in c->in16
+int pmx_ensure_tables(pmx_ctx* c, int in_h, int in_w, int out_h, int out_w, int flip_x = 0);   // up-sampling tables of the post-process

@@ -1,0 +1,221 @@
+// pmx_precise.hip -- the C-ABI entry points of the multi-scale path and of the key-point networks (include/pose_mi355x.h):
+//   pmx_precise_begin / _add_scale / _finish   detect_precise (reference pose_detector.py:433-482) accumulated on the device
+//   pmx_keypoints                              FaceDetector / HandDetector post-process (face_detector.py:37-68, hand_detector.py:41-78)
+// Context, weights, the forward plan and the pose post-process live in pmx_api.hip; the shared context type in pmx_ctx.h.
+#include "pmx_ctx.h"
+
+#include <math.h>
+#include <string.h>
+
+// ---------------------------------------------------------------------------------------- detect_precise on the device
+// OpenCV bicubic tables for one axis (A = -0.75): idx[k][d] (clamped, replicate border) and coef[k][d] float32, k = 0..3.
+// Same float32 expression order as pose_detector.py::_cubic_taps / oracle/precise_ref.py::_coeffs.
+#pragma clang fp contract(off)
+static void make_cubic_table(int dst, int src, int* idx, float* coef)
+{
+    const double scale = 1.0 / ((double)dst / (double)src);
+    const float A = -0.75f;
+    for (int d = 0; d < dst; ++d) {
+        const float f = (float)(((double)d + 0.5) * scale - 0.5);
+        const int s = (int)floorf(f);
+        const float x = f - (float)s;
+        const float x1 = x + 1.0f, xm = 1.0f - x;
+        float c0 = A * x1;  c0 = c0 - 5.0f * A;  c0 = c0 * x1;  c0 = c0 + 8.0f * A;  c0 = c0 * x1;  c0 = c0 - 4.0f * A;
+        float c1 = (A + 2.0f) * x;  c1 = c1 - (A + 3.0f);  c1 = c1 * x;  c1 = c1 * x;  c1 = c1 + 1.0f;
+        float c2 = (A + 2.0f) * xm;  c2 = c2 - (A + 3.0f);  c2 = c2 * xm;  c2 = c2 * xm;  c2 = c2 + 1.0f;
+        float c3 = 1.0f - c0;  c3 = c3 - c1;  c3 = c3 - c2;
+        const float cs[4] = {c0, c1, c2, c3};
+        for (int k = 0; k < 4; ++k) {
+            int i = s - 1 + k;
+            i = i < 0 ? 0 : (i > src - 1 ? src - 1 : i);
+            idx[k * dst + d] = i;
+            coef[k * dst + d] = cs[k];
+        }
+    }
+}
+
+// uploads [xi | yi | xc | yc] (or fixed-point coefficients when `fixed`) for a (sh, sw) -> (dh, dw) cubic resize
+static int upload_cubic_tables(pmx_ctx* c, int sh, int sw, int dh, int dw, bool fixed, int** xi, void** xc, int** yi, void** yc)
+{
+    const size_t n = (size_t)4 * (dw + dh);
+    const size_t bytes = n * 2 * sizeof(int);
+    if (bytes > c->pr_tab_cap) {
+        PMX_HIP(hipStreamSynchronize(c->stream));
+        if (c->pr_tab) (void)hipFree(c->pr_tab);
+        c->pr_tab = nullptr;
+        PMX_HIP(hipMalloc(&c->pr_tab, bytes));
+        c->pr_tab_cap = bytes;
+    }
+    std::vector<int> hi(n);
+    std::vector<float> hc(n);
+    make_cubic_table(dw, sw, hi.data(), hc.data());
+    make_cubic_table(dh, sh, hi.data() + 4 * dw, hc.data() + 4 * dw);
+    PMX_HIP(hipStreamSynchronize(c->stream));     // previous resize may still read the table buffer
+    int* d_i = (int*)c->pr_tab;
+    PMX_HIP(hipMemcpy(d_i, hi.data(), n * sizeof(int), hipMemcpyHostToDevice));
+    if (fixed) {
+        std::vector<int> ha(n);
+        for (size_t k = 0; k < n; ++k) {
+            long v = lrintf(hc[k] * 2048.0f);      // saturate_cast<short>(coef * INTER_RESIZE_COEF_SCALE)
+            ha[k] = (int)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+        }
+        PMX_HIP(hipMemcpy(d_i + n, ha.data(), n * sizeof(int), hipMemcpyHostToDevice));
+    } else {
+        PMX_HIP(hipMemcpy(d_i + n, hc.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    }
+    *xi = d_i; *yi = d_i + 4 * dw;
+    *xc = (void*)(d_i + n); *yc = (void*)((int*)(d_i + n) + 4 * dw);
+    return PMX_OK;
+}
+
+// detect_precise (pose_detector.py:433-470) accumulated on the device.  begin: zero the per-channel sums at the original size.
+extern "C" int pmx_precise_begin(pmx_ctx* c, int orig_h, int orig_w)
+{
+    PMX_CHECK(c && c->kind == NET_POSE, PMX_ERR_INVALID, "pmx_precise_begin: posenet context required");
+    PMX_CHECK(orig_h >= 1 && orig_w >= 1, PMX_ERR_INVALID, "pmx_precise_begin: bad size");
+    PMX_DEV(c);
+    const size_t need = (size_t)orig_h * orig_w;
+    if (need > c->ext_cap) {
+        PMX_HIP(hipStreamSynchronize(c->stream));
+        if (c->ext_paf) (void)hipFree(c->ext_paf);
+        if (c->ext_heat) (void)hipFree(c->ext_heat);
+        c->ext_paf = c->ext_heat = nullptr;
+        PMX_HIP(hipMalloc((void**)&c->ext_paf, need * PMX_N_PAF * 4));
+        PMX_HIP(hipMalloc((void**)&c->ext_heat, need * PMX_N_HEAT * 4));
+        c->ext_cap = need;
+    }
+    PMX_HIP(hipMemsetAsync(c->ext_paf, 0, need * PMX_N_PAF * 4, c->stream));
+    PMX_HIP(hipMemsetAsync(c->ext_heat, 0, need * PMX_N_HEAT * 4, c->stream));
+    c->pr_h = orig_h; c->pr_w = orig_w; c->pr_scales = 0;
+    c->maps_valid = false;
+    return PMX_OK;
+}
+
+// one scale of the loop at :441-467: cubic resize of the uint8 image to (scaled_h, scaled_w) (:443), pad to a multiple of 8
+// with (104, 117, 123) (:445), forward (:451), x8 cubic up-sampling of both outputs (:461,465), crop of the padding
+// (:462,466), cubic resize to the original size and accumulation (:463,467).  `img`: host uint8 orig_h x orig_w x 3.
+extern "C" int pmx_precise_add_scale(pmx_ctx* c, const uint8_t* img, int scaled_h, int scaled_w)
+{
+    PMX_CHECK(c && img && c->pr_h > 0, PMX_ERR_STATE, "pmx_precise_add_scale: call pmx_precise_begin first");
+    PMX_CHECK(scaled_h >= 1 && scaled_w >= 1, PMX_ERR_INVALID, "bad size");
+    PMX_DEV(c);
+    const int oh = c->pr_h, ow = c->pr_w;
+    const int ph = round_up(scaled_h, 8), pw = round_up(scaled_w, 8);
+    PMX_CHECK((size_t)ph * pw <= (size_t)c->max_h * c->max_w && c->max_batch >= 1, PMX_ERR_CAPACITY,
+              "pmx_precise_add_scale: padded size %d x %d exceeds the context capacity %d x %d", ph, pw, c->max_h, c->max_w);
+    int missing = 0;
+    for (auto& l : c->layers) missing += l.set ? 0 : 1;
+    PMX_CHECK(missing == 0, PMX_ERR_WEIGHTS, "pmx_precise_add_scale: %d layers have no weights", missing);
+    int rc;
+    // original image -> device
+    const size_t nsrc = (size_t)oh * ow * 3;
+    if (nsrc > c->u8_src_cap) {
+        PMX_HIP(hipStreamSynchronize(c->stream));
+        if (c->u8_src) (void)hipFree(c->u8_src);
+        c->u8_src = nullptr;
+        PMX_HIP(hipMalloc((void**)&c->u8_src, nsrc));
+        c->u8_src_cap = nsrc;
+    }
+    PMX_HIP(hipMemcpyAsync(c->u8_src, img, nsrc, hipMemcpyHostToDevice, c->stream));
+    int *xi, *yi; void *xc, *yc;
+    // (1) uint8 cubic resize into the padded image
+    if ((rc = launch_fill_bgr(c->u8_tmp, (long long)ph * pw, 104, 117, 123, c->stream))) return rc;
+    if (scaled_h == oh && scaled_w == ow) {
+        PMX_HIP(hipMemcpy2DAsync(c->u8_tmp, (size_t)pw * 3, c->u8_src, (size_t)ow * 3, (size_t)ow * 3, oh, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        if ((rc = upload_cubic_tables(c, oh, ow, scaled_h, scaled_w, true, &xi, &xc, &yi, &yc))) return rc;
+        if ((rc = launch_resize_cubic_u8(c->u8_src, ow, c->u8_tmp, scaled_h, scaled_w, pw, xi, (const int*)xc, yi, (const int*)yc, c->stream))) return rc;
+    }
+    // (2) network
+    if ((rc = launch_prep_u8(c->u8_tmp, c->in16, 1, ph, pw, 255.0f, c->stream))) return rc;
+    if ((rc = pmx_forward_from_in16(c, 1, ph, pw))) return rc;
+    const int fh = ph / 8, fw = pw / 8;
+    // (3) x8 cubic up-sampling of PAF (38) and heat (19) channels into NHWC-57
+    const size_t ntmp = (size_t)ph * pw * 57;
+    if (ntmp > c->pr_tmp_cap) {
+        PMX_HIP(hipStreamSynchronize(c->stream));
+        if (c->pr_tmp) (void)hipFree(c->pr_tmp);
+        c->pr_tmp = nullptr;
+        PMX_HIP(hipMalloc((void**)&c->pr_tmp, ntmp * sizeof(float)));
+        c->pr_tmp_cap = ntmp;
+    }
+    if ((rc = upload_cubic_tables(c, fh, fw, ph, pw, false, &xi, &xc, &yi, &yc))) return rc;
+    const long long sy = (long long)fw * PMX_CAT_C, sx = PMX_CAT_C;
+    // PAF and heat are separate arrays in the reference (two cv2.resize calls); here two launches into one NHWC-57 buffer
+    // would need a strided destination, so each map set gets its own dense NHWC temp region: [ph*pw*38 | ph*pw*19]
+    float* t_paf = c->pr_tmp;
+    float* t_heat = c->pr_tmp + (size_t)ph * pw * PMX_N_PAF;
+    if ((rc = launch_resize_cubic_f32(c->cat + PMX_CAT_PAF, sy, sx, 1, PMX_N_PAF, t_paf, ph, pw, xi, (const float*)xc, yi, (const float*)yc, 0, 0, c->stream))) return rc;
+    if ((rc = launch_resize_cubic_f32(c->cat + PMX_CAT_HEAT, sy, sx, 1, PMX_N_HEAT, t_heat, ph, pw, xi, (const float*)xc, yi, (const float*)yc, 0, 0, c->stream))) return rc;
+    // (4) crop the padding (source extent scaled_h x scaled_w of the padded maps) and cubic resize to the original size, accumulating
+    if ((rc = upload_cubic_tables(c, scaled_h, scaled_w, oh, ow, false, &xi, &xc, &yi, &yc))) return rc;
+    if ((rc = launch_resize_cubic_f32(t_paf, (long long)pw * PMX_N_PAF, PMX_N_PAF, 1, PMX_N_PAF, c->ext_paf, oh, ow, xi, (const float*)xc, yi,
+                                      (const float*)yc, 1, 0, c->stream))) return rc;
+    if ((rc = launch_resize_cubic_f32(t_heat, (long long)pw * PMX_N_HEAT, PMX_N_HEAT, 1, PMX_N_HEAT, c->ext_heat, oh, ow, xi, (const float*)xc, yi,
+                                      (const float*)yc, 1, 0, c->stream))) return rc;
+    c->pr_scales += 1;
+    c->maps_valid = false;       // the cat buffer holds one scale only; the averaged maps become valid in pmx_precise_finish
+    return PMX_OK;
+}
+
+// :469-470: divide the sums by the number of scales and install them as the maps of a batch of one at the original size
+extern "C" int pmx_precise_finish(pmx_ctx* c)
+{
+    PMX_CHECK(c && c->pr_h > 0 && c->pr_scales > 0, PMX_ERR_STATE, "pmx_precise_finish: nothing accumulated");
+    PMX_DEV(c);
+    int rc;
+    const long long n = (long long)c->pr_h * c->pr_w;
+    if ((rc = launch_scale_f32(c->ext_paf, n * PMX_N_PAF, (float)c->pr_scales, c->stream))) return rc;
+    if ((rc = launch_scale_f32(c->ext_heat, n * PMX_N_HEAT, (float)c->pr_scales, c->stream))) return rc;
+    c->maps_valid = true; c->maps_external = true;
+    c->cur_B = 1; c->cur_fh = c->pr_h; c->cur_fw = c->pr_w;
+    c->pp_valid = false;
+    c->pr_scales = 0;
+    return PMX_OK;
+}
+
+// FaceDetector / HandDetector.__call__ post-process (face_detector.py:37-38,58-68; hand_detector.py:41,68-78):
+// F.resize_images(hs[-1], (out_h, out_w)) + gaussian_filter + per-channel arg-max over the n_heat - 1 key-point channels.
+// out: batch x (n_heat - 1) x 4 float64 rows (x, y, confidence, valid); valid = 0 where the reference appends None.
+extern "C" int pmx_keypoints(pmx_ctx* c, int B, int out_h, int out_w, double thresh, double* out)
+{
+    PMX_CHECK(c && out, PMX_ERR_INVALID, "null arg");
+    PMX_CHECK(c->kind != NET_POSE, PMX_ERR_STATE, "pmx_keypoints: facenet / handnet only");
+    PMX_CHECK(c->maps_valid && B == c->cur_B, PMX_ERR_STATE, "pmx_keypoints: no network output for batch %d", B);
+    PMX_CHECK(out_h >= 1 && out_w >= 1 && (long long)out_h * out_w < (1ll << 31), PMX_ERR_INVALID, "pmx_keypoints: bad size");
+    PMX_DEV(c);
+    int rc;
+    if ((rc = pmx_ensure_tables(c, c->cur_fh, c->cur_fw, out_h, out_w, c->opt_kp_flip_x))) return rc;
+    const int n_ch = c->n_heat - 1;
+    const long long fhw = (long long)c->cur_fh * c->cur_fw;
+    PPMaps m;
+    if (c->maps_external) {
+        m.heat = c->ext_heat; m.paf = nullptr; m.sx = 1; m.sy = c->cur_fw; m.sc = fhw; m.sbh = c->n_heat * fhw; m.sbp = 0;
+    } else {
+        m.heat = c->cat + c->cat_heat; m.paf = nullptr; m.sc = 1; m.sx = c->cat_c; m.sy = (long long)c->cur_fw * c->cat_c;
+        m.sbh = fhw * c->cat_c; m.sbp = 0;
+    }
+    m.fh = c->cur_fh; m.fw = c->cur_fw;
+    const size_t need = (size_t)B * n_ch * out_h * out_w;
+    if (need > c->smoothed_cap) {
+        PMX_HIP(hipStreamSynchronize(c->stream));
+        if (c->pp.smoothed) (void)hipFree(c->pp.smoothed);
+        c->pp.smoothed = nullptr;
+        PMX_HIP(hipMalloc((void**)&c->pp.smoothed, need * sizeof(float)));
+        c->smoothed_cap = need;
+    }
+    const size_t nkp = (size_t)B * n_ch * 4;
+    if (nkp > c->kp_cap) {
+        PMX_HIP(hipStreamSynchronize(c->stream));
+        if (c->d_kp) (void)hipFree(c->d_kp);
+        c->d_kp = nullptr;
+        PMX_HIP(hipMalloc((void**)&c->d_kp, nkp * sizeof(double)));
+        c->kp_cap = nkp;
+    }
+    if ((rc = pp_keypoints_launch(m, c->tab, c->pp, B, n_ch, out_h, out_w, thresh, c->d_kp, c->stream))) return rc;
+    PMX_HIP(hipMemcpyAsync(out, c->d_kp, nkp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PMX_HIP(hipStreamSynchronize(c->stream));
+    c->pp_valid = true; c->pp_final = true; c->pp_B = B; c->pp_h = out_h; c->pp_w = out_w;
+    return PMX_OK;
+}
+

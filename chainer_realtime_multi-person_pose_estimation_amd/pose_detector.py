@@ -73,19 +73,34 @@ class PoseDetector(object):
             st = self.engine.state()
             self.engine.close()
             self.engine = None
-        self._cap = (max_batch, mh, mw)
-        self.engine = native.Engine(self._gpu, max_batch=max_batch, max_h=mh, max_w=mw,
-                                    gaussian_sigma=params['gaussian_sigma'])
-        if st is not None:
-            self.engine.load_state(st)
-        elif self._weights is not None:
-            self.engine.set_weights(self._weights)
-        if self._precision == 'bf16x3':
-            self.engine.set_option('precision', 1)
-        if self._gpu_branch_peaks:
-            # the reference's own GPU branch of compute_peaks_from_heatmaps (:111-133): 17x17 un-normalised kernel, zero
-            # padding, '>=' NMS -- NOT the golden CPU semantics; off by default
-            self.engine.set_option('peaks_gpu_branch', 1)
+        try:
+            self.engine = self._new_engine(max_batch, mh, mw, st)
+        except Exception:
+            # a failed growth (device out of memory for an oversized image / batch, rejected capacities) must not leave the
+            # detector without a context: rebuild the previous one from the saved state, keep its capacity, re-raise
+            self.engine = None
+            if st is not None:
+                self.engine = self._new_engine(*self._cap, st)
+            raise
+        self._cap = (max_batch, mh, mw)            # only once the new context is complete
+
+    def _new_engine(self, max_batch, mh, mw, st):
+        eng = native.Engine(self._gpu, max_batch=max_batch, max_h=mh, max_w=mw, gaussian_sigma=params['gaussian_sigma'])
+        try:
+            if st is not None:
+                eng.load_state(st)
+            elif self._weights is not None:
+                eng.set_weights(self._weights)
+            if self._precision == 'bf16x3':
+                eng.set_option('precision', 1)
+            if self._gpu_branch_peaks:
+                # the reference's own GPU branch of compute_peaks_from_heatmaps (:111-133): 17x17 un-normalised kernel, zero
+                # padding, '>=' NMS -- NOT the golden CPU semantics; off by default
+                eng.set_option('peaks_gpu_branch', 1)
+        except Exception:
+            eng.close()
+            raise
+        return eng
 
     # ---- host helpers with the reference's names and semantics -------------------------------------
     def compute_optimal_size(self, orig_img, img_size, stride=8):
