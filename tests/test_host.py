@@ -156,3 +156,49 @@ def test_every_option_key_is_documented_in_the_header():
     for k in keys:
         documented = ('"%s"' % k) in hdr or (k.startswith('force_variant_k') and '"force_variant_k1|k3|k7"' in hdr)
         assert documented, 'option "%s" is not described in include/pose_mi355x.h' % k
+
+
+def test_failed_growth_leaves_a_usable_detector(monkeypatch):
+    """PoseDetector._make_engine closes the old context before the larger one exists; if creating / loading the larger one
+    fails (device out of memory for an oversized image, rejected capacities), the detector must come back with a context at the
+    PREVIOUS capacity carrying the saved state, and _cap must still say so."""
+    PD = pkg('pose_detector')
+    made = []
+
+    class FakeEngine(object):
+        def __init__(self, device, max_batch=1, max_h=368, max_w=368, gaussian_sigma=2.5, arch='posenet'):
+            if max_h * max_w > 1000 * 1000:
+                raise MemoryError('hipMalloc: out of memory')
+            self.cap = (max_batch, max_h, max_w)
+            self.loaded, self.closed, self.opts = None, False, {}
+            made.append(self)
+
+        def state(self):
+            return {'layers': {'conv1_1': 'W'}, 'options': dict(self.opts), 'stream': None, 'caps': {}}
+
+        def load_state(self, st):
+            self.loaded = st
+
+        def set_weights(self, w):
+            self.loaded = {'layers': w}
+
+        def set_option(self, k, v):
+            self.opts[k] = v
+
+        def close(self):
+            self.closed = True
+
+    monkeypatch.setattr(PD.native, 'Engine', FakeEngine)
+    det = PD.PoseDetector(model={'conv1_1': 'W'}, device=0)
+    first = det.engine
+    assert det._cap == (1, 368, 368) and first.cap == (1, 368, 368)
+    det._grow(4, 368, 368)                                   # a growth that works
+    assert det._cap == (4, 368, 368) and det.engine.cap == (4, 368, 368) and first.closed and det.engine.loaded['layers'] == {'conv1_1': 'W'}
+    good = det.engine
+    with pytest.raises(MemoryError):
+        det._grow(4, 2000, 2000)                             # a growth that fails
+    assert det.engine is not None and det.engine is not good and good.closed
+    assert det._cap == (4, 368, 368) and det.engine.cap == (4, 368, 368)          # back at the previous capacity ...
+    assert det.engine.loaded['layers'] == {'conv1_1': 'W'}                            # ... with the saved state
+    det._grow(2, 368, 368)                                   # and the early return of _grow is still truthful
+    assert det.engine.cap == (4, 368, 368)
