@@ -295,26 +295,71 @@ def main():
     d_imgs = torch.from_numpy(imgs).to(dev)          # inputs resident in HBM before the timed region
     torch.cuda.synchronize()
     gather_ms = [0.0]
+    pipe = None
+    if use_group:
+        # N > 1 (and --force-gather): the records travel through dist.RecordPipe -- ONE fixed-size gather per step, issued one step behind
+        # the compute (detect_batch(k + 1) is enqueued before the records of step k are shipped), so ranks never wait for each other
+        # inside the loop; the slot size is agreed once, here, from the record size after one plain step
+        eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(B, S, S), map_h=map_s, map_w=map_s)
+        _, rec_bytes0 = eng.results_layout()
+        pipe = dist_mod.RecordPipe(B * rec_bytes0, dst=0, device=coll_dev)
+    snap_mode = [None, None]
 
-    def step(ptr=None):
+    def enqueue(k, ptr=None):
+        """detect_batch of step k + a stream-ordered snapshot of its records (into the pipe's send slot when it fits); no host sync"""
         eng.detect_batch(device_ptr=d_imgs.data_ptr() if ptr is None else ptr, shape=(B, S, S), map_h=map_s, map_w=map_s)
-        if use_group and a.backend == 'nccl':
-            # RCCL gather (the only collective) straight from the device-resident records, then one D2H copy on rank 0
-            t = time.perf_counter()
-            eng.results_layout()                      # stream sync: the records are final
-            t1 = time.perf_counter()
-            rec = dist_mod.gather_device_records(eng, B, dst=0)
-            gather_ms[0] += (time.perf_counter() - t1) * 1e3
-            return rec
-        rec = eng.results()                           # stream sync + D2H of the records
-        if world > 1:
-            t1 = time.perf_counter()
-            rec = dist_mod.gather_records(rec, dst=0, device=coll_dev)     # smoke mode (gloo): gather through the host
-            gather_ms[0] += (time.perf_counter() - t1) * 1e3
-        return rec
+        slot_ptr, room = pipe.payload_view(k)
+        need = B * native.result_dtype(eng.capacities()['people']).itemsize
+        if slot_ptr is not None and need <= room:
+            eng.results_snapshot(k & 1, slot_ptr, room)
+            snap_mode[k & 1] = None
+        else:                       # gloo smoke mode (the pipe lives on the host) or records larger than the slot: through a staging tensor
+            stage = torch.empty(need, dtype=torch.uint8, device=dev)
+            eng.results_snapshot(k & 1, stage.data_ptr(), need)
+            snap_mode[k & 1] = stage
 
-    for _ in range(a.warmup):
-        rec = step()
+    def ship(j):
+        """records of step j -> the pipe (one gather); on the root: the steps completed by it [(step, records of all ranks)]"""
+        t1 = time.perf_counter()
+        n, cap, rec_bytes, overflow = eng.snapshot_wait(j & 1)
+        if overflow:
+            # an image needed more capacity than the context had: the snapshot is not final.  Rare (capacities grow once): drain, run
+            # the step again through the growing path, send the records from the host (the in-flight next step is re-checked at its turn)
+            eng.synchronize()
+            eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(B, S, S), map_h=map_s, map_w=map_s)
+            r_ = eng.results()
+            done = pipe.send(j, j, len(r_), dist_mod._people_cap(r_.dtype), r_.dtype.itemsize, payload=np.frombuffer(r_.tobytes(), dtype=np.uint8))
+        elif snap_mode[j & 1] is None:
+            done = pipe.send(j, j, n, cap, rec_bytes)
+        else:
+            done = pipe.send(j, j, n, cap, rec_bytes, payload=snap_mode[j & 1][:n * rec_bytes].cpu().numpy())
+        gather_ms[0] += (time.perf_counter() - t1) * 1e3
+        return done or []
+
+    def run_steps(n):
+        """n steps; returns the records of the last one (on rank 0: of all ranks)"""
+        if pipe is None:
+            for _ in range(n):
+                eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(B, S, S), map_h=map_s, map_w=map_s)
+                rec_ = eng.results()                  # stream sync + D2H of the records
+            return rec_
+        got = []
+        for k in range(n):
+            enqueue(k)
+            if k:
+                got += ship(k - 1)
+        got += ship(n - 1)
+        got += pipe.flush() or []
+        if rank == 0:
+            assert [st for st, _ in got] == list(range(n)), ('steps delivered', [st for st, _ in got])
+            return got[-1][1]
+        return None
+
+    def step():
+        return run_steps(1)
+
+    if a.warmup:
+        rec = run_steps(a.warmup)
     profile = not a.no_profile
     if profile:
         # inside the timed region only the dominant kernel's launches carry HIP-event pairs (25 of ~60 launches per step: the
@@ -322,19 +367,20 @@ def main():
         eng.profile_reset()
         eng.profile_enable(2)
     gather_ms[0] = 0.0
+    n_coll0 = pipe.collectives if pipe else 0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        rec = step()
+    rec = run_steps(a.steps)
     eng.synchronize()
     torch.cuda.synchronize()
     dt_local = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    n_coll = (pipe.collectives - n_coll0) if pipe else 0
     per_rank = [B * a.steps / dt_local]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
@@ -374,20 +420,25 @@ def main():
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'batch%d_%dx%d_synthetic_uint8_per_gpu' % (B, S, S), 'per_gpu_batch': B,
                        'global_batch': B * world, 'map': '%dx%d' % (map_s, map_s), 'weights': 'seeded He + calibrated head',
-                       'parallelism': 'dp%d (independent images, %s gather of the result records to rank 0)'
-                                      % (world, 'RCCL' if a.backend == 'nccl' else a.backend),
+                       'parallelism': ('dp%d (independent images, one %s gather of the result records to rank 0 per step, pipelined one step '
+                                       'behind the compute)' % (world, 'RCCL' if a.backend == 'nccl' else a.backend)) if use_group
+                                      else 'dp1 (one process, one GPU: no process group, no collective; records by pmx_get_results)',
                        'records_gathered': int(len(rec)),
                        'people_per_frame_mean': float(np.mean(rec['n_people'])) if len(rec) else 0.0,
                        'peaks_per_frame_mean': float(np.mean(rec['n_peaks'])) if len(rec) else 0.0,
                        'status_bits': status_bits},
             'achieved_tflops_whole_net': FLOP_PER_FRAME * (S * S / (368.0 * 368.0)) * frames / dt / 1e12,
         }
-        if world > 1:
+        if use_group:
             out['per_rank_frames_per_s'] = per_rank
-            out['gather_ms_per_step_rank0'] = gather_ms[0] / a.steps
+            out['per_rank_frames_per_s_min_max'] = [min(per_rank), max(per_rank)]
+            out['gather_ms_per_step_rank0'] = gather_ms[0] / a.steps        # host time of rank 0 inside ship(): overlaps the GPU's next step
+            out['collectives_per_step'] = n_coll / float(a.steps)             # (1.0 + one flush all_reduce per timed region)
+            out['pipeline'] = 'detect_batch(k + 1) enqueued before the records of step k are gathered (dist.RecordPipe, slot %d bytes)' % pipe.slot_bytes
         out['backend'] = ('rccl (torch.distributed "nccl")' if a.backend == 'nccl' else a.backend) if use_group else None
-        out['records_path'] = ('dist.gather_device_records (RCCL gather from the device-resident records)' if use_group and a.backend == 'nccl'
-                               else 'dist.gather_records (host records, %s)' % a.backend if world > 1 else 'pmx_get_results (one D2H copy)')
+        out['records_path'] = ('dist.RecordPipe (pmx_results_snapshot into the send slot on the device -> one RCCL gather per step -> one D2H copy on rank 0)'
+                               if use_group and a.backend == 'nccl' else 'dist.RecordPipe over %s (host slots)' % a.backend if use_group
+                               else 'pmx_get_results (one D2H copy)')
         out['ranks_seen'] = [r_['rank'] for r_ in rank_info]
         out['devices'] = rank_info
         roof = None
@@ -405,7 +456,11 @@ def main():
                 sub_ach = (sum(p_['issued_flop_per_launch'] * p_['launches'] for p_ in sub) / (sum(p_['total_ms'] for p_ in sub) * 1e-3) / 1e12
                            if sub else None)
                 roof = {'kernel': dom_name, 'profile_labels': dom_labels, 'bound': 'mfma', 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS,
-                        'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_src,
+                        'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS, 'issued_frac': ach / FP32_MFMA_PEAK_TFLOPS,
+                        'frac_definition': 'issued MFMA FLOP (= algorithmic x 100/196 for the 7x7 Winograd form) / launch duration / peak -- '
+                                           'NOT the algorithmic figure of the bench contract, which is `algorithmic_frac` (> 1 for a Winograd '
+                                           'kernel); BASELINE.md section 4 states the redefinition',
+                        'traffic': traffic, 'traffic_source': traffic_src,
                         'issued_flop_per_launch': total_issued / launches, 'flop_per_launch': total_flop / launches,
                         'executed_flop_fraction': total_issued / total_flop if total_flop else None,
                         'algorithmic_achieved': ach_alg, 'algorithmic_frac': ach_alg / FP32_MFMA_PEAK_TFLOPS,
@@ -446,12 +501,15 @@ def main():
             out['single_image'] = single_image(eng, d_imgs, S, map_s)
             out['direct_kernels_only'] = direct_only(eng, torch, d_imgs, B, S, map_s, a.steps)
             out['bf16x3'] = bf16x3_mode(eng, torch, dev, d_imgs, B, S, map_s, a.steps)
+            out['rect_368x496'] = rect_inputs(native, weights_mod, torch, dev, local_rank, B, a.steps, frames / dt, S)
+            out['precise'] = precise_mode(weights_mod, local_rank, with_oracle=not a.no_cpu_baseline)
             eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(B, S, S), map_h=map_s, map_w=map_s)     # restore the batch state
             rec = eng.results()                                                                             # for keypoint_match
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'], oracle_results = cpu_baseline(weights, imgs, (map_s, map_s), a.cpu_budget)
             from oracle import conv_fma_ref
             out['keypoint_match'] = keypoint_match(eng, rec, oracle_results, weights, imgs, conv_fma_ref.splitk_plan(prof_all))
+            out['keypoint_match']['census'] = committed_census()
             if not a.no_extras:
                 # the opt-in bf16x3 mode against the same CPU oracle frames (it is compared with the fp32 path above; this is the
                 # figure the north_star tolerance applies to)
@@ -605,6 +663,160 @@ def bf16x3_mode(eng, torch, dev, d_imgs, B, S, map_s, steps, frames=256):
             'note': 'opt-in mode, never the headline: fp32 values as hi + mid + lo bf16, products hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid on '
                     'v_mfma_f32_32x32x16_bf16 with fp32 accumulation; conv1_1 and the 1x1 pairs stay on the fp32 MFMA',
             'agreement_with_f32_path': st}
+
+
+def committed_census():
+    """The margin census of the peak decisions (tools/parity_census.py, run on the GPU box, committed under profiles/): the statement
+    behind "peak indices identical" -- N of M fresh frames identical, every difference a near-tie below X.  Quoted, not re-run."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_parity_census.json')))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        keys = ('frames', 'frames_identical', 'frames_with_identical_peak_indices', 'frames_with_identical_poses', 'peaks_compared',
+                'mismatching_peaks', 'max_margin_of_a_mismatch', 'min_margin_of_accepted_peaks', 'min_abs_margin_of_agreed_decisions',
+                'all_mismatches_are_near_ties', 'max_abs_peak_score_diff', 'max_abs_score_diff_matched_people')
+        return {'source': os.path.basename(files[-1]), 'workload': d.get('workload'),
+                'paths': {name: {k: p_.get(k) for k in keys} for name, p_ in d['paths'].items()}}
+    except Exception as e:
+        return {'error': repr(e)}
+
+
+def rect_inputs(native, weights_mod, torch, dev, device_index, B, steps, square_fps, S):
+    """Landscape / portrait network inputs (compute_optimal_size, reference pose_detector.py:57-73, gives 368 x 496 for a 4:3 COCO
+    frame): the same step at batch B on 46 x 62 / 62 x 46 feature maps -- frames/s, the rate per pixel relative to the square headline
+    (1.0 = the same cost per pixel) and the dominant kernel's issued fraction of the fp32-MFMA peak."""
+    out = {}
+    for name, (h, w) in (('368x496', (368, 496)), ('496x368', (496, 368))):
+        eng = native.Engine(device_index, max_batch=B, max_h=h, max_w=w)
+        try:
+            wts = weights_mod.synthetic_weights(0)
+            eng.set_weights(wts)
+            cal = np.random.default_rng(1234).integers(0, 256, (1, h, w, 3), dtype=np.uint8)
+            eng.forward_u8(cal)
+            paf, heat = eng.get_maps()
+            wts = weights_mod.calibrate_head(wts, paf[0], heat[0])
+            eng.set_weights({k: wts[k] for k in ('Mconv7_stage6_L1', 'Mconv7_stage6_L2')})
+            imgs = torch.from_numpy(np.random.default_rng(2).integers(0, 256, (B, h, w, 3), dtype=np.uint8)).to(dev)
+            mh, mw = h * 320 // 368 // 8 * 8, w * 320 // 368 // 8 * 8
+            for _ in range(2):
+                eng.detect_batch(device_ptr=imgs.data_ptr(), shape=(B, h, w), map_h=mh, map_w=mw); eng.results()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                eng.detect_batch(device_ptr=imgs.data_ptr(), shape=(B, h, w), map_h=mh, map_w=mw); rec = eng.results()
+            eng.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            eng.profile_reset(); eng.profile_enable(1)
+            eng.detect_batch(device_ptr=imgs.data_ptr(), shape=(B, h, w), map_h=mh, map_w=mw); eng.results()
+            prof = eng.profile()
+            eng.profile_enable(False)
+            fps = B / dt
+            o = {'value': fps, 'unit': 'frames/s', 'ms_per_step': dt * 1e3, 'steps': steps, 'batch': B, 'feature_map': '%dx%d' % (h // 8, w // 8),
+                 'rate_per_pixel_vs_square': fps * h * w / (square_fps * S * S), 'people_per_frame_mean': float(np.mean(rec['n_people'])),
+                 'achieved_tflops_whole_net': FLOP_PER_FRAME * (h * w / (368.0 * 368.0)) * fps / 1e12}
+            if prof:
+                nm, total_ms, launches, total_flop, total_issued, labels = dominant_kernel(prof)
+                if launches and total_ms > 0:
+                    o['dominant_kernel'] = {'kernel': nm, 'profile_labels': labels, 'avg_launch_ms': total_ms / launches, 'launches': launches,
+                                            'issued_frac': total_issued / (total_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                            'algorithmic_frac': total_flop / (total_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+                step_issued = sum(p_['issued_flop_per_launch'] * p_['launches'] for p_ in prof)
+                o['step_issued_frac'] = step_issued / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS
+            out[name] = o
+        finally:
+            eng.close()
+    return out
+
+
+def precise_mode(weights_mod, device_index, with_oracle=True, shape=(482, 642)):
+    """BASELINE config 5: PoseDetector(precise=True) (reference pose_detector.py:433-482: four scales 0.5 / 1 / 1.5 / 2, cubic resizes,
+    averaged full-resolution maps, post-process at the original resolution) on one 482 x 642 frame with the native network: ms per
+    image, the dominant kernel, and the key points against oracle/precise_ref driving the torch-CPU network restatement."""
+    PD = importlib.import_module(PKG + '.pose_detector')
+    H, W = shape
+    img = np.random.default_rng(55).integers(0, 256, (H, W, 3), dtype=np.uint8)
+    wts = weights_mod.synthetic_weights(0)
+    big = (-(-int(np.ceil(H * 2 * 368 / min(H, W))) // 8) * 8, -(-int(np.ceil(W * 2 * 368 / min(H, W))) // 8) * 8)
+    det = PD.PoseDetector(weights=wts, device=device_index, precise=True, max_size=big)
+    try:
+        # calibrate the synthetic head on the scale-1 input so that the averaged maps carry a crowd-like load
+        cal = PD.resize_cubic_u8(img, int(np.ceil(W * 368 / min(H, W))), int(np.ceil(H * 368 / min(H, W))))
+        cal, _ = det.pad_image(cal, 8, (104, 117, 123))
+        det.engine.forward_u8(cal[None])
+        paf0, heat0 = det.engine.get_maps()
+        wts = weights_mod.calibrate_head(wts, paf0[0], heat0[0], heat_s=0.2, heat_t=-0.2, paf_s=1.2)
+        det._weights = wts
+        det.engine.set_weights({k: wts[k] for k in ('Mconv7_stage6_L1', 'Mconv7_stage6_L2')})
+        err = None
+        try:
+            poses, scores = det(img)
+        except IndexError as e:           # (the reference raises it too on a third subset match, pose_detector.py:197)
+            err, poses, scores = repr(e), np.zeros((0, 18, 3)), np.zeros(0)
+        n = 5
+        t0 = time.perf_counter()
+        for _ in range(n):
+            try:
+                det._detect_precise_device(img, fetch_maps=False)
+            except IndexError:
+                pass
+        ms = (time.perf_counter() - t0) / n * 1e3
+        scales = [(int(np.ceil(H * s_ * 368 / min(H, W))), int(np.ceil(W * s_ * 368 / min(H, W)))) for s_ in (0.5, 1.0, 1.5, 2.0)]
+        flop = sum(FLOP_PER_FRAME * ((-(-h_ // 8) * 8) * (-(-w_ // 8) * 8)) / (368.0 * 368.0) for h_, w_ in scales)
+        out = {'ms_per_image': ms, 'images_per_s': 1e3 / ms, 'image': '%dx%d' % (H, W), 'scales': [0.5, 1.0, 1.5, 2.0],
+               'network_inputs': ['%dx%d' % (-(-h_ // 8) * 8, -(-w_ // 8) * 8) for h_, w_ in scales], 'flop_per_image': flop,
+               'algorithmic_tflops': flop / (ms * 1e-3) / 1e12, 'peaks': int(len(det.all_peaks)), 'people': int(len(poses)), 'raised': err}
+        det.engine.profile_reset(); det.engine.profile_enable(1)
+        try:
+            det._detect_precise_device(img, fetch_maps=False)
+        except IndexError:
+            pass
+        prof = det.engine.profile()
+        det.engine.profile_enable(False)
+        if prof:
+            nm, total_ms, launches, total_flop, total_issued, labels = dominant_kernel(prof)
+            out['kernel_ms_per_image'] = sum(p_['total_ms'] for p_ in prof)
+            if launches and total_ms > 0:
+                out['dominant_kernel'] = {'kernel': nm, 'profile_labels': labels, 'total_ms': total_ms, 'launches': launches,
+                                          'issued_frac': total_issued / (total_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                          'algorithmic_frac': total_flop / (total_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+        if with_oracle:
+            out['keypoint_match_vs_precise_ref'] = precise_match(det, img, wts, poses, scores)
+        return out
+    finally:
+        det.engine.close()
+
+
+def precise_match(det, img, wts, poses, scores):
+    """detect_precise of the GPU path against oracle/precise_ref (pose_detector.py:433-482 restated; cv2.INTER_CUBIC restated -- parity
+    unpinned against a real OpenCV) driving the torch-CPU network restatement: the averaged full-resolution maps within tolerance, the
+    peak sets through the margin census (every disagreement a near-tie), the people both sides found within 1e-4."""
+    try:
+        from oracle import census, network_ref, precise_ref
+        t0 = time.perf_counter()
+        gpaf, gheat = det.pafs, det.heatmaps
+        ref_paf, ref_heat, sizes = precise_ref.averaged_maps(lambda x: network_ref.forward(wts, x), img)
+        scale = max(1.0, float(np.abs(ref_heat).max()), float(np.abs(ref_paf).max()))
+        o = {'max_abs_diff_averaged_maps_over_scale': float(max(np.abs(gpaf - ref_paf).max(), np.abs(gheat - ref_heat).max()) / scale)}
+        try:
+            ref = precise_ref.detect_precise_from_maps(ref_paf, ref_heat)
+        except IndexError as e:
+            o['oracle_raised'] = repr(e)
+            return o
+        # GPU-side smoothed maps: the post-process is bit-exact given the maps, so the oracle's Gaussian on the GPU's own averaged maps
+        from oracle import postprocess_ref
+        gsm = {}
+        f = census.compare_frame(det.all_peaks, ref['all_peaks'], ref['smoothed'], lambda j: gsm.setdefault(j, postprocess_ref.gaussian_filter_ref(gheat[j])),
+                                 poses, scores, ref['poses'], ref['scores'])
+        s = census.summarize([f], 'precise')
+        for k in ('frames_identical', 'peaks_compared', 'mismatching_peaks', 'max_margin_of_a_mismatch', 'all_mismatches_are_near_ties',
+                  'min_margin_of_accepted_peaks', 'max_abs_peak_score_diff', 'people_cpu', 'matched_people', 'max_abs_score_diff_matched_people'):
+            o[k] = s[k]
+        o['oracle_seconds'] = time.perf_counter() - t0
+        return o
+    except Exception as e:              # the checker must never break the measurement
+        return {'error': repr(e)}
 
 
 def single_image(eng, d_imgs, S, map_s):

@@ -408,6 +408,10 @@ extern "C" void pmx_destroy(pmx_ctx* c)
     for (auto& p : c->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->h_results) (void)hipHostFree(c->h_results);
+    for (int i = 0; i < 2; ++i) {
+        if (c->snap_ev[i]) (void)hipEventDestroy(c->snap_ev[i]);
+        if (c->snap_status[i]) (void)hipHostFree(c->snap_status[i]);
+    }
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1429,6 +1433,38 @@ extern "C" int pmx_results_device_ptr(pmx_ctx* c, void** p, size_t* bytes)
     if (int rc = pp_finalize(c)) return rc;      // never hand out records that still carry capacity-overflow bits / a layout about to change
     *p = c->pp.results;
     *bytes = c->pp.rec_bytes;
+    return PMX_OK;
+}
+
+extern "C" int pmx_results_snapshot(pmx_ctx* c, int slot, void* dst_device, size_t dst_bytes)
+{
+    PMX_CHECK(c && dst_device, PMX_ERR_INVALID, "null arg");
+    PMX_CHECK(slot == 0 || slot == 1, PMX_ERR_INVALID, "pmx_results_snapshot: slot %d (0 | 1)", slot);
+    PMX_CHECK(c->pp_valid, PMX_ERR_STATE, "pmx_results_snapshot: no post-process results yet");
+    PMX_DEV(c);
+    const size_t need = c->pp.rec_bytes * (size_t)c->pp_B;
+    PMX_CHECK(dst_bytes >= need, PMX_ERR_CAPACITY, "pmx_results_snapshot: %zu bytes for %d records of %zu bytes", dst_bytes, c->pp_B, c->pp.rec_bytes);
+    if (!c->snap_ev[slot]) PMX_HIP(hipEventCreateWithFlags(&c->snap_ev[slot], hipEventDisableTiming));
+    if (!c->snap_status[slot]) PMX_HIP(hipHostMalloc((void**)&c->snap_status[slot], sizeof(int) * (size_t)c->max_batch, hipHostMallocDefault));
+    PMX_HIP(hipMemcpyAsync(dst_device, c->pp.results, need, hipMemcpyDeviceToDevice, c->stream));
+    PMX_HIP(hipMemcpyAsync(c->snap_status[slot], c->pp.status, sizeof(int) * (size_t)c->pp_B, hipMemcpyDeviceToHost, c->stream));
+    PMX_HIP(hipEventRecord(c->snap_ev[slot], c->stream));
+    c->snap_B[slot] = c->pp_B; c->snap_cap_ppl[slot] = c->pp.cap_ppl; c->snap_rec[slot] = c->pp.rec_bytes;
+    return PMX_OK;
+}
+
+extern "C" int pmx_snapshot_wait(pmx_ctx* c, int slot, int* batch, int* people_cap, size_t* bytes_per_record, int* status_or)
+{
+    PMX_CHECK(c, PMX_ERR_INVALID, "null ctx");
+    PMX_CHECK((slot == 0 || slot == 1) && c->snap_ev[slot] && c->snap_B[slot] > 0, PMX_ERR_STATE, "pmx_snapshot_wait: slot %d holds no snapshot", slot);
+    PMX_DEV(c);
+    PMX_HIP(hipEventSynchronize(c->snap_ev[slot]));
+    int bits = 0;
+    for (int b = 0; b < c->snap_B[slot]; ++b) bits |= c->snap_status[slot][b];
+    if (batch) *batch = c->snap_B[slot];
+    if (people_cap) *people_cap = c->snap_cap_ppl[slot];
+    if (bytes_per_record) *bytes_per_record = c->snap_rec[slot];
+    if (status_or) *status_or = bits;
     return PMX_OK;
 }
 

@@ -120,3 +120,151 @@ def gather_device_records(engine, n_local, dst=0, group=None):
         return None
     host = big.cpu().numpy()
     return _assemble([host[r * nmax:r * nmax + sizes[r]].tobytes() for r in range(world)], counts, caps)
+
+
+# ---- pipelined gather: ONE collective per step, no per-step size exchange, no host sync in the compute path ------------------------
+# The gather above is serial: results_layout() (stream sync) -> all_gather of (count, capacity) -> gather -> D2H, all before the next
+# batch is enqueued, so every step ends in a global barrier.  RecordPipe turns the records of a rank into a BYTE STREAM that is moved
+# by one fixed-size `gather` per step (slot size agreed once, at construction):
+#
+#     slot   = [ int64 x 4: magic, valid_bytes, slot_seq, 0 ] [ valid_bytes of the rank's stream ] [ padding ]
+#     stream = frame, frame, ...;   frame = [ int64 x 6: magic, step, n_records, people_cap, bytes_per_record, payload_bytes ] [ payload ]
+#
+# In the steady state the stream holds exactly one frame per step and the frame sits in the send slot ALREADY ON THE DEVICE (the engine
+# snapshots its records straight into the slot, pmx_results_snapshot), so a step costs one D2D copy, a 80-byte header write and the
+# gather.  Shards may be uneven and capacities may differ (the frame header carries them; the root re-packs at the largest).  If a
+# rank's frame does not fit the slot (its person capacity grew beyond the agreed headroom) the frame goes through a host-side outbox and
+# crosses in several slots -- later steps queue behind it, nothing is truncated, nobody needs to be told; flush() drains what is left
+# (one all_reduce to agree how many more gathers).  The root assembles per-rank byte streams and hands out a step once every rank's
+# frame of that step is complete.
+_SLOT_MAGIC, _FRAME_MAGIC = 0x504D5853, 0x504D5846
+_SLOT_HDR, _FRAME_HDR = 32, 48
+
+
+class RecordPipe(object):
+    def __init__(self, payload_bytes, dst=0, group=None, device=None, headroom=2.0):
+        """Collective (every rank of `group` must call it): agrees the slot size = headroom x the largest `payload_bytes` (bytes of one
+        step's records of a rank at its current capacity) over the ranks.  `device`: cuda:N (RCCL) or cpu (gloo)."""
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group, self.dst = torch, dist, group, dst
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.dev = torch.device('cpu') if device is None else torch.device(device)
+        t = torch.tensor([int(payload_bytes)], dtype=torch.int64, device=self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        cap = int(t.item())
+        self.slot_bytes = (_SLOT_HDR + _FRAME_HDR + int(cap * headroom) + 255) // 256 * 256
+        self.room = self.slot_bytes - _SLOT_HDR                      # stream bytes one slot carries
+        self.slots = [torch.zeros(self.slot_bytes, dtype=torch.uint8, device=self.dev) for _ in range(2)]
+        self.work = [None, None]
+        self.recv = torch.empty(self.world * self.slot_bytes, dtype=torch.uint8, device=self.dev) if self.rank == dst else None
+        self.outbox = bytearray()                                    # host bytes waiting to cross (slow path only)
+        self.inbox = [bytearray() for _ in range(self.world)] if self.rank == dst else None
+        self.frames = {}                                             # step -> {rank: records}
+        self.seq = 0
+        self.collectives = 0
+
+    # -- sending side --------------------------------------------------------------------------------------------------------------
+    def payload_view(self, k):
+        """(device pointer or None, capacity in bytes) of the place in send slot k & 1 where a frame's payload goes: the engine snapshots
+        its records there (pmx_results_snapshot).  Waits until the gather that last used the slot has read it."""
+        s = k & 1
+        if self.work[s] is not None:
+            self.work[s].wait()
+            if self.dev.type == 'cuda':
+                self.torch.cuda.current_stream(self.dev).synchronize()
+            self.work[s] = None
+        t = self.slots[s][_SLOT_HDR + _FRAME_HDR:]
+        return (t.data_ptr() if self.dev.type == 'cuda' else None), int(t.numel())
+
+    def _frame_header(self, step, n, cap, rec_bytes, payload_bytes):
+        return np.array([_FRAME_MAGIC, step, n, cap, rec_bytes, payload_bytes], dtype=np.int64).tobytes()
+
+    def send(self, k, step, n_records, people_cap, rec_bytes, payload=None):
+        """One step of the pipe = one gather.  `payload` None: the frame's payload already sits in send slot k & 1 (payload_view);
+        else host bytes (np.uint8 / bytes) of the records.  Returns what exchange() returns."""
+        nbytes = int(n_records) * int(rec_bytes)
+        s = k & 1
+        in_place = payload is None and not self.outbox and _FRAME_HDR + nbytes <= self.room
+        if in_place:
+            head = np.frombuffer(np.array([_SLOT_MAGIC, _FRAME_HDR + nbytes, self.seq, 0], dtype=np.int64).tobytes()
+                                 + self._frame_header(step, n_records, people_cap, rec_bytes, nbytes), dtype=np.uint8)
+            self.slots[s][:_SLOT_HDR + _FRAME_HDR].copy_(self.torch.from_numpy(head.copy()))
+            return self._gather(s)
+        if payload is None:                                          # the frame is in the slot but cannot go from there: pull it to the host
+            payload = self.slots[s][_SLOT_HDR + _FRAME_HDR:_SLOT_HDR + _FRAME_HDR + nbytes].cpu().numpy().tobytes()
+        payload = bytes(memoryview(np.ascontiguousarray(payload)).cast('B')) if not isinstance(payload, (bytes, bytearray)) else bytes(payload)
+        assert len(payload) == nbytes, (len(payload), nbytes)
+        self.outbox += self._frame_header(step, n_records, people_cap, rec_bytes, nbytes) + payload
+        return self.exchange(k)
+
+    def exchange(self, k=0):
+        """Send the next (up to one slot of) outbox bytes -- an empty slot if there is nothing to send."""
+        s = k & 1
+        if self.work[s] is not None:                                 # (slow path: the slot may not have gone through payload_view)
+            self.work[s].wait()
+            if self.dev.type == 'cuda':
+                self.torch.cuda.current_stream(self.dev).synchronize()
+            self.work[s] = None
+        n = min(len(self.outbox), self.room)
+        chunk = bytes(self.outbox[:n])
+        del self.outbox[:n]
+        head = np.array([_SLOT_MAGIC, n, self.seq, 0], dtype=np.int64).tobytes()
+        buf = np.frombuffer(head + chunk, dtype=np.uint8)
+        self.slots[s][:len(buf)].copy_(self.torch.from_numpy(buf.copy()))
+        return self._gather(s)
+
+    def pending_slots(self):
+        return (len(self.outbox) + self.room - 1) // self.room
+
+    def flush(self):
+        """Collective: drain every rank's outbox (extra gathers, the same number on every rank).  Returns the steps completed meanwhile."""
+        t = self.torch.tensor([self.pending_slots()], dtype=self.torch.int64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        done = []
+        for i in range(int(t.item())):
+            done += self.exchange(i) or []
+        for s in (0, 1):
+            if self.work[s] is not None:
+                self.work[s].wait()
+                self.work[s] = None
+        return done
+
+    # -- the collective + the root's assembler ---------------------------------------------------------------------------------------
+    def _gather(self, s):
+        self.seq += 1
+        self.collectives += 1
+        outs = list(self.recv.split(self.slot_bytes)) if self.rank == self.dst else None
+        self.work[s] = self.dist.gather(self.slots[s], outs, dst=self.dst, group=self.group, async_op=True)
+        if self.rank != self.dst:
+            return None
+        self.work[s].wait()                                          # root: the slots of all ranks are in `recv` (stream-ordered) ...
+        host = self.recv.cpu().numpy()                               # ... and this copy synchronises with it
+        self.work[s] = None
+        for r in range(self.world):
+            slot = host[r * self.slot_bytes:(r + 1) * self.slot_bytes]
+            magic, valid, _, _ = np.frombuffer(slot[:_SLOT_HDR].tobytes(), dtype=np.int64)
+            assert magic == _SLOT_MAGIC and 0 <= valid <= self.room, ('corrupt slot from rank %d' % r, int(magic), int(valid))
+            self.inbox[r] += slot[_SLOT_HDR:_SLOT_HDR + int(valid)].tobytes()
+        return self._parse()
+
+    def _parse(self):
+        from . import native
+        for r in range(self.world):
+            box = self.inbox[r]
+            while len(box) >= _FRAME_HDR:
+                magic, step, n, cap, rec_bytes, nbytes = np.frombuffer(bytes(box[:_FRAME_HDR]), dtype=np.int64)
+                assert magic == _FRAME_MAGIC and nbytes == n * rec_bytes and rec_bytes == native.result_dtype(int(cap)).itemsize, \
+                    ('corrupt frame from rank %d' % r, int(magic), int(n), int(cap), int(rec_bytes), int(nbytes))
+                if len(box) < _FRAME_HDR + nbytes:
+                    break
+                rec = np.frombuffer(bytes(box[_FRAME_HDR:_FRAME_HDR + int(nbytes)]), dtype=native.result_dtype(int(cap)), count=int(n))
+                del box[:_FRAME_HDR + int(nbytes)]
+                self.frames.setdefault(int(step), {})[r] = rec
+        done = []
+        for step in sorted(self.frames):
+            if len(self.frames[step]) == self.world:
+                per_rank = self.frames.pop(step)
+                cap = max(_people_cap(per_rank[r].dtype) for r in range(self.world))
+                done.append((step, np.concatenate([_repack(per_rank[r], cap) for r in range(self.world)])))
+        return done

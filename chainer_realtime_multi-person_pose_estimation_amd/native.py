@@ -142,6 +142,8 @@ def load():
         'pmx_results_layout': (ci, [vp, ip, C.POINTER(C.c_size_t)]),
         'pmx_get_results': (ci, [vp, ci, vp, C.c_size_t]),
         'pmx_results_device_ptr': (ci, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+        'pmx_results_snapshot': (ci, [vp, ci, vp, C.c_size_t]),
+        'pmx_snapshot_wait': (ci, [vp, ci, ip, ip, C.POINTER(C.c_size_t), ip]),
         'pmx_set_capacities': (ci, [vp, ci, ci, ci, ci]),
         'pmx_get_capacities': (ci, [vp, ip, ip, ip, ip]),
         'pmx_get_peaks': (ci, [vp, ci, vp, ci, ip]),
@@ -422,6 +424,19 @@ class Engine(object):
         n = C.c_size_t()
         self._check(self.lib.pmx_results_device_ptr(self._ctx, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def results_snapshot(self, slot, dst_device_ptr, dst_bytes):
+        """Enqueue (no sync) a device-to-device copy of the last post-process's records to `dst_device_ptr` and mark it with slot's event;
+        the next detect_batch may be enqueued right away (include/pose_mi355x.h: pmx_results_snapshot)."""
+        self._check(self.lib.pmx_results_snapshot(self._ctx, int(slot), C.c_void_p(dst_device_ptr), int(dst_bytes)))
+
+    def snapshot_wait(self, slot):
+        """Block until slot's snapshot copies are done -> (batch, people_cap, bytes_per_record, overflow): `overflow` = an image needed
+        more capacity than the context had (the snapshot is not final: re-run the step through results_layout() / results())."""
+        b, cap, st, rec = C.c_int(0), C.c_int(0), C.c_int(0), C.c_size_t(0)
+        self._check(self.lib.pmx_snapshot_wait(self._ctx, int(slot), C.byref(b), C.byref(cap), C.byref(rec), C.byref(st)))
+        overflow = bool(st.value & (IMG_PEAK_OVERFLOW | IMG_CAND_OVERFLOW | IMG_SUBSET_OVERFLOW | IMG_PEOPLE_OVERFLOW))
+        return b.value, cap.value, rec.value, overflow
 
     def _rows(self, fn, image, width, guess):
         n = C.c_int(0)

@@ -34,13 +34,14 @@ def test_launcher_refuses_without_enough_gpus():
 
 @pytest.mark.gpu
 def test_two_ranks_equal_one_rank(tmp_path):
-    common = ['--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--no-profile', '--no-extras']
+    common = ['--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-profile', '--no-extras']      # (3 steps: the pipeline runs one step behind)
     f2, f1 = str(tmp_path / 'r2.npy'), str(tmp_path / 'r1.npy')
     r2 = _run(['--gpus', '2', '--backend', 'gloo', '--batch', '4', '--dump-records', f2] + common)
     assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
     line2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith('{')][-1])
     assert line2['n_gpus'] == 2 and line2['config']['global_batch'] == 8 and line2['config']['records_gathered'] == 8
     assert len(line2['per_rank_frames_per_s']) == 2 and line2['gather_ms_per_step_rank0'] >= 0
+    assert line2['collectives_per_step'] == 1.0 and 'RecordPipe' in line2['records_path']      # one gather per step, nothing else
     r1 = _run(['--gpus', '1', '--batch', '8', '--dump-records', f1] + common)
     assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-4000:]
     line1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith('{')][-1])
@@ -58,19 +59,21 @@ def test_two_ranks_equal_one_rank(tmp_path):
 
 @pytest.mark.gpu
 def test_one_rank_through_the_rccl_gather_equals_plain_run(tmp_path):
-    """`--force-gather`: N = 1 with a one-rank "nccl" (RCCL) process group, records routed through dist.gather_device_records -- the
-    branch every rank takes at N > 1 -- must give the records of the plain run, and the line must say which path and device it used."""
-    common = ['--gpus', '1', '--batch', '4', '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--no-profile', '--no-extras']
+    """`--force-gather`: N = 1 with a one-rank "nccl" (RCCL) process group, records routed through dist.RecordPipe (engine snapshot into the
+    device send slot, one RCCL gather per step, pipelined one step behind the compute) -- the branch every rank takes at N > 1 -- must give
+    the records of the plain run, and the line must say which path and device it used."""
+    common = ['--gpus', '1', '--batch', '4', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-profile', '--no-extras']
     fg, fp = str(tmp_path / 'g.npy'), str(tmp_path / 'p.npy')
     rg = _run(common + ['--force-gather', '--dump-records', fg])
     assert rg.returncode == 0, rg.stdout[-2000:] + rg.stderr[-4000:]
     lg = json.loads([l for l in rg.stdout.splitlines() if l.startswith('{')][-1])
-    assert 'rccl' in lg['backend'] and 'gather_device_records' in lg['records_path'] and lg['ranks_seen'] == [0]
+    assert 'rccl' in lg['backend'] and 'RecordPipe' in lg['records_path'] and 'RCCL gather' in lg['records_path'] and lg['ranks_seen'] == [0]
+    assert lg['collectives_per_step'] == 1.0 and 'RCCL' in lg['config']['parallelism']
     assert len(lg['devices']) == 1 and (lg['devices'][0]['uuid'] or lg['devices'][0]['pci_bus_id'])
     rp = _run(common + ['--dump-records', fp])
     assert rp.returncode == 0, rp.stdout[-2000:] + rp.stderr[-4000:]
     lp = json.loads([l for l in rp.stdout.splitlines() if l.startswith('{')][-1])
-    assert lp['backend'] is None and 'pmx_get_results' in lp['records_path']
+    assert lp['backend'] is None and 'pmx_get_results' in lp['records_path'] and 'RCCL' not in lp['config']['parallelism']
     a, b = np.load(fg), np.load(fp)
     assert a.dtype == b.dtype and a.tobytes() == b.tobytes() and int(a['n_peaks'].sum()) > 0
 

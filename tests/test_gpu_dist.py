@@ -35,6 +35,35 @@ local = eng.results()
 assert gathered.shape == local.shape, (gathered.shape, local.shape)
 assert gathered.tobytes() == local.tobytes()
 assert int(local["n_peaks"].sum()) > 0
+# the pipelined path: snapshot of step k straight into the pipe's device send slot, step k + 1 enqueued BEFORE step k is shipped; a second
+# batch makes the two steps differ, and a context shrunk to one person per record exercises the overflow answer of snapshot_wait
+pipe = D.RecordPipe(B * local.dtype.itemsize, dst=0, device=torch.device("cuda", 0))
+imgs2 = np.ascontiguousarray(imgs[::-1])
+# (the engine has ONE record array: the snapshots are what keeps step k while step k + 1 runs)
+got = []
+for k, im in enumerate((imgs, imgs2, imgs)):
+    eng.detect_batch(im, 96, 128)
+    ptr, room = pipe.payload_view(k)
+    eng.results_snapshot(k & 1, ptr, room)
+    if k:
+        n, cap, rb, ov = eng.snapshot_wait((k - 1) & 1)
+        assert not ov
+        got += pipe.send(k - 1, k - 1, n, cap, rb)
+n, cap, rb, ov = eng.snapshot_wait(2 & 1)
+got += pipe.send(2, 2, n, cap, rb)
+got += pipe.flush()
+assert [s for s, _ in got] == [0, 1, 2] and pipe.collectives == 3
+eng.detect_batch(imgs2, 96, 128); local2 = eng.results()
+assert got[0][1].tobytes() == local.tobytes() and got[2][1].tobytes() == local.tobytes() and got[1][1].tobytes() == local2.tobytes()
+assert local2.tobytes() != local.tobytes()
+if int(local["n_people"].max()) > 1:
+    eng.set_capacities(people=1)
+    eng.detect_batch(imgs, 96, 128)
+    stage = torch.empty(B * native.result_dtype(1).itemsize, dtype=torch.uint8, device="cuda")
+    eng.results_snapshot(0, stage.data_ptr(), stage.numel())
+    assert eng.snapshot_wait(0)[3] is True          # not final: an image has more people than the record holds ...
+    grown = eng.results()                           # ... and the growing path delivers them
+    assert D._people_cap(grown.dtype) >= int(local["n_people"].max()) and np.array_equal(grown["n_people"], local["n_people"])
 dist.barrier(); dist.destroy_process_group()
 print("RCCL_GATHER_OK")
 '''
