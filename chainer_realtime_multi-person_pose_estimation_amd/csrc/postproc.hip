@@ -186,6 +186,7 @@ __global__ __launch_bounds__(256) void pp_peaks_fast_kernel(PPMaps maps, PPTable
     constexpr int PW = 56;                       // low-resolution patch staged in LDS (rows x cols), covers in == out
     __shared__ float sP[PW * PW];
     __shared__ int sBox[4];                      // patch origin (row, col) and extent
+    __shared__ float sPmax[4];                   // per-wave maximum of the patch (threshold pruning)
 
     const int tid = threadIdx.x;
     const int ch = blockIdx.y, b = blockIdx.z;
@@ -220,11 +221,29 @@ __global__ __launch_bounds__(256) void pp_peaks_fast_kernel(PPMaps maps, PPTable
     const int py0 = sBox[0], px0 = sBox[1], ph = sBox[2], pw = sBox[3];
     const bool patched = ph <= PW && pw <= PW;       // block-uniform
     if (patched) {
+        float pmax = -3.0e38f;
         for (int i = tid; i < ph * pw; i += 256) {
             const int r = i / pw, c = i - r * pw;
-            sP[r * PW + c] = base[(long long)(py0 + r) * maps.sy + (long long)(px0 + c) * maps.sx];
+            const float v = base[(long long)(py0 + r) * maps.sy + (long long)(px0 + c) * maps.sx];
+            sP[r * PW + c] = v;
+            pmax = fmaxf(pmax, v);
+        }
+        // Threshold pruning.  Every smoothed value of this tile is a convex combination (bilinear weights, then Gaussian taps: all
+        // non-negative, each set summing to 1 up to rounding) of the low-resolution pixels of the patch, so it cannot exceed their maximum
+        // by more than rounding noise; a peak needs smoothed > 0.05 (pose_detector.py:97).  If the patch maximum is below the threshold
+        // with a 1e-5 relative safety margin (the rounded weight sums exceed 1 by < 1e-6), no pixel of the tile can be a peak: skip the
+        // two float64 passes and the NMS.  Results are unchanged by construction (real heat maps are ~0 away from the joints: most
+        // tiles take this exit).  Not taken when the smoothed map itself is wanted (keep_smoothed, key-point nets).
+        if (do_nms && !keep_smoothed) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, off));
+            if ((tid & 63) == 0) sPmax[tid >> 6] = pmax;
         }
         __syncthreads();
+        if (do_nms && !keep_smoothed) {
+            const float m = fmaxf(fmaxf(sPmax[0], sPmax[1]), fmaxf(sPmax[2], sPmax[3]));
+            if (m * 1.00001f < PMX_HEATMAP_PEAK_THRESH && m < PMX_HEATMAP_PEAK_THRESH) return;      // block-uniform
+        }
     }
     for (int i = tid; i < UW * UW; i += 256) {
         const int ur = i / UW, uc = i - ur * UW;

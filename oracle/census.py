@@ -126,6 +126,45 @@ def compare_frame(gpu_peaks, cpu_peaks, cpu_smoothed, gpu_smoothed_of, gpu_poses
     return out
 
 
+def candidate_margin(paf_xy, a_xy, b_xy, img_len):
+    """Decision margin of one candidate connection (reference pose_detector.py:135-156, restated as in
+    postprocess_ref.compute_candidate_connections): accepted  <=>  count(ip > 0.05) > 8  and  integ + prior > 0, i.e.
+    min(second-smallest ip - 0.05, score) > 0.  Returns (margin, score, which test is the binding one)."""
+    vx, vy = b_xy[0] - a_xy[0], b_xy[1] - a_xy[1]
+    norm = np.sqrt(vx * vx + vy * vy)
+    if norm == 0:
+        return None, None, 'zero length'
+    ys = np.linspace(a_xy[1], b_xy[1], num=P.N_INTEG_POINTS).round().astype('i')
+    xs = np.linspace(a_xy[0], b_xy[0], num=P.N_INTEG_POINTS).round().astype('i')
+    ip = paf_xy[0][ys, xs].astype(np.float64) * (vx / norm) + paf_xy[1][ys, xs].astype(np.float64) * (vy / norm)
+    score = P._np_sum10(ip) / len(ip) + min(P.LIMB_LENGTH_RATIO * img_len / norm - P.LENGTH_PENALTY_VALUE, 0)
+    need = P.N_INTEG_POINTS - P.N_INTEG_POINTS_THRESH               # at most 1 of the 10 samples may fail
+    m_count = float(np.sort(ip)[need - 1] - P.INNER_PRODUCT_THRESH)   # the 9th largest sample must exceed the threshold
+    return (min(m_count, float(score)), float(score), 'n_valid count' if m_count < score else 'score > 0')
+
+
+def compare_connections(gpu_conns, cpu_conns, peaks, gpu_paf_lo, cpu_paf_lo, map_h, map_w, img_len):
+    """For a frame whose peak sets agree: every connection only one side accepted, with the margin of its acceptance test
+    (candidate_margin) on both sides' PAF maps.  gpu_conns / cpu_conns: rows (limb, id_a, id_b, score); *_paf_lo: (38, h, w)
+    network outputs (the full-resolution PAF of either side is F.resize_images of it, restated bit-exactly)."""
+    g = {(int(r[0]), int(r[1]), int(r[2])): float(r[3]) for r in np.asarray(gpu_conns, dtype=np.float64).reshape(-1, 4)}
+    c = {(int(r[0]), int(r[1]), int(r[2])): float(r[3]) for r in np.asarray(cpu_conns, dtype=np.float64).reshape(-1, 4)}
+    out = []
+    if set(g) == set(c):
+        return out
+    gp, cp = P.resize_images_ref(gpu_paf_lo, map_h, map_w), P.resize_images_ref(cpu_paf_lo, map_h, map_w)
+    pk = np.asarray(peaks, dtype=np.float64).reshape(-1, 5)
+    for (l, ia, ib) in sorted(set(g) ^ set(c)):
+        a_xy, b_xy = pk[ia, 1:3], pk[ib, 1:3]
+        mg, sg, tg = candidate_margin(gp[[2 * l, 2 * l + 1]], a_xy, b_xy, img_len)
+        mc, sc_, tc = candidate_margin(cp[[2 * l, 2 * l + 1]], a_xy, b_xy, img_len)
+        out.append({'limb': l, 'id_a': ia, 'id_b': ib, 'side': 'gpu_only' if (l, ia, ib) in g else 'cpu_only',
+                    'margin_gpu': mg, 'margin_cpu': mc, 'score_gpu': sg, 'score_cpu': sc_, 'binding_test': tg if (mg is not None and abs(mg) <= abs(mc)) else tc,
+                    'max_abs_diff_paf_full_res': float(np.abs(gp[[2 * l, 2 * l + 1]].astype(np.float64) - cp[[2 * l, 2 * l + 1]]).max()),
+                    'acceptance_flipped': bool(mg is not None and (mg > 0) != (mc > 0))})
+    return out
+
+
 def summarize(frames, label):
     """Census object over a list of compare_frame() results."""
     mism = [m for f in frames for m in f['mismatches']]
@@ -152,5 +191,8 @@ def summarize(frames, label):
         'max_abs_score_diff_matched_people': max((f['max_abs_score_diff_matched_people'] for f in frames), default=0.0),
         'max_abs_diff_smoothed_on_mismatching_frames': max((m['frame_max_abs_diff_smoothed'] for m in mism), default=None),
     }
+    cd = [dict(c_, frame=f.get('frame')) for f in frames for c_ in f.get('connection_mismatches', [])]
+    s['connection_mismatches_on_frames_with_identical_peaks'] = cd
+    s['max_margin_of_a_connection_mismatch'] = max((max(abs(c_['margin_gpu']), abs(c_['margin_cpu'])) for c_ in cd if c_['acceptance_flipped']), default=0.0)
     s['all_mismatches_are_near_ties'] = bool(all(m['margin_sum'] <= 2.0 * m['local_abs_diff_smoothed'] * (1 + 1e-9) + 1e-30 for m in mism))
     return s
