@@ -97,6 +97,8 @@ def parse():
                     "for the single-GPU multi-rank smoke test, where all ranks share device 0)")
     ap.add_argument('--dump-records', default=None, help='rank 0 writes the gathered result records of the last step (.npy)')
     ap.add_argument('--no-extras', action='store_true', help='skip the single-image and upload-inclusive measurements')
+    ap.add_argument('--engine-opt', action='append', default=[], metavar='KEY=VALUE', help='pmx_set_option on the engine before the run (A/B '
+                    'switches such as wino_xcd_groups=0); repeatable; recorded in config.engine_options')
     ap.add_argument('--force-gather', action='store_true', help='N = 1: still create a one-rank process group and route the records '
                     'through the RCCL gather (dist.gather_device_records), the code path of N > 1')
     return ap.parse_args()
@@ -284,6 +286,9 @@ def main():
     paf, heat = eng.get_maps()
     weights = weights_mod.calibrate_head(weights, paf[0], heat[0])
     eng.set_weights({k: weights[k] for k in ('Mconv7_stage6_L1', 'Mconv7_stage6_L2')})
+    for kv in a.engine_opt:
+        k_, v_ = kv.split('=')
+        eng.set_option(k_, int(v_))
 
     # the global batch (B * world images, one seeded stream) is sharded contiguously: rank r owns images [r*B, (r+1)*B),
     # so a 2-rank run of --batch 4 sees exactly the images of a 1-rank run of --batch 8
@@ -426,7 +431,7 @@ def main():
                        'records_gathered': int(len(rec)),
                        'people_per_frame_mean': float(np.mean(rec['n_people'])) if len(rec) else 0.0,
                        'peaks_per_frame_mean': float(np.mean(rec['n_peaks'])) if len(rec) else 0.0,
-                       'status_bits': status_bits},
+                       'status_bits': status_bits, 'engine_options': a.engine_opt or None},
             'achieved_tflops_whole_net': FLOP_PER_FRAME * (S * S / (368.0 * 368.0)) * frames / dt / 1e12,
         }
         if use_group:
