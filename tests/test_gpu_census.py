@@ -31,3 +31,22 @@ def test_census_64_frames_default_path_and_bf16x3(native):
     f32 = out['paths']['f32_default_batch_path']
     # healthy fixture => identical: a frame without any near-tie pixel (all margins above the two networks' difference) must match exactly
     assert f32['mismatching_peaks'] == 0 or f32['max_margin_of_a_mismatch'] < 1e-5
+
+
+def test_config5_precise_482x642_native_network_vs_precise_ref(native):
+    """BASELINE config 5 on the NATIVE network (not only through the `model=` seam): PoseDetector(precise=True) on a 482 x 642 frame
+    (four scales up to 736 x 984, cubic resizes and accumulation on the device, post-process at the original resolution: ~800 peaks,
+    ~30 people) against oracle/precise_ref driving the torch-CPU network restatement -- averaged maps within 2e-5 of the map scale, every
+    peak both sides found within 1e-4, every disagreement (if any) a near-tie, every person both sides found within 1e-4."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import importlib
+    out = bench.precise_mode(importlib.import_module(bench.PKG + '.weights'), 0, with_oracle=True)
+    m = out['keypoint_match_vs_precise_ref']
+    print('\n[precise 482x642] %.1f ms per image; %d peaks, %d people; vs precise_ref: %s' % (out['ms_per_image'], out['peaks'], out['people'], json.dumps(m)))
+    assert 'error' not in m and 'oracle_raised' not in m, m
+    assert out['peaks'] >= 300 and out['people'] >= 10
+    assert m['max_abs_diff_averaged_maps_over_scale'] <= 2e-5
+    assert m['all_mismatches_are_near_ties'] and m['max_margin_of_a_mismatch'] <= 1e-5
+    assert m['max_abs_peak_score_diff'] <= 1e-4 and m['max_abs_score_diff_matched_people'] <= 1e-4
+    assert m['matched_people'] >= 0.9 * m['people_cpu']

@@ -29,6 +29,18 @@ shutil.copy(os.path.join(G, 'rp_stats', 'drv_kernel_stats.csv'), os.path.join(P,
 if os.path.exists(os.path.join(G, 'rp_bench', 'bench_kernel_stats.csv')):      # rocprofv3 --kernel-trace --stats -- python bench.py
     shutil.copy(os.path.join(G, 'rp_bench', 'bench_kernel_stats.csv'), os.path.join(P, rnd + '_bench_kernel_stats.csv'))
 
+for sub, stem, dst in (('rp_b1', 'b1', '_b1_kernel_stats.csv'), ('rp_rect', 'rect', '_rect_368x496_kernel_stats.csv'), ('rp_precise', 'precise', '_precise_kernel_stats.csv')):
+    f = os.path.join(G, sub, stem + '_kernel_stats.csv')
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(P, rnd + dst))
+if os.path.exists(os.path.join(G, 'parity_census.json')):
+    shutil.copy(os.path.join(G, 'parity_census.json'), os.path.join(P, rnd + '_parity_census.json'))
+fg = os.path.join(G, 'bench_force_gather.log')
+if os.path.exists(fg):
+    lines = [l for l in open(fg) if l.startswith('{')]
+    if lines:
+        json.dump(json.loads(lines[-1]), open(os.path.join(P, rnd + '_bench_force_gather.json'), 'w'), indent=1)
+
 summary = {'source': 'rocprofv3 --pmc <counters> --kernel-trace -- python tools/profile_driver.py --batch 32 --steps 1 '
                      '(one pass per counter group); rocprofv3 --kernel-trace --stats for durations',
            'units': {'FETCH_SIZE': 'KiB (uncorrected)', 'WRITE_SIZE': 'KiB', 'SQ_*': 'summed over the chip',
@@ -98,7 +110,7 @@ if os.path.exists(bj) and os.path.exists(ks):
                'frac_from_rocprofv3': roof['issued_flop_per_launch'] / (avg_ns * 1e-9) / 1e12 / peak, 'frac_in_bench_line': roof['frac'],
                'algorithmic_frac_from_rocprofv3': roof['flop_per_launch'] / (avg_ns * 1e-9) / 1e12 / peak,
                'algorithmic_frac_in_bench_line': roof.get('algorithmic_frac'),
-               'note': 'rocprofv3 --kernel-trace --stats of `python bench.py` (all its phases: the timed steps, the extras, the batch-1 calls share the '
-                       'kernel name; launches of other batch sizes pull the average down slightly)'}
+               'note': 'rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras (warm-up, timed and the one '
+                       'fully instrumented step; the calibration forward at batch 1 uses other kernels)'}
         json.dump(chk, open(os.path.join(P, rnd + '_roofline_check.json'), 'w'), indent=1)
         print('roofline check', json.dumps(chk))

@@ -136,10 +136,40 @@ def main():
         h = ref
         if name in pool_after:
             h = F.max_pool2d(h, 2, 2)
+    # a 7x7 layer built from F(4x4, 3x3) sub-kernels: taps (0..5, 0..5) as four 3x3 sub-kernels through the prototype (each rounded on its
+    # own and summed -- an upper bound of accumulating them in the transform domain), row 6 / column 6 / tap (6, 6) by the direct chain
+    rng = np.random.default_rng(0)
+    cin, cout, Hs = 128, 128, 46
+    x7 = np.maximum(rng.standard_normal((1, cin, Hs, Hs)), 0).astype('f')
+    w7 = (rng.standard_normal((cout, cin, 7, 7)) / np.sqrt(cin * 49)).astype('f')
+    b7 = np.zeros(cout, 'f')
+    with torch.no_grad():
+        ref7 = F.conv2d(torch.from_numpy(x7).double(), torch.from_numpy(w7).double(), padding=3).numpy()[0]
+    sc7 = float(np.abs(ref7).max())
+    AT, G, BT = variants['F4_lavin_0_1_-1_2_-2']
+    xp = np.zeros((cin, Hs + 6, Hs + 6), np.float32)
+    xp[:, 3:3 + Hs, 3:3 + Hs] = x7[0]
+    acc = np.zeros((cout, Hs, Hs), np.float32)
+    for sy in (0, 3):
+        for sx in (0, 3):
+            sub = np.ascontiguousarray(xp[:, sy:sy + Hs + 2, sx:sx + Hs + 2])[None]
+            yy = proto(sub, np.ascontiguousarray(w7[:, :, sy:sy + 3, sx:sx + 3]), b7, AT, G, BT, 4)[0][:, 1:1 + Hs, 1:1 + Hs]
+            # (proto applies ReLU; undo is impossible -- run it on the negated input too and combine: relu(v) - relu(-v) = v)
+            yn = proto(-sub, np.ascontiguousarray(w7[:, :, sy:sy + 3, sx:sx + 3]), b7, AT, G, BT, 4)[0][:, 1:1 + Hs, 1:1 + Hs]
+            acc = acc + (yy - yn)
+    wr = np.zeros_like(w7)
+    wr[:, :, 6, :] = w7[:, :, 6, :]
+    wr[:, :, :, 6] = w7[:, :, :, 6]
+    tot = acc + R.conv_fma(x7, wr, b7)[0]
+    seven = {'shape': '128 -> 128, 46 x 46, dense post-ReLU Gaussian input', 'direct': float(np.abs(R.conv_fma(x7, w7, b7)[0] - ref7).max() / sc7),
+             'F2_kernel_twin': float(np.abs(R.conv_wino(x7, w7, b7)[0] - ref7).max() / sc7), 'F4_composed': float(np.abs(tot - ref7).max() / sc7)}
+    seven['F4_over_direct'] = seven['F4_composed'] / seven['direct']
+    print('7x7 128->128: direct %.2e  F(2x2) twin %.2e  F(4x4)-composed %.2e  (%.1f x direct)' % (seven['direct'], seven['F2_kernel_twin'], seven['F4_composed'], seven['F4_over_direct']))
     worst = max(r_['best_F4_over_direct'] for r_ in rows)
     out = {'input': '%dx%d synthetic frame, seeded He weights; every layer sees its real (float64-propagated, float32-rounded) input' % (a.size, a.size),
            'metric': 'max |y - y_float64| / max |y_float64| per layer (ReLU applied)', 'rows': rows,
-           'go_rule': 'per-layer error of F(4x4, 3x3) <= 2 x the direct fp32 chain', 'worst_best_F4_over_direct': worst, 'go': bool(worst <= 2.0)}
+           'go_rule': 'per-layer error of F(4x4, 3x3) <= 2 x the direct fp32 chain', 'worst_best_F4_over_direct': worst, 'go': bool(worst <= 2.0),
+           'seven_by_seven_from_F4_sub_kernels': seven}
     json.dump(out, open(a.out, 'w'), indent=1)
     print('worst (best F(4x4) variant) / direct over the layers: %.1f  ->  %s' % (worst, 'GO' if out['go'] else 'NO-GO'))
 
