@@ -788,6 +788,21 @@ def precise_mode(weights_mod, device_index, with_oracle=True, shape=(482, 642)):
                                           'algorithmic_frac': total_flop / (total_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
         if with_oracle:
             out['keypoint_match_vs_precise_ref'] = precise_match(det, img, wts, poses, scores)
+        # the same path for a batch of same-size frames: every scale runs the n images as one batch (PoseDetector.detect_precise_batch)
+        nb = 8
+        batch = [img] + [np.random.default_rng(56 + i).integers(0, 256, (H, W, 3), dtype=np.uint8) for i in range(nb - 1)]
+        try:
+            res_b = det.detect_precise_batch(batch)             # (grows the context to batch 8; first call pays the allocation)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                det.detect_precise_batch(batch)
+            ms_b = (time.perf_counter() - t0) / 3 / nb * 1e3
+            same = bool(len(res_b[0][0]) == len(poses) and np.array_equal(np.asarray(res_b[0][0]), np.asarray(poses)))
+            out['batch8'] = {'ms_per_image': ms_b, 'images_per_s': 1e3 / ms_b, 'algorithmic_tflops': flop / (ms_b * 1e-3) / 1e12,
+                             'speedup_vs_one_image_per_call': ms / ms_b, 'first_image_same_poses_as_single_call': same,
+                             'people_per_image': [int(len(r_[0])) for r_ in res_b]}
+        except IndexError as e:
+            out['batch8'] = {'raised': repr(e)}
         return out
     finally:
         det.engine.close()

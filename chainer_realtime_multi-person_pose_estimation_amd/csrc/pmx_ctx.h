@@ -40,7 +40,7 @@ struct pmx_ctx {
     int cat_c = PMX_CAT_C;           // channels of the cat buffer (192 | 208 | 160)
     int cat_heat = PMX_CAT_HEAT;     // first heat-map channel in the cat buffer (168 | 128 | 128)
     // detect_precise accumulation state (pmx_precise_*)
-    int pr_h = 0, pr_w = 0, pr_scales = 0;
+    int pr_h = 0, pr_w = 0, pr_scales = 0, pr_n = 0;      // original size, scales accumulated so far, images of the batch
     float* pr_tmp = nullptr; size_t pr_tmp_cap = 0;      // x8 up-sampled maps of one scale, NHWC-57
     void* pr_tab = nullptr; size_t pr_tab_cap = 0;       // cubic tables of the current resize
     double* d_kp = nullptr;          // key-point records of pmx_keypoints

@@ -68,107 +68,130 @@ static int upload_cubic_tables(pmx_ctx* c, int sh, int sw, int dh, int dw, bool 
     return PMX_OK;
 }
 
-// detect_precise (pose_detector.py:433-470) accumulated on the device.  begin: zero the per-channel sums at the original size.
-extern "C" int pmx_precise_begin(pmx_ctx* c, int orig_h, int orig_w)
+// detect_precise (pose_detector.py:433-470) accumulated on the device, for a batch of n images of ONE original size (the reference
+// handles one image per call; n = 1 is that call).  Every scale runs the n images as one batch through the network -- a 184 x 248 input of
+// a single image is 23 x 31 maps, far too little for 256 CUs, eight of them are not -- and the (tiny, shared) resize tables are uploaded
+// once per step instead of once per image.  begin: zero the per-channel sums at the original size.
+extern "C" int pmx_precise_begin_batch(pmx_ctx* c, int n_images, int orig_h, int orig_w)
 {
     PMX_CHECK(c && c->kind == NET_POSE, PMX_ERR_INVALID, "pmx_precise_begin: posenet context required");
     PMX_CHECK(orig_h >= 1 && orig_w >= 1, PMX_ERR_INVALID, "pmx_precise_begin: bad size");
+    PMX_CHECK(n_images >= 1 && n_images <= c->max_batch, PMX_ERR_CAPACITY, "pmx_precise_begin: %d images outside 1..%d (the context's batch capacity)",
+              n_images, c->max_batch);
     PMX_DEV(c);
-    const size_t need = (size_t)orig_h * orig_w;
+    const size_t need = (size_t)n_images * orig_h * orig_w;
     if (need > c->ext_cap) {
         PMX_HIP(hipStreamSynchronize(c->stream));
         if (c->ext_paf) (void)hipFree(c->ext_paf);
         if (c->ext_heat) (void)hipFree(c->ext_heat);
-        c->ext_paf = c->ext_heat = nullptr;
+        c->ext_paf = c->ext_heat = nullptr; c->ext_cap = 0;
         PMX_HIP(hipMalloc((void**)&c->ext_paf, need * PMX_N_PAF * 4));
         PMX_HIP(hipMalloc((void**)&c->ext_heat, need * PMX_N_HEAT * 4));
         c->ext_cap = need;
     }
     PMX_HIP(hipMemsetAsync(c->ext_paf, 0, need * PMX_N_PAF * 4, c->stream));
     PMX_HIP(hipMemsetAsync(c->ext_heat, 0, need * PMX_N_HEAT * 4, c->stream));
-    c->pr_h = orig_h; c->pr_w = orig_w; c->pr_scales = 0;
+    c->pr_h = orig_h; c->pr_w = orig_w; c->pr_scales = 0; c->pr_n = n_images;
     c->maps_valid = false;
     return PMX_OK;
 }
+extern "C" int pmx_precise_begin(pmx_ctx* c, int orig_h, int orig_w) { return pmx_precise_begin_batch(c, 1, orig_h, orig_w); }
 
-// one scale of the loop at :441-467: cubic resize of the uint8 image to (scaled_h, scaled_w) (:443), pad to a multiple of 8
-// with (104, 117, 123) (:445), forward (:451), x8 cubic up-sampling of both outputs (:461,465), crop of the padding
-// (:462,466), cubic resize to the original size and accumulation (:463,467).  `img`: host uint8 orig_h x orig_w x 3.
-extern "C" int pmx_precise_add_scale(pmx_ctx* c, const uint8_t* img, int scaled_h, int scaled_w)
+// one scale of the loop at :441-467 for every image of the batch: cubic resize of the uint8 image to (scaled_h, scaled_w) (:443), pad to a
+// multiple of 8 with (104, 117, 123) (:445), forward (:451), x8 cubic up-sampling of both outputs (:461,465), crop of the padding
+// (:462,466), cubic resize to the original size and accumulation (:463,467).  `imgs`: host uint8, n x orig_h x orig_w x 3, contiguous.
+extern "C" int pmx_precise_add_scale_batch(pmx_ctx* c, const uint8_t* imgs, int scaled_h, int scaled_w)
 {
-    PMX_CHECK(c && img && c->pr_h > 0, PMX_ERR_STATE, "pmx_precise_add_scale: call pmx_precise_begin first");
+    PMX_CHECK(c && imgs && c->pr_h > 0 && c->pr_n > 0, PMX_ERR_STATE, "pmx_precise_add_scale: call pmx_precise_begin first");
     PMX_CHECK(scaled_h >= 1 && scaled_w >= 1, PMX_ERR_INVALID, "bad size");
     PMX_DEV(c);
-    const int oh = c->pr_h, ow = c->pr_w;
+    const int oh = c->pr_h, ow = c->pr_w, n = c->pr_n;
     const int ph = round_up(scaled_h, 8), pw = round_up(scaled_w, 8);
-    PMX_CHECK((size_t)ph * pw <= (size_t)c->max_h * c->max_w && c->max_batch >= 1, PMX_ERR_CAPACITY,
-              "pmx_precise_add_scale: padded size %d x %d exceeds the context capacity %d x %d", ph, pw, c->max_h, c->max_w);
+    PMX_CHECK((size_t)ph * pw <= (size_t)c->max_h * c->max_w && c->max_batch >= n, PMX_ERR_CAPACITY,
+              "pmx_precise_add_scale: %d x padded size %d x %d exceeds the context capacity %d x %d x %d", n, ph, pw, c->max_batch, c->max_h, c->max_w);
     int missing = 0;
     for (auto& l : c->layers) missing += l.set ? 0 : 1;
     PMX_CHECK(missing == 0, PMX_ERR_WEIGHTS, "pmx_precise_add_scale: %d layers have no weights", missing);
     int rc;
-    // original image -> device
-    const size_t nsrc = (size_t)oh * ow * 3;
+    // original images -> device
+    const size_t img_bytes = (size_t)oh * ow * 3, nsrc = img_bytes * n;
     if (nsrc > c->u8_src_cap) {
         PMX_HIP(hipStreamSynchronize(c->stream));
         if (c->u8_src) (void)hipFree(c->u8_src);
-        c->u8_src = nullptr;
+        c->u8_src = nullptr; c->u8_src_cap = 0;
         PMX_HIP(hipMalloc((void**)&c->u8_src, nsrc));
         c->u8_src_cap = nsrc;
     }
-    PMX_HIP(hipMemcpyAsync(c->u8_src, img, nsrc, hipMemcpyHostToDevice, c->stream));
+    PMX_HIP(hipMemcpyAsync(c->u8_src, imgs, nsrc, hipMemcpyHostToDevice, c->stream));
     int *xi, *yi; void *xc, *yc;
-    // (1) uint8 cubic resize into the padded image
-    if ((rc = launch_fill_bgr(c->u8_tmp, (long long)ph * pw, 104, 117, 123, c->stream))) return rc;
+    // (1) uint8 cubic resize into the padded images
+    const size_t pad_bytes = (size_t)ph * pw * 3;
+    if ((rc = launch_fill_bgr(c->u8_tmp, (long long)n * ph * pw, 104, 117, 123, c->stream))) return rc;
     if (scaled_h == oh && scaled_w == ow) {
-        PMX_HIP(hipMemcpy2DAsync(c->u8_tmp, (size_t)pw * 3, c->u8_src, (size_t)ow * 3, (size_t)ow * 3, oh, hipMemcpyDeviceToDevice, c->stream));
+        for (int b = 0; b < n; ++b)
+            PMX_HIP(hipMemcpy2DAsync(c->u8_tmp + b * pad_bytes, (size_t)pw * 3, c->u8_src + b * img_bytes, (size_t)ow * 3, (size_t)ow * 3, oh,
+                                     hipMemcpyDeviceToDevice, c->stream));
     } else {
         if ((rc = upload_cubic_tables(c, oh, ow, scaled_h, scaled_w, true, &xi, &xc, &yi, &yc))) return rc;
-        if ((rc = launch_resize_cubic_u8(c->u8_src, ow, c->u8_tmp, scaled_h, scaled_w, pw, xi, (const int*)xc, yi, (const int*)yc, c->stream))) return rc;
+        for (int b = 0; b < n; ++b)
+            if ((rc = launch_resize_cubic_u8(c->u8_src + b * img_bytes, ow, c->u8_tmp + b * pad_bytes, scaled_h, scaled_w, pw, xi, (const int*)xc, yi,
+                                             (const int*)yc, c->stream))) return rc;
     }
-    // (2) network
-    if ((rc = launch_prep_u8(c->u8_tmp, c->in16, 1, ph, pw, 255.0f, c->stream))) return rc;
-    if ((rc = pmx_forward_from_in16(c, 1, ph, pw))) return rc;
+    // (2) network, the n images as one batch
+    if ((rc = launch_prep_u8(c->u8_tmp, c->in16, n, ph, pw, 255.0f, c->stream))) return rc;
+    if ((rc = pmx_forward_from_in16(c, n, ph, pw))) return rc;
     const int fh = ph / 8, fw = pw / 8;
-    // (3) x8 cubic up-sampling of PAF (38) and heat (19) channels into NHWC-57
-    const size_t ntmp = (size_t)ph * pw * 57;
+    // (3) x8 cubic up-sampling of PAF (38) and heat (19) channels, image by image, into dense NHWC temporaries
+    const size_t per_img = (size_t)ph * pw * 57, ntmp = per_img * n;
     if (ntmp > c->pr_tmp_cap) {
         PMX_HIP(hipStreamSynchronize(c->stream));
         if (c->pr_tmp) (void)hipFree(c->pr_tmp);
-        c->pr_tmp = nullptr;
+        c->pr_tmp = nullptr; c->pr_tmp_cap = 0;
         PMX_HIP(hipMalloc((void**)&c->pr_tmp, ntmp * sizeof(float)));
         c->pr_tmp_cap = ntmp;
     }
     if ((rc = upload_cubic_tables(c, fh, fw, ph, pw, false, &xi, &xc, &yi, &yc))) return rc;
-    const long long sy = (long long)fw * PMX_CAT_C, sx = PMX_CAT_C;
-    // PAF and heat are separate arrays in the reference (two cv2.resize calls); here two launches into one NHWC-57 buffer
-    // would need a strided destination, so each map set gets its own dense NHWC temp region: [ph*pw*38 | ph*pw*19]
-    float* t_paf = c->pr_tmp;
-    float* t_heat = c->pr_tmp + (size_t)ph * pw * PMX_N_PAF;
-    if ((rc = launch_resize_cubic_f32(c->cat + PMX_CAT_PAF, sy, sx, 1, PMX_N_PAF, t_paf, ph, pw, xi, (const float*)xc, yi, (const float*)yc, 0, 0, c->stream))) return rc;
-    if ((rc = launch_resize_cubic_f32(c->cat + PMX_CAT_HEAT, sy, sx, 1, PMX_N_HEAT, t_heat, ph, pw, xi, (const float*)xc, yi, (const float*)yc, 0, 0, c->stream))) return rc;
+    const long long sy = (long long)fw * PMX_CAT_C, sx = PMX_CAT_C, sb = (long long)fh * fw * PMX_CAT_C;
+    // PAF and heat are separate arrays in the reference (two cv2.resize calls); each map set of each image gets its own dense NHWC region:
+    // image b: [ph*pw*38 | ph*pw*19]
+    for (int b = 0; b < n; ++b) {
+        float* t_paf = c->pr_tmp + b * per_img;
+        float* t_heat = t_paf + (size_t)ph * pw * PMX_N_PAF;
+        if ((rc = launch_resize_cubic_f32(c->cat + b * sb + PMX_CAT_PAF, sy, sx, 1, PMX_N_PAF, t_paf, ph, pw, xi, (const float*)xc, yi, (const float*)yc, 0, 0, c->stream))) return rc;
+        if ((rc = launch_resize_cubic_f32(c->cat + b * sb + PMX_CAT_HEAT, sy, sx, 1, PMX_N_HEAT, t_heat, ph, pw, xi, (const float*)xc, yi, (const float*)yc, 0, 0, c->stream))) return rc;
+    }
     // (4) crop the padding (source extent scaled_h x scaled_w of the padded maps) and cubic resize to the original size, accumulating
     if ((rc = upload_cubic_tables(c, scaled_h, scaled_w, oh, ow, false, &xi, &xc, &yi, &yc))) return rc;
-    if ((rc = launch_resize_cubic_f32(t_paf, (long long)pw * PMX_N_PAF, PMX_N_PAF, 1, PMX_N_PAF, c->ext_paf, oh, ow, xi, (const float*)xc, yi,
-                                      (const float*)yc, 1, 0, c->stream))) return rc;
-    if ((rc = launch_resize_cubic_f32(t_heat, (long long)pw * PMX_N_HEAT, PMX_N_HEAT, 1, PMX_N_HEAT, c->ext_heat, oh, ow, xi, (const float*)xc, yi,
-                                      (const float*)yc, 1, 0, c->stream))) return rc;
+    const size_t opx = (size_t)oh * ow;
+    for (int b = 0; b < n; ++b) {
+        float* t_paf = c->pr_tmp + b * per_img;
+        float* t_heat = t_paf + (size_t)ph * pw * PMX_N_PAF;
+        if ((rc = launch_resize_cubic_f32(t_paf, (long long)pw * PMX_N_PAF, PMX_N_PAF, 1, PMX_N_PAF, c->ext_paf + b * opx * PMX_N_PAF, oh, ow, xi, (const float*)xc, yi,
+                                          (const float*)yc, 1, 0, c->stream))) return rc;
+        if ((rc = launch_resize_cubic_f32(t_heat, (long long)pw * PMX_N_HEAT, PMX_N_HEAT, 1, PMX_N_HEAT, c->ext_heat + b * opx * PMX_N_HEAT, oh, ow, xi, (const float*)xc, yi,
+                                          (const float*)yc, 1, 0, c->stream))) return rc;
+    }
     c->pr_scales += 1;
     c->maps_valid = false;       // the cat buffer holds one scale only; the averaged maps become valid in pmx_precise_finish
     return PMX_OK;
 }
+extern "C" int pmx_precise_add_scale(pmx_ctx* c, const uint8_t* img, int scaled_h, int scaled_w)
+{
+    PMX_CHECK(c && c->pr_n == 1, PMX_ERR_STATE, "pmx_precise_add_scale: the batch was begun with %d images (use pmx_precise_add_scale_batch)", c ? c->pr_n : 0);
+    return pmx_precise_add_scale_batch(c, img, scaled_h, scaled_w);
+}
 
-// :469-470: divide the sums by the number of scales and install them as the maps of a batch of one at the original size
+// :469-470: divide the sums by the number of scales and install them as the maps of a batch of n at the original size
 extern "C" int pmx_precise_finish(pmx_ctx* c)
 {
-    PMX_CHECK(c && c->pr_h > 0 && c->pr_scales > 0, PMX_ERR_STATE, "pmx_precise_finish: nothing accumulated");
+    PMX_CHECK(c && c->pr_h > 0 && c->pr_scales > 0 && c->pr_n > 0, PMX_ERR_STATE, "pmx_precise_finish: nothing accumulated");
     PMX_DEV(c);
     int rc;
-    const long long n = (long long)c->pr_h * c->pr_w;
+    const long long n = (long long)c->pr_n * c->pr_h * c->pr_w;
     if ((rc = launch_scale_f32(c->ext_paf, n * PMX_N_PAF, (float)c->pr_scales, c->stream))) return rc;
     if ((rc = launch_scale_f32(c->ext_heat, n * PMX_N_HEAT, (float)c->pr_scales, c->stream))) return rc;
     c->maps_valid = true; c->maps_external = true;
-    c->cur_B = 1; c->cur_fh = c->pr_h; c->cur_fw = c->pr_w;
+    c->cur_B = c->pr_n; c->cur_fh = c->pr_h; c->cur_fw = c->pr_w;
     c->pp_valid = false;
     c->pr_scales = 0;
     return PMX_OK;

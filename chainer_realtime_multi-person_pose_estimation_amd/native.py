@@ -124,6 +124,8 @@ def load():
         'pmx_precise_begin': (ci, [vp, ci, ci]),
         'pmx_precise_add_scale': (ci, [vp, vp, ci, ci]),
         'pmx_precise_finish': (ci, [vp]),
+        'pmx_precise_begin_batch': (ci, [vp, ci, ci, ci]),
+        'pmx_precise_add_scale_batch': (ci, [vp, vp, ci, ci]),
         'pmx_destroy': (None, [vp]),
         'pmx_set_stream': (ci, [vp, vp]),
         'pmx_synchronize': (ci, [vp]),
@@ -337,17 +339,20 @@ class Engine(object):
         self._B = B
         self._fhw = (fh, fw)
 
-    def precise_begin(self, orig_h, orig_w):
-        self._check(self.lib.pmx_precise_begin(self._ctx, int(orig_h), int(orig_w)))
+    def precise_begin(self, orig_h, orig_w, n_images=1):
+        self._check(self.lib.pmx_precise_begin_batch(self._ctx, int(n_images), int(orig_h), int(orig_w)))
         self._precise_hw = (int(orig_h), int(orig_w))
+        self._precise_n = int(n_images)
 
     def precise_add_scale(self, img_u8, scaled_h, scaled_w):
+        """img_u8: (H, W, 3) for a batch of one, (n, H, W, 3) for the n images precise_begin announced."""
         img = np.ascontiguousarray(img_u8, dtype=np.uint8)
-        self._check(self.lib.pmx_precise_add_scale(self._ctx, _ptr(img), int(scaled_h), int(scaled_w)))
+        assert img.shape[-3:-1] == self._precise_hw and img.size == self._precise_n * self._precise_hw[0] * self._precise_hw[1] * 3, img.shape
+        self._check(self.lib.pmx_precise_add_scale_batch(self._ctx, _ptr(img), int(scaled_h), int(scaled_w)))
 
     def precise_finish(self):
         self._check(self.lib.pmx_precise_finish(self._ctx))
-        self._B = 1
+        self._B = self._precise_n
         self._fhw = self._precise_hw
 
     def keypoints(self, out_h, out_w, thresh):

@@ -192,26 +192,48 @@ class PoseDetector(object):
 
     def _detect_precise_device(self, orig_img, fetch_maps=True):
         """detect_precise with everything between the uint8 image and the result record on the device."""
+        try:
+            return self.detect_precise_batch([orig_img], fetch_maps=fetch_maps)[0]
+        finally:                                    # (also when the reference's IndexError condition is raised: the maps and peaks exist)
+            if fetch_maps and getattr(self, 'pafs', None) is not None and np.ndim(self.pafs) == 4:
+                self.pafs, self.heatmaps = self.pafs[0], self.heatmaps[0]
+
+    def detect_precise_batch(self, imgs, fetch_maps=False):
+        """`detect_precise` (reference pose_detector.py:433-482) for a list of uint8 BGR images of ONE common size -> list of (poses, scores).
+        The reference handles one image per call; here every inference scale runs the n images as ONE batch through the network (a single
+        0.5x input is 23 x 31 feature maps -- too little for 256 CUs), the cubic resizes and the accumulation stay on the device per image,
+        and the full-resolution post-process runs on the n averaged map sets at once.  Per image the result equals the single-image call up
+        to the network's kernel-choice-by-launch-size rounding.  Native network only (`model=` callables: loop)."""
+        if self.model is not None:
+            return [self.detect_precise(im) for im in imgs]
         if self._weights is None:
             raise RuntimeError('PoseDetector has no weights: pass weights_file=, weights= or model=')
-        orig_img_h, orig_img_w, _ = orig_img.shape
+        imgs = [np.ascontiguousarray(im, dtype=np.uint8) for im in imgs]
+        shape = imgs[0].shape
+        for im in imgs:
+            if im.shape != shape or im.ndim != 3 or im.shape[2] != 3:
+                raise ValueError('detect_precise_batch needs uint8 H x W x 3 images of one common size')
+        orig_img_h, orig_img_w, _ = shape
+        n = len(imgs)
         sizes = []
         for scale in params['inference_scales']:
-            multiplier = scale * params['inference_img_size'] / min(orig_img.shape[:2])            # :442
+            multiplier = scale * params['inference_img_size'] / min(shape[:2])                     # :442
             sizes.append((math.ceil(orig_img_h * multiplier), math.ceil(orig_img_w * multiplier)))
         ds = params['downscale']
         big = max(sizes)
-        self._grow(1, -(-big[0] // ds) * ds, -(-big[1] // ds) * ds)
-        self.engine.precise_begin(orig_img_h, orig_img_w)
+        self._grow(n, -(-big[0] // ds) * ds, -(-big[1] // ds) * ds)
+        batch = np.stack(imgs)
+        self.engine.precise_begin(orig_img_h, orig_img_w, n)
         for sh, sw in sizes:
-            self.engine.precise_add_scale(orig_img, sh, sw)                                          # :443-467
+            self.engine.precise_add_scale(batch, sh, sw)                                             # :443-467
         self.engine.precise_finish()                                                                 # :469-470
         if fetch_maps:
-            pafs, heatmaps = self.engine.get_maps()
-            self.pafs, self.heatmaps = pafs[0], heatmaps[0]
+            self.pafs, self.heatmaps = self.engine.get_maps()                                       # (n, 38 | 19, H, W)
         self.engine.postprocess(orig_img_h, orig_img_w, img_len=orig_img_w, scale_xy=None)           # :475-481
-        self.all_peaks = self.engine.peaks(0)
-        return unpack_results(self.engine.results())[0]
+        rec = self.engine.results()
+        if n == 1:
+            self.all_peaks = self.engine.peaks(0)                                                    # :475 (kept as the reference keeps it)
+        return unpack_results(rec)
 
     # ---- demo-chain helpers (reference pose_detector.py:267-424): host geometry that feeds the face / hand detectors -------
     _UNIT_BASE_LIMBS = (14, 3, 0, 13, 9)            # nose-neck, neck-left hip, neck-right hip, shoulder-ear (left, right)

@@ -178,6 +178,12 @@ int pmx_postprocess(pmx_ctx* ctx, int batch, int map_h, int map_w, double img_le
 int pmx_precise_begin(pmx_ctx* ctx, int orig_h, int orig_w);
 int pmx_precise_add_scale(pmx_ctx* ctx, const uint8_t* bgr_hwc, int scaled_h, int scaled_w);
 int pmx_precise_finish(pmx_ctx* ctx);
+/* the same for n images of ONE original size (n <= the context's batch capacity; the reference handles one image per call): every
+ * scale runs the n images as one batch through the network; finish() installs a batch of n -> pmx_postprocess(ctx, n, orig_h, orig_w,
+ * orig_w, NULL).  bgr_nhwc: n x orig_h x orig_w x 3, contiguous.  Per image the results equal the single-image calls up to the
+ * kernel-choice-by-launch-size rounding of the network. */
+int pmx_precise_begin_batch(pmx_ctx* ctx, int n_images, int orig_h, int orig_w);
+int pmx_precise_add_scale_batch(pmx_ctx* ctx, const uint8_t* bgr_nhwc, int scaled_h, int scaled_w);
 
 /* FaceDetector / HandDetector post-process (face_detector.py:37-38,58-68; hand_detector.py:41,68-78) for facenet / handnet
  * contexts: F.resize_images(hs[-1], (out_h, out_w)) + gaussian_filter + per-channel arg-max.  out: batch x (maps - 1) x 4

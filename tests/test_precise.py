@@ -184,3 +184,56 @@ def test_detect_precise_crowd_config5(native):
         ds.append(min(np.mean(np.hypot(person[vis, 0] - q[vis, 0], person[vis, 1] - q[vis, 1])) for q in poses))
     assert np.median(ds) < 8.0, np.median(ds)
     det.engine.close()
+
+
+@pytest.mark.gpu
+def test_detect_precise_batch_equals_one_image_per_call(native):
+    """PoseDetector.detect_precise_batch (every inference scale of n same-size images as ONE network batch, pmx_precise_*_batch) against
+    detect_precise image by image: the averaged full-resolution maps agree to the network's kernel-choice-by-launch-size rounding
+    (<= 2e-5 of the map scale: the resizes and the accumulation are the same device code per image), the peak sets differ at most by
+    near-ties, and a batch of ONE is the single call bit for bit."""
+    PD = pkg('pose_detector')
+    W_ = pkg('weights')
+    weights = W_.synthetic_weights(0)
+    rng = np.random.default_rng(21)
+    imgs = [rng.integers(0, 256, (120, 152, 3), dtype=np.uint8) for _ in range(3)]
+    det = PD.PoseDetector(weights=weights, device=0, precise=True, max_size=(368, 472))
+    cal = PD.resize_cubic_u8(imgs[0], 467, 368)
+    cal, _ = det.pad_image(cal, 8, (104, 117, 123))
+    det.engine.forward_u8(cal[None])
+    paf0, heat0 = det.engine.get_maps()
+    weights = W_.calibrate_head(weights, paf0[0], heat0[0], heat_s=0.1, heat_t=-0.2)
+    det._weights = weights
+    det.engine.set_weights({k: weights[k] for k in ('Mconv7_stage6_L1', 'Mconv7_stage6_L2')})
+    single = []
+    for im in imgs:
+        try:
+            r = det(im)
+        except IndexError:
+            r = None
+        single.append((r, det.pafs.copy(), det.heatmaps.copy(), det.all_peaks.copy()))
+    # a batch of one IS the single call
+    try:
+        r1 = det.detect_precise_batch([imgs[1]], fetch_maps=True)[0]
+    except IndexError:
+        r1 = None
+    assert np.array_equal(det.pafs[0], single[1][1]) and np.array_equal(det.heatmaps[0], single[1][2])
+    assert (r1 is None) == (single[1][0] is None)
+    if r1 is not None:
+        assert np.array_equal(np.asarray(r1[0]), np.asarray(single[1][0][0])) and np.array_equal(np.asarray(r1[1]), np.asarray(single[1][0][1]))
+    try:
+        rb = det.detect_precise_batch(imgs, fetch_maps=True)
+    except IndexError:
+        rb = None
+    assert det.pafs.shape == (3, 38, 120, 152) and det.heatmaps.shape == (3, 19, 120, 152)
+    for i in range(3):
+        scale = max(1.0, float(np.abs(single[i][1]).max()), float(np.abs(single[i][2]).max()))
+        assert float(np.abs(det.pafs[i] - single[i][1]).max()) <= 2e-5 * scale
+        assert float(np.abs(det.heatmaps[i] - single[i][2]).max()) <= 2e-5 * scale
+        pb, ps = det.engine.peaks(i), single[i][3]
+        sb = {(int(r[0]), int(r[1]), int(r[2])) for r in pb}
+        ss = {(int(r[0]), int(r[1]), int(r[2])) for r in ps}
+        assert len(sb ^ ss) <= max(2, len(ss) // 100), (i, len(sb), len(ss), len(sb ^ ss))
+        if rb is not None and single[i][0] is not None and sb == ss:
+            assert len(rb[i][0]) == len(single[i][0][0])
+    det.engine.close()
