@@ -300,6 +300,7 @@ def main():
     d_imgs = torch.from_numpy(imgs).to(dev)          # inputs resident in HBM before the timed region
     torch.cuda.synchronize()
     gather_ms = [0.0]
+    wait_ms = [0.0]
     pipe = None
     if use_group:
         # N > 1 (and --force-gather): the records travel through dist.RecordPipe -- ONE fixed-size gather per step, issued one step behind
@@ -325,8 +326,10 @@ def main():
 
     def ship(j):
         """records of step j -> the pipe (one gather); on the root: the steps completed by it [(step, records of all ranks)]"""
+        t_w = time.perf_counter()
+        n, cap, rec_bytes, overflow = eng.snapshot_wait(j & 1)           # (the host runs one step ahead: this waits for the GPU to finish step j)
         t1 = time.perf_counter()
-        n, cap, rec_bytes, overflow = eng.snapshot_wait(j & 1)
+        wait_ms[0] += (t1 - t_w) * 1e3
         if overflow:
             # an image needed more capacity than the context had: the snapshot is not final.  Rare (capacities grow once): drain, run
             # the step again through the growing path, send the records from the host (the in-flight next step is re-checked at its turn)
@@ -371,7 +374,7 @@ def main():
         # events cost ~5 us of idle each); the per-kernel split of a whole step is measured on one extra, untimed step below
         eng.profile_reset()
         eng.profile_enable(2)
-    gather_ms[0] = 0.0
+    gather_ms[0] = wait_ms[0] = 0.0
     n_coll0 = pipe.collectives if pipe else 0
     torch.cuda.synchronize()
     if world > 1:
@@ -437,7 +440,8 @@ def main():
         if use_group:
             out['per_rank_frames_per_s'] = per_rank
             out['per_rank_frames_per_s_min_max'] = [min(per_rank), max(per_rank)]
-            out['gather_ms_per_step_rank0'] = gather_ms[0] / a.steps        # host time of rank 0 inside ship(): overlaps the GPU's next step
+            out['gather_ms_per_step_rank0'] = gather_ms[0] / a.steps        # header write + gather + D2H + parse on rank 0 (host time; the GPU runs the next step meanwhile)
+            out['host_wait_for_gpu_ms_per_step_rank0'] = wait_ms[0] / a.steps  # the host is one step ahead: time it spent waiting for the step's snapshot event
             out['collectives_per_step'] = n_coll / float(a.steps)             # (1.0 + one flush all_reduce per timed region)
             out['pipeline'] = 'detect_batch(k + 1) enqueued before the records of step k are gathered (dist.RecordPipe, slot %d bytes)' % pipe.slot_bytes
         out['backend'] = ('rccl (torch.distributed "nccl")' if a.backend == 'nccl' else a.backend) if use_group else None
