@@ -1245,6 +1245,22 @@ __device__ __forceinline__ f32x4 pk_sub4(f32x4 a, f32x4 b)
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
 
+// Diagnostic build only (tools/block_timing.py compiles this file with -DPMX_BLOCK_TIMING into its own library; the product library
+// never defines it): thread 0 of the first 8192 blocks of a Winograd launch stamps the 100 MHz wall clock at entry / pipeline primed /
+// before the stores / exit, and the CU it runs on.  (The stamps perturb the register allocation of the loops -- a 7x7 block runs 1.4x
+// slower in that build -- so only the prologue, the epilogue and the hand-over gap between two blocks on a CU are read off it.)
+#ifdef PMX_BLOCK_TIMING
+__device__ unsigned long long g_blk_t[8192 * 8];
+extern "C" int pmx_debug_block_times(unsigned long long* out, size_t n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blk_t), n * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#define PMX_T(k) do { if (threadIdx.x == 0) { const unsigned lin_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+                                              if (lin_ < 8192) g_blk_t[lin_ * 8 + (k)] = (k) == 7 ? (unsigned long long)__smid() : wall_clock64(); } } while (0)
+#else
+#define PMX_T(k)
+#endif
+
 // GEOM 0: a block = 4 x 8 Winograd tiles = an 8 x 16 pixel output rectangle (any map size).
 // GEOM 1 ("runs", 46-pixel-wide maps = the 46 x 46 maps of a 368 x 368 input): a block = 32 CONSECUTIVE Winograd tiles in row-major order
 // of the 23-tile-wide grid of one image (at most 3 tile rows): a 46 x 46 map is 529 tiles = 16 full blocks + 17 tiles instead of 18
@@ -1275,6 +1291,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     // ONE unit of the work -- unit u < nu1: pass 1 over the chunks [u g, u g + g) (g = a.kbounds); 7x7: unit nu1: row 6 (pass 2a without
     // tap (6, 6)); unit nu1 + 1: column 6 (pass 2b); unit nu1 + 2: tap (6, 6) -- and writes its untransformed share of y (no bias / ReLU) to slab `unit`; conv_splitk_reduce_kernel adds the slabs in unit order
     extern __shared__ float4 smem4[];
+    PMX_T(0); PMX_T(7);
     float* const s_raw = reinterpret_cast<float*>(smem4);
     float* const s_u = s_raw + C::RAW_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
@@ -1530,6 +1547,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
         }
     };
     static_assert(40 + C::NHF <= 64, "halo slots");
+    PMX_T(2);
     for (int ch = c0; ch < c1; ++ch) {
         const bool more = ch + 1 < c1;
         const unsigned chunk_b = (unsigned)ch * panel_b;
@@ -1798,41 +1816,73 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
         }
     }
 
-    // ---- bias, ReLU, (pool), store
+    // ---- bias, ReLU, (pool), store.  The stores go through a buffer resource that spans exactly this image's output (32-bit byte offsets,
+    // an out-of-range offset = the store is dropped): no 64-bit address arithmetic and no branch per store.  (Written with pointers and
+    // `if (inside) out[...] = v` this epilogue compiled to ~1100 instructions -- 270 quarter-rate integer multiplies / 64-bit mads, 80
+    // exec-mask branches -- and took 4-5 us of a block that lasts 23 us (conv2_1) to 200 us (7x7): tools/block_timing.py.)
+    PMX_T(5);
     const bool nok = n < G.cout;
     const int Hp = H >> 1, Wp = W >> 1;
-    float* out_b = G.out + (size_t)bimg * (POOL ? Hp * Wp : H * W) * a.ldc + n;
+    const int opix = POOL ? Hp * Wp : H * W;                         // output pixels per image
+    const int ldc_b = a.ldc * 4;
+    if (UNIT && GEOM) {
+        // unit mode of a run (the part-filled last block of an image): compact slab [image][block of the launch][tile][pixel][cout_pad];
+        // conv_wino_tail_reduce_kernel adds the units in order and drops the tiles past the end of the map
+        const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(G.out + (size_t)(bslab * a.run_nb + trem) * (32 * 4) * a.ldc, 0,
+                                                                                  (unsigned)(32 * 4 * ldc_b), 0x00020000);
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int mr = (reg & 3) + 8 * (reg >> 2) + 4 * kh;          // Winograd tile of this register row
-        float y00 = y[0][reg], y01 = y[1][reg], y10 = y[2][reg], y11 = y[3][reg];
-        if (UNIT && GEOM) {
-            // unit mode of a run (the part-filled last block of an image): compact slab [image][block of the launch][tile][pixel][cout_pad];
-            // conv_wino_tail_reduce_kernel adds the units in order and drops the tiles past the end of the map
-            float* oc = G.out + (((size_t)(bslab * a.run_nb + trem) * 32 + mr) * 4) * a.ldc + n;
-            oc[0] = y00; oc[a.ldc] = y01; oc[2 * a.ldc] = y10; oc[3 * a.ldc] = y11;
-            continue;
+        for (int reg = 0; reg < 16; ++reg) {
+            const int mr = (reg & 3) + 8 * (reg >> 2) + 4 * kh;      // Winograd tile of this register row
+            const int o = (int)__umul24(mr * 4, ldc_b) + n * 4;
+            // (through float temporaries: __builtin_bit_cast applied directly to the vector element y[k][reg] compiled to element 0 for every reg)
+            const float y00 = y[0][reg], y01 = y[1][reg], y10 = y[2][reg], y11 = y[3][reg];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y00), srsrc, o, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y01), srsrc, o + ldc_b, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y10), srsrc, o + 2 * ldc_b, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y11), srsrc, o + 3 * ldc_b, 0, 0);
         }
-        int gy, gx;
-        if (GEOM) {
-            const int t = t0 + mr, ty = t / C::RUN_TX;                // tiles past the end of the map land on rows >= H
-            gy = 2 * ty; gx = x0 + 2 * (t - ty * C::RUN_TX);
-        } else {
-            gy = y0 + 2 * (mr >> 3); gx = x0 + 2 * (mr & 7);
-        }
-        if (POOL) {
-            float v = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)) + bias;
-            if (a.relu) v = fmaxf(v, 0.f);
-            if (nok && (gy >> 1) < Hp && (gx >> 1) < Wp) out_b[((size_t)(gy >> 1) * Wp + (gx >> 1)) * a.ldc] = v;
-        } else {
-            y00 += bias; y01 += bias; y10 += bias; y11 += bias;
-            if (a.relu) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
-            if (nok && gy < H && gx < W) out_b[((size_t)gy * W + gx) * a.ldc] = y00;
-            if (nok && gy < H && gx + 1 < W) out_b[((size_t)gy * W + gx + 1) * a.ldc] = y01;
-            if (nok && gy + 1 < H && gx < W) out_b[((size_t)(gy + 1) * W + gx) * a.ldc] = y10;
-            if (nok && gy + 1 < H && gx + 1 < W) out_b[((size_t)(gy + 1) * W + gx + 1) * a.ldc] = y11;
+    } else {
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(G.out + (size_t)bimg * opix * a.ldc, 0, (unsigned)(opix * ldc_b), 0x00020000);
+        const int n_b = nok ? n * 4 : -1;                            // (a lane without a real output channel: every offset out of range)
+        // run geometry: (tile row, tile column) of the lane's first tile by one division, then stepped from register row to register row
+        // (the rows of a lane are the tiles tb + 0, 1, 2, 3, 8, 9, ...: steps of 1 or 5 < 23, at most one wrap)
+        const unsigned tb = (unsigned)(t0 + 4 * kh);
+        int rty = (int)(tb / (unsigned)C::RUN_TX), rtx = (int)(tb - (unsigned)rty * (unsigned)C::RUN_TX);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int mrc = (reg & 3) + 8 * (reg >> 2);              // (+ 4 kh): Winograd tile of this register row
+            float y00 = y[0][reg], y01 = y[1][reg], y10 = y[2][reg], y11 = y[3][reg];
+            int gy, gx;
+            if (GEOM) {
+                if (reg) {
+                    rtx += (reg & 3) ? 1 : 5;
+                    const bool wrap = rtx >= C::RUN_TX;
+                    rtx = wrap ? rtx - C::RUN_TX : rtx;
+                    rty += wrap ? 1 : 0;
+                }
+                gy = 2 * rty; gx = x0 + 2 * rtx;                     // tiles past the end of the map land on rows >= H
+            } else {
+                gy = y0 + 2 * ((mrc >> 3)) ; gx = x0 + 2 * ((mrc & 7) + 4 * kh);
+            }
+            if (POOL) {
+                float v = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)) + bias;
+                if (a.relu) v = fmaxf(v, 0.f);
+                const int py = gy >> 1, px = gx >> 1;
+                const int o = (py < Hp && px < Wp && nok) ? (int)__umul24(__umul24(py, Wp) + px, ldc_b) + n_b : -1;      // (24-bit operands: full-rate multiplies)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, o, 0, 0);
+            } else {
+                y00 += bias; y01 += bias; y10 += bias; y11 += bias;
+                if (a.relu) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
+                const int o00 = (int)__umul24(__umul24(gy, W) + gx, ldc_b) + n_b;      // (24-bit operands: full-rate multiplies; < 2^31 by the launcher's check)
+                const bool r0 = gy < H && nok, r1 = gy + 1 < H && nok, c0v = gx < W, c1v = gx + 1 < W;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y00), orsrc, (r0 && c0v) ? o00 : -1, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y01), orsrc, (r0 && c1v) ? o00 + ldc_b : -1, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y10), orsrc, (r1 && c0v) ? o00 + W * ldc_b : -1, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y11), orsrc, (r1 && c1v) ? o00 + (W + 1) * ldc_b : -1, 0, 0);
+            }
         }
     }
+    PMX_T(6);
 }
 
 // ---- conv1_1: 3 input channels ---------------------------------------------------------------------------------------
@@ -2733,6 +2783,7 @@ static int launch_wino(const ConvArgs& a0, int groups, hipStream_t stream)
     PMX_CHECK(!POOL || (a.H % 2 == 0 && a.W % 2 == 0), PMX_ERR_INVALID, "conv: pooled layer needs even H, W");
     PMX_CHECK(a.cout_pad % 128 == 0, PMX_ERR_INVALID, "conv wino: cout_pad %d not a multiple of 128", a.cout_pad);
     PMX_CHECK((long long)a.H * a.W * a.lda < (1ll << 31), PMX_ERR_INVALID, "conv: image too large for 32-bit offsets");
+    PMX_CHECK((long long)(a.H + 2) * (a.W + 2) * a.ldc * 4 < (1ll << 31), PMX_ERR_INVALID, "conv: output image too large for 32-bit byte offsets");
     a.tiles_x = (a.W + C::TW - 1) / C::TW;
     a.tiles_y = (a.H + C::TH - 1) / C::TH;
     a.run_j0 = a.run_nb = 0;
@@ -2772,6 +2823,7 @@ static int launch_wino_run_g(const ConvArgs& a0, int groups, hipStream_t stream)
     a.run_nslab = a.W / C::RUN_W;
     PMX_CHECK(a.cout_pad % 128 == 0, PMX_ERR_INVALID, "conv wino: cout_pad %d not a multiple of 128", a.cout_pad);
     PMX_CHECK((long long)a.H * a.W * a.lda * 4 < (1ll << 31), PMX_ERR_INVALID, "conv: image too large for 32-bit offsets");
+    PMX_CHECK((long long)(a.H + 2) * (a.W + 2) * a.ldc * 4 < (1ll << 31), PMX_ERR_INVALID, "conv: output image too large for 32-bit byte offsets");
     const int nblk = (C::RUN_TX * ((a.H + 1) / 2) + PMX_WINO_RUN_TILES - 1) / PMX_WINO_RUN_TILES;
     PMX_CHECK(a.run_j0 >= 0 && a.run_nb >= 1 && a.run_j0 + a.run_nb <= nblk, PMX_ERR_INVALID, "conv wino runs: blocks [%d, %d) of %d", a.run_j0, a.run_j0 + a.run_nb, nblk);
     a.tiles_x = a.tiles_y = 0;
