@@ -1329,8 +1329,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     const int n0 = blockIdx.y * 128;
     const int n = n0 + wave * 32 + li;
     const float* in_b = G.in + (size_t)bimg * H * W * a.lda;
-    float bias = G.bias[n];
-    asm volatile("" : "+v"(bias));
+    float bias = G.bias[n];                       // (pinned to a register further down, once the first halo loads are on their way:
+                                                  //  pinned here the block waited a full memory round trip before issuing anything else)
     const int nch = a.nch;                        // chunks of 32 input channels
     const int ug = UNIT ? (int)a.kbounds : nch;   // chunks per pass-1 unit
     const int nu1 = UNIT ? (nch + ug - 1) / ug : 1;
@@ -1363,15 +1363,26 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     const int hbase_b = (((y0 - C::PADK) * W + x0 - C::PADK) * a.lda + (tid & 7) * 4) * 4;     // byte offset of halo pixel (0, 0), may be negative
     const int hrow_skip = SLABS ? W - C::HW : -(KS - 1);                                     // image pixels between the end of a halo row and the next
     const int lda_b = a.lda * 4;
+    // GEOM 1 / 2: byte offset of slot r's pixel in the image for chunk 0, computed ONCE with the first halo load (0x80000000 = the column is
+    // outside the map: stays out of the buffer's range whatever chunk offset is added) and kept in registers -- recomputed per use, the
+    // compiler hoisted a second copy of this arithmetic (20 slots x (mul_hi, mul_lo, mad, cmp)) to right in front of the first MFMA
+    // (7x7 only: on the 3x3 instantiations the kept offsets measured slower -- conv3_3 +6 % -- than the compiler's own placement)
+    constexpr bool HOFF = GEOM != 0 && KS == 7;
+    int h_off[HOFF ? C::NHF : 1];
+    auto halo_off_calc = [&](int r) -> int {
+        const unsigned hp = (unsigned)(tid >> 3) + 32u * r;
+        const unsigned hy = hp / (unsigned)C::HW, hx = hp - hy * (unsigned)C::HW;
+        // halo pixel (hy, hx) = image pixel (y0 - PADK + hy, x0 - PADK + hx): hp + (W - HW) hy pixels after halo pixel (0, 0) in the image
+        int off = hbase_b + ((int)hp + (int)hy * hrow_skip) * lda_b;
+        if (SLABS ? (unsigned)(x0 - C::PADK) + hx >= (unsigned)W          // (left of the map the sum wraps around: also out)
+                  : hx - (unsigned)C::PADK >= (unsigned)C::RUN_W) off = (int)0x80000000;
+        return off;
+    };
+    auto halo_off_init = [&](int r) { if constexpr (HOFF) h_off[r] = halo_off_calc(r); };
     auto halo_load_slot = [&](float4 (&hv)[C::NHF], int chunk, int r) {       // r is a compile-time constant at every call
         if constexpr (GEOM != 0) {
-            const unsigned hp = (unsigned)(tid >> 3) + 32u * r;
-            const unsigned hy = hp / (unsigned)C::HW, hx = hp - hy * (unsigned)C::HW;
-            // halo pixel (hy, hx) = image pixel (y0 - PADK + hy, x0 - PADK + hx): hp + (W - HW) hy pixels after halo pixel (0, 0) in the image
-            int off = hbase_b + ((int)hp + (int)hy * hrow_skip) * lda_b + chunk * (C::CKW * 4);
-            if (SLABS ? (unsigned)(x0 - C::PADK) + hx >= (unsigned)W      // (left of the map the sum wraps around: also out)
-                      : hx - (unsigned)C::PADK >= (unsigned)C::RUN_W) off = -1;
-            hv[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, 0));
+            const int off0 = HOFF ? h_off[HOFF ? r : 0] : halo_off_calc(r);
+            hv[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off0 + chunk * (C::CKW * 4), 0, 0));
         } else {
             hv[r] = *reinterpret_cast<const float4*>(in_b + h_goff[GEOM ? 0 : r] + chunk * C::CKW);
         }
@@ -1417,10 +1428,17 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     const unsigned freq_b = panel_b * (unsigned)nch;                       // bytes between planes (sub-kernel * 16 + frequency)
 
     f32x16 acc[16];
+    // the 256 accumulator registers are zeroed in the shadow of the first halo / weight loads (left to the compiler the 256
+    // v_accvgpr_write sat right in front of the first MFMA, after both prologue barriers: ~0.5 us per block, fully exposed)
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int f = 0; f < 16; ++f)
+        for (int f = 0; f < 16; ++f) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[f][i] = 0.f;
+            for (int i = 0; i < 16; ++i) acc[f][i] = 0.f;
+            asm volatile("" : "+a"(acc[f]));
+        }
+    };
+    if (UNIT) zero_acc();                         // (a unit block may skip pass 1 altogether)
 
     // ---- pass 1, software pipeline.  A (chunk, sub-kernel) step is two PHASES of 8 frequencies x 4 k8-steps x 4 MFMAs: phase 0 runs
     // the frequencies 0..7 (rows 0, 1 of V, U half 0) while the threads transform rows 2, 3 of the same window into U half 1; phase 1
@@ -1433,11 +1451,21 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     const int a_off = li * C::LDU + kh * 4;
     f32x4 bw[16];
     if (do_p1) {
-    halo_load(hreg, c0);
+#pragma unroll
+    for (int r = 0; r < C::NHF; ++r) {               // first halo: offsets computed and loads issued slot by slot
+        if (GEOM) halo_off_init(r);
+        halo_load_slot(hreg, c0, r);
+    }
 #pragma unroll
     for (int st8 = 0; st8 < 8; ++st8)                 // steps 0..7 of the first phase: frequencies 0, 1 (x 4 k8-steps) of plane 0
         bw[st8] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off, (unsigned)c0 * panel_b + (unsigned)(st8 >> 2) * freq_b + (unsigned)(st8 & 3) * st_b, 0));
+    if (!UNIT) {
+        __builtin_amdgcn_sched_barrier(0);
+        zero_acc();
+        __builtin_amdgcn_sched_barrier(0);
+    }
     halo_store(hreg);
+    asm volatile("" : "+v"(bias));
     __syncthreads();
     if (c1 - c0 > 1) {
         halo_load(hreg, c0 + 1);
@@ -1653,6 +1681,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
 #pragma unroll
         for (int st = 0; st < 4; ++st) bd[st] = wload(PD, 0u, st);
         if (UNIT) {                                 // standalone: stage chunk 0, keep chunk 1 in the registers
+            if (GEOM) {
+#pragma unroll
+                for (int r = 0; r < C::NHF; ++r) halo_off_init(r);
+            }
             halo_load(hreg, 0);
             halo_store(hreg);
             __syncthreads();
@@ -1732,6 +1764,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
         if (do_p2b) {
         zero8();
         if (UNIT) {                                 // standalone: stage chunk 0, first weights, sub-kernel 0 of chunk 0 (not overlapped)
+            if (GEOM) {
+#pragma unroll
+                for (int r = 0; r < C::NHF; ++r) halo_off_init(r);
+            }
             halo_load(hreg, 0);
 #pragma unroll
             for (int s2n = 0; s2n < 4; ++s2n) bwr[s2n] = wload(PV + 0, 0u, s2n);
@@ -1792,6 +1828,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
         if (do_pd) {
             // ================= unit mode: tap (6, 6) over all chunks, straight from the raw halo =================
             f32x4 bdn[4];
+            if (GEOM) {
+#pragma unroll
+                for (int r = 0; r < C::NHF; ++r) halo_off_init(r);
+            }
             halo_load(hreg, 0);
 #pragma unroll
             for (int st = 0; st < 4; ++st) bd[st] = wload(PD, 0u, st);
@@ -1874,7 +1914,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                 y00 += bias; y01 += bias; y10 += bias; y11 += bias;
                 if (a.relu) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
                 const int o00 = (int)__umul24(__umul24(gy, W) + gx, ldc_b) + n_b;      // (24-bit operands: full-rate multiplies; < 2^31 by the launcher's check)
-                const bool r0 = gy < H && nok, r1 = gy + 1 < H && nok, c0v = gx < W, c1v = gx + 1 < W;
+                // (run geometry: the map is a whole number of 46-column slabs and a tile column is < 23, so both pixel columns are inside)
+                const bool r0 = gy < H && nok, r1 = gy + 1 < H && nok, c0v = GEOM ? true : gx < W, c1v = GEOM ? true : gx + 1 < W;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y00), orsrc, (r0 && c0v) ? o00 : -1, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y01), orsrc, (r0 && c1v) ? o00 + ldc_b : -1, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y10), orsrc, (r1 && c0v) ? o00 + W * ldc_b : -1, 0, 0);
