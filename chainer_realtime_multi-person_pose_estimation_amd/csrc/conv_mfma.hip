@@ -1438,7 +1438,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
             asm volatile("" : "+a"(acc[f]));
         }
     };
-    if (UNIT) zero_acc();                         // (a unit block may skip pass 1 altogether)
 
     // ---- pass 1, software pipeline.  A (chunk, sub-kernel) step is two PHASES of 8 frequencies x 4 k8-steps x 4 MFMAs: phase 0 runs
     // the frequencies 0..7 (rows 0, 1 of V, U half 0) while the threads transform rows 2, 3 of the same window into U half 1; phase 1
@@ -1459,11 +1458,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
 #pragma unroll
     for (int st8 = 0; st8 < 8; ++st8)                 // steps 0..7 of the first phase: frequencies 0, 1 (x 4 k8-steps) of plane 0
         bw[st8] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off, (unsigned)c0 * panel_b + (unsigned)(st8 >> 2) * freq_b + (unsigned)(st8 & 3) * st_b, 0));
-    if (!UNIT) {
-        __builtin_amdgcn_sched_barrier(0);
-        zero_acc();
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    __builtin_amdgcn_sched_barrier(0);
+    zero_acc();
+    __builtin_amdgcn_sched_barrier(0);
     halo_store(hreg);
     asm volatile("" : "+v"(bias));
     __syncthreads();
@@ -1594,16 +1591,25 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
 
     // ---- output transform Y = A^T M A per (tile, channel): y[2 * i + j] = pixel (i, j) of the tile
     f32x16 y[4];
+    if (!UNIT || do_p1) {
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        float t0[4], t1[4];
+        for (int reg = 0; reg < 16; ++reg) {
+            float t0[4], t1[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            t0[j] = (acc[0 + j][reg] + acc[4 + j][reg]) + acc[8 + j][reg];
-            t1[j] = (acc[4 + j][reg] - acc[8 + j][reg]) - acc[12 + j][reg];
+            for (int j = 0; j < 4; ++j) {
+                t0[j] = (acc[0 + j][reg] + acc[4 + j][reg]) + acc[8 + j][reg];
+                t1[j] = (acc[4 + j][reg] - acc[8 + j][reg]) - acc[12 + j][reg];
+            }
+            y[0][reg] = (t0[0] + t0[1]) + t0[2]; y[1][reg] = (t0[1] - t0[2]) - t0[3];
+            y[2][reg] = (t1[0] + t1[1]) + t1[2]; y[3][reg] = (t1[1] - t1[2]) - t1[3];
         }
-        y[0][reg] = (t0[0] + t0[1]) + t0[2]; y[1][reg] = (t0[1] - t0[2]) - t0[3];
-        y[2][reg] = (t1[0] + t1[1]) + t1[2]; y[3][reg] = (t1[1] - t1[2]) - t1[3];
+    } else {
+        // a unit block without pass 1 (row 6 / column 6 / tap (6, 6)): the transform of all-zero accumulators is +0 -- no accumulator
+        // is zeroed or read for it
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) y[pp][reg] = 0.f;
     }
 
     if (C::NDIR > 0) {
