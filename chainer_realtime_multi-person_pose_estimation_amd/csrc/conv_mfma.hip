@@ -1267,9 +1267,16 @@ extern "C" int pmx_debug_block_times(unsigned long long* out, size_t n)
 // rectangles (8.9 % padding), and the 16 full blocks of 32 images x 2 branch groups are exactly 4 rounds of 256 CUs; the part-filled last
 // block of every image runs in unit mode (pmx_api.hip::run_conv).  Raw halo = the 6 + KS - 1 input rows the three tile rows touch x all
 // 46 + KS - 1 columns (7x7: 12 x 52 pixels x 32 channels = 90 KB next to the 74 KB of U: 256 bytes short of the 160 KB LDS).
+#ifndef PMX_WINO_LDR3
+#define PMX_WINO_LDR3 48
+#endif
 template <int KS, int GEOM>
 struct WinoCfg {
-    static constexpr int TH = 8, TW = 16, PADK = KS / 2, CKW = 32, LDR = CKW + 4, LDU = CKW + 4;
+    static constexpr int TH = 8, TW = 16, PADK = KS / 2, CKW = 32, LDU = CKW + 4;
+    // raw-halo pixel pitch (floats).  36 (7x7: all the LDS allows): a transform read of 16 lanes covers two tiles 2 pixels = 72 floats
+    // apart -> their 128-byte rows overlap in 24 of 64 banks (PMC: 25 % of the LDS cycles are bank conflicts).  3x3: the halo is small
+    // enough for a pitch of 48 -> 2 pixels = 96 floats = 32 banks apart, no overlap
+    static constexpr int LDR = (KS == 3 && PMX_WINO_LDR3 > 0) ? PMX_WINO_LDR3 : CKW + 4;
     static constexpr int RUN_TX = PMX_WINO_RUN_TX, RUN_W = 2 * RUN_TX;
     static constexpr int HH = GEOM ? 6 + KS - 1 : TH + KS - 1, HW = GEOM ? RUN_W + KS - 1 : TW + KS - 1, NPX = HH * HW;
     static constexpr int NSUB = KS == 3 ? 1 : 4;                       // 3x3 sub-kernels done as Winograd products
