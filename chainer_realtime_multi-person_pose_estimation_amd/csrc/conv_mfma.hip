@@ -568,8 +568,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_v6_kernel(const ConvArgs a)
     const int n0 = blockIdx.y * 128;
     const int n = n0 + wave * 32 + li;                      // this lane's output channel
     const float* in_b = G.in + (size_t)bimg * H * W * a.lda;
-    float bias = G.bias[n];                                 // padded to cout_pad
-    asm volatile("" : "+v"(bias));
+    float bias = G.bias[n];                                 // padded to cout_pad (pinned to a register below, once the first halo loads are issued)
 
     // LDS element offsets of this lane's pixel in each row tile (kernel row 0, tap column 0, buffer 0); advanced per
     // kernel row and rewound / switched to the other buffer per chunk
@@ -632,6 +631,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_v6_kernel(const ConvArgs a)
         for (int r = 0; r < C::NHF; ++r) hv[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r]);
         halo_store(s_in, hv);
     }
+    asm volatile("" : "+v"(bias));       // (pinned right after its load, the block waited a memory round trip before issuing anything else)
     __syncthreads();
 
     f32x4 av[C::RING];
@@ -837,8 +837,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_kernel(const ConvArgs a)
     const int n0 = blockIdx.y * 128;
     const int n = n0 + wave * 32 + li;
     const float* in_b = G.in + (size_t)bimg * H * W * a.lda;
-    float bias = G.bias[n];
-    asm volatile("" : "+v"(bias));
+    float bias = G.bias[n];                       // (pinned to a register below, once the first halo loads are issued)
 
     // LDS byte offsets of this lane's pixel in each row tile (kernel row 0, tap column 0, plane 0)
     int a_cur[MT];
@@ -900,6 +899,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_kernel(const ConvArgs a)
         for (int r = 0; r < C::NHF; ++r) hv[r] = *reinterpret_cast<const float4*>(in_b + h_goff[r]);
         halo_store(hv);
     }
+    asm volatile("" : "+v"(bias));
     __syncthreads();
 
     // The row tiles are processed in PAIRS (t, t + 1): the six products of the two tiles are interleaved, so consecutive MFMAs
