@@ -40,6 +40,9 @@ PKG = 'chainer_realtime_multi-person_pose_estimation_amd'
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 FLOP_PER_FRAME = 271868013568          # 2 x MACs of the 92 convs at 368 x 368
 DOMINANT_LAYERS = ('Mconv2_', 'Mconv3_', 'Mconv4_', 'Mconv5_')   # 7x7 128->128, 20 launches per step
+PIPE_DEPTH = 1       # N > 1: the gather of step k is issued after step k + PIPE_DEPTH has been enqueued.  (Measured through a one-rank RCCL group:
+                     # depth 1 868 frames/s, depth 2 865 -- the host-side copies / collectives of torch's streams complete late in the step that
+                     # was enqueued in front of them whatever the depth, and one step in flight already keeps the GPU fed.)
 
 
 def rocprof_kernel(label):
@@ -308,26 +311,28 @@ def main():
         # inside the loop; the slot size is agreed once, here, from the record size after one plain step
         eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(B, S, S), map_h=map_s, map_w=map_s)
         _, rec_bytes0 = eng.results_layout()
-        pipe = dist_mod.RecordPipe(B * rec_bytes0, dst=0, device=coll_dev)
-    snap_mode = [None, None]
+        pipe = dist_mod.RecordPipe(B * rec_bytes0, dst=0, device=coll_dev, nslots=PIPE_DEPTH + 2)
+    snap_mode = [None] * (PIPE_DEPTH + 2)
 
     def enqueue(k, ptr=None):
         """detect_batch of step k + a stream-ordered snapshot of its records (into the pipe's send slot when it fits); no host sync"""
         eng.detect_batch(device_ptr=d_imgs.data_ptr() if ptr is None else ptr, shape=(B, S, S), map_h=map_s, map_w=map_s)
         slot_ptr, room = pipe.payload_view(k)
         need = B * native.result_dtype(eng.capacities()['people']).itemsize
+        sl = k % (PIPE_DEPTH + 2)
         if slot_ptr is not None and need <= room:
-            eng.results_snapshot(k & 1, slot_ptr, room)
-            snap_mode[k & 1] = None
+            eng.results_snapshot(sl, slot_ptr, room)
+            snap_mode[sl] = None
         else:                       # gloo smoke mode (the pipe lives on the host) or records larger than the slot: through a staging tensor
             stage = torch.empty(need, dtype=torch.uint8, device=dev)
-            eng.results_snapshot(k & 1, stage.data_ptr(), need)
-            snap_mode[k & 1] = stage
+            eng.results_snapshot(sl, stage.data_ptr(), need)
+            snap_mode[sl] = stage
 
     def ship(j):
         """records of step j -> the pipe (one gather); on the root: the steps completed by it [(step, records of all ranks)]"""
         t_w = time.perf_counter()
-        n, cap, rec_bytes, overflow = eng.snapshot_wait(j & 1)           # (the host runs one step ahead: this waits for the GPU to finish step j)
+        sl = j % (PIPE_DEPTH + 2)
+        n, cap, rec_bytes, overflow = eng.snapshot_wait(sl)              # (the host runs ahead of the GPU: this waits for it to finish step j)
         t1 = time.perf_counter()
         wait_ms[0] += (t1 - t_w) * 1e3
         if overflow:
@@ -337,10 +342,10 @@ def main():
             eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(B, S, S), map_h=map_s, map_w=map_s)
             r_ = eng.results()
             done = pipe.send(j, j, len(r_), dist_mod._people_cap(r_.dtype), r_.dtype.itemsize, payload=np.frombuffer(r_.tobytes(), dtype=np.uint8))
-        elif snap_mode[j & 1] is None:
+        elif snap_mode[sl] is None:
             done = pipe.send(j, j, n, cap, rec_bytes)
         else:
-            done = pipe.send(j, j, n, cap, rec_bytes, payload=snap_mode[j & 1][:n * rec_bytes].cpu().numpy())
+            done = pipe.send(j, j, n, cap, rec_bytes, payload=snap_mode[sl][:n * rec_bytes].cpu().numpy())
         gather_ms[0] += (time.perf_counter() - t1) * 1e3
         return done or []
 
@@ -354,9 +359,10 @@ def main():
         got = []
         for k in range(n):
             enqueue(k)
-            if k:
-                got += ship(k - 1)
-        got += ship(n - 1)
+            if k >= PIPE_DEPTH:
+                got += ship(k - PIPE_DEPTH)
+        for j in range(max(0, n - PIPE_DEPTH), n):
+            got += ship(j)
         got += pipe.flush() or []
         if rank == 0:
             assert [st for st, _ in got] == list(range(n)), ('steps delivered', [st for st, _ in got])
@@ -443,7 +449,7 @@ def main():
             out['gather_ms_per_step_rank0'] = gather_ms[0] / a.steps        # header write + gather + D2H + parse on rank 0 (host time; the GPU runs the next step meanwhile)
             out['host_wait_for_gpu_ms_per_step_rank0'] = wait_ms[0] / a.steps  # the host is one step ahead: time it spent waiting for the step's snapshot event
             out['collectives_per_step'] = n_coll / float(a.steps)             # (1.0 + one flush all_reduce per timed region)
-            out['pipeline'] = 'detect_batch(k + 1) enqueued before the records of step k are gathered (dist.RecordPipe, slot %d bytes)' % pipe.slot_bytes
+            out['pipeline'] = 'detect_batch(k + %d) enqueued before the records of step k are gathered (dist.RecordPipe, slot %d bytes)' % (PIPE_DEPTH, pipe.slot_bytes)
         out['backend'] = ('rccl (torch.distributed "nccl")' if a.backend == 'nccl' else a.backend) if use_group else None
         out['records_path'] = ('dist.RecordPipe (pmx_results_snapshot into the send slot on the device -> one RCCL gather per step -> one D2H copy on rank 0)'
                                if use_group and a.backend == 'nccl' else 'dist.RecordPipe over %s (host slots)' % a.backend if use_group

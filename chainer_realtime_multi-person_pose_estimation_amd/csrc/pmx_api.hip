@@ -408,7 +408,7 @@ extern "C" void pmx_destroy(pmx_ctx* c)
     for (auto& p : c->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->h_results) (void)hipHostFree(c->h_results);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < PMX_SNAPSHOT_SLOTS; ++i) {
         if (c->snap_ev[i]) (void)hipEventDestroy(c->snap_ev[i]);
         if (c->snap_status[i]) (void)hipHostFree(c->snap_status[i]);
     }
@@ -1439,7 +1439,7 @@ extern "C" int pmx_results_device_ptr(pmx_ctx* c, void** p, size_t* bytes)
 extern "C" int pmx_results_snapshot(pmx_ctx* c, int slot, void* dst_device, size_t dst_bytes)
 {
     PMX_CHECK(c && dst_device, PMX_ERR_INVALID, "null arg");
-    PMX_CHECK(slot == 0 || slot == 1, PMX_ERR_INVALID, "pmx_results_snapshot: slot %d (0 | 1)", slot);
+    PMX_CHECK(slot >= 0 && slot < PMX_SNAPSHOT_SLOTS, PMX_ERR_INVALID, "pmx_results_snapshot: slot %d outside 0..%d", slot, PMX_SNAPSHOT_SLOTS - 1);
     PMX_CHECK(c->pp_valid, PMX_ERR_STATE, "pmx_results_snapshot: no post-process results yet");
     PMX_DEV(c);
     const size_t need = c->pp.rec_bytes * (size_t)c->pp_B;
@@ -1456,7 +1456,7 @@ extern "C" int pmx_results_snapshot(pmx_ctx* c, int slot, void* dst_device, size
 extern "C" int pmx_snapshot_wait(pmx_ctx* c, int slot, int* batch, int* people_cap, size_t* bytes_per_record, int* status_or)
 {
     PMX_CHECK(c, PMX_ERR_INVALID, "null ctx");
-    PMX_CHECK((slot == 0 || slot == 1) && c->snap_ev[slot] && c->snap_B[slot] > 0, PMX_ERR_STATE, "pmx_snapshot_wait: slot %d holds no snapshot", slot);
+    PMX_CHECK(slot >= 0 && slot < PMX_SNAPSHOT_SLOTS && c->snap_ev[slot] && c->snap_B[slot] > 0, PMX_ERR_STATE, "pmx_snapshot_wait: slot %d holds no snapshot", slot);
     PMX_DEV(c);
     PMX_HIP(hipEventSynchronize(c->snap_ev[slot]));
     int bits = 0;

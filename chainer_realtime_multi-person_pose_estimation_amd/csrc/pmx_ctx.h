@@ -74,11 +74,11 @@ struct pmx_ctx {
     double* d_scale = nullptr;
     unsigned char* h_results = nullptr;         // pinned staging for pmx_get_results (pageable D2H is slow and jittery)
     size_t h_results_bytes = 0;
-    // pmx_results_snapshot / pmx_snapshot_wait: two slots (event, pinned status words, layout at snapshot time)
-    hipEvent_t snap_ev[2] = {nullptr, nullptr};
-    int* snap_status[2] = {nullptr, nullptr};
-    int snap_B[2] = {0, 0}, snap_cap_ppl[2] = {0, 0};
-    size_t snap_rec[2] = {0, 0};
+    // pmx_results_snapshot / pmx_snapshot_wait: PMX_SNAPSHOT_SLOTS slots (event, pinned status words, layout at snapshot time)
+    hipEvent_t snap_ev[PMX_SNAPSHOT_SLOTS] = {};
+    int* snap_status[PMX_SNAPSHOT_SLOTS] = {};
+    int snap_B[PMX_SNAPSHOT_SLOTS] = {}, snap_cap_ppl[PMX_SNAPSHOT_SLOTS] = {};
+    size_t snap_rec[PMX_SNAPSHOT_SLOTS] = {};
     bool pp_valid = false;
     bool pp_final = false;                      // statuses checked: no image of the last post-process overflowed a capacity
     int pp_B = 0, pp_h = 0, pp_w = 0;

@@ -142,9 +142,10 @@ _SLOT_HDR, _FRAME_HDR = 32, 48
 
 
 class RecordPipe(object):
-    def __init__(self, payload_bytes, dst=0, group=None, device=None, headroom=2.0):
+    def __init__(self, payload_bytes, dst=0, group=None, device=None, headroom=2.0, nslots=3):
         """Collective (every rank of `group` must call it): agrees the slot size = headroom x the largest `payload_bytes` (bytes of one
-        step's records of a rank at its current capacity) over the ranks.  `device`: cuda:N (RCCL) or cpu (gloo)."""
+        step's records of a rank at its current capacity) over the ranks.  `device`: cuda:N (RCCL) or cpu (gloo).  `nslots`: send slots =
+        steps the consumer may run behind the compute + 1 (slot of step k: k % nslots)."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group, self.dst = torch, dist, group, dst
@@ -155,9 +156,21 @@ class RecordPipe(object):
         cap = int(t.item())
         self.slot_bytes = (_SLOT_HDR + _FRAME_HDR + int(cap * headroom) + 255) // 256 * 256
         self.room = self.slot_bytes - _SLOT_HDR                      # stream bytes one slot carries
-        self.slots = [torch.zeros(self.slot_bytes, dtype=torch.uint8, device=self.dev) for _ in range(2)]
-        self.work = [None, None]
-        self.recv = torch.empty(self.world * self.slot_bytes, dtype=torch.uint8, device=self.dev) if self.rank == dst else None
+        self.slots = [torch.zeros(self.slot_bytes, dtype=torch.uint8, device=self.dev) for _ in range(nslots)]
+        self.nslots = nslots
+        # headers go host -> device from PINNED staging (one per send slot) with a non-blocking copy: from pageable memory the 80-byte copy
+        # blocked the host until the device had drained most of the step that was just enqueued (measured: 29 ms of a 36 ms step)
+        self.hdr = [torch.zeros(_SLOT_HDR + _FRAME_HDR, dtype=torch.uint8).pin_memory() if self.dev.type == 'cuda'
+                    else torch.zeros(_SLOT_HDR + _FRAME_HDR, dtype=torch.uint8) for _ in range(nslots)]
+        self.work = [None] * nslots
+        # root: receive buffer, pinned host copy and a "copy done" event per slot -- the device-to-host copy of a gather is issued
+        # without waiting and parsed when the NEXT gather is issued (or in flush()): a blocking copy kept the host inside it until the
+        # device had drained the step enqueued in front of it, and the GPU then idled while the host enqueued the next one
+        root, cuda = self.rank == dst, self.dev.type == 'cuda'
+        self.recv = [torch.empty(self.world * self.slot_bytes, dtype=torch.uint8, device=self.dev) for _ in range(nslots)] if root else None
+        self.host = [torch.empty(self.world * self.slot_bytes, dtype=torch.uint8).pin_memory() for _ in range(nslots)] if root and cuda else None
+        self.ev = [torch.cuda.Event() for _ in range(nslots)] if root and cuda else None
+        self.pending = []                                            # slots whose device-to-host copy has been issued, oldest first
         self.outbox = bytearray()                                    # host bytes waiting to cross (slow path only)
         self.inbox = [bytearray() for _ in range(self.world)] if self.rank == dst else None
         self.frames = {}                                             # step -> {rank: records}
@@ -166,30 +179,41 @@ class RecordPipe(object):
 
     # -- sending side --------------------------------------------------------------------------------------------------------------
     def payload_view(self, k):
-        """(device pointer or None, capacity in bytes) of the place in send slot k & 1 where a frame's payload goes: the engine snapshots
+        """(device pointer or None, capacity in bytes) of the place in send slot k % nslots where a frame's payload goes: the engine snapshots
         its records there (pmx_results_snapshot).  Waits until the gather that last used the slot has read it."""
-        s = k & 1
-        if self.work[s] is not None:
-            self.work[s].wait()
-            if self.dev.type == 'cuda':
-                self.torch.cuda.current_stream(self.dev).synchronize()
-            self.work[s] = None
+        s = k % self.nslots
+        self._free_slot(s)
         t = self.slots[s][_SLOT_HDR + _FRAME_HDR:]
         return (t.data_ptr() if self.dev.type == 'cuda' else None), int(t.numel())
+
+    def _free_slot(self, s):
+        """Slot s may be rewritten once the gather that last sent it has completed.  With nslots >= 2 that was one or more steps ago:
+        normally a completed-flag check; only if it is still in flight does the host wait (a blocking wait here would keep the host
+        from enqueuing the next step until the device has drained the current one)."""
+        if self.rank == self.dst and self.pending and s in self.pending:
+            self._collect(upto=s)
+        w = self.work[s]
+        if w is not None:
+            if not w.is_completed():
+                w.wait()
+                if self.dev.type == 'cuda':
+                    self.torch.cuda.current_stream(self.dev).synchronize()
+            self.work[s] = None
 
     def _frame_header(self, step, n, cap, rec_bytes, payload_bytes):
         return np.array([_FRAME_MAGIC, step, n, cap, rec_bytes, payload_bytes], dtype=np.int64).tobytes()
 
     def send(self, k, step, n_records, people_cap, rec_bytes, payload=None):
-        """One step of the pipe = one gather.  `payload` None: the frame's payload already sits in send slot k & 1 (payload_view);
+        """One step of the pipe = one gather.  `payload` None: the frame's payload already sits in send slot k % nslots (payload_view);
         else host bytes (np.uint8 / bytes) of the records.  Returns what exchange() returns."""
         nbytes = int(n_records) * int(rec_bytes)
-        s = k & 1
+        s = k % self.nslots
         in_place = payload is None and not self.outbox and _FRAME_HDR + nbytes <= self.room
         if in_place:
             head = np.frombuffer(np.array([_SLOT_MAGIC, _FRAME_HDR + nbytes, self.seq, 0], dtype=np.int64).tobytes()
                                  + self._frame_header(step, n_records, people_cap, rec_bytes, nbytes), dtype=np.uint8)
-            self.slots[s][:_SLOT_HDR + _FRAME_HDR].copy_(self.torch.from_numpy(head.copy()))
+            self.hdr[s].numpy()[:] = head            # (slot s's previous gather has completed: payload_view waited for it)
+            self.slots[s][:_SLOT_HDR + _FRAME_HDR].copy_(self.hdr[s], non_blocking=True)
             return self._gather(s)
         if payload is None:                                          # the frame is in the slot but cannot go from there: pull it to the host
             payload = self.slots[s][_SLOT_HDR + _FRAME_HDR:_SLOT_HDR + _FRAME_HDR + nbytes].cpu().numpy().tobytes()
@@ -200,12 +224,8 @@ class RecordPipe(object):
 
     def exchange(self, k=0):
         """Send the next (up to one slot of) outbox bytes -- an empty slot if there is nothing to send."""
-        s = k & 1
-        if self.work[s] is not None:                                 # (slow path: the slot may not have gone through payload_view)
-            self.work[s].wait()
-            if self.dev.type == 'cuda':
-                self.torch.cuda.current_stream(self.dev).synchronize()
-            self.work[s] = None
+        s = k % self.nslots
+        self._free_slot(s)                                           # (slow path: the slot may not have gone through payload_view)
         n = min(len(self.outbox), self.room)
         chunk = bytes(self.outbox[:n])
         del self.outbox[:n]
@@ -224,7 +244,9 @@ class RecordPipe(object):
         done = []
         for i in range(int(t.item())):
             done += self.exchange(i) or []
-        for s in (0, 1):
+        if self.rank == self.dst:
+            done += self._collect()
+        for s in range(self.nslots):
             if self.work[s] is not None:
                 self.work[s].wait()
                 self.work[s] = None
@@ -234,19 +256,40 @@ class RecordPipe(object):
     def _gather(self, s):
         self.seq += 1
         self.collectives += 1
-        outs = list(self.recv.split(self.slot_bytes)) if self.rank == self.dst else None
+        outs = list(self.recv[s].split(self.slot_bytes)) if self.rank == self.dst else None
         self.work[s] = self.dist.gather(self.slots[s], outs, dst=self.dst, group=self.group, async_op=True)
         if self.rank != self.dst:
             return None
-        self.work[s].wait()                                          # root: the slots of all ranks are in `recv` (stream-ordered) ...
-        host = self.recv.cpu().numpy()                               # ... and this copy synchronises with it
-        self.work[s] = None
+        # root: first hand out what earlier gathers delivered (their copies are long done), then issue this one's copy without waiting
+        done = self._collect()
+        self.work[s].wait()                                          # (stream-ordered: the slots of all ranks are in recv[s] before the copy)
+        if self.host is not None:
+            self.host[s].copy_(self.recv[s], non_blocking=True)
+            self.ev[s].record()
+            self.pending.append(s)
+        else:                                                        # gloo: the collective has completed on return from wait()
+            self._absorb(self.recv[s].numpy())
+            done += self._parse()
+        return done
+
+    def _collect(self, upto=None):
+        """Root: parse every pending slot (oldest first; stops after slot `upto` if given) -- waits for its copy event, normally long set."""
+        done = []
+        while self.pending:
+            s = self.pending.pop(0)
+            self.ev[s].synchronize()
+            self._absorb(self.host[s].numpy())
+            done += self._parse()
+            if upto is not None and s == upto:
+                break
+        return done
+
+    def _absorb(self, host):
         for r in range(self.world):
             slot = host[r * self.slot_bytes:(r + 1) * self.slot_bytes]
             magic, valid, _, _ = np.frombuffer(slot[:_SLOT_HDR].tobytes(), dtype=np.int64)
             assert magic == _SLOT_MAGIC and 0 <= valid <= self.room, ('corrupt slot from rank %d' % r, int(magic), int(valid))
             self.inbox[r] += slot[_SLOT_HDR:_SLOT_HDR + int(valid)].tobytes()
-        return self._parse()
 
     def _parse(self):
         from . import native

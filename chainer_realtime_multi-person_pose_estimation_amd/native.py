@@ -22,6 +22,7 @@ HEADERS = ['pmx_common.h', 'pmx_ctx.h', HEADER]
 N_JOINTS, N_LIMBS, N_PAF, N_HEAT = 18, 19, 38, 19
 # initial capacities of a context (PMX_INIT_* in the header); they grow on demand, results are never truncated
 INIT_PEAKS_PER_JOINT, INIT_SUBSETS, INIT_PEOPLE = 128, 128, 64
+SNAPSHOT_SLOTS = 4                             # PMX_SNAPSHOT_SLOTS: results_snapshot slots of a context
 
 IMG_PEAK_OVERFLOW, IMG_CAND_OVERFLOW, IMG_SUBSET_OVERFLOW, IMG_TRIPLE_MATCH, IMG_PEOPLE_OVERFLOW = 1, 2, 4, 8, 16
 

@@ -206,10 +206,12 @@ int pmx_results_device_ptr(pmx_ctx* ctx, void** dev_ptr, size_t* bytes_per_recor
 /* pipelined consumers (a multi-GPU gather that runs one step behind the compute): pmx_results_snapshot enqueues, stream-ordered after
  * the last post-process and WITHOUT synchronising, a device-to-device copy of its `batch` records to dst_device (>= batch *
  * bytes_per_record at the context's current layout, else PMX_ERR_CAPACITY) plus a copy of the per-image status words to pinned host
- * memory, and marks the point with the event of `slot` (0 | 1).  The caller may then enqueue the next pmx_detect_batch.
+ * memory, and marks the point with the event of `slot` (0 .. PMX_SNAPSHOT_SLOTS - 1: a consumer that runs d steps behind needs d + 1).  The caller
+ * may then enqueue the next pmx_detect_batch.
  * pmx_snapshot_wait blocks until slot's copies are done (not until the stream is idle) and returns the layout the snapshot was
  * taken at and the OR of the status words: if it carries a capacity bit (PMX_IMG_*_OVERFLOW) the snapshot is NOT final -- run the
  * step again and fetch it through pmx_results_layout / pmx_get_results, which grow the capacities (docs: INTEGRATION.md). */
+#define PMX_SNAPSHOT_SLOTS 4
 int pmx_results_snapshot(pmx_ctx* ctx, int slot, void* dst_device, size_t dst_bytes);
 int pmx_snapshot_wait(pmx_ctx* ctx, int slot, int* batch, int* people_cap, size_t* bytes_per_record, int* status_or);
 /* capacities: pre-size a context for crowds (or shrink them in tests to exercise the growth path); 0 keeps a value.

@@ -121,7 +121,7 @@ def _pipe_worker(rank, world, port, n_items, steps, headroom, grow_at, q):
         raw = np.frombuffer(rec.tobytes(), dtype=np.uint8)
         if len(raw) <= room and k % 2 == 0:
             # the steady-state path: the payload is written straight into the send slot (what pmx_results_snapshot does on the device)
-            pipe.slots[k & 1][d._SLOT_HDR + d._FRAME_HDR:d._SLOT_HDR + d._FRAME_HDR + len(raw)] = torch.from_numpy(raw.copy())
+            pipe.slots[k % pipe.nslots][d._SLOT_HDR + d._FRAME_HDR:d._SLOT_HDR + d._FRAME_HDR + len(raw)] = torch.from_numpy(raw.copy())
             done = pipe.send(k, k, len(rec), cap, rec.dtype.itemsize)
         else:
             done = pipe.send(k, k, len(rec), cap, rec.dtype.itemsize, payload=raw)
