@@ -1267,18 +1267,36 @@ extern "C" int pmx_debug_block_times(unsigned long long* out, size_t n)
 // rectangles (8.9 % padding), and the 16 full blocks of 32 images x 2 branch groups are exactly 4 rounds of 256 CUs; the part-filled last
 // block of every image runs in unit mode (pmx_api.hip::run_conv).  Raw halo = the 6 + KS - 1 input rows the three tile rows touch x all
 // 46 + KS - 1 columns (7x7: 12 x 52 pixels x 32 channels = 90 KB next to the 74 KB of U: 256 bytes short of the 160 KB LDS).
+// GEOM 3 ("merged tails", unit mode only): the part-filled last blocks of ALL images of the launch as one stream -- image b's tail tiles
+// [32 nfull, ntiles) (they lie in one tile row; nt of them, 16 <= nt <= 23) are the stream positions [b nt, (b + 1) nt), and block j owns the
+// positions [32 j, 32 j + 32): up to three images' segments, every MFMA row a real tile (46 x 46: 17 tiles per image -- one image per block
+// filled 17 of the 32 rows).  Raw halo = one tile row, the segments side by side, each with its own KS - 1 columns of overlap.
 #ifndef PMX_WINO_LDR3
 #define PMX_WINO_LDR3 48
 #endif
+// how far ahead of their MFMAs the transformed weights are requested: pass 1 in steps of 4 MFMAs (ring of 16), pass 2 in steps of 8 (ring
+// of 8).  8 / 4 = ~2000 cycles; 10 / 5, 12 / 6 and 15 / 7 measured 0.5 - 3 % slower on the 7x7 layers (tools/kernel_variants.py): the
+// weight stream is not what the matrix pipe waits for
+#ifndef PMX_WINO_WLEAD1
+#define PMX_WINO_WLEAD1 8
+#endif
+#ifndef PMX_WINO_WLEAD2
+#define PMX_WINO_WLEAD2 4
+#endif
+static_assert(PMX_WINO_WLEAD1 >= 4 && PMX_WINO_WLEAD1 <= 15 && PMX_WINO_WLEAD2 >= 4 && PMX_WINO_WLEAD2 <= 7, "weight ring lead");
 template <int KS, int GEOM>
 struct WinoCfg {
     static constexpr int TH = 8, TW = 16, PADK = KS / 2, CKW = 32, LDU = CKW + 4;
     // raw-halo pixel pitch (floats).  36 (7x7: all the LDS allows): a transform read of 16 lanes covers two tiles 2 pixels = 72 floats
     // apart -> their 128-byte rows overlap in 24 of 64 banks (PMC: 25 % of the LDS cycles are bank conflicts).  3x3: the halo is small
     // enough for a pitch of 48 -> 2 pixels = 96 floats = 32 banks apart, no overlap
-    static constexpr int LDR = (KS == 3 && PMX_WINO_LDR3 > 0) ? PMX_WINO_LDR3 : CKW + 4;
+    // (GEOM 3, 7x7: 8 x 82 pixels only fit with a pitch of 32 -- two tiles of a transform read then share their banks: 2-way conflicts,
+    //  on a launch that is 3 % of a layer)
+    static constexpr int LDR = (KS == 3 && PMX_WINO_LDR3 > 0) ? PMX_WINO_LDR3 : GEOM == 3 ? CKW : CKW + 4;
     static constexpr int RUN_TX = PMX_WINO_RUN_TX, RUN_W = 2 * RUN_TX;
-    static constexpr int HH = GEOM ? 6 + KS - 1 : TH + KS - 1, HW = GEOM ? RUN_W + KS - 1 : TW + KS - 1, NPX = HH * HW;
+    // GEOM 3 ("merged tails"): one tile row of up to three images side by side: 32 tiles + three times the KS - 1 columns of overlap
+    static constexpr int HH = GEOM == 3 ? 2 + KS - 1 : GEOM ? 6 + KS - 1 : TH + KS - 1;
+    static constexpr int HW = GEOM == 3 ? 2 * PMX_WINO_RUN_TILES + 3 * (KS - 1) : GEOM ? RUN_W + KS - 1 : TW + KS - 1, NPX = HH * HW;
     static constexpr int NSUB = KS == 3 ? 1 : 4;                       // 3x3 sub-kernels done as Winograd products
     static constexpr int NDIR = KS == 3 ? 0 : 13;                      // taps outside the 3x3 sub-kernels (KS = 7: row 6, column 6 -> pass 2)
     static constexpr int RAW_ELEMS = NPX * LDR, U_ELEMS = 16 * 32 * LDU;
@@ -1294,6 +1312,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     using C = WinoCfg<KS, GEOM>;
     static_assert(!(POOL && KS != 3), "pooling only with the 3x3 variant");
     static_assert(!(UNIT && POOL), "unit mode: the combine kernel pools");
+    static_assert(GEOM != 3 || UNIT, "merged tails run in unit mode");
+    constexpr bool MERGE = GEOM == 3;
     // UNIT (single images: 36 blocks of a 46x46 7x7 layer cannot fill 256 CUs): blockIdx.z = unit * groups + group, and a block runs
     // ONE unit of the work -- unit u < nu1: pass 1 over the chunks [u g, u g + g) (g = a.kbounds); 7x7: unit nu1: row 6 (pass 2a without
     // tap (6, 6)); unit nu1 + 1: column 6 (pass 2b); unit nu1 + 2: tap (6, 6) -- and writes its untransformed share of y (no bias / ReLU) to slab `unit`; conv_splitk_reduce_kernel adds the slabs in unit order
@@ -1321,7 +1341,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     // GEOM 1: the map is cut into vertical slabs of 46 columns (23 tile columns; 46 / 92 / 184-wide maps = 1 / 2 / 4 slabs); block trem of
     // this launch in (image, slab) bslab = the 32 consecutive Winograd tiles [t0, t0 + 32) of that slab (row-major), tile rows r0 .. r0 + 2;
     // raw halo row 0 / column 0 = image row 2 r0 - PADK / column 46 slab - PADK (halo columns inside the map come from the neighbour slab)
-    const int tiles_per_img = GEOM ? a.run_nb : a.tiles_x * a.tiles_y;
+    const int tiles_per_img = MERGE ? 1 : GEOM ? a.run_nb : a.tiles_x * a.tiles_y;
     const int bslab = tile / tiles_per_img;
     const int trem = tile - bslab * tiles_per_img;
     // (GEOM 1 = a single slab, the 46-wide maps of the 7x7 layers: the slab arithmetic is compiled out -- its extra scalar registers
@@ -1329,13 +1349,19 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     constexpr bool SLABS = GEOM == 2;
     const int bimg = SLABS ? bslab / a.run_nslab : bslab;
     const int sx0 = SLABS ? (bslab - bimg * a.run_nslab) * C::RUN_W : 0;
-    const int t0 = GEOM ? (a.run_j0 + trem) * PMX_WINO_RUN_TILES : 0;
+    const int t0 = MERGE ? a.run_j0 * PMX_WINO_RUN_TILES : GEOM ? (a.run_j0 + trem) * PMX_WINO_RUN_TILES : 0;      // (MERGE: first tail tile of an image)
     const int r0 = GEOM ? t0 / C::RUN_TX : 0;
     const int ntiles = C::RUN_TX * ((a.H + 1) >> 1);
     const int y0 = GEOM ? 2 * r0 : (trem / a.tiles_x) * C::TH, x0 = GEOM ? sx0 : (trem % a.tiles_x) * C::TW;
+    // MERGE: block `tile` = stream positions [32 tile, 32 tile + 32) = segment s (s = 0, 1, 2) of image mg_img0 + s: mg_n0 / mg_n1 / the
+    // rest tiles from tail tile mg_tt0 (s = 0) / 0 on, halo columns from 0 / mg_cb1 / mg_cb2 on (2 n + KS - 1 of them)
+    const int mg_nt = ntiles - t0, mg_tx0 = t0 - r0 * C::RUN_TX;
+    const int mg_p0 = tile * PMX_WINO_RUN_TILES, mg_img0 = MERGE ? mg_p0 / mg_nt : 0, mg_tt0 = mg_p0 - mg_img0 * mg_nt;
+    const int mg_n0 = min(mg_nt - mg_tt0, PMX_WINO_RUN_TILES), mg_n1 = min(mg_nt, PMX_WINO_RUN_TILES - mg_n0);
+    const int mg_cb1 = 2 * mg_n0 + KS - 1, mg_cb2 = mg_cb1 + 2 * mg_n1 + KS - 1;
     const int n0 = blockIdx.y * 128;
     const int n = n0 + wave * 32 + li;
-    const float* in_b = G.in + (size_t)bimg * H * W * a.lda;
+    const float* in_b = G.in + (MERGE ? (size_t)0 : (size_t)bimg * H * W * a.lda);
     float bias = G.bias[n];                       // (pinned to a register further down, once the first halo loads are on their way:
                                                   //  pinned here the block waited a full memory round trip before issuing anything else)
     const int nch = a.nch;                        // chunks of 32 input channels
@@ -1366,7 +1392,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
             h_ok |= (slot && inb) ? (1u << r) : 0u;
         }
     }
-    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, GEOM ? (unsigned)(H * W * a.lda) * 4u : 0u, 0x00020000);
+    // (MERGE: the resource spans the whole batch -- rows outside an image would land in its neighbour, so they are masked like the columns)
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0,
+                                                                           MERGE ? (unsigned)(a.B * H * W * a.lda) * 4u : GEOM ? (unsigned)(H * W * a.lda) * 4u : 0u, 0x00020000);
     const int hbase_b = (((y0 - C::PADK) * W + x0 - C::PADK) * a.lda + (tid & 7) * 4) * 4;     // byte offset of halo pixel (0, 0), may be negative
     const int hrow_skip = SLABS ? W - C::HW : -(KS - 1);                                     // image pixels between the end of a halo row and the next
     const int lda_b = a.lda * 4;
@@ -1374,11 +1402,20 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     // outside the map: stays out of the buffer's range whatever chunk offset is added) and kept in registers -- recomputed per use, the
     // compiler hoisted a second copy of this arithmetic (20 slots x (mul_hi, mul_lo, mad, cmp)) to right in front of the first MFMA
     // (7x7 only: on the 3x3 instantiations the kept offsets measured slower -- conv3_3 +6 % -- than the compiler's own placement)
-    constexpr bool HOFF = GEOM != 0 && KS == 7;
+    constexpr bool HOFF = (GEOM != 0 && KS == 7) || GEOM == 3;     // (merged tails: the per-slot segment arithmetic is never repeated)
     int h_off[HOFF ? C::NHF : 1];
     auto halo_off_calc = [&](int r) -> int {
         const unsigned hp = (unsigned)(tid >> 3) + 32u * r;
         const unsigned hy = hp / (unsigned)C::HW, hx = hp - hy * (unsigned)C::HW;
+        if constexpr (MERGE) {
+            const int sg = (int)hx >= mg_cb2 ? 2 : (int)hx >= mg_cb1 ? 1 : 0;
+            const int lx = (int)hx - (sg == 2 ? mg_cb2 : sg == 1 ? mg_cb1 : 0);
+            const int ns = sg == 2 ? PMX_WINO_RUN_TILES - mg_n0 - mg_n1 : sg == 1 ? mg_n1 : mg_n0;
+            const int img = mg_img0 + sg;
+            const int gy = y0 - C::PADK + (int)hy, gx = 2 * (mg_tx0 + (sg == 0 ? mg_tt0 : 0)) - C::PADK + lx;
+            const bool ok = lx < 2 * ns + KS - 1 && img < a.B && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && hy < (unsigned)C::HH;
+            return ok ? (((img * H + gy) * W + gx) * a.lda + (tid & 7) * 4) * 4 : (int)0x80000000;
+        }
         // halo pixel (hy, hx) = image pixel (y0 - PADK + hy, x0 - PADK + hx): hp + (W - HW) hy pixels after halo pixel (0, 0) in the image
         int off = hbase_b + ((int)hp + (int)hy * hrow_skip) * lda_b;
         if (SLABS ? (unsigned)(x0 - C::PADK) + hx >= (unsigned)W          // (left of the map the sum wraps around: also out)
@@ -1413,6 +1450,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     // position of Winograd tile m of the block in the raw halo (top-left pixel of sub-kernel 0's 4 x 4 window), in pixels.
     // GEOM 0: 4 x 8 grid; GEOM 1: tile t0 + m of the row-major run (tiles past the end of the map repeat the last one; never stored)
     auto tile_px = [&](int m) -> int {
+        if (MERGE) {         // (positions past the end of the stream repeat the last tile of the last image; never read back)
+            const int mc = min(m, a.B * mg_nt - 1 - mg_p0);
+            const int sg = mc >= mg_n0 + mg_n1 ? 2 : mc >= mg_n0 ? 1 : 0;
+            return (sg == 2 ? mg_cb2 - 2 * (mg_n0 + mg_n1) : sg == 1 ? mg_cb1 - 2 * mg_n0 : 0) + 2 * mc;
+        }
         if (GEOM) {
             const int t = min(t0 + m, ntiles - 1);
             const int ty = t / C::RUN_TX;
@@ -1463,7 +1505,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
         halo_load_slot(hreg, c0, r);
     }
 #pragma unroll
-    for (int st8 = 0; st8 < 8; ++st8)                 // steps 0..7 of the first phase: frequencies 0, 1 (x 4 k8-steps) of plane 0
+    for (int st8 = 0; st8 < PMX_WINO_WLEAD1; ++st8)   // the first steps of the first phase: frequencies 0, 1, .. (x 4 k8-steps) of plane 0
         bw[st8] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off, (unsigned)c0 * panel_b + (unsigned)(st8 >> 2) * freq_b + (unsigned)(st8 & 3) * st_b, 0));
     __builtin_amdgcn_sched_barrier(0);
     zero_acc();
@@ -1529,8 +1571,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 3][e], bw[s & 15][e], acc[f], 0, 0, 0);
-                    if (e == 0) {                                       // weights of step s + 8
-                        const int sn = s + 8;
+                    if (e == 0) {                                       // weights of step s + lead
+                        const int sn = s + PMX_WINO_WLEAD1;
                         unsigned so;
                         if (sn < 32) so = plane_b + (unsigned)(r * 8 + (sn >> 2)) * freq_b;
                         else if (r == 0) so = plane_b + (unsigned)(8 + ((sn - 32) >> 2)) * freq_b;
@@ -1629,6 +1671,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
         // H1 phases (16 steps x 8 MFMAs; during H0 sub-kernel 1 is transformed, during H1 the raw halo of the next chunk replaces this
         // one); then y += A^T-transform of the row planes.  Pass 2b per chunk: V0, V1 phases; then y += transform of the column planes.
         constexpr int PH = 64, PV = 72, PD = 80;
+        constexpr int HBAR = C::NHF > 20 ? C::NHF : 20;      // H1 / V1: the slot of the barrier behind the halo stores (slots 0 .. NHF - 1)
         f32x16 e8[8];
         f32x4 bwr[8], bd[4], av[4];
         auto zero8 = [&]() {
@@ -1671,8 +1714,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                     const int l = m >> 2, e = m & 3;
                     e8[l * 4 + f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(s2 & 1) * 2 + l][e], bwr[s2 & 7][e], e8[l * 4 + f], 0, 0, 0);
                     if (m == 0) {
-                        if (s2 + 4 < 16) bwr[(s2 + 4) & 7] = wload(wplane + ((s2 + 4) >> 2), chb, (s2 + 4) & 3);
-                        else wnext(s2 + 4 - 16);
+                        constexpr int L2 = PMX_WINO_WLEAD2;
+                        if (s2 + L2 < 16) bwr[(s2 + L2) & 7] = wload(wplane + ((s2 + L2) >> 2), chb, (s2 + L2) & 3);
+                        else wnext(s2 + L2 - 16);
                         __builtin_amdgcn_sched_barrier(0);
                     } else if ((m == 1 || m == 5) && s2 + 1 < 16) {
                         const int ln = m == 1 ? 0 : 1, fn = (s2 + 1) >> 2, sn = (s2 + 1) & 3;
@@ -1720,7 +1764,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                     for (int e = 0; e < 4; ++e) {
                         if (!UNIT) y[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[q & 3][e], bd[st][e], y[pp], 0, 0, 0);
                         if (e == 0) {
-                            if (q < 4) { bwr[q] = wload(PH + 0, chb, q); __builtin_amdgcn_sched_barrier(0); }
+                            if (q < PMX_WINO_WLEAD2) { bwr[q] = wload(PH + (q >> 2), chb, q & 3); __builtin_amdgcn_sched_barrier(0); }
                         } else if (e == 1) {
                             if (q + 2 < 16) {
                                 const int qn = q + 2, pn = qn & 3, sn = qn >> 2;
@@ -1752,13 +1796,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
             // tap-(6,6) weights
             phase8(s_u + 8 * 32 * C::LDU, PH + 4, chb,
                    [&](int s2n) {
-                       bd[s2n] = wload(PD, nxb, s2n);
-                       bwr[(s2n + 16) & 7] = wload(PV + 0, 0u, s2n);              // pass 2b's first weights (used after the last chunk)
+                       if (s2n < 4) bd[s2n] = wload(PD, nxb, s2n);
+                       bwr[(s2n + 16) & 7] = wload(PV + (s2n >> 2), 0u, s2n & 3);  // pass 2b's first weights (used after the last chunk)
                    },
                    [&](int t) {
                        if (t < C::NHF) { halo_store_slot(hreg, t); __builtin_amdgcn_sched_barrier(0); }
-                       else if (t == 20) { __syncthreads(); __builtin_amdgcn_sched_barrier(0); }
-                       else if (t >= 22) side1d(t - 20, t_raw + (0 * C::HW + 6) * C::LDR, C::LDR, C::HW * C::LDR, u0);
+                       else if (t == HBAR) { __syncthreads(); __builtin_amdgcn_sched_barrier(0); }
+                       else if (t >= HBAR + 2) side1d(t - HBAR, t_raw + (0 * C::HW + 6) * C::LDR, C::LDR, C::HW * C::LDR, u0);
                    });
         }
         __syncthreads();                            // U half 0 = column-6 sub-kernel 0 of chunk 0
@@ -1783,7 +1827,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
             }
             halo_load(hreg, 0);
 #pragma unroll
-            for (int s2n = 0; s2n < 4; ++s2n) bwr[s2n] = wload(PV + 0, 0u, s2n);
+            for (int s2n = 0; s2n < PMX_WINO_WLEAD2; ++s2n) bwr[s2n] = wload(PV + (s2n >> 2), 0u, s2n & 3);
             halo_store(hreg);
             __syncthreads();
             if (nch > 1) {
@@ -1816,8 +1860,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                        [&](int s2n) { bwr[(s2n + 16) & 7] = wload(PV + 0 + (s2n >> 2), nxb, s2n & 3); },
                        [&](int t) {
                            if (t < C::NHF) { halo_store_slot(hreg, t); __builtin_amdgcn_sched_barrier(0); }
-                           else if (t == 20) { __syncthreads(); __builtin_amdgcn_sched_barrier(0); }
-                           else if (t >= 22) side1d(t - 20, t_raw + (0 * C::HW + 6) * C::LDR, C::LDR, C::HW * C::LDR, u0);
+                           else if (t == HBAR) { __syncthreads(); __builtin_amdgcn_sched_barrier(0); }
+                           else if (t >= HBAR + 2) side1d(t - HBAR, t_raw + (0 * C::HW + 6) * C::LDR, C::LDR, C::HW * C::LDR, u0);
                        });
             else
                 phase8(s_u + 8 * 32 * C::LDU, PV + 4, chb,
@@ -1825,7 +1869,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                        [&](int) {});
             __syncthreads();
         };
-        static_assert(C::NHF <= 20 && 28 + C::NHF <= 64, "halo slots");
+        static_assert(HBAR + 28 <= 64 && 28 + C::NHF <= 64, "halo slots");
         for (int ch = 0; ch < nch - 1; ++ch) p2b_chunk(std::true_type{}, ch);
         p2b_chunk(std::false_type{}, nch - 1);
         // y += A^T-transform of the column planes: e8[j * 4 + f]
@@ -1881,7 +1925,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     if (UNIT && GEOM) {
         // unit mode of a run (the part-filled last block of an image): compact slab [image][block of the launch][tile][pixel][cout_pad];
         // conv_wino_tail_reduce_kernel adds the units in order and drops the tiles past the end of the map
-        const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(G.out + (size_t)(bslab * a.run_nb + trem) * (32 * 4) * a.ldc, 0,
+        // (MERGE: bslab * 1 + 0 = the block of the stream)
+        const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(G.out + (size_t)(bslab * (MERGE ? 1 : a.run_nb) + trem) * (32 * 4) * a.ldc, 0,
                                                                                   (unsigned)(32 * 4 * ldc_b), 0x00020000);
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -2902,6 +2947,31 @@ static int launch_wino_run(const ConvArgs& a, int groups, hipStream_t stream)
     return a.W == 2 * PMX_WINO_RUN_TX ? launch_wino_run_g<KS, POOL, UNIT, 1>(a, groups, stream) : launch_wino_run_g<KS, POOL, UNIT, 2>(a, groups, stream);
 }
 
+template <int KS>
+static int launch_wino_merged(const ConvArgs& a0, int groups, hipStream_t stream)
+{
+    using C = WinoCfg<KS, 3>;
+    ConvArgs a = a0;
+    PMX_CHECK(wino_tail_mergeable(a.B, a.H, a.W) && a.run_j0 == C::RUN_TX * ((a.H + 1) / 2) / PMX_WINO_RUN_TILES, PMX_ERR_INVALID,
+              "conv wino merged tails: not a mergeable tail (B %d, %d x %d, full blocks %d)", a.B, a.H, a.W, a.run_j0);
+    PMX_CHECK(a.cout_pad % 128 == 0, PMX_ERR_INVALID, "conv wino: cout_pad %d not a multiple of 128", a.cout_pad);
+    PMX_CHECK((long long)a.B * a.H * a.W * a.lda * 4 < (1ll << 31), PMX_ERR_INVALID, "conv wino merged tails: batch too large for 32-bit offsets");
+    PMX_CHECK(a.ksplit >= 2 && a.ksplit <= 8 && a.kbounds >= 1, PMX_ERR_INVALID, "conv wino: bad unit plan");
+    a.run_nslab = 1; a.run_nb = wino_tail_merged_blocks(a.B, a.H); a.tiles_x = a.tiles_y = 0; a.ngroups = groups;
+    auto kern = conv_wino_kernel<KS, 0, 1, 3>;
+    static bool attr_set[PMX_MAX_DEVICES] = {};
+    if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(kern), attr_set)) return rc;
+    dim3 grid((unsigned)a.run_nb, (unsigned)(a.cout_pad / 128), (unsigned)(groups * a.ksplit));
+    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, a);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+int conv_wino_merged_tail_launch(const ConvArgs& a, int ks, int groups, hipStream_t stream)
+{
+    return ks == 7 ? launch_wino_merged<7>(a, groups, stream) : launch_wino_merged<3>(a, groups, stream);
+}
+
 int conv_wino_run_launch(const ConvArgs& a, int ks, int groups, hipStream_t stream)
 {
     if (a.ksplit > 1) return ks == 7 ? launch_wino_run<7, 0, 1>(a, groups, stream) : launch_wino_run<3, 0, 1>(a, groups, stream);      // (the combine pools)
@@ -2922,19 +2992,27 @@ __global__ __launch_bounds__(256) void conv_wino_tail_reduce_kernel(const WinoTa
     const int c4n = cout >> 2;
     // pooled layers: one thread per TILE (its four pixels are the pooling window), else one per pixel
     const int ppt = r.pool ? 1 : 4;
-    const long long total = (long long)r.B * r.nslab * r.run_nb * (PMX_WINO_RUN_TILES * ppt) * c4n;
+    const int nt = PMX_WINO_RUN_TX * ((r.H + 1) >> 1) - r.run_j0 * PMX_WINO_RUN_TILES;     // merged: tail tiles per image
+    const long long total = r.merged ? (long long)r.B * nt * ppt * c4n : (long long)r.B * r.nslab * r.run_nb * (PMX_WINO_RUN_TILES * ppt) * c4n;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int c = (int)(i % c4n) * 4;
     const long long q = i / c4n;                        // ((image-slab * run_nb + block) * 32 + tile) [* 4 + pixel]
     const int k = r.pool ? 0 : (int)(q & 3);
     const long long qt = r.pool ? q : q >> 2;           // (image-slab * run_nb + block) * 32 + tile
-    const int m = (int)(qt & (PMX_WINO_RUN_TILES - 1));
-    const long long bj = qt >> 5;
-    const int jl = (int)(bj % r.run_nb);
-    const long long bs = bj / r.run_nb;
-    const int b = (int)(bs / r.nslab), sx0 = (int)(bs % r.nslab) * (2 * PMX_WINO_RUN_TX);
-    const int t = (r.run_j0 + jl) * PMX_WINO_RUN_TILES + m, ty = t / PMX_WINO_RUN_TX, tx = t - ty * PMX_WINO_RUN_TX;
+    int b, sx0, t;
+    if (r.merged) {                                     // qt = stream position: image * nt + tail tile (= block of the stream * 32 + row)
+        b = (int)(qt / nt); sx0 = 0;
+        t = r.run_j0 * PMX_WINO_RUN_TILES + (int)(qt - (long long)b * nt);
+    } else {
+        const int m = (int)(qt & (PMX_WINO_RUN_TILES - 1));
+        const long long bj = qt >> 5;
+        const int jl = (int)(bj % r.run_nb);
+        const long long bs = bj / r.run_nb;
+        b = (int)(bs / r.nslab); sx0 = (int)(bs % r.nslab) * (2 * PMX_WINO_RUN_TX);
+        t = (r.run_j0 + jl) * PMX_WINO_RUN_TILES + m;
+    }
+    const int ty = t / PMX_WINO_RUN_TX, tx = t - ty * PMX_WINO_RUN_TX;
     float4 best;
     for (int kk = 0; kk < (r.pool ? 4 : 1); ++kk) {
         const int kq = r.pool ? kk : k;
@@ -2966,7 +3044,8 @@ int conv_wino_tail_reduce(const WinoTailReduceArgs& r, int groups, hipStream_t s
     PMX_CHECK(r.cout[0] % 4 == 0 && (groups < 2 || r.cout[1] == r.cout[0]) && r.ldc % 4 == 0 && r.ld_slab % 4 == 0, PMX_ERR_INVALID,
               "winograd tail reduce: channel counts / strides must be multiples of 4");
     static_assert(PMX_WINO_RUN_TILES == 32, "tile index bits");
-    const long long total = (long long)r.B * r.nslab * r.run_nb * (PMX_WINO_RUN_TILES * (r.pool ? 1 : 4)) * (r.cout[0] / 4);
+    const int nt = PMX_WINO_RUN_TX * ((r.H + 1) / 2) - r.run_j0 * PMX_WINO_RUN_TILES;
+    const long long total = (r.merged ? (long long)r.B * nt * (r.pool ? 1 : 4) : (long long)r.B * r.nslab * r.run_nb * (PMX_WINO_RUN_TILES * (r.pool ? 1 : 4))) * (r.cout[0] / 4);
     hipLaunchKernelGGL(conv_wino_tail_reduce_kernel, dim3((unsigned)((total + 255) / 256), 1, (unsigned)groups), dim3(256), 0, stream, r);
     PMX_HIP(hipGetLastError());
     return PMX_OK;

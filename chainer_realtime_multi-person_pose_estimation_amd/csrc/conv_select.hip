@@ -91,7 +91,10 @@ int wino_select(const WinoSelectOpts& o, int ks, int cin_pad, int cout_pad, int 
         struct Key { int ks, nch, forced; long long nblk, ncu; bool operator<(const Key& k) const { return std::tie(ks, nch, forced, nblk, ncu) < std::tie(k.ks, k.nch, k.forced, k.nblk, k.ncu); } };
         static std::mutex mu;
         static std::map<Key, std::pair<double, int>> memo;
-        const Key key{ks, nch, o.wino_tail_g, (long long)images * nslab * nb, ncu};
+        // (merged tails: the tail tiles of a group's images as one stream, 32 per block)
+        const int grp = std::max(1, o.groups);
+        const bool merge = o.wino_tail_merge != 0 && wino_tail_mergeable(images / grp, H, W);
+        const Key key{ks, nch, o.wino_tail_g, merge ? (long long)grp * wino_tail_merged_blocks(images / grp, H) * nb : (long long)images * nslab * nb, ncu};
         double best = 1e30;
         int best_g = 0;
         bool hit = false;

@@ -453,6 +453,7 @@ extern "C" int pmx_set_option(pmx_ctx* c, const char* key, int value)
     else if (!strcmp(key, "wino_geom")) c->opt_wino_geom = value;
     else if (!strcmp(key, "wino_tail")) c->opt_wino_tail = value;
     else if (!strcmp(key, "wino_tail_g")) c->opt_wino_tail_g = value;
+    else if (!strcmp(key, "wino_tail_merge")) c->opt_wino_tail_merge = value;
     else if (!strcmp(key, "ksplit")) c->opt_ksplit = value;
     else if (!strcmp(key, "ksplit_plan")) c->opt_ksplit = value > 0 ? -value : 0;     // decimal digits = chunks per slice, e.g. 3221
     else if (!strcmp(key, "conv_min_lds")) conv_set_min_lds(value);
@@ -634,6 +635,11 @@ static int launch_wino_units(pmx_ctx* c, const ConvArgs& a0, int ks, int groups,
 // kernel.  B = 32 at 46 x 46: 16 x 32 x 2 = 1024 full blocks = exactly 4 rounds of the 256 CUs, then 64 x 7 short unit blocks, instead of
 // 5 rounds of 18 x 32 x 2 rectangles.  tail_g = 0: every block (also the part-filled one) in the plain launch.
 struct WinoProf { std::string name; double flops, bytes, issued; };      // profile entry of the layer (null: not profiled)
+// the tails of all images of the launch as one stream of tiles, 32 per block (conv_wino_kernel<KS, 0, 1, 3>)?
+static bool wino_tail_merged(const pmx_ctx* c, const ConvArgs& a)
+{
+    return c->opt_wino_tail_merge != 0 && wino_tail_mergeable(a.B, a.H, a.W) && (long long)a.B * a.H * a.W * a.lda * 4 < (1ll << 31);
+}
 static int launch_wino_run(pmx_ctx* c, const ConvArgs& a0, int ks, int groups, int tail_g, const WinoProf* pf = nullptr)
 {
     const int ntiles = PMX_WINO_RUN_TX * ((a0.H + 1) / 2), nblk = (ntiles + PMX_WINO_RUN_TILES - 1) / PMX_WINO_RUN_TILES, nfull = ntiles / PMX_WINO_RUN_TILES;
@@ -666,7 +672,10 @@ static int launch_wino_run(pmx_ctx* c, const ConvArgs& a0, int ks, int groups, i
     PMX_CHECK(S >= 2 && S <= 8, PMX_ERR_INVALID, "winograd tail: %d slabs", S);
     PMX_CHECK(a0.cout_pad <= SK_ZERO_BIAS, PMX_ERR_INVALID, "split-K: cout_pad %d too large", a0.cout_pad);
     const int nslab = a0.W / (2 * PMX_WINO_RUN_TX);
-    const size_t slab = (size_t)a0.B * nslab * PMX_WINO_RUN_TILES * 4 * a0.cout_pad;      // one block per (image, slab): [image][slab][tile][pixel][cout_pad]
+    // merged: the tails of all images as one stream of tiles, 32 per block (46 x 46: 17 tiles per image -- every MFMA row a real tile)
+    const bool merged = wino_tail_merged(c, a0);
+    const size_t slab = merged ? (size_t)wino_tail_merged_blocks(a0.B, a0.H) * PMX_WINO_RUN_TILES * 4 * a0.cout_pad      // [block of the stream][tile][pixel][cout_pad]
+                               : (size_t)a0.B * nslab * PMX_WINO_RUN_TILES * 4 * a0.cout_pad;      // one block per (image, slab): [image][slab][tile][pixel][cout_pad]
     const size_t need = slab * S * groups;
     if (need > c->sk_floats) {
         PMX_HIP(hipStreamSynchronize(c->stream));
@@ -689,12 +698,12 @@ static int launch_wino_run(pmx_ctx* c, const ConvArgs& a0, int ks, int groups, i
     a.ldc = a0.cout_pad; a.relu = 0; a.pool = 0; a.ksplit = S; a.slab_stride = (long long)slab; a.kbounds = (unsigned long long)tail_g;
     a.run_j0 = nfull; a.run_nb = 1;
     r.slab_stride = (long long)slab; r.S = S; r.B = a0.B; r.H = a0.H; r.W = a0.W; r.ld_slab = a0.cout_pad; r.ldc = a0.ldc;
-    r.relu = a0.relu; r.run_j0 = nfull; r.run_nb = 1; r.nslab = nslab; r.pool = a0.pool;
+    r.relu = a0.relu; r.run_j0 = nfull; r.run_nb = 1; r.nslab = nslab; r.pool = a0.pool; r.merged = merged;
     // (profile mode 2 -- the dominant kernel only, inside timed regions -- leaves these two short launches without events: an event pair
     //  costs ~5 us of idle stream)
     const bool pf_all = pf && c->prof_on == 1;
     if (pf_all && (rc = prof_begin(c, pf->name + ":units", pf->flops * (1.0 - share), 0.0, pf->issued * (1.0 - share)))) return rc;
-    if ((rc = conv_wino_run_launch(a, ks, groups, c->stream))) return rc;
+    if ((rc = merged ? conv_wino_merged_tail_launch(a, ks, groups, c->stream) : conv_wino_run_launch(a, ks, groups, c->stream))) return rc;
     if (pf_all && (rc = prof_end(c))) return rc;
     if (pf_all && (rc = prof_begin(c, pf->name + ":combine", 0.0, 0.0, 0.0))) return rc;
     if ((rc = conv_wino_tail_reduce(r, groups, c->stream))) return rc;
@@ -704,12 +713,12 @@ static int launch_wino_run(pmx_ctx* c, const ConvArgs& a0, int ks, int groups, i
 // Which form a 3x3 / 7x7 layer takes (conv_select.hip): 0 = direct kernels (+ split-K), 1 = the Winograd kernel (*run: in the run geometry,
 // *tail_g > 0: its part-filled last blocks in unit mode), 2 = the Winograd kernel in unit mode (*unit_g = chunks per pass-1 unit)
 static int wino_mode(const pmx_ctx* c, int ks, int cin_pad, int cout_pad, int cout, int ldc, int images, int H, int W, int pool, int* unit_g,
-                     int* run, int* tail_g)
+                     int* run, int* tail_g, int groups = 1)
 {
     WinoSelectOpts o;
     o.conv_algo = c->opt_conv_algo; o.precision = c->opt_precision; o.forced_variant = c->opt_force[ks]; o.ksplit = c->opt_ksplit;
     o.wino_unit_eff = c->opt_wino_unit_eff; o.wino_min_fill = c->opt_wino_min_fill; o.wino_geom = c->opt_wino_geom; o.wino_tail = c->opt_wino_tail;
-    o.wino_tail_g = c->opt_wino_tail_g;
+    o.wino_tail_g = c->opt_wino_tail_g; o.wino_tail_merge = c->opt_wino_tail_merge; o.groups = groups;
     return wino_select(o, ks, cin_pad, cout_pad, cout, ldc, images, H, W, pool, unit_g, run, tail_g);
 }
 
@@ -743,7 +752,7 @@ static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float
     const bool wino_ok = wino_eligible(L0.ks, L0.cin_pad, L0.cout_pad) &&
                          (groups == 1 || (wino_eligible(c->layers[li1].ks, c->layers[li1].cin_pad, c->layers[li1].cout_pad) && c->layers[li1].cout == L0.cout));
     int ug = 0, wrun = 0, wtail = 0;
-    const int wmode = wino_ok ? wino_mode(c, L0.ks, L0.cin_pad, L0.cout_pad, L0.cout, ldc, B * groups, H, W, pool, &ug, &wrun, &wtail) : 0;
+    const int wmode = wino_ok ? wino_mode(c, L0.ks, L0.cin_pad, L0.cout_pad, L0.cout, ldc, B * groups, H, W, pool, &ug, &wrun, &wtail, groups) : 0;
     const bool wino_plain = wmode == 1;
     if (wmode && ((rc = ensure_wino_pack(c->layers[li0])) || (groups == 2 && (rc = ensure_wino_pack(c->layers[li1]))))) return rc;
     if (wmode == 2) {
@@ -767,7 +776,7 @@ static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float
             // "r": run geometry; "/t<g>": its part-filled last blocks in unit mode, g chunks per pass-1 unit (part of the arithmetic)
             std::string kn = L0.ks == 7 ? "|conv_wino_f2x2_7x7" : "|conv_wino_f2x2_3x3";
             if (wrun) kn += "r";
-            if (wtail) kn += "/t" + std::to_string(wtail);
+            if (wtail) kn += "/t" + std::to_string(wtail) + (wrun && wino_tail_merged(c, a) ? "m" : "");      // "m": merged tails
             // products per 2 x 2 output tile and channel pair: 3x3: 16 of 36; 7x7: 4 x 16 + 4 x 8 + 4 = 100 of 196
             const double issued = flops * (L0.ks == 7 ? 100.0 / 196.0 : 16.0 / 36.0);
             if (wrun) {

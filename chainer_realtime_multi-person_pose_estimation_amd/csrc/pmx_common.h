@@ -95,15 +95,32 @@ struct WinoTailReduceArgs {
     long long slab_stride;   // floats between the unit slabs of one group
     int S, B, H, W, ld_slab, ldc, relu, run_j0, run_nb;
     int nslab, pool;         // slabs per image; pool: 2x2 max over the tile's four pixels before the bias
+    int merged;              // 1: slabs of the merged-tail launch -- [unit][stream position b * nt + tail tile][pixel 4][ld_slab] (run_nb unused)
 };
+// Merged tails (conv_wino_kernel<KS, 0, 1, 3>): the part-filled last blocks of all images of a launch as one stream of tiles, 32 per block.
+// Possible when the tail lies in one tile row of a single-slab map and is long enough that a block meets at most three images.
+inline bool wino_tail_mergeable(int B, int H, int W)
+{
+    const int ntiles = PMX_WINO_RUN_TX * ((H + 1) / 2), t0 = ntiles / PMX_WINO_RUN_TILES * PMX_WINO_RUN_TILES, nt = ntiles - t0;
+    return B >= 2 && W == 2 * PMX_WINO_RUN_TX && nt >= 16 && t0 % PMX_WINO_RUN_TX + nt <= PMX_WINO_RUN_TX;
+}
+inline int wino_tail_merged_blocks(int B, int H)
+{
+    const int ntiles = PMX_WINO_RUN_TX * ((H + 1) / 2), nt = ntiles % PMX_WINO_RUN_TILES;
+    return (B * nt + PMX_WINO_RUN_TILES - 1) / PMX_WINO_RUN_TILES;
+}
 int conv_wino_tail_reduce(const WinoTailReduceArgs& r, int groups, hipStream_t stream);
 // launch of the run-geometry Winograd kernel (a.W % 46 == 0); a.ksplit > 1: unit mode writing compact slabs (see WinoTailReduceArgs)
 int conv_wino_run_launch(const ConvArgs& a, int ks, int groups, hipStream_t stream);
+// launch of the merged-tail kernel (unit mode; a.run_j0 = the number of full blocks per image; wino_tail_mergeable(a.B, a.H, a.W))
+int conv_wino_merged_tail_launch(const ConvArgs& a, int ks, int groups, hipStream_t stream);
 // start / stop events for the next conv_wino_run_launch of this thread (stamped by the dispatch itself: hipExtLaunchKernelGGL)
 void conv_set_launch_events(hipEvent_t e0, hipEvent_t e1);
 // ---- kernel selection for the 3x3 / 7x7 layers (conv_select.hip) ------------------------------------------------------------
 struct WinoSelectOpts {      // the context options the choice depends on (pmx_set_option keys of the same names)
     int conv_algo, precision, forced_variant, ksplit, wino_unit_eff, wino_min_fill, wino_geom, wino_tail, wino_tail_g;
+    int wino_tail_merge = 1;     // the tails of all images as one stream of tiles (0: one part-filled block per image)
+    int groups = 1;              // branch groups in the launch (`images` counts images x groups)
 };
 bool wino_eligible(int ks, int cin_pad, int cout_pad);
 // returns 0 = direct kernels (+ split-K), 1 = the Winograd kernel (*run = 1: run geometry; *tail_g > 0: chunks per pass-1 unit of its

@@ -104,6 +104,7 @@ struct pmx_ctx {
                                      // of every other map size (same bits either way)
     int opt_wino_tail = -1;          // run geometry: the part-filled last block of every image in unit mode (K units + combine) -- -1 by the cost
                                      // model (conv_algo 1), 0 never, 1 wherever a unit plan exists.  Changes the summation of those tiles (C twin: unit_from)
+    int opt_wino_tail_merge = 1;     // the tails of all images of a launch as one stream of tiles, 32 per block (0: one part-filled block per image)
     int opt_wino_tail_g = 0;         // tuning: chunks per pass-1 unit of the tail (0 = automatic)
     int opt_precision = 0;           // 0: fp32 MFMA everywhere (the path whose results are specified); 1: bf16x3 kernels where a
                                      // v6 kernel would run (fp32-grade accuracy at 2.67x the matrix rate, NOT the fp32 FMA chain)

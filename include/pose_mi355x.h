@@ -118,6 +118,9 @@ int pmx_synchronize(pmx_ctx* ctx);                    /* cuda.get_device_from_id
  *                              0 never, 1 wherever a unit plan exists.  The tiles of that block (row-major index >= 32 * full blocks)
  *                              are then summed unit by unit (C twin: `unit_from`); profile label "...r/t<chunks per unit>"
  *   "wino_tail_g" n            tuning: chunks per pass-1 unit of those tails (0 = automatic)
+ *   "wino_tail_merge" 1 | 0    batches of 46-wide maps whose tail lies in one tile row (46 x 46: 17 tiles per image): 1 (default) = the
+ *                              tails of all images of the launch as one stream of tiles, 32 per block (every MFMA row a real tile);
+ *                              0 = one part-filled block per image.  Same units, same bits; profile label "...r/t<g>m"
  *   "precision" 0 | 1          0 (default): every convolution is the fp32 FMA chain the parity tests specify.  1: the 3x3 / 7x7
  *                              layers that run on the one-block-per-CU kernels use the bf16 matrix cores with every fp32 value
  *                              split into three bf16 terms (six products, fp32 accumulate): fp32-grade accuracy, 2.67x the

@@ -147,6 +147,59 @@ def test_winograd_run_tail_in_unit_mode_bit_exact_vs_c_twin(engine, B, cin, H, W
     assert np.abs(y - t).max() <= TOL * max(1.0, np.abs(t).max())
 
 
+@pytest.mark.parametrize('B,cin,H,cout,k,relu', [
+    (2, 128, 46, 128, 7, True),        # 34 tail tiles: a block of 17 + 15 tiles, one of 2
+    (5, 192, 46, 128, 7, True),        # 85 tiles: blocks 17 + 15 | 2 + 17 + 13 (three images in one block) | 4 + 17 (part-filled)
+    (3, 64, 38, 256, 7, False),        # 19 tile rows: 21 tail tiles per image; two 128-channel blocks
+    (6, 64, 45, 128, 7, True),         # odd H (the last tile row is half outside the map)
+    (4, 256, 46, 128, 3, True),        # conv4_4
+    (7, 64, 24, 132, 3, True)])        # 20 tail tiles per image, cout padded to 256
+def test_winograd_merged_tails_bit_exact_vs_c_twin(engine, B, cin, H, cout, k, relu):
+    """Batches: the part-filled last blocks of all images run as ONE stream of tiles, 32 per block (conv_wino_kernel<KS, 0, 1, 3>:
+    up to three images' segments side by side in a block) instead of one part-filled block per image.  Same units, same chains: the
+    output equals the per-image form (option wino_tail_merge = 0) and the twin bit for bit."""
+    W = 46
+    x, w, b = _data(13 * B + cin + H + k, B, cin, H, W, cout, k)
+    nch = (cin + 31) // 32
+    g = -(-nch // (8 - (3 if k == 7 else 0)))
+    engine.set_option('wino_tail', 1)
+    try:
+        y = _run(engine, x, w, b, relu, False, 2)
+        engine.set_option('wino_tail_merge', 0)
+        y_img = _run(engine, x, w, b, relu, False, 2)
+    finally:
+        engine.set_option('wino_tail_merge', 1)
+        engine.set_option('wino_tail', -1)
+    uf = R.wino_run_unit_from(H, W)
+    ntiles = 23 * ((H + 1) // 2)
+    assert 16 <= ntiles - uf <= 23 and uf % 23 + (ntiles - uf) == 23, 'not a mergeable tail: the test would compare the per-image form with itself'
+    ref = R.conv_wino(x, w, b, relu, False, unit_g=g, unit_from=uf)
+    assert np.array_equal(y_img, ref), (np.abs(y_img - ref).max(), int((y_img != ref).sum()))
+    assert np.array_equal(y, ref), (np.abs(y - ref).max(), int((y != ref).sum()), np.argwhere(y != ref)[:8].tolist())
+
+
+def test_two_images_368_merged_tails_bit_exact(native):
+    """Two 368x368 images through the whole network, plain Winograd kernel forced on every eligible layer, tails in unit mode: the
+    46x46 layers take the merged-tail launch (profile labels ".../t<g>m") and forward_fma with that plan reproduces both images' maps
+    bit for bit."""
+    weights = pkg('weights').synthetic_weights(0)
+    eng = native.Engine(0, max_batch=2, max_h=368, max_w=368)
+    eng.set_weights(weights)
+    imgs = np.random.default_rng(23).integers(0, 256, (2, 368, 368, 3), dtype=np.uint8)
+    eng.set_option('conv_algo', 2)
+    eng.set_option('wino_tail', 1)
+    eng.profile_enable(True); eng.forward_u8(imgs); prof = eng.profile(); eng.profile_enable(False)
+    paf, heat = eng.get_maps()
+    eng.close()
+    import re
+    merged = {e['layer'] for e in prof if re.search(r'/t\d+m', e['kernel'])}
+    assert 'Mconv3_stage4' in merged and 'conv4_2' in merged and 'conv3_2' not in merged and len(merged) >= 30, sorted(merged)
+    plan = R.splitk_plan(prof)
+    x = np.stack([P.preprocess(im)[0] for im in imgs])
+    rpaf, rheat = R.forward_fma(weights, x, splitk=plan)
+    assert np.array_equal(paf, rpaf) and np.array_equal(heat, rheat), (np.abs(paf - rpaf).max(), np.abs(heat - rheat).max())
+
+
 def test_single_image_368_runs_and_tails_bit_exact(native):
     """One 368x368 image with the plain Winograd kernel forced on every eligible layer and the tails in unit mode: the 46x46 layers
     (conv4_x, conv5_x, all 7x7 layers) and the 92- / 184-wide ones of the stem (two / four slabs) take the run geometry (labels

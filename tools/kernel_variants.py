@@ -1,0 +1,79 @@
+#!/usr/bin/env python
+"""A/B builds of the convolution kernels: conv_mfma.hip compiled with extra -D flags, linked with the product's other objects into
+tools/_build/libpose_var_<tag>.so (the product library is untouched), and timed through the whole network with the layer profile on.
+
+    python tools/kernel_variants.py build base: lead12:PMX_WINO_WLEAD1=12 lead12_6:PMX_WINO_WLEAD1=12,PMX_WINO_WLEAD2=6      (here: hipcc cross-compiles)
+    python tools/kernel_variants.py time [--steps 5] [--json out.json]                                                     (on the GPU box)
+"""
+import glob, importlib, json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = 'chainer_realtime_multi-person_pose_estimation_amd'
+OUT = os.path.join(ROOT, 'tools', '_build')
+
+
+def build(specs):
+    native = importlib.import_module(PKG + '.native')
+    native.build()
+    os.makedirs(OUT, exist_ok=True)
+    for spec in specs:
+        tag, _, defs = spec.partition(':')
+        flags = ['-D' + d for d in defs.split(',') if d]
+        objs = []
+        for src, extra in native.SOURCES:
+            if src == 'conv_mfma.hip':
+                o = os.path.join(OUT, 'conv_mfma.var_%s.o' % tag)
+                subprocess.check_call([native._hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + flags + extra +
+                                      ['-c', os.path.join(native.CSRC, src), '-o', o], cwd=native.CSRC)
+            else:
+                o = os.path.join(native.CSRC, src.replace('.hip', '.o'))
+            objs.append(o)
+        lib = os.path.join(OUT, 'libpose_var_%s.so' % tag)
+        subprocess.check_call([native._hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs)
+        print('built', lib, ' '.join(flags))
+
+
+def group(layer, kernel):
+    if kernel.endswith(':units') or kernel.endswith(':combine'):
+        return 'tails'
+    if '7x7' in kernel:
+        return '7x7 main'
+    if 'f2x2_3x3' in kernel:
+        return '3x3 main'
+    if kernel.startswith('pp_'):
+        return 'post-process'
+    return 'other'
+
+
+def time_all(steps, out_json):
+    res = {}
+    for lib in sorted(glob.glob(os.path.join(OUT, 'libpose_var_*.so'))):
+        tag = os.path.basename(lib)[len('libpose_var_'):-3]
+        pj = os.path.join('/tmp', 'var_%s.json' % tag)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'profile_driver.py'), '--lib', lib, '--batch', '32', '--steps', str(steps),
+                            '--profile-json', pj], capture_output=True, text=True, timeout=300)
+        if r.returncode:
+            print(tag, 'FAILED', r.stderr[-400:]); continue
+        d = json.load(open(pj))
+        g = {}
+        for e in d['entries']:
+            k = group(e['layer'], e['kernel'])
+            g[k] = g.get(k, 0.0) + e['avg_ms']
+        g['sum'] = sum(g.values())
+        res[tag] = g
+        print('%-16s' % tag, ' '.join('%s %.3f' % kv for kv in sorted(g.items())), '|', r.stdout.strip().splitlines()[-2])
+        sys.stdout.flush()
+    if out_json:
+        json.dump(res, open(out_json, 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'build':
+        build(sys.argv[2:])
+    elif len(sys.argv) > 1 and sys.argv[1] == 'time':
+        import argparse
+        ap = argparse.ArgumentParser(); ap.add_argument('cmd'); ap.add_argument('--steps', type=int, default=5); ap.add_argument('--json', default=None)
+        a = ap.parse_args()
+        time_all(a.steps, a.json)
+    else:
+        print(__doc__)

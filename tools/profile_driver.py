@@ -25,9 +25,12 @@ ap.add_argument('--gen', type=int, default=0, help='kernel generation (0 = libra
 ap.add_argument('--profile-json', default=None)
 ap.add_argument('--precision', type=int, default=0, help='1 = bf16x3 kernels where a v6 kernel would run')
 ap.add_argument('--algo', type=int, default=0, help='conv_algo option: 1 = Winograd F(2x2,3x3) for the 3x3 / 7x7 layers of large launches')
+ap.add_argument('--lib', default=None, help='load this build of the library instead of the product one (tools/kernel_variants.py)')
 ap.add_argument('--opt', action='append', default=[], help='engine option key=value (repeatable), e.g. --opt wino_geom=0')
 a = ap.parse_args()
 native = importlib.import_module(PKG + '.native')
+if a.lib:
+    native.LIB_PATH = os.path.abspath(a.lib)
 weights_mod = importlib.import_module(PKG + '.weights')
 B, S = a.batch, a.size
 eng = native.Engine(0, max_batch=B, max_h=S, max_w=S)
