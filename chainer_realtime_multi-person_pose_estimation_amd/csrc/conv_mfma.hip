@@ -1283,6 +1283,19 @@ extern "C" int pmx_debug_block_times(unsigned long long* out, size_t n)
 #ifndef PMX_WINO_WLEAD2
 #define PMX_WINO_WLEAD2 4
 #endif
+// Diagnostic builds only (tools/kernel_variants.py; the product library is built with 0): leave out parts of the phases' side work to see
+// what the matrix pipe waits for -- 1: the transform slots (LDS reads of the raw halo, B^T d B, U stores, halo staging), 2: the weight
+// loads, 4: the A-fragment LDS reads, 8: the barriers inside the phases; pass 1 only: 16: the raw-halo LDS reads of the transform, 32: its
+// VALU work, 64: its U stores, 128 / 256: the halo staging's LDS stores / global loads.  The results are wrong; only the launch time is read.
+#ifndef PMX_ABLATE
+#define PMX_ABLATE 0
+#endif
+#ifndef PMX_WINO_HOFF3
+#define PMX_WINO_HOFF3 0
+#endif
+#ifndef PMX_WINO_SOFF
+#define PMX_WINO_SOFF 1
+#endif
 static_assert(PMX_WINO_WLEAD1 >= 4 && PMX_WINO_WLEAD1 <= 15 && PMX_WINO_WLEAD2 >= 4 && PMX_WINO_WLEAD2 <= 7, "weight ring lead");
 template <int KS, int GEOM>
 struct WinoCfg {
@@ -1402,7 +1415,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     // outside the map: stays out of the buffer's range whatever chunk offset is added) and kept in registers -- recomputed per use, the
     // compiler hoisted a second copy of this arithmetic (20 slots x (mul_hi, mul_lo, mad, cmp)) to right in front of the first MFMA
     // (7x7 only: on the 3x3 instantiations the kept offsets measured slower -- conv3_3 +6 % -- than the compiler's own placement)
-    constexpr bool HOFF = (GEOM != 0 && KS == 7) || GEOM == 3;     // (merged tails: the per-slot segment arithmetic is never repeated)
+    constexpr bool HOFF = (GEOM != 0 && (KS == 7 || PMX_WINO_HOFF3)) || GEOM == 3;     // (merged tails: the per-slot segment arithmetic is never repeated)
     int h_off[HOFF ? C::NHF : 1];
     auto halo_off_calc = [&](int r) -> int {
         const unsigned hp = (unsigned)(tid >> 3) + 32u * r;
@@ -1426,7 +1439,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     auto halo_load_slot = [&](float4 (&hv)[C::NHF], int chunk, int r) {       // r is a compile-time constant at every call
         if constexpr (GEOM != 0) {
             const int off0 = HOFF ? h_off[HOFF ? r : 0] : halo_off_calc(r);
-            hv[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off0 + chunk * (C::CKW * 4), 0, 0));
+            // (the chunk's byte offset goes into the scalar offset, which the range check ignores: a pixel outside the image stays out of
+            //  range, a pixel inside it stays inside its own channel row -- one VALU add less per load)
+            if (PMX_WINO_SOFF) hv[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off0, chunk * (C::CKW * 4), 0));
+            else hv[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off0 + chunk * (C::CKW * 4), 0, 0));
         } else {
             hv[r] = *reinterpret_cast<const float4*>(in_b + h_goff[GEOM ? 0 : r] + chunk * C::CKW);
         }
@@ -1535,6 +1551,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
         }
     }
     __syncthreads();
+    // A fragments of the first two steps of the first phase; every phase requests those of the phase after it (steps 30, 31)
+    f32x4 av[4];
+    av[0] = *reinterpret_cast<const f32x4*>(&s_u[a_off]);
+    av[1] = *reinterpret_cast<const f32x4*>(&s_u[a_off + 8]);
 
     // one (chunk, sub-kernel) step = the two phases.  LAST (compile time): the last sub-kernel of a chunk, whose second phase transforms the
     // first window of the NEXT chunk -- the raw halo is replaced in between, spread over the free side slots so that the matrix pipe never
@@ -1562,9 +1582,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
             const int src = (r == 0 ? src_cur : src_nxt) + q * C::HW * C::LDR;      // d rows q .. q + 2
             float* const udst = s_u + (q * 8) * 32 * C::LDU + t_u;
             f32x4 dd[3][4], wv[2][4], vv;
-            f32x4 av[4];
-            av[0] = *reinterpret_cast<const f32x4*>(&s_u[(r * 8) * 32 * C::LDU + a_off]);
-            av[1] = *reinterpret_cast<const f32x4*>(&s_u[(r * 8) * 32 * C::LDU + a_off + 8]);
 #pragma unroll
             for (int s = 0; s < 32; ++s) {                              // step = (frequency r * 8 + s / 4, k8-step s % 4)
                 const int f = r * 8 + (s >> 2);
@@ -1577,18 +1594,26 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                         if (sn < 32) so = plane_b + (unsigned)(r * 8 + (sn >> 2)) * freq_b;
                         else if (r == 0) so = plane_b + (unsigned)(8 + ((sn - 32) >> 2)) * freq_b;
                         else so = nplane_b + (unsigned)((sn - 32) >> 2) * freq_b;
+                        if (!(PMX_ABLATE & 2))
                         bw[sn & 15] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off, so + (unsigned)(sn & 3) * st_b, 0));
+                        // THE barrier of the phase sits here, eight MFMAs before its end: U half q is complete (its last store is in slot
+                        // 39; LAST, r = 0: and the new raw halo, slot 40 + NHF - 1 <= 60), every wave has read all it needs of U half r (the
+                        // fragments of steps 30, 31 were requested at steps 28, 29).  The MFMAs that follow have their operands in
+                        // registers, and the next phase's first two fragments are requested behind it -- at the phase boundary itself
+                        // nothing waits (with the barrier there, the first MFMA of every phase waited for the barrier AND an LDS read)
+                        if (s == 30 && !(PMX_ABLATE & 8)) __syncthreads();
                         __builtin_amdgcn_sched_barrier(0);
-                    } else if (e == 1) {                                // A fragment of step s + 2
-                        if (s + 2 < 32) {
-                            const int fn = r * 8 + ((s + 2) >> 2), sn = (s + 2) & 3;
-                            av[(s + 2) & 3] = *reinterpret_cast<const f32x4*>(&s_u[fn * 32 * C::LDU + a_off + sn * 8]);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    } else {                                            // transform slot t
+                    } else if (e == 1) {                                // A fragment of step s + 2 (steps 30, 31: of the next phase's steps 0, 1)
+                        const int fn = s + 2 < 32 ? r * 8 + ((s + 2) >> 2) : q * 8, sn = (s + 2) & 3;
+                        if (!(PMX_ABLATE & 4))
+                        av[(s + 2) & 3] = *reinterpret_cast<const f32x4*>(&s_u[fn * 32 * C::LDU + a_off + sn * 8]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if (!(PMX_ABLATE & 1)) {                     // transform slot t
                         const int t = 2 * s + (e - 2);
                         if (t >= 2 && t < 14) {                         // 12 reads: d rows q .. q + 2, column by column
                             const int jx = (t - 2) / 3, ri = (t - 2) % 3;
+                            if (PMX_ABLATE & 16) asm volatile("" : "=v"(dd[ri][jx]));
+                            else
                             dd[ri][jx] = *reinterpret_cast<const f32x4*>(&s_raw[src + (ri * C::HW + jx) * C::LDR]);
                             __builtin_amdgcn_sched_barrier(0);
                         } else if (LAST && t == 14 && r == 0) {         // every wave has read what it needs of the old halo
@@ -1596,31 +1621,38 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                             __builtin_amdgcn_sched_barrier(0);
                         } else if (t >= 16 && t < 24) {                 // B^T d: q = 0: (d0 - d2, d1 + d2); q = 1: (d2 - d1, d1 - d3)
                             const int jx = (t - 16) >> 1, wi = (t - 16) & 1;
-                            if (q == 0) wv[wi][jx] = wi == 0 ? pk_sub4(dd[0][jx], dd[2][jx]) : pk_add4(dd[1][jx], dd[2][jx]);
+                            if (PMX_ABLATE & 32) asm volatile("" : "=v"(wv[wi][jx]));
+                            else if (q == 0) wv[wi][jx] = wi == 0 ? pk_sub4(dd[0][jx], dd[2][jx]) : pk_add4(dd[1][jx], dd[2][jx]);
                             else wv[wi][jx] = wi == 0 ? pk_sub4(dd[1][jx], dd[0][jx]) : pk_sub4(dd[0][jx], dd[2][jx]);
                             __builtin_amdgcn_sched_barrier(0);
                         } else if (t >= 24 && t < 40) {                 // (.) B, one column per two slots: compute, store
                             const int pidx = (t - 24) >> 1, il = pidx >> 2, jv = pidx & 3;
                             if (((t - 24) & 1) == 0) {
+                                if (PMX_ABLATE & 32) asm volatile("" : "=v"(vv));
+                                else
                                 vv = jv == 0 ? pk_sub4(wv[il][0], wv[il][2]) : jv == 1 ? pk_add4(wv[il][1], wv[il][2]) : jv == 2 ? pk_sub4(wv[il][2], wv[il][1]) : pk_sub4(wv[il][1], wv[il][3]);
+                            } else if (PMX_ABLATE & 64) {
+                                asm volatile("" :: "v"(vv));
                             } else {
                                 *reinterpret_cast<f32x4*>(&udst[(4 * il + jv) * 32 * C::LDU]) = vv;
                             }
                             __builtin_amdgcn_sched_barrier(0);
-                        } else if (LAST && t >= 40 && t < 40 + C::NHF) { // the halo of the next chunk -> LDS (r = 0) / of the one after it -> registers
+                        } else if (LAST && ((t >= 40 && t < 40 + (C::NHF < 20 ? C::NHF : 20)) || (C::NHF > 20 && t == 15))) {
+                            // the halo of the next chunk -> LDS (r = 0) / of the one after it -> registers: slots 40 .. 59 (before the
+                            // phase's barrier in step 30), a 21st staging slot (merged tails, 7x7) in slot 15 right behind the barrier
+                            const int hs = t == 15 ? 20 : t - 40;       // (a constant once the loops are unrolled)
                             if (repl) {
-                                if (r == 0) halo_store_slot(hreg, t - 40);
-                                else halo_load_slot(hreg, cn, t - 40);
+                                if (r == 0) { if (!(PMX_ABLATE & 128)) halo_store_slot(hreg, hs); }
+                                else if (!(PMX_ABLATE & 256)) halo_load_slot(hreg, cn, hs);
                             }
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
                 }
             }
-            __syncthreads();            // U half q is complete, U half r is free (LAST, r = 0: and the new raw halo is in place)
         }
     };
-    static_assert(40 + C::NHF <= 64, "halo slots");
+    static_assert(C::NHF <= 21, "halo slots");
     PMX_T(2);
     for (int ch = c0; ch < c1; ++ch) {
         const bool more = ch + 1 < c1;
@@ -1715,14 +1747,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                     e8[l * 4 + f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(s2 & 1) * 2 + l][e], bwr[s2 & 7][e], e8[l * 4 + f], 0, 0, 0);
                     if (m == 0) {
                         constexpr int L2 = PMX_WINO_WLEAD2;
-                        if (s2 + L2 < 16) bwr[(s2 + L2) & 7] = wload(wplane + ((s2 + L2) >> 2), chb, (s2 + L2) & 3);
+                        if (PMX_ABLATE & 2) {}
+                        else if (s2 + L2 < 16) bwr[(s2 + L2) & 7] = wload(wplane + ((s2 + L2) >> 2), chb, (s2 + L2) & 3);
                         else wnext(s2 + L2 - 16);
                         __builtin_amdgcn_sched_barrier(0);
                     } else if ((m == 1 || m == 5) && s2 + 1 < 16) {
                         const int ln = m == 1 ? 0 : 1, fn = (s2 + 1) >> 2, sn = (s2 + 1) & 3;
+                        if (!(PMX_ABLATE & 4))
                         av[((s2 + 1) & 1) * 2 + ln] = *reinterpret_cast<const f32x4*>(&ub[(ln * 4 + fn) * 32 * C::LDU + a_off + sn * 8]);
                         __builtin_amdgcn_sched_barrier(0);
-                    } else if (m == 2 || m == 3 || m == 6 || m == 7) {
+                    } else if ((m == 2 || m == 3 || m == 6 || m == 7) && !(PMX_ABLATE & 1)) {
                         side(4 * s2 + (m < 4 ? m - 2 : m - 4));
                     }
                 }

@@ -4,6 +4,7 @@ tools/_build/libpose_var_<tag>.so (the product library is untouched), and timed 
 
     python tools/kernel_variants.py build base: lead12:PMX_WINO_WLEAD1=12 lead12_6:PMX_WINO_WLEAD1=12,PMX_WINO_WLEAD2=6      (here: hipcc cross-compiles)
     python tools/kernel_variants.py time [--steps 5] [--json out.json]                                                     (on the GPU box)
+    python tools/kernel_variants.py time-conv [--iters 5] [--json out.json]            (GPU box: single layers through pmx_conv2d -- ablation builds)
 """
 import glob, importlib, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -67,9 +68,47 @@ def time_all(steps, out_json):
         json.dump(res, open(out_json, 'w'), indent=1)
 
 
+def time_conv(iters, out_json):
+    """Per-layer timing through pmx_conv2d (no post-process: also for ablation builds whose results are wrong)."""
+    code = r'''
+import importlib, json, sys, numpy as np
+sys.path.insert(0, %r)
+native = importlib.import_module(%r + '.native')
+native.LIB_PATH = sys.argv[1]
+eng = native.Engine(0, max_batch=64, max_h=368, max_w=368)
+eng.set_option('conv_algo', 1)
+rng = np.random.default_rng(0)
+res = {}
+for name, (B, cin, hw, cout, k, pool) in {'7x7_128_46': (64, 128, 46, 128, 7, 0), '7x7_192_46': (64, 192, 46, 128, 7, 0), 'conv2_2': (32, 128, 184, 128, 3, 1),
+                                           'conv3_2': (32, 256, 92, 256, 3, 0), 'conv2_1': (32, 64, 184, 128, 3, 0), 'conv4_2': (32, 512, 46, 512, 3, 0)}.items():
+    x = np.maximum(rng.standard_normal((B, cin, hw, hw)), 0).astype('f')
+    w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype('f')
+    b = rng.standard_normal(cout).astype('f')
+    y, ms = eng.conv2d(x, w, b, relu=True, pool=bool(pool), iters=int(sys.argv[2]))
+    res[name] = ms
+print(json.dumps(res))
+''' % (ROOT, PKG)
+    res = {}
+    for lib in sorted(glob.glob(os.path.join(OUT, 'libpose_var_*.so'))):
+        tag = os.path.basename(lib)[len('libpose_var_'):-3]
+        r = subprocess.run([sys.executable, '-c', code, lib, str(iters)], capture_output=True, text=True, timeout=300)
+        if r.returncode:
+            print(tag, 'FAILED', r.stderr[-400:]); continue
+        res[tag] = json.loads(r.stdout.strip().splitlines()[-1])
+        print('%-12s' % tag, ' '.join('%s %.4f' % kv for kv in res[tag].items()))
+        sys.stdout.flush()
+    if out_json:
+        json.dump(res, open(out_json, 'w'), indent=1)
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'build':
         build(sys.argv[2:])
+    elif len(sys.argv) > 1 and sys.argv[1] == 'time-conv':
+        import argparse
+        ap = argparse.ArgumentParser(); ap.add_argument('cmd'); ap.add_argument('--iters', type=int, default=5); ap.add_argument('--json', default=None)
+        a = ap.parse_args()
+        time_conv(a.iters, a.json)
     elif len(sys.argv) > 1 and sys.argv[1] == 'time':
         import argparse
         ap = argparse.ArgumentParser(); ap.add_argument('cmd'); ap.add_argument('--steps', type=int, default=5); ap.add_argument('--json', default=None)
