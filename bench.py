@@ -49,13 +49,13 @@ def rocprof_kernel(label):
     """HIP kernel (as rocprofv3 --kernel-trace names it) behind an engine profile label -- the key the live HIP-event figures and
     the committed rocprofv3 / PMC summaries share.  Labels: csrc/pmx_api.hip::run_conv."""
     import re
-    m = re.match(r'conv_wino_f2x2_(\d)x\d(r?)(/[ut]\d+)?(:units|:combine)?$', label)
+    m = re.match(r'conv_wino_f2x2_(\d)x\d(r?)(/[ut]\d+m?)?(:units|:combine)?$', label)      # ".../t<g>m": merged tails
     if m:
         ks, run, plan, part = m.group(1), m.group(2), m.group(3) or '', m.group(4) or ''
         if part == ':combine':
             return 'conv_wino_tail_reduce_kernel'
         if part == ':units':
-            return 'conv_wino_kernel<%s, 0, 1, 1>' % ks                     # <KS, POOL, UNIT, GEOM>
+            return 'conv_wino_kernel<%s, 0, 1, %d>' % (ks, 3 if plan.endswith('m') else 1)      # <KS, POOL, UNIT, GEOM>
         if plan.startswith('/u'):
             return 'conv_wino_kernel<%s, 0, 1, 0>' % ks                     # (+ conv_splitk_reduce_kernel inside the same event pair)
         return 'conv_wino_kernel<%s, 0, 0, %d>' % (ks, 1 if run else 0)     # (the pooled 3x3 layers are <3, 1, 0, 0>)

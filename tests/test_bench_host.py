@@ -14,6 +14,9 @@ def test_profile_labels_map_to_hip_kernels():
     m = bench.rocprof_kernel
     assert m('conv_wino_f2x2_7x7r/t2') == m('conv_wino_f2x2_7x7r/t3') == m('conv_wino_f2x2_7x7r') == 'conv_wino_kernel<7, 0, 0, 1>'
     assert m('conv_wino_f2x2_7x7r/t2:units') == 'conv_wino_kernel<7, 0, 1, 1>'
+    # merged tails (label ".../t<g>m"): the full runs are the same kernel, the units the merged-tail instantiation
+    assert m('conv_wino_f2x2_7x7r/t1m') == m('conv_wino_f2x2_7x7r/t2m') == 'conv_wino_kernel<7, 0, 0, 1>'
+    assert m('conv_wino_f2x2_7x7r/t1m:units') == 'conv_wino_kernel<7, 0, 1, 3>' and m('conv_wino_f2x2_3x3r/t6m:combine') == 'conv_wino_tail_reduce_kernel'
     assert m('conv_wino_f2x2_3x3r/t8:combine') == 'conv_wino_tail_reduce_kernel'
     assert m('conv_wino_f2x2_7x7/u1') == 'conv_wino_kernel<7, 0, 1, 0>'
     assert m('conv_wino_f2x2_3x3') == 'conv_wino_kernel<3, 0, 0, 0>'
