@@ -39,12 +39,13 @@ def run_census(frames=512, batch=32, size=368, seed0=7000, bf16x3=False, threads
         from bench import usable_cores          # (min of os.cpu_count, the affinity mask and the cgroup CPU quota)
         threads = min(usable_cores(), 32)
     torch.set_num_threads(threads)
-    S, B = size, batch
-    map_s = 320 if S == 368 else (S * 320) // 368 // 8 * 8
-    eng = native.Engine(0, max_batch=B, max_h=S, max_w=S)
+    SH, SW = (size, size) if isinstance(size, int) else size         # network input height, width (368 x 496: the 46 x 62 maps of a 4:3 frame)
+    B = batch
+    map_h, map_w = (320 if SH == 368 else (SH * 320) // 368 // 8 * 8), (320 if SW == 368 else (SW * 320) // 368 // 8 * 8)
+    eng = native.Engine(0, max_batch=B, max_h=SH, max_w=SW)
     w = weights_mod.synthetic_weights(0)
     eng.set_weights(w)
-    cal = np.random.default_rng(1234).integers(0, 256, (1, S, S, 3), dtype=np.uint8)     # as bench.py
+    cal = np.random.default_rng(1234).integers(0, 256, (1, SH, SW, 3), dtype=np.uint8)     # as bench.py
     eng.forward_u8(cal)
     paf, heat = eng.get_maps()
     w = weights_mod.calibrate_head(w, paf[0], heat[0])
@@ -55,18 +56,18 @@ def run_census(frames=512, batch=32, size=368, seed0=7000, bf16x3=False, threads
     t_gpu = t_cpu = 0.0
     nb = (frames + B - 1) // B
     for it in range(nb):
-        imgs = np.random.default_rng(seed0 + it).integers(0, 256, (B, S, S, 3), dtype=np.uint8)
+        imgs = np.random.default_rng(seed0 + it).integers(0, 256, (B, SH, SW, 3), dtype=np.uint8)
         t0 = time.perf_counter()
         oracle = []
         for i in range(B):
             opaf, oheat = network_ref.forward(w, postprocess_ref.preprocess(imgs[i]))
-            o = postprocess_ref.postprocess_from_net_output(opaf[0], oheat[0], map_s, map_s)
+            o = postprocess_ref.postprocess_from_net_output(opaf[0], oheat[0], map_h, map_w)
             oracle.append(dict({k: o[k] for k in ('all_peaks', 'poses', 'scores', 'smoothed', 'connections')}, paf_lo=opaf[0]))
         t_cpu += time.perf_counter() - t0
         for name, prec in modes:
             eng.set_option('precision', prec)
             t0 = time.perf_counter()
-            eng.detect_batch(imgs, map_s, map_s)
+            eng.detect_batch(imgs, map_h, map_w)
             rec = eng.results()
             t_gpu += time.perf_counter() - t0
             assert int(np.bitwise_or.reduce(rec['status'])) == 0, 'status bits set'
@@ -84,7 +85,7 @@ def run_census(frames=512, batch=32, size=368, seed0=7000, bf16x3=False, threads
                         maps_cache[name] = eng.get_maps()
                     f['connection_mismatches'] = census.compare_connections(
                         eng.connections(i), np.concatenate([np.column_stack([np.full(len(c_), l), c_]) for l, c_ in enumerate(oracle[i]['connections'])] or [np.zeros((0, 4))]),
-                        oracle[i]['all_peaks'], maps_cache[name][0][i], oracle[i]['paf_lo'], map_s, map_s, map_s)
+                        oracle[i]['all_peaks'], maps_cache[name][0][i], oracle[i]['paf_lo'], map_h, map_w, map_w)
                 f['frame'] = it * B + i
                 f['seed'] = seed0 + it
                 per_mode[name].append(f)
@@ -95,7 +96,7 @@ def run_census(frames=512, batch=32, size=368, seed0=7000, bf16x3=False, threads
                 '%s: %d identical, %d mismatching peaks' % (nm, sum(1 for f in fr if f['identical_peaks'] and f['identical_poses']),
                                                          sum(len(f['mismatches']) for f in fr)) for nm, fr in per_mode.items())))
     eng.close()
-    out = {'workload': 'batch%d_%dx%d_synthetic_uint8 (bench.py weights: seeded He + calibrated head), seeds %d..%d' % (B, S, S, seed0, seed0 + nb - 1),
+    out = {'workload': 'batch%d_%dx%d_synthetic_uint8 (bench.py weights: seeded He + calibrated head), seeds %d..%d' % (B, SH, SW, seed0, seed0 + nb - 1),
            'oracle': 'torch-CPU fp32 network restatement + NumPy restatement of the reference post-process (oracle/network_ref, postprocess_ref)',
            'decision': 'reference pose_detector.py:96-102: smoothed > 0.05 and > up, down, left, right (strict, float32); margin = min of the five differences',
            'seconds': {'gpu_paths': t_gpu, 'cpu_oracle': t_cpu}, 'paths': {}, 'mismatches': {}}
@@ -124,9 +125,11 @@ def main():
     ap.add_argument('--seed0', type=int, default=7000)
     ap.add_argument('--bf16x3', action='store_true')
     ap.add_argument('--threads', type=int, default=0)
+    ap.add_argument('--h', type=int, default=368, help='network input height (multiple of 8)')
+    ap.add_argument('--w', type=int, default=368, help='network input width: --h 368 --w 496 = the 46 x 62 maps of a 4:3 frame')
     ap.add_argument('--out', default=None)
     a = ap.parse_args()
-    out = run_census(a.frames, a.batch, 368, a.seed0, a.bf16x3, a.threads or None, log=lambda s: print(s, file=sys.stderr, flush=True))
+    out = run_census(a.frames, a.batch, (a.h, a.w), a.seed0, a.bf16x3, a.threads or None, log=lambda s: print(s, file=sys.stderr, flush=True))
     check(out)
     txt = json.dumps(out, indent=1)
     if a.out:
