@@ -1211,7 +1211,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_small_kernel(const ConvArg
 // U[plane][tile][channel] LDS buffer, every thread transforms its (tile, 4 channels) item of the raw halo for the next phase into the
 // other half, one LDS / VALU instruction per slot between two MFMAs; the transformed weights stream from L2 in a register ring 32 MFMAs
 // ahead (pinned with sched_barrier: left alone the compiler sinks the loads to one step ahead and the single wave per SIMD stalls on
-// L2); one s_barrier per phase.  Epilogue: A^T M A per lane (the 16 frequencies of a (tile, channel) sit in one lane's registers),
+// L2); one s_barrier per phase (eight MFMAs before its end: see p1_step).  Epilogue: A^T M A per lane (the 16 frequencies of a (tile, channel) sit in one lane's registers),
 // bias, ReLU, 2x2 max-pool = max over the tile's four outputs.
 // KS = 7 (the 7x7 layers of stages 2-6), 100 instead of 196 products per tile and channel pair: pass 1 -- the taps (0..5, 0..5) are four
 // 3x3 sub-kernels, each a Winograd product on its own shifted window, all four accumulated in the SAME frequency-domain accumulators
@@ -1559,7 +1559,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     // one (chunk, sub-kernel) step = the two phases.  LAST (compile time): the last sub-kernel of a chunk, whose second phase transforms the
     // first window of the NEXT chunk -- the raw halo is replaced in between, spread over the free side slots so that the matrix pipe never
     // waits for it: phase 0 reads the old halo in slots 2..13, then one barrier (slot 14: every wave is done with the old halo) and one
-    // ds_write_b128 of the new halo per slot from slot 40 on (the barrier that ends the phase publishes it); phase 1 issues one global
+    // ds_write_b128 of the new halo per slot from slot 40 on (the phase's barrier in step 30 publishes it); phase 1 issues one global
     // load of the chunk after next per slot from slot 40 on.  (Before: 10 / 20 stores + a barrier + the loads in one clump in slot 0 of
     // phase 1, exposed: +4 % per block with the 12 x 52 halo of the run geometry.)
     auto p1_step = [&](auto sub_c, int ch, bool more, unsigned chunk_b, unsigned next_b) {
