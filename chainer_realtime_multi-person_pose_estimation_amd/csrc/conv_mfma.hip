@@ -1487,8 +1487,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     // weight panels are [plane][chunk32][k8-step 4][cout_pad][8]: the 64 lanes of one fragment load (32 channels x 2 halves x 16 B)
     // read 1 KB of contiguous, fully used cache lines (with the channel-major [cout_pad][32] layout each load touched 32 lines and used a
     // quarter of each, relying on the 32 KB L1 to keep them for the next three k8-steps -- it did not: weight loads cost 7.5 %)
-    const unsigned b_off = (unsigned)((n * 8 + kh * 4) * 4);
-    const unsigned st_b = (unsigned)a.cout_pad * 8u * 4u;                  // bytes between the k8-steps of a panel
+    // (PMX_WINO_WLAYOUT 1: [plane][chunk32][cout_pad / 32][k8-step 4][32][8] -- the k8-steps of this wave's 32 channels are 1 KB apart: a
+    //  constant on the vector offset = the load's immediate offset, no scalar add per load)
+    const unsigned b_off = PMX_WINO_WLAYOUT ? (unsigned)(((n >> 5) * 1024 + (n & 31) * 8 + kh * 4) * 4) : (unsigned)((n * 8 + kh * 4) * 4);
+    const unsigned st_b = PMX_WINO_WLAYOUT ? 0u : (unsigned)a.cout_pad * 8u * 4u;      // bytes between the k8-steps of a panel (in the scalar offset)
+    constexpr unsigned st_v = PMX_WINO_WLAYOUT ? 1024u : 0u;                               // ... (in the vector offset)
     const unsigned panel_b = (unsigned)a.cout_pad * C::CKW * 4u;          // bytes of one (plane, chunk) panel
     const unsigned freq_b = panel_b * (unsigned)nch;                       // bytes between planes (sub-kernel * 16 + frequency)
 
@@ -1522,7 +1525,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     }
 #pragma unroll
     for (int st8 = 0; st8 < PMX_WINO_WLEAD1; ++st8)   // the first steps of the first phase: frequencies 0, 1, .. (x 4 k8-steps) of plane 0
-        bw[st8] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off, (unsigned)c0 * panel_b + (unsigned)(st8 >> 2) * freq_b + (unsigned)(st8 & 3) * st_b, 0));
+        bw[st8] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off + (unsigned)(st8 & 3) * st_v, (unsigned)c0 * panel_b + (unsigned)(st8 >> 2) * freq_b + (unsigned)(st8 & 3) * st_b, 0));
     __builtin_amdgcn_sched_barrier(0);
     zero_acc();
     __builtin_amdgcn_sched_barrier(0);
@@ -1595,7 +1598,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                         else if (r == 0) so = plane_b + (unsigned)(8 + ((sn - 32) >> 2)) * freq_b;
                         else so = nplane_b + (unsigned)((sn - 32) >> 2) * freq_b;
                         if (!(PMX_ABLATE & 2))
-                        bw[sn & 15] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off, so + (unsigned)(sn & 3) * st_b, 0));
+                        bw[sn & 15] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off + (unsigned)(sn & 3) * st_v, so + (unsigned)(sn & 3) * st_b, 0));
                         // THE barrier of the phase sits here, eight MFMAs before its end: U half q is complete (its last store is in slot
                         // 39; LAST, r = 0: and the new raw halo, slot 40 + NHF - 1 <= 60), every wave has read all it needs of U half r (the
                         // fragments of steps 30, 31 were requested at steps 28, 29).  The MFMAs that follow have their operands in
@@ -1713,7 +1716,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                 for (int r16 = 0; r16 < 16; ++r16) e8[pl][r16] = 0.f;
         };
         auto wload = [&](int plane, unsigned chb, int st) -> f32x4 {
-            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off, chb + (unsigned)plane * freq_b + (unsigned)st * st_b, 0));
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off + (unsigned)st * st_v, chb + (unsigned)plane * freq_b + (unsigned)st * st_b, 0));
         };
         // 1-D transform of this thread's (tile, 4 channels): two lines (output rows i for the row class, output columns j for the
         // column class) of 4 samples each -> (d0 - d2, d1 + d2, d2 - d1, d1 - d3), slot by slot

@@ -134,8 +134,11 @@ static void pack_wino(const std::vector<float>& wp, int ks, int nch16, int cout_
     auto tapw = [&](int ky, int kx, int n, int ci) -> double {
         return wp[(((size_t)(ky * ks + kx) * nch16 + ci / CK) * cout_pad + n) * CK + ci % CK];
     };
-    auto put = [&](int plane, int n, int ci, double v) {      // [plane][chunk32][k8-step][cout_pad][8]
-        out[((((size_t)plane * nch32 + ci / 32) * 4 + (ci % 32) / 8) * cout_pad + n) * 8 + ci % 8] = (float)v;
+    auto put = [&](int plane, int n, int ci, double v) {
+        if (PMX_WINO_WLAYOUT)      // [plane][chunk32][cout_pad / 32][k8-step][32][8]
+            out[(((((size_t)plane * nch32 + ci / 32) * (cout_pad / 32) + n / 32) * 4 + (ci % 32) / 8) * 32 + n % 32) * 8 + ci % 8] = (float)v;
+        else                       // [plane][chunk32][k8-step][cout_pad][8]
+            out[((((size_t)plane * nch32 + ci / 32) * 4 + (ci % 32) / 8) * cout_pad + n) * 8 + ci % 8] = (float)v;
     };
     for (int n = 0; n < cout_pad; ++n)
         for (int ci = 0; ci < cin_pad; ++ci) {

@@ -82,6 +82,12 @@ struct ConvArgs {
     int run_j0, run_nb;
     int run_nslab;           // slabs of 46 columns per image (W / 46)
 };
+// Transformed Winograd weights (pmx_api.hip::pack_wino -> conv_wino_kernel): 1 = [plane][chunk32][cout_pad / 32][k8-step 4][32][8] -- the four
+// k8-steps of a wave's 32 channels are 1 KB apart, an immediate offset of the load; 0 = [plane][chunk32][k8-step 4][cout_pad][8] (a scalar
+// add per load)
+#ifndef PMX_WINO_WLAYOUT
+#define PMX_WINO_WLAYOUT 1
+#endif
 // Winograd run geometry: tile columns of a 46-pixel-wide map / tiles per block
 #define PMX_WINO_RUN_TX 23
 #define PMX_WINO_RUN_TILES 32

@@ -22,8 +22,8 @@ def build(specs):
         flags = ['-D' + d for d in defs.split(',') if d]
         objs = []
         for src, extra in native.SOURCES:
-            if src == 'conv_mfma.hip':
-                o = os.path.join(OUT, 'conv_mfma.var_%s.o' % tag)
+            if src in ('conv_mfma.hip', 'pmx_api.hip'):      # (the kernels, and the host side that packs their weights)
+                o = os.path.join(OUT, '%s.var_%s.o' % (src[:-4], tag))
                 subprocess.check_call([native._hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + flags + extra +
                                       ['-c', os.path.join(native.CSRC, src), '-o', o], cwd=native.CSRC)
             else:
