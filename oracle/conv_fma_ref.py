@@ -63,6 +63,30 @@ def wino_run_unit_from(H, W):
     return ((H + 1) // 2) * RUN_TX // 32 * 32
 
 
+def wino_merged_tail_blocks(B, H, W, ks):
+    """Geometry of the merged-tail launch (csrc/conv_mfma.hip: GEOM 3; csrc/pmx_common.h::wino_tail_mergeable): the part-filled last
+    blocks of all B images as one stream -- image b's tail tile t sits at position b * nt + t, block j owns the positions [32 j, 32 j + 32).
+    Returns None when the tails are not mergeable (then every image keeps its own part-filled block), else a list of blocks, each a list of
+    segments (image, first tail tile, tiles, first halo column): a segment's halo is 2 * tiles + ks - 1 columns wide, the segments of a
+    block lie side by side.  The arithmetic per tile does not depend on this placement (conv_wino(unit_from=...) restates it)."""
+    ntiles = RUN_TX * ((H + 1) // 2)
+    t0 = ntiles // 32 * 32
+    nt = ntiles - t0
+    if not (B >= 2 and W == 2 * RUN_TX and nt >= 16 and t0 % RUN_TX + nt <= RUN_TX):
+        return None
+    blocks = []
+    for j in range((B * nt + 31) // 32):
+        segs, col, p = [], 0, 32 * j
+        while p < min(32 * j + 32, B * nt):
+            img, tt = divmod(p, nt)
+            n = min(nt - tt, 32 * j + 32 - p)
+            segs.append((img, tt, n, col))
+            col += 2 * n + ks - 1
+            p += n
+        blocks.append(segs)
+    return blocks
+
+
 def conv_wino(x, w, b, relu=False, pool=False, unit_g=0, unit_from=0, run_tx=None):
     """The Winograd F(2x2, 3x3) kernel's arithmetic (csrc/conv_mfma.hip::conv_wino_kernel, option "conv_algo"): same shapes as
     conv_fma, 3x3 or 7x7 (four 3x3 sub-kernels in the frequency domain + row 6 / column 6 as 1-D sub-kernels + tap (6, 6)).  Defined order, but not the direct

@@ -139,3 +139,32 @@ def test_launch_plan_from_profile_labels():
         t = torch.relu(torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=k // 2)).numpy()
         assert np.abs(y - t).max() <= 1e-5 * max(1.0, np.abs(t).max())
         assert not np.array_equal(y, R.conv_wino(x, w, b, relu=True)), 'the unit form is a different summation'
+
+
+def test_merged_tail_geometry_covers_every_tail_tile_once():
+    """The stream decomposition behind the merged-tail launch (csrc/conv_mfma.hip GEOM 3, restated in
+    conv_fma_ref.wino_merged_tail_blocks): every tail tile of every image in exactly one block row, at most three images per block, the
+    side-by-side halos within the 2 * 32 + 3 * (ks - 1) columns the kernel's LDS tile holds; maps whose tail wraps over two tile rows
+    or is shorter than 16 tiles are not merged."""
+    from oracle import conv_fma_ref as R
+    merge_h = set()
+    for ks in (3, 7):
+        for H in range(1, 70):
+            for B in (1, 2, 3, 5, 7, 31, 32, 33, 64):
+                blocks = R.wino_merged_tail_blocks(B, H, 46, ks)
+                ntiles = 23 * ((H + 1) // 2)
+                nt = ntiles % 32
+                if blocks is None:
+                    assert B < 2 or nt < 16 or (ntiles - nt) % 23 + nt > 23, (B, H)
+                    continue
+                merge_h.add(H)
+                seen = []
+                for segs in blocks:
+                    assert 1 <= len(segs) <= 3 and sum(n for _, _, n, _ in segs) <= 32
+                    assert segs[-1][3] + 2 * segs[-1][2] + ks - 1 <= 2 * 32 + 3 * (ks - 1)
+                    assert all(a[3] + 2 * a[2] + ks - 1 == b[3] for a, b in zip(segs, segs[1:]))          # side by side, no overlap
+                    seen += [(img, tt + i) for img, tt, n, _ in segs for i in range(n)]
+                assert seen == [(b, t) for b in range(B) for t in range(nt)]                                # stream order, each tile once
+                assert all(sum(n for _, _, n, _ in segs) == 32 for segs in blocks[:-1])                      # only the last block is part-filled
+    assert {45, 46, 37, 38, 23, 24, 51, 52} <= merge_h and 44 not in merge_h and 40 not in merge_h
+    assert [len(s) for s in R.wino_merged_tail_blocks(5, 46, 46, 7)] == [2, 3, 2]                            # 17 + 15 | 2 + 17 + 13 | 4 + 17
