@@ -1296,6 +1296,15 @@ extern "C" int pmx_debug_block_times(unsigned long long* out, size_t n)
 #ifndef PMX_WINO_SOFF
 #define PMX_WINO_SOFF 1
 #endif
+// The transform's packed adds in ONE gap per group (1) instead of two per gap (0, the default).  tools/mfma_gap_probe.hip
+// (profiles/r04_mfma_gap_probe.json): LDS reads, buffer loads and scalar instructions between two MFMAs of the single wave on a SIMD are
+// free, but a v_pk_add_f32 is not -- a gap that holds VALU work costs ~3.2 ns of matrix-pipe time once plus ~2.2 ns per instruction (2 in
+// every 2nd gap: 3.3 ns each, 8 in every 8th: 2.6 ns each).  In the kernel the clustered schedule (bit-identical, 60 Winograd tests) measured
+// +0.5 % on the 7x7 layers and -1.3 % on conv4_2 (profiles/r04_wino_ablation.json "vcluster"): the cluster waits for all twelve raw-halo
+// reads at once where the spread schedule waits for two -- not adopted
+#ifndef PMX_WINO_VCLUSTER
+#define PMX_WINO_VCLUSTER 0
+#endif
 static_assert(PMX_WINO_WLEAD1 >= 4 && PMX_WINO_WLEAD1 <= 15 && PMX_WINO_WLEAD2 >= 4 && PMX_WINO_WLEAD2 <= 7, "weight ring lead");
 template <int KS, int GEOM>
 struct WinoCfg {
@@ -1327,6 +1336,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     static_assert(!(UNIT && POOL), "unit mode: the combine kernel pools");
     static_assert(GEOM != 3 || UNIT, "merged tails run in unit mode");
     constexpr bool MERGE = GEOM == 3;
+    // the transform's packed adds clustered into one gap per group (PMX_WINO_VCLUSTER): the run-geometry and merged-tail forms only -- on
+    // the rectangle and multi-slab forms the register allocator answers the clusters with 3.4 KB of scratch per lane
+    constexpr bool VCL = PMX_WINO_VCLUSTER && (GEOM == 1 || GEOM == 3);
     // UNIT (single images: 36 blocks of a 46x46 7x7 layer cannot fill 256 CUs): blockIdx.z = unit * groups + group, and a block runs
     // ONE unit of the work -- unit u < nu1: pass 1 over the chunks [u g, u g + g) (g = a.kbounds); 7x7: unit nu1: row 6 (pass 2a without
     // tap (6, 6)); unit nu1 + 1: column 6 (pass 2b); unit nu1 + 2: tap (6, 6) -- and writes its untransformed share of y (no bias / ReLU) to slab `unit`; conv_splitk_reduce_kernel adds the slabs in unit order
@@ -1584,7 +1596,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
             const int q = r ^ 1;                                        // V row pair produced
             const int src = (r == 0 ? src_cur : src_nxt) + q * C::HW * C::LDR;      // d rows q .. q + 2
             float* const udst = s_u + (q * 8) * 32 * C::LDU + t_u;
-            f32x4 dd[3][4], wv[2][4], vv;
+            f32x4 dd[3][4], wv[2][4], vv, vvs[8];
 #pragma unroll
             for (int s = 0; s < 32; ++s) {                              // step = (frequency r * 8 + s / 4, k8-step s % 4)
                 const int f = r * 8 + (s >> 2);
@@ -1622,6 +1634,29 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                         } else if (LAST && t == 14 && r == 0) {         // every wave has read what it needs of the old halo
                             if (repl) __syncthreads();
                             __builtin_amdgcn_sched_barrier(0);
+                        } else if (VCL && (t == 16 || t == 24)) {
+                            // the 16 packed adds of B^T d (slot 16) / of (.) B (slot 24) in one gap each; the eight U stores follow one per slot
+#pragma unroll
+                            for (int k8 = 0; k8 < 8; ++k8) {
+                                if (t == 16) {
+                                    const int jx = k8 >> 1, wi = k8 & 1;
+                                    if (PMX_ABLATE & 32) asm volatile("" : "=v"(wv[wi][jx]));
+                                    else if (q == 0) wv[wi][jx] = wi == 0 ? pk_sub4(dd[0][jx], dd[2][jx]) : pk_add4(dd[1][jx], dd[2][jx]);
+                                    else wv[wi][jx] = wi == 0 ? pk_sub4(dd[1][jx], dd[0][jx]) : pk_sub4(dd[0][jx], dd[2][jx]);
+                                } else {
+                                    const int il = k8 >> 2, jv = k8 & 3;
+                                    if (PMX_ABLATE & 32) asm volatile("" : "=v"(vvs[k8]));
+                                    else vvs[k8] = jv == 0 ? pk_sub4(wv[il][0], wv[il][2]) : jv == 1 ? pk_add4(wv[il][1], wv[il][2]) : jv == 2 ? pk_sub4(wv[il][2], wv[il][1]) : pk_sub4(wv[il][1], wv[il][3]);
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        } else if (VCL && t >= 25 && t < 33) {
+                            const int k8 = t - 25, il = k8 >> 2, jv = k8 & 3;
+                            if (PMX_ABLATE & 64) asm volatile("" :: "v"(vvs[k8]));
+                            else *reinterpret_cast<f32x4*>(&udst[(4 * il + jv) * 32 * C::LDU]) = vvs[k8];
+                            __builtin_amdgcn_sched_barrier(0);
+                        } else if (VCL && t >= 16 && t < 40) {
+                            // (nothing: the spread schedule's slots)
                         } else if (t >= 16 && t < 24) {                 // B^T d: q = 0: (d0 - d2, d1 + d2); q = 1: (d2 - d1, d1 - d3)
                             const int jx = (t - 16) >> 1, wi = (t - 16) & 1;
                             if (PMX_ABLATE & 32) asm volatile("" : "=v"(wv[wi][jx]));
@@ -1726,7 +1761,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                 const int l = (t - 2) >> 2, c = (t - 2) & 3;
                 dd[l][c] = *reinterpret_cast<const f32x4*>(&s_raw[base + l * line_stride + c * samp_stride]);
                 __builtin_amdgcn_sched_barrier(0);
-            } else if (t >= 12 && t < 20) {
+            } else if (VCL && t == 12) {                 // the 16 packed adds in one gap
+#pragma unroll
+                for (int k8 = 0; k8 < 8; ++k8) {
+                    const int l = k8 >> 2, f = k8 & 3;
+                    vv[l][f] = f == 0 ? pk_sub4(dd[l][0], dd[l][2]) : f == 1 ? pk_add4(dd[l][1], dd[l][2]) : f == 2 ? pk_sub4(dd[l][2], dd[l][1]) : pk_sub4(dd[l][1], dd[l][3]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (!VCL && t >= 12 && t < 20) {
                 const int l = (t - 12) >> 2, f = (t - 12) & 3;
                 vv[l][f] = f == 0 ? pk_sub4(dd[l][0], dd[l][2]) : f == 1 ? pk_add4(dd[l][1], dd[l][2]) : f == 2 ? pk_sub4(dd[l][2], dd[l][1]) : pk_sub4(dd[l][1], dd[l][3]);
                 __builtin_amdgcn_sched_barrier(0);
