@@ -116,6 +116,9 @@ inline int wino_tail_merged_blocks(int B, int H)
     return (B * nt + PMX_WINO_RUN_TILES - 1) / PMX_WINO_RUN_TILES;
 }
 int conv_wino_tail_reduce(const WinoTailReduceArgs& r, int groups, hipStream_t stream);
+// dynamic LDS above 64 KB must be allowed per kernel AND per device (conv_mfma.hip; shared with conv_wino.hip)
+constexpr int PMX_MAX_DEVICES = 64;
+int conv_allow_big_lds(const void* kern, bool (&done)[PMX_MAX_DEVICES]);
 // launch of the run-geometry Winograd kernel (a.W % 46 == 0); a.ksplit > 1: unit mode writing compact slabs (see WinoTailReduceArgs)
 int conv_wino_run_launch(const ConvArgs& a, int ks, int groups, hipStream_t stream);
 // launch of the merged-tail kernel (unit mode; a.run_j0 = the number of full blocks per image; wino_tail_mergeable(a.B, a.H, a.W))

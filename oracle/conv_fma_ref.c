@@ -61,7 +61,7 @@ void conv_fma_ref(const float* x, const float* w, const float* bias, float* y, i
                 }
 }
 
-/* Winograd F(2x2, 3x3) twin of csrc/conv_mfma.hip::conv_wino_kernel (option "conv_algo"; 3x3 and 7x7 layers, cin % 32 == 0):
+/* Winograd F(2x2, 3x3) twin of csrc/conv_wino.hip::conv_wino_kernel (option "conv_algo"; 3x3 and 7x7 layers, cin % 32 == 0):
  *   U = G g G^T in double, rounded once to fp32 (csrc/pmx_api.hip::pack_wino);
  *   V = B^T d B in fp32, rows first then columns, each entry one add/subtract of two terms;
  *   16 frequency-wise sequential fmaf chains over (32-channel chunk -> sub-kernel -> 8-channel step -> e in 0..3: k = e, then e + 4);

@@ -58,13 +58,13 @@ RUN_TX = 23       # tile columns of a slab of the run geometry (46 pixels)
 def wino_run_unit_from(H, W):
     """First Winograd tile (row-major index inside a slab) of the part-filled last block of an (image, slab) in the kernel's run
     geometry: the map is cut into slabs of 46 columns and a block owns 32 consecutive tiles of the ceil(H / 2) x 23 grid of one slab
-    (csrc/conv_mfma.hip: GEOM 1, maps whose width is a multiple of 46)."""
+    (csrc/conv_wino.hip: GEOM 1, maps whose width is a multiple of 46)."""
     assert W % (2 * RUN_TX) == 0
     return ((H + 1) // 2) * RUN_TX // 32 * 32
 
 
 def wino_merged_tail_blocks(B, H, W, ks):
-    """Geometry of the merged-tail launch (csrc/conv_mfma.hip: GEOM 3; csrc/pmx_common.h::wino_tail_mergeable): the part-filled last
+    """Geometry of the merged-tail launch (csrc/conv_wino.hip: GEOM 3; csrc/pmx_common.h::wino_tail_mergeable): the part-filled last
     blocks of all B images as one stream -- image b's tail tile t sits at position b * nt + t, block j owns the positions [32 j, 32 j + 32).
     Returns None when the tails are not mergeable (then every image keeps its own part-filled block), else a list of blocks, each a list of
     segments (image, first tail tile, tiles, first halo column): a segment's halo is 2 * tiles + ks - 1 columns wide, the segments of a
@@ -88,7 +88,7 @@ def wino_merged_tail_blocks(B, H, W, ks):
 
 
 def conv_wino(x, w, b, relu=False, pool=False, unit_g=0, unit_from=0, run_tx=None):
-    """The Winograd F(2x2, 3x3) kernel's arithmetic (csrc/conv_mfma.hip::conv_wino_kernel, option "conv_algo"): same shapes as
+    """The Winograd F(2x2, 3x3) kernel's arithmetic (csrc/conv_wino.hip::conv_wino_kernel, option "conv_algo"): same shapes as
     conv_fma, 3x3 or 7x7 (four 3x3 sub-kernels in the frequency domain + row 6 / column 6 as 1-D sub-kernels + tap (6, 6)).  Defined order, but not the direct
     kernels' chain: the two agree to ~1e-6 of the map scale.  unit_g > 0 (7x7): the kernel's unit mode for single images -- pass 1 in
     units of unit_g 32-channel chunks, pass 2a, pass 2b, each summed from 0 and added in that order (kernel label ".../u<g>").

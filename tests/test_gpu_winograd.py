@@ -1,4 +1,4 @@
-"""GPU: the Winograd F(2x2, 3x3) fp32 kernel (csrc/conv_mfma.hip::conv_wino_kernel, option "conv_algo": 1 = the 3x3 / 7x7
+"""GPU: the Winograd F(2x2, 3x3) fp32 kernel (csrc/conv_wino.hip::conv_wino_kernel, option "conv_algo": 1 = the 3x3 / 7x7
 layers of launches that fill the chip, 2 = every eligible layer) -- the replacement for L.Convolution2D on those layers
 (models/CocoPoseNet.py:28-129).  Bars: bit-identical to its plain-C twin (oracle/conv_fma_ref.c::conv_wino_ref: transforms,
 plane-wise FMA chains and output transforms in the kernel's order); within fp32 rounding of the float64 convolution; the whole
@@ -92,7 +92,7 @@ def test_winograd_launch_selection_by_round_fill(engine):
     (1, 32, 9, 138, 128, 7, True, False)])         # three slabs, 7x7, odd H
 def test_winograd_run_geometry_bit_exact_vs_c_twin(engine, B, cin, H, W, cout, k, relu, pool):
     """Maps whose width is a multiple of 46 take the run geometry of the Winograd kernel (vertical slabs of 46 columns, blocks of 32
-    consecutive tiles of a slab in row-major order instead of 8 x 16 pixel rectangles; conv_mfma.hip GEOM 1): same arithmetic per
+    consecutive tiles of a slab in row-major order instead of 8 x 16 pixel rectangles; conv_wino.hip GEOM 1): same arithmetic per
     tile, so the same bits as the rectangles and as the twin."""
     x, w, b = _data(7 * B + cin + H + k + W, B, cin, H, W, cout, k)
     y = _run(engine, x, w, b, relu, pool, 2)

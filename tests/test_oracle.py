@@ -142,7 +142,7 @@ def test_launch_plan_from_profile_labels():
 
 
 def test_merged_tail_geometry_covers_every_tail_tile_once():
-    """The stream decomposition behind the merged-tail launch (csrc/conv_mfma.hip GEOM 3, restated in
+    """The stream decomposition behind the merged-tail launch (csrc/conv_wino.hip GEOM 3, restated in
     conv_fma_ref.wino_merged_tail_blocks): every tail tile of every image in exactly one block row, at most three images per block, the
     side-by-side halos within the 2 * 32 + 3 * (ks - 1) columns the kernel's LDS tile holds; maps whose tail wraps over two tile rows
     or is shorter than 16 tiles are not merged."""

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Where does a Winograd block's time go?  Diagnostic build of the library (conv_mfma.hip compiled with -DPMX_BLOCK_TIMING: thread 0 of a
+"""Where does a Winograd block's time go?  Diagnostic build of the library (conv_wino.hip compiled with -DPMX_BLOCK_TIMING: thread 0 of a
 block stamps the 100 MHz wall clock at entry / pipeline primed / before the stores / exit (more stamps perturb the loops: six of them made a 7x7 block 1.5x slower),
 and the CU it runs on) -> per-block phase durations and the gap between consecutive blocks on one CU, for one layer shape.
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""A/B builds of the convolution kernels: conv_mfma.hip compiled with extra -D flags, linked with the product's other objects into
+"""A/B builds of the convolution kernels: conv_mfma.hip / conv_wino.hip (and pmx_api.hip, which packs their weights) compiled with extra -D flags, linked with the product's other objects into
 tools/_build/libpose_var_<tag>.so (the product library is untouched), and timed through the whole network with the layer profile on.
 
     python tools/kernel_variants.py build base: lead12:PMX_WINO_WLEAD1=12 lead12_6:PMX_WINO_WLEAD1=12,PMX_WINO_WLEAD2=6      (here: hipcc cross-compiles)
@@ -22,7 +22,7 @@ def build(specs):
         flags = ['-D' + d for d in defs.split(',') if d]
         objs = []
         for src, extra in native.SOURCES:
-            if src in ('conv_mfma.hip', 'pmx_api.hip'):      # (the kernels, and the host side that packs their weights)
+            if src in ('conv_mfma.hip', 'conv_wino.hip', 'pmx_api.hip'):      # (the kernels, and the host side that packs their weights)
                 o = os.path.join(OUT, '%s.var_%s.o' % (src[:-4], tag))
                 subprocess.check_call([native._hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + flags + extra +
                                       ['-c', os.path.join(native.CSRC, src), '-o', o], cwd=native.CSRC)
