@@ -18,11 +18,13 @@ def build(specs):
     native.build()
     os.makedirs(OUT, exist_ok=True)
     for spec in specs:
+        spec, _, only = spec.partition('@')      # tag:DEF=1,DEF2=2[@file.hip+file2.hip]: the sources the flags apply to (default: the three below)
         tag, _, defs = spec.partition(':')
         flags = ['-D' + d for d in defs.split(',') if d]
         objs = []
+        varied = tuple(only.split('+')) if only else ('conv_mfma.hip', 'conv_wino.hip', 'pmx_api.hip')
         for src, extra in native.SOURCES:
-            if src in ('conv_mfma.hip', 'conv_wino.hip', 'pmx_api.hip'):      # (the kernels, and the host side that packs their weights)
+            if src in varied:      # (the kernels, and the host side that packs their weights)
                 o = os.path.join(OUT, '%s.var_%s.o' % (src[:-4], tag))
                 subprocess.check_call([native._hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + flags + extra +
                                       ['-c', os.path.join(native.CSRC, src), '-o', o], cwd=native.CSRC)
