@@ -4,9 +4,9 @@ collective; the only exchange is the final GATHER of the result records to rank 
 backend is "nccl": implemented by RCCL as grouped send/recv into the root; gloo on CPU in the tests).  Nothing in the
 reference to mirror: it has no distributed code at all.
 
-Records are moved as raw bytes.  Their size depends on the rank's current person capacity (native.result_dtype), which grows
-on demand, and shards may be uneven, so (count, people_cap) of every rank travels first (one small all_gather) and the root
-re-packs everything at the largest capacity."""
+Records are moved as raw bytes by ONE mechanism, RecordPipe: a byte stream of self-describing frames over fixed-size gathers.  A
+record's size depends on the rank's current person capacity (native.result_dtype), which grows on demand, and shards may be uneven:
+the frame header carries (count, people_cap) and the root re-packs everything at the largest capacity."""
 import numpy as np
 
 
@@ -36,51 +36,28 @@ def _repack(records, people_cap):
     return out
 
 
-def _exchange_meta(n_local, people_cap, group, dev):
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    mine = torch.tensor([n_local, people_cap], dtype=torch.int64, device=dev)
-    metas = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(metas, mine, group=group)
-    metas = [[int(v) for v in m.cpu()] for m in metas]
-    return [m[0] for m in metas], [m[1] for m in metas]
-
-
-def _assemble(chunks, counts, caps):
-    from . import native
-    cap = max(caps)
-    parts = []
-    for raw, n, c in zip(chunks, counts, caps):
-        dt = native.result_dtype(c)
-        parts.append(_repack(np.frombuffer(raw, dtype=dt, count=n), cap))
-    return np.concatenate(parts) if parts else np.zeros(0, dtype=native.result_dtype(cap))
+def _one_shot(pipe, n_records, people_cap, rec_bytes, payload):
+    """One frame through a fresh pipe (every rank calls it): the root gets the concatenated records, the others None."""
+    done = pipe.send(0, 0, n_records, people_cap, rec_bytes, payload=payload) or []
+    done += pipe.flush() or []
+    if pipe.rank != pipe.dst:
+        return None
+    assert [step for step, _ in done] == [0], [step for step, _ in done]
+    return done[0][1]
 
 
 def gather_records(local_records, dst=0, group=None, device=None):
-    """Final gather of per-image result records (host NumPy structured arrays) to rank `dst`.
+    """Final gather of per-image result records (host NumPy structured arrays) to rank `dst`: a one-shot RecordPipe (below) -- the
+    only record path there is; uneven shards and mixed person capacities are carried by the frame headers.
 
     Returns the concatenation in rank order on `dst` and None on the other ranks (world size 1: a copy).
     `device`: torch device the collective runs on (cuda:N for nccl, cpu for gloo)."""
-    import torch
     import torch.distributed as dist
-    from . import native
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local_records.copy()
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    dev = torch.device('cpu') if device is None else torch.device(device)
-    counts, caps = _exchange_meta(len(local_records), _people_cap(local_records.dtype), group, dev)
-    sizes = [n * native.result_dtype(c).itemsize for n, c in zip(counts, caps)]
-    nmax = max(max(sizes), 1)
-    buf = torch.zeros(nmax, dtype=torch.uint8, device=dev)
-    raw = np.frombuffer(np.ascontiguousarray(local_records).tobytes(), dtype=np.uint8)
-    if len(raw):
-        buf[:len(raw)] = torch.from_numpy(raw.copy()).to(dev)
-    outs = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
-    dist.gather(buf, outs, dst=dst, group=group)
-    if rank != dst:
-        return None
-    return _assemble([outs[r][:sizes[r]].cpu().numpy().tobytes() for r in range(world)], counts, caps)
+    rec = np.ascontiguousarray(local_records)
+    pipe = RecordPipe(rec.nbytes, dst=dst, group=group, device=device, headroom=1.0, nslots=1)
+    return _one_shot(pipe, len(rec), _people_cap(rec.dtype), rec.dtype.itemsize, rec.tobytes())
 
 
 class _DeviceBytes(object):
@@ -92,40 +69,31 @@ class _DeviceBytes(object):
 
 
 def gather_device_records(engine, n_local, dst=0, group=None):
-    """RCCL gather to rank `dst` out of the engine's device-resident result records: no host round trip before the collective (one
-    device-to-device copy into a torch-owned send buffer), one device-to-host copy of the gathered records on the root after it.
+    """RCCL gather to rank `dst` out of the engine's device-resident result records, as a one-shot RecordPipe: no host round trip
+    before the collective (one device-to-device copy into the pipe's torch-owned send slot -- RCCL only ever sees allocations of
+    torch's caching allocator), one device-to-host copy of the gathered slots on the root after it.
 
     `engine.results_layout()` first makes the records final (stream sync; capacity growth + re-run if an image needed it).
-    The collective runs on torch's RCCL stream.  Returns the records of all ranks on `dst`, None elsewhere."""
+    Returns the records of all ranks on `dst`, None elsewhere.  (The steady-state loop of bench.py keeps ONE pipe alive and runs
+    it a step behind the compute instead: RecordPipe + pmx_results_snapshot.)"""
     import torch
-    import torch.distributed as dist
-    from . import native
     people_cap, rec_bytes = engine.results_layout()
     ptr, rec_bytes2 = engine.results_device_ptr()
     assert rec_bytes == rec_bytes2
     dev = torch.device('cuda', engine.device)
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    counts, caps = _exchange_meta(n_local, people_cap, group, dev)
-    sizes = [n * native.result_dtype(c).itemsize for n, c in zip(counts, caps)]
-    nmax = max(max(sizes), 1)
-    # send buffer = a torch-owned staging tensor filled by one device-to-device copy out of the engine's records (<= 1 MB per 32
-    # frames): RCCL then only ever sees allocations of torch's caching allocator (buffer registration / IPC for the xGMI transport
-    # never meets a foreign hipMalloc block), and uneven shards / capacities need no special case
-    view = torch.zeros(nmax, dtype=torch.uint8, device=dev)
-    if sizes[rank]:
-        view[:sizes[rank]].copy_(torch.as_tensor(_DeviceBytes(ptr, sizes[rank]), device=dev))
-    big = torch.empty(world * nmax, dtype=torch.uint8, device=dev) if rank == dst else None
-    dist.gather(view, list(big.split(nmax)) if rank == dst else None, dst=dst, group=group)
-    if rank != dst:
-        return None
-    host = big.cpu().numpy()
-    return _assemble([host[r * nmax:r * nmax + sizes[r]].tobytes() for r in range(world)], counts, caps)
+    pipe = RecordPipe(n_local * rec_bytes, dst=dst, group=group, device=dev, headroom=1.0, nslots=1)
+    nbytes = n_local * rec_bytes
+    if nbytes:
+        s = pipe.slots[0][_SLOT_HDR + _FRAME_HDR:_SLOT_HDR + _FRAME_HDR + nbytes]
+        s.copy_(torch.as_tensor(_DeviceBytes(ptr, nbytes), device=dev))
+    return _one_shot(pipe, n_local, people_cap, rec_bytes, None)
 
 
 # ---- pipelined gather: ONE collective per step, no per-step size exchange, no host sync in the compute path ------------------------
-# The gather above is serial: results_layout() (stream sync) -> all_gather of (count, capacity) -> gather -> D2H, all before the next
-# batch is enqueued, so every step ends in a global barrier.  RecordPipe turns the records of a rank into a BYTE STREAM that is moved
-# by one fixed-size `gather` per step (slot size agreed once, at construction):
+# (Until round 4 a second, serial path lived here: results_layout() (stream sync) -> all_gather of (count, capacity) -> gather -> D2H before
+# the next batch was enqueued, i.e. a global barrier per step; gather_records / gather_device_records above are now one-shot pipes.)
+# RecordPipe turns the records of a rank into a BYTE STREAM that is moved by one fixed-size `gather` per step (slot size agreed once, at
+# construction):
 #
 #     slot   = [ int64 x 4: magic, valid_bytes, slot_seq, 0 ] [ valid_bytes of the rank's stream ] [ padding ]
 #     stream = frame, frame, ...;   frame = [ int64 x 6: magic, step, n_records, people_cap, bytes_per_record, payload_bytes ] [ payload ]
@@ -174,6 +142,7 @@ class RecordPipe(object):
         self.outbox = bytearray()                                    # host bytes waiting to cross (slow path only)
         self.inbox = [bytearray() for _ in range(self.world)] if self.rank == dst else None
         self.frames = {}                                             # step -> {rank: records}
+        self.ready = []                                              # root: steps completed inside _free_slot, handed out by the next call
         self.seq = 0
         self.collectives = 0
 
@@ -191,7 +160,9 @@ class RecordPipe(object):
         normally a completed-flag check; only if it is still in flight does the host wait (a blocking wait here would keep the host
         from enqueuing the next step until the device has drained the current one)."""
         if self.rank == self.dst and self.pending and s in self.pending:
-            self._collect(upto=s)
+            # (nslots = consumer depth + 1: the slot being reused still has its device-to-host copy pending.  The steps that parsing it
+            #  completes are kept and handed out by the next send / exchange / flush -- dropped here they were lost for good)
+            self.ready += self._collect(upto=s)
         w = self.work[s]
         if w is not None:
             if not w.is_completed():
@@ -245,11 +216,18 @@ class RecordPipe(object):
         for i in range(int(t.item())):
             done += self.exchange(i) or []
         if self.rank == self.dst:
-            done += self._collect()
+            done += self.ready + self._collect()
+            self.ready = []
+        busy = False
         for s in range(self.nslots):
             if self.work[s] is not None:
+                busy = busy or not self.work[s].is_completed()
                 self.work[s].wait()
                 self.work[s] = None
+        # (an RCCL work's wait() only orders torch's current stream behind the collective; the engine's stream and the pinned header
+        #  staging are not ordered against it, so before the slots may be rewritten the host really waits)
+        if busy and self.dev.type == 'cuda':
+            self.torch.cuda.current_stream(self.dev).synchronize()
         return done
 
     # -- the collective + the root's assembler ---------------------------------------------------------------------------------------
@@ -261,7 +239,8 @@ class RecordPipe(object):
         if self.rank != self.dst:
             return None
         # root: first hand out what earlier gathers delivered (their copies are long done), then issue this one's copy without waiting
-        done = self._collect()
+        done = self.ready + self._collect()
+        self.ready = []
         self.work[s].wait()                                          # (stream-ordered: the slots of all ranks are in recv[s] before the copy)
         if self.host is not None:
             self.host[s].copy_(self.recv[s], non_blocking=True)

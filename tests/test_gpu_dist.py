@@ -56,6 +56,23 @@ assert [s for s, _ in got] == [0, 1, 2] and pipe.collectives == 3
 eng.detect_batch(imgs2, 96, 128); local2 = eng.results()
 assert got[0][1].tobytes() == local.tobytes() and got[2][1].tobytes() == local.tobytes() and got[1][1].tobytes() == local2.tobytes()
 assert local2.tobytes() != local.tobytes()
+# nslots = consumer depth + 1 (what the header documents): the slot a step reuses still has its device-to-host copy pending on the root;
+# the steps completed while freeing it must be handed out by the next call, not dropped (round-4 advice: they were lost)
+pipe2 = D.RecordPipe(B * local.dtype.itemsize, dst=0, device=torch.device("cuda", 0), nslots=2)
+got2, seq = [], (imgs, imgs2, imgs, imgs2, imgs)
+for k, im in enumerate(seq):
+    eng.detect_batch(im, 96, 128)
+    ptr, room = pipe2.payload_view(k)
+    eng.results_snapshot(k & 1, ptr, room)             # (payload_view(k) of k >= 2 finds slot k % 2 still pending: step k - 2's copy)
+    if k:
+        n, cap, rb, ov = eng.snapshot_wait((k - 1) & 1)
+        assert not ov
+        got2 += pipe2.send(k - 1, k - 1, n, cap, rb)
+n, cap, rb, ov = eng.snapshot_wait((len(seq) - 1) & 1)
+got2 += pipe2.send(len(seq) - 1, len(seq) - 1, n, cap, rb)
+got2 += pipe2.flush()
+assert [s for s, _ in got2] == list(range(len(seq))) and pipe2.collectives == len(seq), ([s for s, _ in got2], pipe2.collectives)
+assert all(r.tobytes() == (local if k % 2 == 0 else local2).tobytes() for k, (_, r) in enumerate(got2))
 if int(local["n_people"].max()) > 1:
     eng.set_capacities(people=1)
     eng.detect_batch(imgs, 96, 128)
