@@ -198,12 +198,16 @@ class PoseDetector(object):
             if fetch_maps and getattr(self, 'pafs', None) is not None and np.ndim(self.pafs) == 4:
                 self.pafs, self.heatmaps = self.pafs[0], self.heatmaps[0]
 
-    def detect_precise_batch(self, imgs, fetch_maps=False):
+    def detect_precise_batch(self, imgs, fetch_maps=False, return_exceptions=False):
         """`detect_precise` (reference pose_detector.py:433-482) for a list of uint8 BGR images of ONE common size -> list of (poses, scores).
         The reference handles one image per call; here every inference scale runs the n images as ONE batch through the network (a single
         0.5x input is 23 x 31 feature maps -- too little for 256 CUs), the cubic resizes and the accumulation stay on the device per image,
         and the full-resolution post-process runs on the n averaged map sets at once.  Per image the result equals the single-image call up
-        to the network's kernel-choice-by-launch-size rounding.  Native network only (`model=` callables: loop)."""
+        to the network's kernel-choice-by-launch-size rounding.  Native network only (`model=` callables: loop).
+        Where the reference would raise for ONE image (IndexError, :197) the default raises as it does; `return_exceptions=True` puts the
+        exception object into that image's slot and returns everybody else's result (a per-image loop over the reference loses nothing)."""
+        if len(imgs) == 0:
+            raise ValueError('detect_precise_batch needs at least one image')
         if self.model is not None:
             return [self.detect_precise(im) for im in imgs]
         if self._weights is None:
@@ -231,9 +235,8 @@ class PoseDetector(object):
             self.pafs, self.heatmaps = self.engine.get_maps()                                       # (n, 38 | 19, H, W)
         self.engine.postprocess(orig_img_h, orig_img_w, img_len=orig_img_w, scale_xy=None)           # :475-481
         rec = self.engine.results()
-        if n == 1:
-            self.all_peaks = self.engine.peaks(0)                                                    # :475 (kept as the reference keeps it)
-        return unpack_results(rec)
+        self.all_peaks = self.engine.peaks(0) if n == 1 else None                                    # :475 (kept as the reference keeps it; a batch has no single set)
+        return unpack_results(rec, return_exceptions=return_exceptions)
 
     # ---- demo-chain helpers (reference pose_detector.py:267-424): host geometry that feeds the face / hand detectors -------
     _UNIT_BASE_LIMBS = (14, 3, 0, 13, 9)            # nose-neck, neck-left hip, neck-right hip, shoulder-ear (left, right)
@@ -384,14 +387,20 @@ def _data(v):
     return getattr(v, 'data', v)      # chainer.Variable-like or plain array
 
 
-def unpack_results(records):
-    """Device result records -> [(poses, scores)] with the reference's return shapes and error behaviour."""
+def unpack_results(records, return_exceptions=False):
+    """Device result records -> [(poses, scores)] with the reference's return shapes and error behaviour.
+    `return_exceptions`: an image on which the reference would raise (IndexError, :197) gets the exception OBJECT in its list slot
+    instead of aborting the whole batch -- the reference, called once per image, only ever fails that image."""
     out = []
     for r in records:
         st = int(r['status'])
         if st & native.IMG_TRIPLE_MATCH:
             # the reference fails with IndexError at pose_detector.py:197 when a third subset matches
-            raise IndexError('list assignment index out of range')
+            err = IndexError('list assignment index out of range')
+            if not return_exceptions:
+                raise err
+            out.append(err)
+            continue
         # (capacity bits never reach this point: the library grows its buffers and re-runs the post-process, the reference
         #  has no limits on peaks / candidates / subsets / people)
         n = int(r['n_people'])

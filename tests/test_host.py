@@ -202,3 +202,24 @@ def test_failed_growth_leaves_a_usable_detector(monkeypatch):
     assert det.engine.loaded['layers'] == {'conv1_1': 'W'}                            # ... with the saved state
     det._grow(2, 368, 368)                                   # and the early return of _grow is still truthful
     assert det.engine.cap == (4, 368, 368)
+
+
+def test_unpack_results_per_image_error_behaviour():
+    """The reference raises IndexError (pose_detector.py:197) for the ONE image it is called on; a batch must not lose the others:
+    `return_exceptions=True` keeps the exception in that image's slot, the default raises as the reference does."""
+    PD, native = pkg('pose_detector'), pkg('native')
+    rec = np.zeros(3, dtype=native.result_dtype(4))
+    rec[0]['n_peaks'], rec[0]['n_people'] = 7, 2
+    rec[0]['scores'][:2] = [1.5, 2.5]
+    rec[1]['n_peaks'], rec[1]['status'] = 9, native.IMG_TRIPLE_MATCH
+    rec[2]['n_peaks'] = 0
+    with pytest.raises(IndexError):
+        PD.unpack_results(rec)
+    out = PD.unpack_results(rec, return_exceptions=True)
+    assert len(out) == 3 and isinstance(out[1], IndexError)
+    assert out[0][0].shape == (2, 18, 3) and list(out[0][1]) == [1.5, 2.5]
+    assert out[2][0].shape == (0, 18, 3) and out[2][1].shape == (0,)
+    det = PD.PoseDetector.__new__(PD.PoseDetector)
+    det.model = None
+    with pytest.raises(ValueError):
+        PD.PoseDetector.detect_precise_batch(det, [])
