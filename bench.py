@@ -100,10 +100,12 @@ def parse():
                     "for the single-GPU multi-rank smoke test, where all ranks share device 0)")
     ap.add_argument('--dump-records', default=None, help='rank 0 writes the gathered result records of the last step (.npy)')
     ap.add_argument('--no-extras', action='store_true', help='skip the single-image and upload-inclusive measurements')
+    ap.add_argument('--bf16x3', action='store_true', help='also run the opt-in split-bf16 mode (frozen after round 5: never the headline, no longer '
+                    'part of the default run -- DESIGN.md section 7)')
     ap.add_argument('--engine-opt', action='append', default=[], metavar='KEY=VALUE', help='pmx_set_option on the engine before the run (A/B '
                     'switches such as wino_xcd_groups=0); repeatable; recorded in config.engine_options')
     ap.add_argument('--force-gather', action='store_true', help='N = 1: still create a one-rank process group and route the records '
-                    'through the RCCL gather (dist.gather_device_records), the code path of N > 1')
+                    'through the RCCL gather (dist.RecordPipe), the code path of N > 1')
     return ap.parse_args()
 
 
@@ -515,7 +517,8 @@ def main():
             out['value_incl_h2d'] = upload_inclusive(eng, torch, dev, imgs, a.steps, map_s)
             out['single_image'] = single_image(eng, d_imgs, S, map_s)
             out['direct_kernels_only'] = direct_only(eng, torch, d_imgs, B, S, map_s, a.steps)
-            out['bf16x3'] = bf16x3_mode(eng, torch, dev, d_imgs, B, S, map_s, a.steps)
+            if a.bf16x3:
+                out['bf16x3'] = bf16x3_mode(eng, torch, dev, d_imgs, B, S, map_s, a.steps)
             out['rect_368x496'] = rect_inputs(native, weights_mod, torch, dev, local_rank, B, a.steps, frames / dt, S)
             out['precise'] = precise_mode(weights_mod, local_rank, with_oracle=not a.no_cpu_baseline)
             eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(B, S, S), map_h=map_s, map_w=map_s)     # restore the batch state
@@ -525,7 +528,7 @@ def main():
             from oracle import conv_fma_ref
             out['keypoint_match'] = keypoint_match(eng, rec, oracle_results, weights, imgs, conv_fma_ref.splitk_plan(prof_all))
             out['keypoint_match']['census'] = committed_census()
-            if not a.no_extras:
+            if not a.no_extras and a.bf16x3:
                 # the opt-in bf16x3 mode against the same CPU oracle frames (it is compared with the fp32 path above; this is the
                 # figure the north_star tolerance applies to)
                 eng.set_option('precision', 1)

@@ -93,7 +93,7 @@ int wino_select(const WinoSelectOpts& o, int ks, int cin_pad, int cout_pad, int 
         static std::map<Key, std::pair<double, int>> memo;
         // (merged tails: the tail tiles of a group's images as one stream, 32 per block)
         const int grp = std::max(1, o.groups);
-        const bool merge = o.wino_tail_merge != 0 && wino_tail_mergeable(images / grp, H, W);
+        const bool merge = o.wino_tail_merge != 0 && wino_tail_mergeable(images / grp, H, W, o.lda);
         const Key key{ks, nch, o.wino_tail_g, merge ? (long long)grp * wino_tail_merged_blocks(images / grp, H) * nb : (long long)images * nslab * nb, ncu};
         double best = 1e30;
         int best_g = 0;

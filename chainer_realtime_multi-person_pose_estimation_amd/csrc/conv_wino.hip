@@ -7,8 +7,7 @@
 #include <type_traits>
 #include "pmx_common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "wino_util.h"
 
 // ---- Winograd F(2x2, 3x3) (fp32, option "conv_algo") ------------------------------------------------------------------
 // Y = A^T [ (G g G^T) (.) (B^T d B) ] A: a 2 x 2 output tile from a 4 x 4 input window costs 16 multiplies per channel pair instead of
@@ -32,27 +31,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // is not the direct kernels' chain (results agree to fp32 rounding, ~1e-6 of the map scale).
 // float4 add / subtract as two packed-fp32 instructions (v_pk_add_f32, the subtrahend negated by the source modifier: same rounding as
 // v_sub_f32); the scheduler-pinned one-op-per-slot transform code otherwise compiles to four scalar VALU instructions per float4
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 pk_add2(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ f32x2 pk_sub2(f32x2 a, f32x2 b)
-{
-    f32x2 d;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-__device__ __forceinline__ f32x4 pk_add4(f32x4 a, f32x4 b)
-{
-    const f32x2 lo = pk_add2(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1));
-    const f32x2 hi = pk_add2(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3));
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
-}
-__device__ __forceinline__ f32x4 pk_sub4(f32x4 a, f32x4 b)
-{
-    const f32x2 lo = pk_sub2(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1));
-    const f32x2 hi = pk_sub2(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3));
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
-}
-
 // Diagnostic build only (tools/block_timing.py compiles this file with -DPMX_BLOCK_TIMING into its own library; the product library
 // never defines it): thread 0 of the first 8192 blocks of a Winograd launch stamps the 100 MHz wall clock at entry / pipeline primed /
 // before the stores / exit, and the CU it runs on.  (The stamps perturb the register allocation of the loops -- a 7x7 block runs 1.4x
@@ -950,7 +928,7 @@ static int launch_wino_merged(const ConvArgs& a0, int groups, hipStream_t stream
 {
     using C = WinoCfg<KS, 3>;
     ConvArgs a = a0;
-    PMX_CHECK(wino_tail_mergeable(a.B, a.H, a.W) && a.run_j0 == C::RUN_TX * ((a.H + 1) / 2) / PMX_WINO_RUN_TILES, PMX_ERR_INVALID,
+    PMX_CHECK(wino_tail_mergeable(a.B, a.H, a.W, a.lda) && a.run_j0 == C::RUN_TX * ((a.H + 1) / 2) / PMX_WINO_RUN_TILES, PMX_ERR_INVALID,
               "conv wino merged tails: not a mergeable tail (B %d, %d x %d, full blocks %d)", a.B, a.H, a.W, a.run_j0);
     PMX_CHECK(a.cout_pad % 128 == 0, PMX_ERR_INVALID, "conv wino: cout_pad %d not a multiple of 128", a.cout_pad);
     PMX_CHECK((long long)a.B * a.H * a.W * a.lda * 4 < (1ll << 31), PMX_ERR_INVALID, "conv wino merged tails: batch too large for 32-bit offsets");

@@ -404,10 +404,11 @@ extern "C" void pmx_destroy(pmx_ctx* c)
     (void)hipDeviceSynchronize();
     for (auto& l : c->layers) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); if (l.d_w3) (void)hipFree(l.d_w3); if (l.d_ww) (void)hipFree(l.d_ww); }
     pp_free(c);
-    void* ptrs[] = {c->sk_scratch, c->sk_zero_bias, c->pr_tmp, c->pr_tab, c->d_kp, c->u8_src, c->rs_tab, c->in16, c->act0, c->act1, c->cat, c->brA, c->brB, c->brT, c->nchw_tmp, c->u8_tmp, c->ext_paf, c->ext_heat,
+    void* ptrs[] = {c->sk_scratch, c->sk_zero_bias, c->pr_tmp, c->d_kp, c->u8_src, c->rs_tab, c->in16, c->act0, c->act1, c->cat, c->brA, c->brB, c->brT, c->nchw_tmp, c->u8_tmp, c->ext_paf, c->ext_heat,
                     c->pp.smoothed, c->d_scale, c->tab.xi0, c->tab.xi1, c->tab.xlo, c->tab.xhi, c->tab.yi0, c->tab.yi1,
                     c->tab.ylo, c->tab.yhi, c->tab.gauss};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& kv : c->pr_tabs) (void)hipFree(kv.second);
     for (auto& p : c->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->h_results) (void)hipHostFree(c->h_results);
@@ -449,6 +450,7 @@ extern "C" int pmx_set_option(pmx_ctx* c, const char* key, int value)
     else if (!strcmp(key, "kernel_gen")) c->opt_kernel_gen = value;
     else if (!strcmp(key, "fuse_pairs")) c->opt_fuse_pairs = value;
     else if (!strcmp(key, "fuse_conv1")) c->opt_fuse_conv1 = value;
+    else if (!strcmp(key, "conv1_wino")) c->opt_conv1_wino = value;
     else if (!strcmp(key, "precision")) c->opt_precision = value;
     else if (!strcmp(key, "conv_algo")) c->opt_conv_algo = value;
     else if (!strcmp(key, "wino_min_fill")) c->opt_wino_min_fill = value;
@@ -641,7 +643,7 @@ struct WinoProf { std::string name; double flops, bytes, issued; };      // prof
 // the tails of all images of the launch as one stream of tiles, 32 per block (conv_wino_kernel<KS, 0, 1, 3>)?
 static bool wino_tail_merged(const pmx_ctx* c, const ConvArgs& a)
 {
-    return c->opt_wino_tail_merge != 0 && wino_tail_mergeable(a.B, a.H, a.W) && (long long)a.B * a.H * a.W * a.lda * 4 < (1ll << 31);
+    return c->opt_wino_tail_merge != 0 && wino_tail_mergeable(a.B, a.H, a.W, a.lda);
 }
 static int launch_wino_run(pmx_ctx* c, const ConvArgs& a0, int ks, int groups, int tail_g, const WinoProf* pf = nullptr)
 {
@@ -716,12 +718,12 @@ static int launch_wino_run(pmx_ctx* c, const ConvArgs& a0, int ks, int groups, i
 // Which form a 3x3 / 7x7 layer takes (conv_select.hip): 0 = direct kernels (+ split-K), 1 = the Winograd kernel (*run: in the run geometry,
 // *tail_g > 0: its part-filled last blocks in unit mode), 2 = the Winograd kernel in unit mode (*unit_g = chunks per pass-1 unit)
 static int wino_mode(const pmx_ctx* c, int ks, int cin_pad, int cout_pad, int cout, int ldc, int images, int H, int W, int pool, int* unit_g,
-                     int* run, int* tail_g, int groups = 1)
+                     int* run, int* tail_g, int groups = 1, int lda = 0)
 {
     WinoSelectOpts o;
     o.conv_algo = c->opt_conv_algo; o.precision = c->opt_precision; o.forced_variant = c->opt_force[ks]; o.ksplit = c->opt_ksplit;
     o.wino_unit_eff = c->opt_wino_unit_eff; o.wino_min_fill = c->opt_wino_min_fill; o.wino_geom = c->opt_wino_geom; o.wino_tail = c->opt_wino_tail;
-    o.wino_tail_g = c->opt_wino_tail_g; o.wino_tail_merge = c->opt_wino_tail_merge; o.groups = groups;
+    o.wino_tail_g = c->opt_wino_tail_g; o.wino_tail_merge = c->opt_wino_tail_merge; o.groups = groups; o.lda = lda;
     return wino_select(o, ks, cin_pad, cout_pad, cout, ldc, images, H, W, pool, unit_g, run, tail_g);
 }
 
@@ -755,7 +757,7 @@ static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float
     const bool wino_ok = wino_eligible(L0.ks, L0.cin_pad, L0.cout_pad) &&
                          (groups == 1 || (wino_eligible(c->layers[li1].ks, c->layers[li1].cin_pad, c->layers[li1].cout_pad) && c->layers[li1].cout == L0.cout));
     int ug = 0, wrun = 0, wtail = 0;
-    const int wmode = wino_ok ? wino_mode(c, L0.ks, L0.cin_pad, L0.cout_pad, L0.cout, ldc, B * groups, H, W, pool, &ug, &wrun, &wtail, groups) : 0;
+    const int wmode = wino_ok ? wino_mode(c, L0.ks, L0.cin_pad, L0.cout_pad, L0.cout, ldc, B * groups, H, W, pool, &ug, &wrun, &wtail, groups, lda) : 0;
     const bool wino_plain = wmode == 1;
     if (wmode && ((rc = ensure_wino_pack(c->layers[li0])) || (groups == 2 && (rc = ensure_wino_pack(c->layers[li1]))))) return rc;
     if (wmode == 2) {
@@ -860,6 +862,18 @@ static int run_conv1(pmx_ctx* c, int B, int H, int W)
     a.g[0].in = c->in16; a.g[0].w = L2.d_w; a.g[0].bias = L2.d_b; a.g[0].out = c->act1; a.g[0].cout = L2.cout;
     a.g[1].w = L1.d_w; a.g[1].bias = L1.d_b;
     a.B = B; a.H = H; a.W = W; a.lda = PMX_IN_C; a.ldc = 64; a.nch = L2.nch; a.cout_pad = L2.cout_pad; a.relu = 1; a.pool = 1;
+    // conv1_2 as Winograd F(2x2, 3x3) on 16 x 16 squares (conv1_wino.hip) wherever the Winograd kernels are allowed (conv_algo >= 1) and
+    // the launch has at least one block per CU (smaller launches: the 8 x 16 direct tiles give twice the blocks)
+    if (c->opt_conv1_wino && c->opt_conv_algo >= 1 && (c->opt_conv1_wino == 2 || (long long)B * ((H + 15) / 16) * ((W + 15) / 16) >= conv_num_cus())) {
+        if ((rc = ensure_wino_pack(c->layers[i2]))) return rc;
+        a.g[0].w = L2.d_ww;
+        if (c->prof_on == 1) {
+            const double f1 = 2.0 * B * H * W * 9.0 * (double)L1.cout * L1.cin, f2 = 2.0 * B * H * W * 9.0 * (double)L2.cout * L2.cin;
+            if ((rc = prof_begin(c, "conv1_1+conv1_2|conv_wino1_f2x2_t16x16", f1 + f2, 4.0 * B * H * W * (3 + 64 / 4), f1 + f2 * 16.0 / 36.0))) return rc;
+        }
+        if ((rc = conv1_wino_launch(a, c->stream))) return rc;
+        return prof_end(c);
+    }
     if (c->prof_on == 1) {
         const double flops = 2.0 * B * H * W * 9.0 * ((double)L1.cout * L1.cin + (double)L2.cout * L2.cin);
         if ((rc = prof_begin(c, "conv1_1+conv1_2|conv1_fused_t8x16_n64", flops, 4.0 * B * H * W * (3 + 64 / 4)))) return rc;
@@ -1691,7 +1705,7 @@ extern "C" int pmx_conv2d(pmx_ctx* c, const float* x, const float* w, const floa
     if (cout % 4 != 0) plan.S = 1;
     float* d_ww = nullptr;
     int ug = 0, wrun = 0, wtail = 0;
-    const int wmode = wino_mode(c, ks, cin_pad, cpad, cout, cout, B, H, W, pool, &ug, &wrun, &wtail);
+    const int wmode = wino_mode(c, ks, cin_pad, cpad, cout, cout, B, H, W, pool, &ug, &wrun, &wtail, 1, a.lda);
     const bool wino = wmode == 1;
     if (wino) {
         std::vector<float> ww;

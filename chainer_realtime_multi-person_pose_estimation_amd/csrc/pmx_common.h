@@ -105,10 +105,13 @@ struct WinoTailReduceArgs {
 };
 // Merged tails (conv_wino_kernel<KS, 0, 1, 3>): the part-filled last blocks of all images of a launch as one stream of tiles, 32 per block.
 // Possible when the tail lies in one tile row of a single-slab map and is long enough that a block meets at most three images.
-inline bool wino_tail_mergeable(int B, int H, int W)
+// `lda` (input channel stride, floats): the merged launch reads every image through ONE buffer resource, so the batch must stay below 2^31
+// bytes -- part of the predicate, so that the selection (conv_select.hip) and the launch (pmx_api.hip) can never disagree; 0 = not checked
+inline bool wino_tail_mergeable(int B, int H, int W, int lda = 0)
 {
     const int ntiles = PMX_WINO_RUN_TX * ((H + 1) / 2), t0 = ntiles / PMX_WINO_RUN_TILES * PMX_WINO_RUN_TILES, nt = ntiles - t0;
-    return B >= 2 && W == 2 * PMX_WINO_RUN_TX && nt >= 16 && t0 % PMX_WINO_RUN_TX + nt <= PMX_WINO_RUN_TX;
+    return B >= 2 && W == 2 * PMX_WINO_RUN_TX && nt >= 16 && t0 % PMX_WINO_RUN_TX + nt <= PMX_WINO_RUN_TX &&
+           (long long)B * H * W * lda * 4 < (1ll << 31);
 }
 inline int wino_tail_merged_blocks(int B, int H)
 {
@@ -130,6 +133,7 @@ struct WinoSelectOpts {      // the context options the choice depends on (pmx_s
     int conv_algo, precision, forced_variant, ksplit, wino_unit_eff, wino_min_fill, wino_geom, wino_tail, wino_tail_g;
     int wino_tail_merge = 1;     // the tails of all images as one stream of tiles (0: one part-filled block per image)
     int groups = 1;              // branch groups in the launch (`images` counts images x groups)
+    int lda = 0;                 // input channel stride (floats) of the launch: bounds the merged-tail form (wino_tail_mergeable)
 };
 bool wino_eligible(int ks, int cin_pad, int cout_pad);
 // returns 0 = direct kernels (+ split-K), 1 = the Winograd kernel (*run = 1: run geometry; *tail_g > 0: chunks per pass-1 unit of its
@@ -169,6 +173,8 @@ bool conv_pair_supported(int cin, int cmid, int cout_pad);
 // conv1_1 (3 -> 64) recomputed on the halo + conv1_2 (64 -> 64 [+ pool]) in one launch: a.g[0] = conv1_2 (in = padded network input),
 // a.g[1].w / .bias = conv1_1's packed weights / bias
 int conv1_fused_launch(const ConvArgs& a, hipStream_t stream);
+// the same pair with conv1_2 in Winograd F(2x2, 3x3) (conv1_wino.hip): a.g[0].w = conv1_2's TRANSFORMED weights (pack_wino, cout_pad 64)
+int conv1_wino_launch(const ConvArgs& a, hipStream_t stream);
 // Winograd F(2x2, 3x3): a.nch = cin / 32, a.g[].w = transformed weights [plane][chunk32][k8-step][cout_pad][8] (G g G^T, host);
 // ks = 7: planes 0..63 = four 3x3 sub-kernels (taps 0..5 x 0..5), 64..71 row 6, 72..79 column 6 (1-D G g), 80 = tap (6, 6)
 int conv_wino_launch(const ConvArgs& a, int ks, int groups, hipStream_t stream);
@@ -198,10 +204,12 @@ int launch_prep_u8(const uint8_t* bgr, float* out16, int B, int H, int W, float 
 int launch_prep_f32(const float* x_nchw, float* out16, int B, int H, int W, hipStream_t s);
 int launch_resize_linear_u8(const uint8_t* src, uint8_t* dst, const int* xtab, const int* ytab, int B, int sh, int sw, int dh, int dw,
                             hipStream_t s);
-int launch_resize_cubic_f32(const float* src, long long sy, long long sx, long long sc, int C, float* dst, int dh, int dw,
-                            const int* xi, const float* xc, const int* yi, const float* yc, int accumulate, int dst_c0, hipStream_t s);
+// cubic resize of B x C planes in one launch: source element (b, c, y, x) = src[b * sb + c * sc + y * sy + x * sx], planar destination
+// dst[((b * C + c) * dh + y) * dw + x] (accumulate: +=)
+int launch_resize_cubic_f32_planar(const float* src, long long sb, long long sc, long long sy, long long sx, int B, int C, float* dst, int dh, int dw,
+                                   const int* xi, const float* xc, const int* yi, const float* yc, int accumulate, hipStream_t s);
 int launch_resize_cubic_u8(const uint8_t* src, int sw, uint8_t* dst, int dh, int dw, int dpitch, const int* xi, const int* xa,
-                           const int* yi, const int* ya, hipStream_t s);
+                           const int* yi, const int* ya, int B, long long sbytes, long long dbytes, hipStream_t s);
 int launch_fill_bgr(uint8_t* dst, long long npix, int b, int g, int r, hipStream_t s);
 int launch_scale_f32(float* p, long long n, float divisor, hipStream_t s);
 int launch_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, int ldc, int coff, hipStream_t s);

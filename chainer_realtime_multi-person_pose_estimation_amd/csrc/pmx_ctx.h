@@ -4,6 +4,7 @@
 #include "pmx_common.h"
 
 #include <map>
+#include <tuple>
 #include <string>
 #include <vector>
 
@@ -41,8 +42,9 @@ struct pmx_ctx {
     int cat_heat = PMX_CAT_HEAT;     // first heat-map channel in the cat buffer (168 | 128 | 128)
     // detect_precise accumulation state (pmx_precise_*)
     int pr_h = 0, pr_w = 0, pr_scales = 0, pr_n = 0;      // original size, scales accumulated so far, images of the batch
-    float* pr_tmp = nullptr; size_t pr_tmp_cap = 0;      // x8 up-sampled maps of one scale, NHWC-57
-    void* pr_tab = nullptr; size_t pr_tab_cap = 0;       // cubic tables of the current resize
+    float* pr_tmp = nullptr; size_t pr_tmp_cap = 0;      // x8 up-sampled maps of one scale, planar [n][38][ph][pw] | [n][19][ph][pw]
+    std::map<std::tuple<int, int, int>, int*> pr_tabs;   // cubic tables per axis, keyed (src, dst, fixed point?): built once, kept
+    const uint8_t* pr_src = nullptr;                     // host images of the current begin / finish sequence already in u8_src
     double* d_kp = nullptr;          // key-point records of pmx_keypoints
     size_t kp_cap = 0;
     int device = 0;
@@ -108,6 +110,7 @@ struct pmx_ctx {
     int opt_wino_tail_g = 0;         // tuning: chunks per pass-1 unit of the tail (0 = automatic)
     int opt_precision = 0;           // 0: fp32 MFMA everywhere (the path whose results are specified); 1: bf16x3 kernels where a
                                      // v6 kernel would run (fp32-grade accuracy at 2.67x the matrix rate, NOT the fp32 FMA chain)
+    int opt_conv1_wino = 1;          // fused conv1_1 + conv1_2 with conv1_2 as Winograd F(2x2, 3x3) (conv1_wino_kernel) where conv_algo allows Winograd
     int opt_fuse_conv1 = 1;          // conv1_1 recomputed on conv1_2's halo tile, one launch (conv1_fused_kernel); identical bits
     int opt_fuse_pairs = 1;          // the two 1x1 layers that end every stage run as one launch (conv1x1_pair_kernel)
     int opt_ksplit = 0;              // 0: automatic split-K for small launches; n > 0: force n K slices where split-K applies

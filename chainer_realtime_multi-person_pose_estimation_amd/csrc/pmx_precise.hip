@@ -6,6 +6,7 @@
 
 #include <math.h>
 #include <string.h>
+#include <tuple>
 
 // ---------------------------------------------------------------------------------------- detect_precise on the device
 // OpenCV bicubic tables for one axis (A = -0.75): idx[k][d] (clamped, replicate border) and coef[k][d] float32, k = 0..3.
@@ -34,37 +35,44 @@ static void make_cubic_table(int dst, int src, int* idx, float* coef)
     }
 }
 
-// uploads [xi | yi | xc | yc] (or fixed-point coefficients when `fixed`) for a (sh, sw) -> (dh, dw) cubic resize
-static int upload_cubic_tables(pmx_ctx* c, int sh, int sw, int dh, int dw, bool fixed, int** xi, void** xc, int** yi, void** yc)
+// Device copy of the cubic table of ONE axis for (src -> dst): [4 dst indices | 4 dst coefficients (float32, or 11-bit fixed point when
+// `fixed`)].  Tables are a pure function of (src, dst, fixed) and detect_precise asks for the same dozen on every call (4 scales x 3 resizes x
+// 2 axes), so they are built once and kept for the life of the context: no stream synchronisation and no blocking copy per scale (round 4
+// rebuilt and re-uploaded them three times per scale behind a hipStreamSynchronize each).  A fresh table is a fresh allocation, so nothing
+// in flight can be reading the memory it is copied to.
+static int cubic_table(pmx_ctx* c, int src, int dst, bool fixed, const int** idx, const void** coef)
 {
-    const size_t n = (size_t)4 * (dw + dh);
-    const size_t bytes = n * 2 * sizeof(int);
-    if (bytes > c->pr_tab_cap) {
-        PMX_HIP(hipStreamSynchronize(c->stream));
-        if (c->pr_tab) (void)hipFree(c->pr_tab);
-        c->pr_tab = nullptr;
-        PMX_HIP(hipMalloc(&c->pr_tab, bytes));
-        c->pr_tab_cap = bytes;
-    }
-    std::vector<int> hi(n);
-    std::vector<float> hc(n);
-    make_cubic_table(dw, sw, hi.data(), hc.data());
-    make_cubic_table(dh, sh, hi.data() + 4 * dw, hc.data() + 4 * dw);
-    PMX_HIP(hipStreamSynchronize(c->stream));     // previous resize may still read the table buffer
-    int* d_i = (int*)c->pr_tab;
-    PMX_HIP(hipMemcpy(d_i, hi.data(), n * sizeof(int), hipMemcpyHostToDevice));
-    if (fixed) {
-        std::vector<int> ha(n);
-        for (size_t k = 0; k < n; ++k) {
-            long v = lrintf(hc[k] * 2048.0f);      // saturate_cast<short>(coef * INTER_RESIZE_COEF_SCALE)
-            ha[k] = (int)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+    const auto key = std::make_tuple(src, dst, fixed ? 1 : 0);
+    auto it = c->pr_tabs.find(key);
+    if (it == c->pr_tabs.end()) {
+        if (c->pr_tabs.size() >= 256) {                       // (a context fed ever new sizes: start over rather than grow without bound)
+            PMX_HIP(hipStreamSynchronize(c->stream));
+            for (auto& kv : c->pr_tabs) (void)hipFree(kv.second);
+            c->pr_tabs.clear();
         }
-        PMX_HIP(hipMemcpy(d_i + n, ha.data(), n * sizeof(int), hipMemcpyHostToDevice));
-    } else {
-        PMX_HIP(hipMemcpy(d_i + n, hc.data(), n * sizeof(float), hipMemcpyHostToDevice));
+        const size_t n = (size_t)4 * dst;
+        std::vector<int> hi(2 * n);
+        std::vector<float> hc(n);
+        make_cubic_table(dst, src, hi.data(), hc.data());
+        if (fixed) {
+            for (size_t k = 0; k < n; ++k) {
+                long v = lrintf(hc[k] * 2048.0f);              // saturate_cast<short>(coef * INTER_RESIZE_COEF_SCALE)
+                hi[n + k] = (int)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+            }
+        } else {
+            memcpy(hi.data() + n, hc.data(), n * sizeof(float));
+        }
+        int* d = nullptr;
+        PMX_HIP(hipMalloc((void**)&d, 2 * n * sizeof(int)));
+        if (hipMemcpy(d, hi.data(), 2 * n * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(d);
+            pmx_set_error("cubic table upload failed");
+            return PMX_ERR_HIP;
+        }
+        it = c->pr_tabs.emplace(key, d).first;
     }
-    *xi = d_i; *yi = d_i + 4 * dw;
-    *xc = (void*)(d_i + n); *yc = (void*)((int*)(d_i + n) + 4 * dw);
+    *idx = it->second;
+    *coef = (const void*)(it->second + (size_t)4 * dst);
     return PMX_OK;
 }
 
@@ -91,7 +99,7 @@ extern "C" int pmx_precise_begin_batch(pmx_ctx* c, int n_images, int orig_h, int
     }
     PMX_HIP(hipMemsetAsync(c->ext_paf, 0, need * PMX_N_PAF * 4, c->stream));
     PMX_HIP(hipMemsetAsync(c->ext_heat, 0, need * PMX_N_HEAT * 4, c->stream));
-    c->pr_h = orig_h; c->pr_w = orig_w; c->pr_scales = 0; c->pr_n = n_images;
+    c->pr_h = orig_h; c->pr_w = orig_w; c->pr_scales = 0; c->pr_n = n_images; c->pr_src = nullptr;
     c->maps_valid = false;
     return PMX_OK;
 }
@@ -113,18 +121,22 @@ extern "C" int pmx_precise_add_scale_batch(pmx_ctx* c, const uint8_t* imgs, int 
     for (auto& l : c->layers) missing += l.set ? 0 : 1;
     PMX_CHECK(missing == 0, PMX_ERR_WEIGHTS, "pmx_precise_add_scale: %d layers have no weights", missing);
     int rc;
-    // original images -> device
+    // original images -> device, ONCE per begin / finish sequence: every scale resizes the same originals (the caller passes the same
+    // images to every pmx_precise_add_scale* of a sequence -- include/pose_mi355x.h; round 4 uploaded them again from pageable memory per scale)
     const size_t img_bytes = (size_t)oh * ow * 3, nsrc = img_bytes * n;
-    if (nsrc > c->u8_src_cap) {
-        PMX_HIP(hipStreamSynchronize(c->stream));
-        if (c->u8_src) (void)hipFree(c->u8_src);
-        c->u8_src = nullptr; c->u8_src_cap = 0;
-        PMX_HIP(hipMalloc((void**)&c->u8_src, nsrc));
-        c->u8_src_cap = nsrc;
+    if (c->pr_scales == 0 || c->pr_src != imgs) {
+        if (nsrc > c->u8_src_cap) {
+            PMX_HIP(hipStreamSynchronize(c->stream));
+            if (c->u8_src) (void)hipFree(c->u8_src);
+            c->u8_src = nullptr; c->u8_src_cap = 0;
+            PMX_HIP(hipMalloc((void**)&c->u8_src, nsrc));
+            c->u8_src_cap = nsrc;
+        }
+        PMX_HIP(hipMemcpyAsync(c->u8_src, imgs, nsrc, hipMemcpyHostToDevice, c->stream));
+        c->pr_src = imgs;
     }
-    PMX_HIP(hipMemcpyAsync(c->u8_src, imgs, nsrc, hipMemcpyHostToDevice, c->stream));
-    int *xi, *yi; void *xc, *yc;
-    // (1) uint8 cubic resize into the padded images
+    const int *xi, *yi; const void *xc, *yc;
+    // (1) uint8 cubic resize into the padded images (all images in one launch)
     const size_t pad_bytes = (size_t)ph * pw * 3;
     if ((rc = launch_fill_bgr(c->u8_tmp, (long long)n * ph * pw, 104, 117, 123, c->stream))) return rc;
     if (scaled_h == oh && scaled_w == ow) {
@@ -132,17 +144,17 @@ extern "C" int pmx_precise_add_scale_batch(pmx_ctx* c, const uint8_t* imgs, int 
             PMX_HIP(hipMemcpy2DAsync(c->u8_tmp + b * pad_bytes, (size_t)pw * 3, c->u8_src + b * img_bytes, (size_t)ow * 3, (size_t)ow * 3, oh,
                                      hipMemcpyDeviceToDevice, c->stream));
     } else {
-        if ((rc = upload_cubic_tables(c, oh, ow, scaled_h, scaled_w, true, &xi, &xc, &yi, &yc))) return rc;
-        for (int b = 0; b < n; ++b)
-            if ((rc = launch_resize_cubic_u8(c->u8_src + b * img_bytes, ow, c->u8_tmp + b * pad_bytes, scaled_h, scaled_w, pw, xi, (const int*)xc, yi,
-                                             (const int*)yc, c->stream))) return rc;
+        if ((rc = cubic_table(c, ow, scaled_w, true, &xi, &xc)) || (rc = cubic_table(c, oh, scaled_h, true, &yi, &yc))) return rc;
+        if ((rc = launch_resize_cubic_u8(c->u8_src, ow, c->u8_tmp, scaled_h, scaled_w, pw, xi, (const int*)xc, yi, (const int*)yc, n, (long long)img_bytes,
+                                         (long long)pad_bytes, c->stream))) return rc;
     }
     // (2) network, the n images as one batch
     if ((rc = launch_prep_u8(c->u8_tmp, c->in16, n, ph, pw, 255.0f, c->stream))) return rc;
     if ((rc = pmx_forward_from_in16(c, n, ph, pw))) return rc;
     const int fh = ph / 8, fw = pw / 8;
-    // (3) x8 cubic up-sampling of PAF (38) and heat (19) channels, image by image, into dense NHWC temporaries
-    const size_t per_img = (size_t)ph * pw * 57, ntmp = per_img * n;
+    // (3) x8 cubic up-sampling of the PAF (38) and heat (19) channels of all images into PLANAR temporaries [n][38][ph][pw] | [n][19][ph][pw]
+    // (two cv2.resize calls per image in the reference; planar so that step (4) reads rows of one channel and both steps store full rows)
+    const size_t ppx = (size_t)ph * pw, ntmp = ppx * 57 * n;
     if (ntmp > c->pr_tmp_cap) {
         PMX_HIP(hipStreamSynchronize(c->stream));
         if (c->pr_tmp) (void)hipFree(c->pr_tmp);
@@ -150,27 +162,18 @@ extern "C" int pmx_precise_add_scale_batch(pmx_ctx* c, const uint8_t* imgs, int 
         PMX_HIP(hipMalloc((void**)&c->pr_tmp, ntmp * sizeof(float)));
         c->pr_tmp_cap = ntmp;
     }
-    if ((rc = upload_cubic_tables(c, fh, fw, ph, pw, false, &xi, &xc, &yi, &yc))) return rc;
+    float* const t_paf = c->pr_tmp;
+    float* const t_heat = c->pr_tmp + ppx * PMX_N_PAF * n;
+    if ((rc = cubic_table(c, fw, pw, false, &xi, &xc)) || (rc = cubic_table(c, fh, ph, false, &yi, &yc))) return rc;
     const long long sy = (long long)fw * PMX_CAT_C, sx = PMX_CAT_C, sb = (long long)fh * fw * PMX_CAT_C;
-    // PAF and heat are separate arrays in the reference (two cv2.resize calls); each map set of each image gets its own dense NHWC region:
-    // image b: [ph*pw*38 | ph*pw*19]
-    for (int b = 0; b < n; ++b) {
-        float* t_paf = c->pr_tmp + b * per_img;
-        float* t_heat = t_paf + (size_t)ph * pw * PMX_N_PAF;
-        if ((rc = launch_resize_cubic_f32(c->cat + b * sb + PMX_CAT_PAF, sy, sx, 1, PMX_N_PAF, t_paf, ph, pw, xi, (const float*)xc, yi, (const float*)yc, 0, 0, c->stream))) return rc;
-        if ((rc = launch_resize_cubic_f32(c->cat + b * sb + PMX_CAT_HEAT, sy, sx, 1, PMX_N_HEAT, t_heat, ph, pw, xi, (const float*)xc, yi, (const float*)yc, 0, 0, c->stream))) return rc;
-    }
+    if ((rc = launch_resize_cubic_f32_planar(c->cat + PMX_CAT_PAF, sb, 1, sy, sx, n, PMX_N_PAF, t_paf, ph, pw, xi, (const float*)xc, yi, (const float*)yc, 0, c->stream))) return rc;
+    if ((rc = launch_resize_cubic_f32_planar(c->cat + PMX_CAT_HEAT, sb, 1, sy, sx, n, PMX_N_HEAT, t_heat, ph, pw, xi, (const float*)xc, yi, (const float*)yc, 0, c->stream))) return rc;
     // (4) crop the padding (source extent scaled_h x scaled_w of the padded maps) and cubic resize to the original size, accumulating
-    if ((rc = upload_cubic_tables(c, scaled_h, scaled_w, oh, ow, false, &xi, &xc, &yi, &yc))) return rc;
-    const size_t opx = (size_t)oh * ow;
-    for (int b = 0; b < n; ++b) {
-        float* t_paf = c->pr_tmp + b * per_img;
-        float* t_heat = t_paf + (size_t)ph * pw * PMX_N_PAF;
-        if ((rc = launch_resize_cubic_f32(t_paf, (long long)pw * PMX_N_PAF, PMX_N_PAF, 1, PMX_N_PAF, c->ext_paf + b * opx * PMX_N_PAF, oh, ow, xi, (const float*)xc, yi,
-                                          (const float*)yc, 1, 0, c->stream))) return rc;
-        if ((rc = launch_resize_cubic_f32(t_heat, (long long)pw * PMX_N_HEAT, PMX_N_HEAT, 1, PMX_N_HEAT, c->ext_heat + b * opx * PMX_N_HEAT, oh, ow, xi, (const float*)xc, yi,
-                                          (const float*)yc, 1, 0, c->stream))) return rc;
-    }
+    if ((rc = cubic_table(c, scaled_w, ow, false, &xi, &xc)) || (rc = cubic_table(c, scaled_h, oh, false, &yi, &yc))) return rc;
+    if ((rc = launch_resize_cubic_f32_planar(t_paf, (long long)ppx * PMX_N_PAF, (long long)ppx, pw, 1, n, PMX_N_PAF, c->ext_paf, oh, ow, xi, (const float*)xc, yi,
+                                             (const float*)yc, 1, c->stream))) return rc;
+    if ((rc = launch_resize_cubic_f32_planar(t_heat, (long long)ppx * PMX_N_HEAT, (long long)ppx, pw, 1, n, PMX_N_HEAT, c->ext_heat, oh, ow, xi, (const float*)xc, yi,
+                                             (const float*)yc, 1, c->stream))) return rc;
     c->pr_scales += 1;
     c->maps_valid = false;       // the cat buffer holds one scale only; the averaged maps become valid in pmx_precise_finish
     return PMX_OK;

@@ -106,56 +106,61 @@ __global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __
 }
 
 // ---- cv2.resize(..., interpolation=cv2.INTER_CUBIC) restated (detect_precise, reference pose_detector.py:443,461-467) ----
-// Tables per axis (host, pmx_api.hip::make_cubic_table): 4 clamped source indices and 4 float32 coefficients (OpenCV's
+// Tables per axis (host, pmx_precise.hip::make_cubic_table): 4 clamped source indices and 4 float32 coefficients (OpenCV's
 // bicubic, A = -0.75) per destination coordinate, laid out [k][dst].  Arithmetic order = the NumPy restatement
 // (pose_detector.py::resize_cubic_*, oracle/precise_ref.py): horizontal 4-tap sums for the 4 source rows, then the
 // vertical 4-tap sum, float32 products added left to right (this file is compiled with -ffp-contract=off).
 
-// float32: src(y, x, c) = src[y * sy + x * sx + c * sc], C channels; dst either NHWC (dst[(y * dw + x) * C + c], accumulate = 0)
-// or planar with accumulation (dst[(c * dh + y) * dw + x] += v, accumulate = 1; the per-scale sums of :463,467)
-__global__ __launch_bounds__(256) void resize_cubic_f32_kernel(const float* __restrict__ src, long long sy, long long sx, long long sc,
-                                                               int C, float* __restrict__ dst, int dh, int dw,
-                                                               const int* __restrict__ xi, const float* __restrict__ xc,
-                                                               const int* __restrict__ yi, const float* __restrict__ yc,
-                                                               int accumulate, int dst_c0)
+// float32, PLANAR destination, a whole batch per launch: one thread per destination element with x the FASTEST thread index, so a wave's
+// stores (and, in the accumulating form, its read-modify-writes) are one contiguous 256-byte run of the destination row and its gathers land
+// in a handful of neighbouring cache lines of the source rows (round 4 ran one thread per element with the CHANNEL fastest and accumulated
+// with a stride of dh * dw floats between neighbouring threads: 11 % of detect_precise's device time, 16.6 ms for one launch of the
+// batch-of-8 form).  Source element (b, c, y, x) = src[b * sb + c * sc + y * sy + x * sx] (the network's NHWC cat buffer for the x8
+// up-sampling, the planar intermediate for the resize to the original size); destination dst[((b * C + c) * dh + y) * dw + x],
+// ACC: += (the per-scale sums of :463,467).  blockIdx = (x / 256, y, b * C + c); the row's y taps are uniform (scalar loads).
+template <int ACC>
+__global__ __launch_bounds__(256) void resize_cubic_f32_planar_kernel(const float* __restrict__ src, long long sb, long long sc, long long sy, long long sx,
+                                                                      int C, float* __restrict__ dst, int dh, int dw,
+                                                                      const int* __restrict__ xi, const float* __restrict__ xc,
+                                                                      const int* __restrict__ yi, const float* __restrict__ yc)
 {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long n = (long long)dh * dw * C;
-    if (i >= n) return;
-    const int c = (int)(i % C);
-    const long long p = i / C;
-    const int x = (int)(p % dw), y = (int)(p / dw);
-    const float* s = src + (long long)c * sc;
+    const int x = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const int y = (int)blockIdx.y, bc = (int)blockIdx.z;
+    if (x >= dw) return;
+    const int b = bc / C, c = bc - b * C;
+    const float* s = src + (long long)b * sb + (long long)c * sc;
+    const long long x0 = (long long)xi[x] * sx, x1 = (long long)xi[dw + x] * sx, x2 = (long long)xi[2 * dw + x] * sx, x3 = (long long)xi[3 * dw + x] * sx;
+    const float c0 = xc[x], c1 = xc[dw + x], c2 = xc[2 * dw + x], c3 = xc[3 * dw + x];
     float rows[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float* r = s + (long long)yi[k * dh + y] * sy;
-        float a = r[(long long)xi[x] * sx] * xc[x];
-        a = a + r[(long long)xi[dw + x] * sx] * xc[dw + x];
-        a = a + r[(long long)xi[2 * dw + x] * sx] * xc[2 * dw + x];
-        a = a + r[(long long)xi[3 * dw + x] * sx] * xc[3 * dw + x];
+        float a = r[x0] * c0;
+        a = a + r[x1] * c1;
+        a = a + r[x2] * c2;
+        a = a + r[x3] * c3;
         rows[k] = a;
     }
     float v = rows[0] * yc[y];
     v = v + rows[1] * yc[dh + y];
     v = v + rows[2] * yc[2 * dh + y];
     v = v + rows[3] * yc[3 * dh + y];
-    if (accumulate) {
-        float* d = dst + ((long long)(dst_c0 + c) * dh + y) * dw + x;
-        *d = *d + v;
-    } else {
-        dst[p * C + c] = v;
-    }
+    float* d = dst + ((long long)bc * dh + y) * dw + x;
+    if (ACC) *d = *d + v;
+    else *d = v;
 }
 
 // uint8 HWC, 11-bit fixed point: rows = sum(src * ax) (int32), out = (sum(rows * ay) + (1 << 21)) >> 22, saturated.
 // dst has row pitch `dpitch` pixels (the resized image is written into the top-left corner of the padded image, :445)
+// blockIdx.y = image of the batch (source / destination images `sbytes` / `dbytes` apart)
 __global__ __launch_bounds__(256) void resize_cubic_u8_kernel(const uint8_t* __restrict__ src, int sw, uint8_t* __restrict__ dst,
                                                               int dh, int dw, int dpitch, const int* __restrict__ xi,
-                                                              const int* __restrict__ xa, const int* __restrict__ yi, const int* __restrict__ ya)
+                                                              const int* __restrict__ xa, const int* __restrict__ yi, const int* __restrict__ ya,
+                                                              long long sbytes, long long dbytes)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)dh * dw) return;
+    src += (long long)blockIdx.y * sbytes; dst += (long long)blockIdx.y * dbytes;
     const int x = (int)(i % dw), y = (int)(i / dw);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -231,20 +236,23 @@ int launch_resize_linear_u8(const uint8_t* src, uint8_t* dst, const int* xtab, c
     return PMX_OK;
 }
 
-int launch_resize_cubic_f32(const float* src, long long sy, long long sx, long long sc, int C, float* dst, int dh, int dw,
-                            const int* xi, const float* xc, const int* yi, const float* yc, int accumulate, int dst_c0, hipStream_t s)
+int launch_resize_cubic_f32_planar(const float* src, long long sb, long long sc, long long sy, long long sx, int B, int C, float* dst, int dh, int dw,
+                                   const int* xi, const float* xc, const int* yi, const float* yc, int accumulate, hipStream_t s)
 {
-    const long long n = (long long)dh * dw * C;
-    hipLaunchKernelGGL(resize_cubic_f32_kernel, dim3(nblocks(n)), dim3(256), 0, s, src, sy, sx, sc, C, dst, dh, dw, xi, xc, yi, yc,
-                       accumulate, dst_c0);
+    PMX_CHECK(dh >= 1 && dh <= 65535 && (long long)B * C >= 1 && (long long)B * C <= 65535, PMX_ERR_INVALID,
+              "cubic resize: %d rows x %d planes outside the launch grid", dh, B * C);
+    const dim3 grid((unsigned)((dw + 255) / 256), (unsigned)dh, (unsigned)(B * C));
+    if (accumulate) hipLaunchKernelGGL(resize_cubic_f32_planar_kernel<1>, grid, dim3(256), 0, s, src, sb, sc, sy, sx, C, dst, dh, dw, xi, xc, yi, yc);
+    else hipLaunchKernelGGL(resize_cubic_f32_planar_kernel<0>, grid, dim3(256), 0, s, src, sb, sc, sy, sx, C, dst, dh, dw, xi, xc, yi, yc);
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
 
 int launch_resize_cubic_u8(const uint8_t* src, int sw, uint8_t* dst, int dh, int dw, int dpitch, const int* xi, const int* xa,
-                           const int* yi, const int* ya, hipStream_t s)
+                           const int* yi, const int* ya, int B, long long sbytes, long long dbytes, hipStream_t s)
 {
-    hipLaunchKernelGGL(resize_cubic_u8_kernel, dim3(nblocks((long long)dh * dw)), dim3(256), 0, s, src, sw, dst, dh, dw, dpitch, xi, xa, yi, ya);
+    hipLaunchKernelGGL(resize_cubic_u8_kernel, dim3(nblocks((long long)dh * dw), (unsigned)B), dim3(256), 0, s, src, sw, dst, dh, dw, dpitch, xi, xa, yi, ya,
+                       sbytes, dbytes);
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }

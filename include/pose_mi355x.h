@@ -126,6 +126,8 @@ int pmx_synchronize(pmx_ctx* ctx);                    /* cuda.get_device_from_id
  *                              split into three bf16 terms (six products, fp32 accumulate): fp32-grade accuracy, 2.67x the
  *                              matrix rate, results equal to the fp32 path only to summation-order-sized noise
  *   "fuse_conv1" 1 | 0         conv1_1 recomputed on conv1_2's halo tiles, one launch instead of two (default 1); identical bits
+ *   "conv1_wino" 1 | 0 | 2     that launch with conv1_2 as Winograd F(2x2, 3x3) on 16 x 16 squares (default 1: where "conv_algo" >= 1
+ *                              and the launch has a block per CU; 2: whatever the launch size); 0: the direct 8 x 16 tiles everywhere
  *   "fuse_pairs" 1 | 0         the two 1x1 layers that end every stage as one launch (default) or as two; identical bits
  *   "ksplit" 0 | 1 | n         split-K of the 3x3 / 7x7 launches that cannot fill the chip (single images): 0 = automatic,
  *                              1 = never, n = n K slices wherever split-K applies.  The slices are combined in a fixed
@@ -177,7 +179,9 @@ int pmx_postprocess(pmx_ctx* ctx, int batch, int map_h, int map_w, double img_le
 /* ---- detect_precise (pose_detector.py:433-482) accumulated on the device ------------------------------------
  * begin(orig size) -> add_scale(host uint8 orig image, scaled size = ceil(orig * multiplier), :442-443) per inference scale ->
  * finish() (average, :469-470; installs the full-resolution maps as a batch of one) -> pmx_postprocess(ctx, 1, orig_h,
- * orig_w, img_len = orig_w, NULL) (:475-481).  cv2.resize(INTER_CUBIC) is restated (uint8 fixed-point and float32 paths). */
+ * orig_w, img_len = orig_w, NULL) (:475-481).  cv2.resize(INTER_CUBIC) is restated (uint8 fixed-point and float32 paths).
+ * Every add_scale of one begin / finish sequence resizes the SAME original image(s): the host buffer is uploaded by the first call and
+ * a later call that passes the same pointer reuses the device copy, so the pixels must not change between begin and finish. */
 int pmx_precise_begin(pmx_ctx* ctx, int orig_h, int orig_w);
 int pmx_precise_add_scale(pmx_ctx* ctx, const uint8_t* bgr_hwc, int scaled_h, int scaled_w);
 int pmx_precise_finish(pmx_ctx* ctx);

@@ -160,8 +160,14 @@ def splitk_plan(profile):
 
 
 def wino_layers(profile):
-    """Layer labels the engine ran with the Winograd kernel (kernel label "conv_wino_f2x2_3x3" in an engine profile)."""
-    return {e['layer'] for e in profile if e['kernel'].startswith('conv_wino')}
+    """Layer labels the engine ran with the Winograd kernel (kernel label "conv_wino_f2x2_3x3" in an engine profile).  The fused
+    conv1_1 + conv1_2 launch with conv1_2 in Winograd form (label "conv_wino1_...", csrc/conv1_wino.hip) counts as `conv1_2`: conv1_1
+    keeps the direct chain inside it."""
+    out = {e['layer'] for e in profile if e['kernel'].startswith('conv_wino')}
+    if 'conv1_1+conv1_2' in out:
+        out.discard('conv1_1+conv1_2')
+        out.add('conv1_2')
+    return out
 
 
 def forward_fma(weights, x, splitk=None, wino=()):

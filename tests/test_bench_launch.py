@@ -58,6 +58,25 @@ def test_two_ranks_equal_one_rank(tmp_path):
 
 
 @pytest.mark.gpu
+def test_eight_ranks_through_the_launcher(tmp_path):
+    """Pre-flight for the driver's 8-GPU run (BASELINE config 4): `bench.py --gpus 8` starts its own eight ranks, every rank takes the
+    N > 1 path (RecordPipe, one gather per step, pipelined) and rank 0 prints what the SCALE record needs -- here over gloo with the
+    eight ranks sharing the one GPU of the test box (the RCCL transport itself needs eight GPUs: only the driver has them)."""
+    f8 = str(tmp_path / 'r8.npy')
+    r = _run(['--gpus', '8', '--backend', 'gloo', '--batch', '2', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-profile', '--no-extras',
+              '--dump-records', f8], timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 8 and line['ranks_seen'] == list(range(8)) and len(line['devices']) == 8
+    assert line['config']['global_batch'] == 16 and line['config']['records_gathered'] == 16
+    assert line['collectives_per_step'] == 1.0 and 'RecordPipe' in line['records_path']
+    assert len(line['per_rank_frames_per_s']) == 8 and len(line['per_rank_frames_per_s_min_max']) == 2
+    assert line['gather_ms_per_step_rank0'] >= 0 and line['scaling'] == 'weak'
+    rec = np.load(f8)
+    assert len(rec) == 16 and int(rec['n_peaks'].sum()) > 0
+
+
+@pytest.mark.gpu
 def test_one_rank_through_the_rccl_gather_equals_plain_run(tmp_path):
     """`--force-gather`: N = 1 with a one-rank "nccl" (RCCL) process group, records routed through dist.RecordPipe (engine snapshot into the
     device send slot, one RCCL gather per step, pipelined one step behind the compute) -- the branch every rank takes at N > 1 -- must give

@@ -149,12 +149,14 @@ def test_kernel_generations_compute_identical_bits(engine):
     img = np.random.default_rng(5).integers(0, 256, (2, 184, 184, 3), dtype=np.uint8)
     maps = {}
     engine.set_option('ksplit', 1)          # (split-K changes the summation tree of small launches: compared separately)
+    engine.set_option('conv1_wino', 0)      # (the fused conv1 launch of generation 6 in its direct form: the Winograd form is another arithmetic)
     for gen in (1, 5, 6):
         engine.set_option('kernel_gen', gen)
         engine.forward_u8(img)
         maps[gen] = engine.get_maps()
     engine.set_option('kernel_gen', 6)      # library default (v6 only engages on maps a multiple of 46 wide: see below)
     engine.set_option('ksplit', 0)
+    engine.set_option('conv1_wino', 1)
     for gen in (5, 6):
         assert np.array_equal(maps[1][0], maps[gen][0]) and np.array_equal(maps[1][1], maps[gen][1])
 
@@ -355,6 +357,7 @@ def test_fused_conv1_equals_separate_layers_bitwise(native, arch, B, hw):
     eng.set_weights(pkg('weights').synthetic_weights(4, arch))
     imgs = np.random.default_rng(B + hw[1]).integers(0, 256, (B,) + hw + (3,), dtype=np.uint8)
     outs = {}
+    eng.set_option('conv1_wino', 0)      # (the direct form of the fused launch; its Winograd form is another arithmetic: test_conv1_wino_* below)
     for fuse in (0, 1):
         eng.set_option('fuse_conv1', fuse)
         eng.profile_reset()
@@ -369,3 +372,38 @@ def test_fused_conv1_equals_separate_layers_bitwise(native, arch, B, hw):
         assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     else:
         assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize('B,hw', [(7, (88, 104)), (2, (184, 248)), (1, (368, 368))])
+def test_conv1_wino_network_bit_exact_vs_twin(native, B, hw):
+    """conv1_1 + conv1_2 as one launch with conv1_2 in Winograd F(2x2, 3x3) on 16 x 16 squares (conv1_wino_kernel: conv1_1 recomputed on
+    the 18 x 18 halo, the direct chain; conv1_2 = conv_wino_kernel<3, pool>'s arithmetic at 64 tiles x 64 channels per block) through the
+    whole network against the order-defined twin (conv_fma for conv1_1, conv_wino_ref for conv1_2 and every other Winograd layer), bit
+    for bit.  Sizes: maps that are no multiple of the 16-pixel squares (clipped squares, masked stores), a batch, one full frame."""
+    from conftest import pkg
+    from oracle import conv_fma_ref, postprocess_ref
+    w = pkg('weights').synthetic_weights(5)
+    eng = native.Engine(0, max_batch=B, max_h=hw[0], max_w=hw[1])
+    eng.set_weights(w)
+    eng.set_option('conv1_wino', 2)       # (2: also where the launch has fewer blocks than CUs)
+    imgs = np.random.default_rng(B * 1000 + hw[1]).integers(0, 256, (B,) + hw + (3,), dtype=np.uint8)
+    eng.profile_reset(); eng.profile_enable(True)
+    eng.forward_u8(imgs)
+    prof = eng.profile()
+    eng.profile_enable(False)
+    assert any(e['kernel'].startswith('conv_wino1_') for e in prof), {e['kernel'] for e in prof}
+    paf, heat = eng.get_maps()
+    # the same images with the direct fused launch: another fp32 arithmetic, the maps agree to rounding
+    eng.set_option('conv1_wino', 0)
+    eng.forward_u8(imgs)
+    dpaf, dheat = eng.get_maps()
+    eng.close()
+    plan = conv_fma_ref.splitk_plan(prof)
+    assert 'conv1_2' in plan.wino
+    nb = min(B, 2)                         # (the twin is a plain-C loop: two images are enough to see the batch stride)
+    x = np.concatenate([postprocess_ref.preprocess(im) for im in imgs[:nb]])
+    epaf, eheat = conv_fma_ref.forward_fma(w, x, splitk=plan)
+    assert np.array_equal(paf[:nb], epaf) and np.array_equal(heat[:nb], eheat)
+    scale = max(np.abs(dpaf).max(), np.abs(dheat).max(), 1.0)
+    assert max(np.abs(paf - dpaf).max(), np.abs(heat - dheat).max()) <= 1e-4 * scale
+    assert not np.array_equal(paf, dpaf)
