@@ -10,8 +10,9 @@
 // instead of eight: phases of 4 planes x 4 k8-steps x 4 MFMAs = 64 MFMAs per wave, during which every thread transforms its two (tile, 4
 // channels) items of the next row (8 raw reads, 8 packed-add pairs, 4 U stores each), one instruction per slot between two MFMAs.
 // Cin = 64 is two chunks of 32: 8 phases = 512 MFMAs per wave and block.
-// conv1_1 is RECOMPUTED on the block's 18 x 18 halo from a 20 x 20 x 3 input patch (as conv1_fused_kernel does on its 10 x 18 halo): 11
-// row tiles of 32 pixels x 2 channel halves x 14 MFMAs (K = 27 packed tap-major into 14 k-pairs), bias + ReLU, zero outside the image
+// conv1_1 is RECOMPUTED on the block's 18 x 18 halo from a 20 x 20 x 3 input patch (as conv1_fused_kernel does on its 10 x 18 halo): 10
+// row tiles of 32 pixels x 2 channel halves x 14 MFMAs (K = 27 packed tap-major into 14 k-pairs; the last 4 of the 324 pixels on the
+// vector ALU), bias + ReLU, zero outside the image
 // (= conv1_2's padding), into LDS, where all 64 channels stay for the whole block -- the 1.1 GB round trip of conv1_1's output (batch 32)
 // never happens and the phases have no halo staging at all.
 // LDS: raw halo 324 pixels x 68 floats (88 128 B) + U 2 x 4 x 64 x 36 floats (73 728 B) + 64 bias values = 162 112 of 163 840 bytes.
@@ -22,6 +23,12 @@
 #include "pmx_common.h"
 #include "wino_util.h"
 
+// Diagnostic builds only (tools/kernel_variants.py; the product is built with 0; results are wrong, only the time is read): leave out
+// 1: conv1_1 (tiles and the vector-ALU pixels), 2: the phases' transform slots, 4: their weight loads, 8: the phases altogether, 16: the
+// output stores, 32: the per-lane gather of conv1_1's weights
+#ifndef PMX_C1W_ABLATE
+#define PMX_C1W_ABLATE 0
+#endif
 namespace {
 constexpr int TT = 8;                     // Winograd tiles per block side (16 x 16 output pixels before the pool)
 constexpr int HW1 = 2 * TT + 2;           // halo of conv1_2's input = conv1_1's output: 18 x 18 pixels
@@ -82,12 +89,11 @@ __global__ __launch_bounds__(256, 1) void conv1_wino_kernel(const ConvArgs a)
     float wv[14];
     int koff[14];
     {
-        const float* wp = a.g[1].w;                     // packed [tap][1 chunk][64][16]
+        const float* wp = a.g[1].w + chh * (14 * 64) + lane;      // packed for this kernel [half][k-pair 14][k of the pair 2][32] (pmx_api.hip::ensure_conv1_pack)
 #pragma unroll
         for (int s = 0; s < 14; ++s) {
             const int k = 2 * s + kh, kk = k < 27 ? k : 26;
-            const float w = wp[(size_t)((kk / 3) * 64 + chh * 32 + li) * 16 + kk % 3];
-            wv[s] = k < 27 ? w : 0.f;
+            wv[s] = (PMX_C1W_ABLATE & 32) ? 1.f : wp[s * 64];     // (k = 27: the pack holds 0)
             const int tap = kk / 3;
             koff[s] = ((tap / 3) * PW + tap % 3) * 3 + kk % 3;
         }
@@ -111,35 +117,73 @@ __global__ __launch_bounds__(256, 1) void conv1_wino_kernel(const ConvArgs a)
     for (int g = 0; g < 8; ++g) bw[g] = wload(g);
     __syncthreads();
 
-    // ---- conv1_1 on the halo: wave = channel half chh x row tiles (wave >> 1) + 2 i.  The weights are the matrix core's ROW operand, so a
-    // lane ends up with 16 channels of ITS pixel: four 16-byte LDS stores per row tile, pixel validity per lane
+    // ---- conv1_1 on the halo.  Pixels 0..319 = ten row tiles of 32 on the matrix core: wave = channel half chh x row tiles (wave >> 1)
+    // + 2 i, i = 0..4, as a software pipeline -- while the 14 MFMAs of tile i run, the lane gathers the patch values of tile i + 1 (one
+    // ds_read_b32 per gap) and finishes tile i - 1 (accumulator -> bias, ReLU, padding mask -> LDS), a few instructions per gap; left as
+    // five sequential chains every tile paid its gather latency, an s_nop 15 and its 70-instruction epilogue with the matrix pipe idle.
+    // The weights are the matrix core's ROW operand, so a lane ends up with 16 channels of ITS pixel: four 16-byte LDS stores per tile.
+    // The last four pixels (320..323) are one (pixel, channel) per thread on the vector ALU, the same fused-multiply-add chain k = 0..26
+    // (an eleventh row tile would be two more 14-MFMA jobs for four pixels, on two of the four waves only).
+    const float b1s = a.g[1].bias[chh * 32 + li];
+    int c1_m[5], c1_pb[5];
+    float c1_hi[5];                                    // upper clamp of the tile's pixel: +inf inside the image, 0 outside (conv1_2's zero padding)
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int rt = (wave >> 1) + 2 * i;
-        if (rt * 32 < NPX) {
-            const int m = min(rt * 32 + li, NPX - 1);
-            const int hy = m / HW1, hx = m - hy * HW1;
-            const int pbase = (hy * PW + hx) * 3;
-            f32x16 acc1;
+    for (int i = 0; i < 5; ++i) {
+        const int m = ((wave >> 1) + 2 * i) * 32 + li;
+        const int hy = m / HW1, hx = m - hy * HW1;
+        c1_m[i] = m;
+        c1_pb[i] = (hy * PW + hx) * 3;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        c1_hi[i] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? __builtin_inff() : 0.f;
+    }
+    if (!(PMX_C1W_ABLATE & 1)) {
+        const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float pa[2][14];
+        f32x16 acc1[2];
+        f32x4 ev;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+        for (int sg = 0; sg < 14; ++sg) pa[0][sg] = s_patch[c1_pb[0] + koff[sg]];
+        // piece `sg` of the epilogue of a finished tile: quad q = sg / 3 of its 16 channels: (0) out of the accumulator + bias, (1) ReLU
+        // and mask in one median -- med3(x, 0, +inf) = max(x, 0), med3(x, 0, 0) = 0 --, (2) the 16-byte store
+        auto c1_finish = [&](const f32x16& acc, int i, int sg) {
+            const int q = sg / 3, part = sg - 3 * q;
+            if (q >= 4) return;
+            if (part == 0) ev = pk_add4(f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]}, b1[q]);
+            else if (part == 1) {
 #pragma unroll
-            for (int s = 0; s < 14; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[s], s_patch[pbase + koff[s]], acc1, 0, 0, 0);
-            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-            const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;       // (outside: conv1_2's zero padding)
-            if (rt * 32 + li < NPX) {
+                for (int e = 0; e < 4; ++e) ev[e] = __builtin_amdgcn_fmed3f(ev[e], 0.f, c1_hi[i]);
+            } else *reinterpret_cast<f32x4*>(&s_raw[c1_m[i] * LDA + chh * 32 + 8 * q + 4 * kh]) = ev;
+        };
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 v;
+        for (int i = 0; i < 5; ++i) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float t = fmaxf(acc1[4 * q + e] + b1[q][e], 0.f);
-                        v[e] = inside ? t : 0.f;
-                    }
-                    *reinterpret_cast<f32x4*>(&s_raw[m * LDA + chh * 32 + 8 * q + 4 * kh]) = v;
-                }
+            for (int sg = 0; sg < 14; ++sg) {
+                acc1[i & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[sg], pa[i & 1][sg], sg == 0 ? z16 : acc1[i & 1], 0, 0, 0);
+                if (i + 1 < 5) pa[(i + 1) & 1][sg] = s_patch[c1_pb[i + 1] + koff[sg]];
+                if (i > 0) c1_finish(acc1[(i - 1) & 1], i - 1, sg);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        // pixels 320..323 (halo row 17, columns 14..17) while the last tile's MFMAs drain: thread = channel chh * 32 + li of pixel
+        // 320 + 2 (wave >> 1) + kh; the odd / even k's of the channel sit in the other half of the wave
+        {
+            const int p4 = 2 * (wave >> 1) + kh, m = 320 + p4;
+            const int hy = m / HW1, hx = m - hy * HW1, pb = (hy * PW + hx) * 3;
+            float accv = 0.f;
+#pragma unroll
+            for (int sg = 0; sg < 14; ++sg) {
+                const float other = __shfl_xor(wv[sg], 32);
+                const float we = kh ? other : wv[sg], wo = kh ? wv[sg] : other;
+                const int k0 = 2 * sg, k1 = 2 * sg + 1;
+                accv = __builtin_fmaf(s_patch[pb + ((k0 / 9) * PW + (k0 / 3) % 3) * 3 + k0 % 3], we, accv);
+                if (k1 < 27) accv = __builtin_fmaf(s_patch[pb + ((k1 / 9) * PW + (k1 / 3) % 3) * 3 + k1 % 3], wo, accv);
+            }
+            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            const float hi = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? __builtin_inff() : 0.f;
+            s_raw[m * LDA + chh * 32 + li] = __builtin_amdgcn_fmed3f(accv + b1s, 0.f, hi);
+        }
+#pragma unroll
+        for (int sg = 0; sg < 12; ++sg) c1_finish(acc1[0], 4, sg);      // (tile 4 = acc1[4 & 1])
     }
     __syncthreads();
 
@@ -207,7 +251,7 @@ __global__ __launch_bounds__(256, 1) void conv1_wino_kernel(const ConvArgs a)
                 // (a chain starts from the constant 0: no accumulator is zeroed, and none is live while conv1_1 uses the matrix core)
                 acc[f] = wino_mfma(av[s & 3][e], bw[g & 15][e], (ch == 0 && (s & 3) == 0 && e == 0) ? zero16 : acc[f]);
                 if (e == 0) {
-                    if (g + 8 < 128) bw[(g + 8) & 15] = wload(g + 8);
+                    if (g + 8 < 128 && !(PMX_C1W_ABLATE & 4)) bw[(g + 8) & 15] = wload(g + 8);
                     if (s == 14 && P < 7) __syncthreads();
                     __builtin_amdgcn_sched_barrier(0);
                 } else if (e == 1) {
@@ -216,16 +260,21 @@ __global__ __launch_bounds__(256, 1) void conv1_wino_kernel(const ConvArgs a)
                     else if (P < 7) av[sn & 3] = *reinterpret_cast<const f32x4*>(&s_u[halfn * U_HALF + a_off + (sn & 3) * 8]);
                     __builtin_amdgcn_sched_barrier(0);
                 } else {
-                    if (P < 7) side(2 * s + (e - 2), chn, in, halfn);
+                    if (P < 7 && !(PMX_C1W_ABLATE & 2)) side(2 * s + (e - 2), chn, in, halfn);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
     };
     // (explicit instances: left as a loop the compiler does not unroll all eight phases and the accumulator array goes to scratch)
+    if (!(PMX_C1W_ABLATE & 8)) {
     phase(std::integral_constant<int, 0>{}); phase(std::integral_constant<int, 1>{}); phase(std::integral_constant<int, 2>{});
     phase(std::integral_constant<int, 3>{}); phase(std::integral_constant<int, 4>{}); phase(std::integral_constant<int, 5>{});
     phase(std::integral_constant<int, 6>{}); phase(std::integral_constant<int, 7>{});
+    } else {
+#pragma unroll
+        for (int f = 0; f < 16; ++f) acc[f] = zero16;
+    }
     // (every accumulator stays an AGPR tile until all phases are done: left alone the register allocator starts reading finished tiles out
     //  between the MFMAs of the last chunk -- copies, write-backs and an s_nop 15 per tile in the middle of the matrix pipe's work)
     __builtin_amdgcn_sched_barrier(0);
@@ -266,12 +315,13 @@ __global__ __launch_bounds__(256, 1) void conv1_wino_kernel(const ConvArgs a)
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(pooled[4 * q + e] + bq[q][e], lo);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, o + q * 32, 0, 0);
+        if (PMX_C1W_ABLATE & 16) asm volatile("" :: "v"(v));
+        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, o + q * 32, 0, 0);
     }
 }
 
-// a.g[0] = conv1_2 (in = the 16-channel padded network input, w = its TRANSFORMED weights, pack_wino with cout_pad 64), a.g[1].w / .bias =
-// conv1_1's packed direct weights / bias
+// a.g[0] = conv1_2 (in = the 16-channel padded network input, w = its TRANSFORMED weights, pack_wino with cout_pad 64), a.g[1].w = conv1_1's
+// weights in lane order (pmx_api.hip::ensure_conv1_pack), a.g[1].bias = its bias
 int conv1_wino_launch(const ConvArgs& a0, hipStream_t stream)
 {
     ConvArgs a = a0;

@@ -536,6 +536,32 @@ static int ensure_wino_pack(PackedLayer& L)
     L.d_ww = d;
     return PMX_OK;
 }
+// conv1_1's weights in the order conv1_wino_kernel's lanes want them: [channel half 2][k-pair 14][k of the pair 2][channel 32] (the 28th k is
+// zero) -- one contiguous 256-byte run per wave and k-pair.  Read out of the direct pack [tap][1 chunk][64][16] each lane gathered 14 dwords
+// 64 bytes apart: 1.7 us of a 25 us block (profiles/r05_conv1_wino_ablation.json).  Lives in the layer's otherwise unused Winograd slot.
+static int ensure_conv1_pack(PackedLayer& L)
+{
+    if (L.d_ww) return PMX_OK;
+    std::vector<float> wp;
+    if (int rc = fetch_packed(L, wp)) return rc;
+    std::vector<float> w1(2 * 14 * 2 * 32, 0.f);
+    for (int hf = 0; hf < 2; ++hf)
+        for (int sp = 0; sp < 14; ++sp)
+            for (int kk = 0; kk < 2; ++kk)
+                for (int n = 0; n < 32; ++n) {
+                    const int k = 2 * sp + kk;
+                    if (k < 27) w1[((hf * 14 + sp) * 2 + kk) * 32 + n] = wp[((size_t)(k / 3) * L.cout_pad + hf * 32 + n) * CK + k % 3];
+                }
+    float* d = nullptr;
+    PMX_HIP(hipMalloc((void**)&d, w1.size() * sizeof(float)));
+    if (hipMemcpy(d, w1.data(), w1.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        pmx_set_error("conv1_1 weight pack: host-to-device copy failed: %s", hipGetErrorString(hipGetLastError()));
+        return PMX_ERR_HIP;
+    }
+    L.d_ww = d;
+    return PMX_OK;
+}
 static int ensure_bf16x3_pack(PackedLayer& L)
 {
     if (L.d_w3) return PMX_OK;
@@ -865,8 +891,9 @@ static int run_conv1(pmx_ctx* c, int B, int H, int W)
     // conv1_2 as Winograd F(2x2, 3x3) on 16 x 16 squares (conv1_wino.hip) wherever the Winograd kernels are allowed (conv_algo >= 1) and
     // the launch has at least one block per CU (smaller launches: the 8 x 16 direct tiles give twice the blocks)
     if (c->opt_conv1_wino && c->opt_conv_algo >= 1 && (c->opt_conv1_wino == 2 || (long long)B * ((H + 15) / 16) * ((W + 15) / 16) >= conv_num_cus())) {
-        if ((rc = ensure_wino_pack(c->layers[i2]))) return rc;
+        if ((rc = ensure_wino_pack(c->layers[i2])) || (rc = ensure_conv1_pack(c->layers[i1]))) return rc;
         a.g[0].w = L2.d_ww;
+        a.g[1].w = L1.d_ww;
         if (c->prof_on == 1) {
             const double f1 = 2.0 * B * H * W * 9.0 * (double)L1.cout * L1.cin, f2 = 2.0 * B * H * W * 9.0 * (double)L2.cout * L2.cin;
             if ((rc = prof_begin(c, "conv1_1+conv1_2|conv_wino1_f2x2_t16x16", f1 + f2, 4.0 * B * H * W * (3 + 64 / 4), f1 + f2 * 16.0 / 36.0))) return rc;

@@ -45,6 +45,8 @@ def group(layer, kernel):
         return '3x3 main'
     if kernel.startswith('pp_'):
         return 'post-process'
+    if layer.startswith('conv1_1'):
+        return 'conv1'
     return 'other'
 
 
