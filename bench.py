@@ -799,6 +799,33 @@ def precise_mode(weights_mod, device_index, with_oracle=True, shape=(482, 642)):
                 out['dominant_kernel'] = {'kernel': nm, 'profile_labels': labels, 'total_ms': total_ms, 'launches': launches,
                                           'issued_frac': total_issued / (total_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                                           'algorithmic_frac': total_flop / (total_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+        # where the time of one image goes, scale by scale: the same four pmx_precise_add_scale calls with the per-launch profile reset
+        # in between (conv kernel forms by HIP kernel, the resizes and the rest of a scale's launches are the wall-clock remainder)
+        try:
+            eng_ = det.engine
+            per_scale = []
+            eng_.precise_begin(H, W, 1)
+            for (sh_, sw_) in scales:
+                eng_.profile_reset(); eng_.profile_enable(1)
+                eng_.synchronize(); t1 = time.perf_counter()
+                eng_.precise_add_scale(img[None], sh_, sw_)
+                eng_.synchronize(); wall = (time.perf_counter() - t1) * 1e3
+                pr = eng_.profile()
+                eng_.profile_enable(False)
+                forms = {}
+                for p_ in pr:
+                    if p_['kernel'].startswith('conv'):
+                        k_ = rocprof_kernel(p_['kernel'])
+                        forms[k_] = forms.get(k_, 0.0) + p_['total_ms']
+                issued = sum(p_['issued_flop_per_launch'] * p_['launches'] for p_ in pr)
+                conv_ms = sum(forms.values())
+                per_scale.append({'network_input': '%dx%d' % (-(-sh_ // 8) * 8, -(-sw_ // 8) * 8), 'wall_ms': wall, 'conv_ms': conv_ms,
+                                  'conv_issued_frac': issued / (conv_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS if conv_ms > 0 else None,
+                                  'conv_ms_by_kernel': {k_: round(v_, 4) for k_, v_ in sorted(forms.items(), key=lambda kv: -kv[1])}})
+            eng_.precise_finish()
+            out['per_scale'] = per_scale
+        except Exception as e:          # (diagnostic only: never fail the bench line over it)
+            out['per_scale'] = {'error': repr(e)}
         if with_oracle:
             out['keypoint_match_vs_precise_ref'] = precise_match(det, img, wts, poses, scores)
         # the same path for a batch of same-size frames: every scale runs the n images as one batch (PoseDetector.detect_precise_batch)

@@ -76,6 +76,11 @@ extern "C" int pmx_debug_block_times(unsigned long long* out, size_t n)
 #ifndef PMX_ABLATE
 #define PMX_ABLATE 0
 #endif
+// the output transform two registers at a time through v_pk_add_f32 (1) or scalar (0): the same roundings; packed = 130 - 230 VALU
+// instructions less per block, 7x7 layers -0.5 %, 3x3 -0.3 % (profiles/r05_pkout_ab.json)
+#ifndef PMX_WINO_PKOUT
+#define PMX_WINO_PKOUT 1
+#endif
 #ifndef PMX_WINO_HOFF3
 #define PMX_WINO_HOFF3 0
 #endif
@@ -495,8 +500,26 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     }   // do_p1
 
     // ---- output transform Y = A^T M A per (tile, channel): y[2 * i + j] = pixel (i, j) of the tile
+    // (PMX_WINO_PKOUT: two registers at a time through the packed-fp32 adds -- the same roundings, half the VALU instructions)
     f32x16 y[4];
     if (!UNIT || do_p1) {
+#if PMX_WINO_PKOUT
+#pragma unroll
+        for (int rp = 0; rp < 8; ++rp) {
+            f32x2 t0[4], t1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x2 m0 = {acc[0 + j][2 * rp], acc[0 + j][2 * rp + 1]}, m1 = {acc[4 + j][2 * rp], acc[4 + j][2 * rp + 1]};
+                const f32x2 m2 = {acc[8 + j][2 * rp], acc[8 + j][2 * rp + 1]}, m3 = {acc[12 + j][2 * rp], acc[12 + j][2 * rp + 1]};
+                t0[j] = pk_add2(pk_add2(m0, m1), m2);
+                t1[j] = pk_sub2(pk_sub2(m1, m2), m3);
+            }
+            const f32x2 o0 = pk_add2(pk_add2(t0[0], t0[1]), t0[2]), o1 = pk_sub2(pk_sub2(t0[1], t0[2]), t0[3]);
+            const f32x2 o2 = pk_add2(pk_add2(t1[0], t1[1]), t1[2]), o3 = pk_sub2(pk_sub2(t1[1], t1[2]), t1[3]);
+            y[0][2 * rp] = o0[0]; y[0][2 * rp + 1] = o0[1]; y[1][2 * rp] = o1[0]; y[1][2 * rp + 1] = o1[1];
+            y[2][2 * rp] = o2[0]; y[2][2 * rp + 1] = o2[1]; y[3][2 * rp] = o3[0]; y[3][2 * rp + 1] = o3[1];
+        }
+#else
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             float t0[4], t1[4];
@@ -508,6 +531,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
             y[0][reg] = (t0[0] + t0[1]) + t0[2]; y[1][reg] = (t0[1] - t0[2]) - t0[3];
             y[2][reg] = (t1[0] + t1[1]) + t1[2]; y[3][reg] = (t1[1] - t1[2]) - t1[3];
         }
+#endif
     } else {
         // a unit block without pass 1 (row 6 / column 6 / tap (6, 6)): the transform of all-zero accumulators is +0 -- no accumulator
         // is zeroed or read for it

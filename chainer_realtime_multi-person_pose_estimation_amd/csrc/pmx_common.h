@@ -208,6 +208,7 @@ int launch_resize_linear_u8(const uint8_t* src, uint8_t* dst, const int* xtab, c
 // dst[((b * C + c) * dh + y) * dw + x] (accumulate: +=)
 int launch_resize_cubic_f32_planar(const float* src, long long sb, long long sc, long long sy, long long sx, int B, int C, float* dst, int dh, int dw,
                                    const int* xi, const float* xc, const int* yi, const float* yc, int accumulate, hipStream_t s);
+void prep_set_cubic_rows(int on);     // 1 (default): separable form through LDS; 0: one thread per element (same bits)
 int launch_resize_cubic_u8(const uint8_t* src, int sw, uint8_t* dst, int dh, int dw, int dpitch, const int* xi, const int* xa,
                            const int* yi, const int* ya, int B, long long sbytes, long long dbytes, hipStream_t s);
 int launch_fill_bgr(uint8_t* dst, long long npix, int b, int g, int r, hipStream_t s);

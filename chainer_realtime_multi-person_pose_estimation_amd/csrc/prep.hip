@@ -150,6 +150,58 @@ __global__ __launch_bounds__(256) void resize_cubic_f32_planar_kernel(const floa
     else *d = v;
 }
 
+// The same resize, separable through LDS: a block = 256 consecutive x of RB consecutive destination rows of one plane.  The horizontal
+// 4-tap sum depends only on (source row, x), so a thread computes it ONCE per source row the block touches (rows yi[0][y0] .. yi[3][y0 + RB - 1]:
+// RB / scale + 3 of them) into its own LDS column, then every destination row takes its four sums from there: 4 / RB ... 28 / RB gathers per
+// output instead of 16 (x8 up-sampling: 1.5; the largest down-scale of detect_precise: ~7).  Same float32 operations in the same order per
+// output -> bit-identical to the one-thread-per-element form above, which stays as the fallback for blocks that need more than NR source rows.
+template <int ACC, int RB, int NR>
+__global__ __launch_bounds__(256) void resize_cubic_f32_rows_kernel(const float* __restrict__ src, long long sb, long long sc, long long sy, long long sx,
+                                                                    int C, float* __restrict__ dst, int dh, int dw,
+                                                                    const int* __restrict__ xi, const float* __restrict__ xc,
+                                                                    const int* __restrict__ yi, const float* __restrict__ yc)
+{
+    __shared__ float sH[NR * 256];
+    const int tid = (int)threadIdx.x, x = (int)blockIdx.x * 256 + tid;
+    const int y0 = (int)blockIdx.y * RB, y1 = min(y0 + RB, dh) - 1, bc = (int)blockIdx.z;
+    const int b = bc / C, c = bc - b * C;
+    const float* s = src + (long long)b * sb + (long long)c * sc;
+    const int r_lo = yi[y0], r_hi = yi[3 * dh + y1];          // (tap indices are clamped and non-decreasing in k and y)
+    const int nrows = r_hi - r_lo + 1;                        // block-uniform
+    const bool live = x < dw;
+    const int xq = live ? x : dw - 1;
+    const long long x0 = (long long)xi[xq] * sx, x1 = (long long)xi[dw + xq] * sx, x2 = (long long)xi[2 * dw + xq] * sx, x3 = (long long)xi[3 * dw + xq] * sx;
+    const float c0 = xc[xq], c1 = xc[dw + xq], c2 = xc[2 * dw + xq], c3 = xc[3 * dw + xq];
+    auto hsum = [&](int sr) -> float {
+        const float* r = s + (long long)sr * sy;
+        float a = r[x0] * c0;
+        a = a + r[x1] * c1;
+        a = a + r[x2] * c2;
+        a = a + r[x3] * c3;
+        return a;
+    };
+    if (nrows <= NR) {
+        for (int r = 0; r < nrows; ++r) sH[r * 256 + tid] = hsum(r_lo + r);     // (own column: written and read by this thread only)
+    }
+    if (!live) return;
+    for (int y = y0; y <= y1; ++y) {
+        float h0, h1, h2, h3;
+        if (nrows <= NR) {
+            h0 = sH[(yi[y] - r_lo) * 256 + tid]; h1 = sH[(yi[dh + y] - r_lo) * 256 + tid];
+            h2 = sH[(yi[2 * dh + y] - r_lo) * 256 + tid]; h3 = sH[(yi[3 * dh + y] - r_lo) * 256 + tid];
+        } else {
+            h0 = hsum(yi[y]); h1 = hsum(yi[dh + y]); h2 = hsum(yi[2 * dh + y]); h3 = hsum(yi[3 * dh + y]);
+        }
+        float v = h0 * yc[y];
+        v = v + h1 * yc[dh + y];
+        v = v + h2 * yc[2 * dh + y];
+        v = v + h3 * yc[3 * dh + y];
+        float* d = dst + ((long long)bc * dh + y) * dw + x;
+        if (ACC) *d = *d + v;
+        else *d = v;
+    }
+}
+
 // uint8 HWC, 11-bit fixed point: rows = sum(src * ax) (int32), out = (sum(rows * ay) + (1 << 21)) >> 22, saturated.
 // dst has row pitch `dpitch` pixels (the resized image is written into the top-left corner of the padded image, :445)
 // blockIdx.y = image of the batch (source / destination images `sbytes` / `dbytes` apart)
@@ -236,11 +288,23 @@ int launch_resize_linear_u8(const uint8_t* src, uint8_t* dst, const int* xtab, c
     return PMX_OK;
 }
 
+// 1: the separable form through LDS (default); 0: one thread per element (A/B and tests: the two must agree bit for bit)
+static int g_cubic_rows = 1;
+void prep_set_cubic_rows(int on) { g_cubic_rows = on; }
+
 int launch_resize_cubic_f32_planar(const float* src, long long sb, long long sc, long long sy, long long sx, int B, int C, float* dst, int dh, int dw,
                                    const int* xi, const float* xc, const int* yi, const float* yc, int accumulate, hipStream_t s)
 {
     PMX_CHECK(dh >= 1 && dh <= 65535 && (long long)B * C >= 1 && (long long)B * C <= 65535, PMX_ERR_INVALID,
               "cubic resize: %d rows x %d planes outside the launch grid", dh, B * C);
+    if (g_cubic_rows) {
+        constexpr int RB = 16, NR = 32;
+        const dim3 grid((unsigned)((dw + 255) / 256), (unsigned)((dh + RB - 1) / RB), (unsigned)(B * C));
+        if (accumulate) hipLaunchKernelGGL((resize_cubic_f32_rows_kernel<1, RB, NR>), grid, dim3(256), 0, s, src, sb, sc, sy, sx, C, dst, dh, dw, xi, xc, yi, yc);
+        else hipLaunchKernelGGL((resize_cubic_f32_rows_kernel<0, RB, NR>), grid, dim3(256), 0, s, src, sb, sc, sy, sx, C, dst, dh, dw, xi, xc, yi, yc);
+        PMX_HIP(hipGetLastError());
+        return PMX_OK;
+    }
     const dim3 grid((unsigned)((dw + 255) / 256), (unsigned)dh, (unsigned)(B * C));
     if (accumulate) hipLaunchKernelGGL(resize_cubic_f32_planar_kernel<1>, grid, dim3(256), 0, s, src, sb, sc, sy, sx, C, dst, dh, dw, xi, xc, yi, yc);
     else hipLaunchKernelGGL(resize_cubic_f32_planar_kernel<0>, grid, dim3(256), 0, s, src, sb, sc, sy, sx, C, dst, dh, dw, xi, xc, yi, yc);

@@ -110,16 +110,19 @@ def test_detect_precise_native_network(native):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('rows', [1, 0])
 @pytest.mark.parametrize('shape', [(120, 152), (97, 141), (368, 368)])
-def test_device_cubic_path_equals_host_restatement(native, shape):
+def test_device_cubic_path_equals_host_restatement(native, shape, rows):
     """pmx_precise_* (cubic uint8 / float32 resizes, crop, accumulation, average on the device) is bit-identical to the
-    host restatement of the same steps fed by the same network kernels (the `model=` seam wrapping the engine)."""
+    host restatement of the same steps fed by the same network kernels (the `model=` seam wrapping the engine) -- with the
+    float32 resizes in their separable LDS form (rows = 1, the default) and one thread per element (rows = 0)."""
     PD = pkg('pose_detector')
     W_ = pkg('weights')
     weights = W_.synthetic_weights(0)
     rng = np.random.default_rng(shape[0])
     img = rng.integers(0, 256, shape + (3,), dtype=np.uint8)
     dev = PD.PoseDetector(weights=weights, device=0, precise=True, max_size=(368, 472))
+    dev.engine.set_option('cubic_rows', rows)
     res_dev = None
     try:
         res_dev = dev(img)
@@ -144,6 +147,7 @@ def test_device_cubic_path_equals_host_restatement(native, shape):
         assert np.array_equal(np.asarray(res_dev[0]), np.asarray(res_host[0]))
         assert np.array_equal(np.asarray(res_dev[1]), np.asarray(res_host[1]))
     host.engine.close()
+    dev.engine.set_option('cubic_rows', 1)
     dev.engine.close()
 
 

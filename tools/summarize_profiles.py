@@ -55,7 +55,7 @@ for d in sorted(os.listdir(G)):
         agg[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
         agg[r['Kernel_Name']]['_dur_ns_' + d].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
     for k, cs in agg.items():
-        if not any(t in k for t in ('conv_mfma', 'conv_wino', 'conv1_fused', 'conv_bf16x3', 'conv1x1_pair', 'conv3x3_c3', 'conv_splitk', 'prep')) and not k.startswith('pp_'):
+        if not any(t in k for t in ('conv_mfma', 'conv_wino', 'conv1_wino', 'conv1_fused', 'conv_bf16x3', 'conv1x1_pair', 'conv3x3_c3', 'conv_splitk', 'prep', 'resize_cubic')) and not k.startswith('pp_'):
             continue
         e = summary['kernels'].setdefault(k, {})
         for c, vals in cs.items():
