@@ -374,7 +374,7 @@ def test_fused_conv1_equals_separate_layers_bitwise(native, arch, B, hw):
         assert np.array_equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize('B,hw', [(7, (88, 104)), (2, (184, 248)), (1, (368, 368))])
+@pytest.mark.parametrize('B,hw', [(7, (88, 104)), (2, (184, 248)), (1, (368, 368)), (2, (16, 24)), (3, (24, 40)), (2, (72, 16)), (1, (56, 120))])
 def test_conv1_wino_network_bit_exact_vs_twin(native, B, hw):
     """conv1_1 + conv1_2 as one launch with conv1_2 in Winograd F(2x2, 3x3) on 16 x 16 squares (conv1_wino_kernel: conv1_1 recomputed on
     the 18 x 18 halo, the direct chain; conv1_2 = conv_wino_kernel<3, pool>'s arithmetic at 64 tiles x 64 channels per block) through the
