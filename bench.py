@@ -804,6 +804,7 @@ def precise_mode(weights_mod, device_index, with_oracle=True, shape=(482, 642)):
         try:
             eng_ = det.engine
             per_scale = []
+            eng_.set_option('precise_lanes', 1)      # (one scale at a time on the context's stream: the figures of a scale running alone)
             eng_.precise_begin(H, W, 1)
             for (sh_, sw_) in scales:
                 eng_.profile_reset(); eng_.profile_enable(1)
@@ -823,9 +824,12 @@ def precise_mode(weights_mod, device_index, with_oracle=True, shape=(482, 642)):
                                   'conv_issued_frac': issued / (conv_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS if conv_ms > 0 else None,
                                   'conv_ms_by_kernel': {k_: round(v_, 4) for k_, v_ in sorted(forms.items(), key=lambda kv: -kv[1])}})
             eng_.precise_finish()
-            out['per_scale'] = per_scale
+            out['per_scale_running_alone'] = per_scale
+            out['scales_in_flight'] = 4
         except Exception as e:          # (diagnostic only: never fail the bench line over it)
-            out['per_scale'] = {'error': repr(e)}
+            out['per_scale_running_alone'] = {'error': repr(e)}
+        finally:
+            det.engine.set_option('precise_lanes', 4)
         if with_oracle:
             out['keypoint_match_vs_precise_ref'] = precise_match(det, img, wts, poses, scores)
         # the same path for a batch of same-size frames: every scale runs the n images as one batch (PoseDetector.detect_precise_batch)

@@ -409,6 +409,16 @@ extern "C" void pmx_destroy(pmx_ctx* c)
                     c->tab.ylo, c->tab.yhi, c->tab.gauss};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : c->pr_tabs) (void)hipFree(kv.second);
+    for (float* q : c->pr_part) if (q) (void)hipFree(q);
+    for (int i = 1; i < PMX_PR_LANES; ++i) {
+        PrLane& l = c->pr_lane[i];
+        void* lp[] = {l.in16, l.act0, l.act1, l.cat, l.brA, l.brB, l.brT, l.u8_tmp, l.pr_tmp, l.sk_scratch};
+        for (void* q : lp) if (q) (void)hipFree(q);
+        if (l.stream) (void)hipStreamDestroy(l.stream);
+    }
+    for (int i = 0; i < PMX_PR_LANES; ++i) if (c->pr_lane[i].done) (void)hipEventDestroy(c->pr_lane[i].done);
+    if (c->pr_src_ready) (void)hipEventDestroy(c->pr_src_ready);
+    if (c->pr_fin) (void)hipEventDestroy(c->pr_fin);
     for (auto& p : c->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->h_results) (void)hipHostFree(c->h_results);
@@ -451,6 +461,7 @@ extern "C" int pmx_set_option(pmx_ctx* c, const char* key, int value)
     else if (!strcmp(key, "fuse_pairs")) c->opt_fuse_pairs = value;
     else if (!strcmp(key, "fuse_conv1")) c->opt_fuse_conv1 = value;
     else if (!strcmp(key, "conv1_wino")) c->opt_conv1_wino = value;
+    else if (!strcmp(key, "precise_lanes")) c->opt_precise_lanes = value < 1 ? 1 : (value > PMX_PR_LANES ? PMX_PR_LANES : value);
     else if (!strcmp(key, "cubic_rows")) prep_set_cubic_rows(value);      // (process-wide, like the other kernel-form switches of prep / post-process)
     else if (!strcmp(key, "precision")) c->opt_precision = value;
     else if (!strcmp(key, "conv_algo")) c->opt_conv_algo = value;
@@ -584,7 +595,7 @@ static int ensure_bf16x3_pack(PackedLayer& L)
 // Launches one convolution (1 or 2 groups) whose ConvArgs describe the FINAL result (real bias, ReLU, pool, output slices).
 // With S > 1 K slices the slice blocks write raw partial sums into the context's slab scratch and conv_splitk_reduce
 // produces the final result (slabs added in slice order, then bias, ReLU, pool).
-static const int SK_ZERO_BIAS = 1024;
+static const int SK_ZERO_BIAS = PMX_SK_ZERO_BIAS;
 static int launch_conv(pmx_ctx* c, const ConvArgs& a0, int groups, int v, const SplitPlan& plan)
 {
     const int S = plan.S;
@@ -879,8 +890,13 @@ static int run_conv1(pmx_ctx* c, int B, int H, int W)
     const int v2 = conv_pick_variant(3, L2.cout_pad, H, W, B, c->opt_force[3], c->opt_kernel_gen, 1, L2.cin, 0);
     const bool fuse = c->opt_fuse_conv1 && c->opt_kernel_gen >= 6 && c->opt_precision == 0 && c->opt_force[3] < 0 && L1.cin == 3 && L1.cout == 64 &&
                       L2.cin == 64 && L2.cout == 64 && !strcmp(conv_variant(v2).name, "conv3x3_v5_t8x16_n64");
+    // conv1_2 as Winograd F(2x2, 3x3) on 16 x 16 squares (conv1_wino.hip) wherever the Winograd kernels are allowed (conv_algo >= 1) and
+    // the launch has at least one block per CU (smaller launches: the 8 x 16 direct tiles give twice the blocks); conv1_wino = 2: always
+    const bool pair_ok = c->opt_precision == 0 && c->opt_force[3] < 0 && L1.cin == 3 && L1.cout == 64 && L2.cin == 64 && L2.cout == 64 && H % 2 == 0 && W % 2 == 0;
+    const bool wino1 = pair_ok && c->opt_conv1_wino && c->opt_conv_algo >= 1 &&
+                       (c->opt_conv1_wino == 2 || (fuse && (long long)B * ((H + 15) / 16) * ((W + 15) / 16) >= conv_num_cus()));
     int rc;
-    if (!fuse) {
+    if (!fuse && !wino1) {
         if ((rc = run_conv(c, "conv1_1", i1, -1, c->in16, nullptr, PMX_IN_C, c->act0, nullptr, 64, B, H, W, 1, 0))) return rc;
         return run_conv(c, "conv1_2", i2, -1, c->act0, nullptr, 64, c->act1, nullptr, 64, B, H, W, 1, 1);
     }
@@ -889,9 +905,7 @@ static int run_conv1(pmx_ctx* c, int B, int H, int W)
     a.g[0].in = c->in16; a.g[0].w = L2.d_w; a.g[0].bias = L2.d_b; a.g[0].out = c->act1; a.g[0].cout = L2.cout;
     a.g[1].w = L1.d_w; a.g[1].bias = L1.d_b;
     a.B = B; a.H = H; a.W = W; a.lda = PMX_IN_C; a.ldc = 64; a.nch = L2.nch; a.cout_pad = L2.cout_pad; a.relu = 1; a.pool = 1;
-    // conv1_2 as Winograd F(2x2, 3x3) on 16 x 16 squares (conv1_wino.hip) wherever the Winograd kernels are allowed (conv_algo >= 1) and
-    // the launch has at least one block per CU (smaller launches: the 8 x 16 direct tiles give twice the blocks)
-    if (c->opt_conv1_wino && c->opt_conv_algo >= 1 && (c->opt_conv1_wino == 2 || (long long)B * ((H + 15) / 16) * ((W + 15) / 16) >= conv_num_cus())) {
+    if (wino1) {
         if ((rc = ensure_wino_pack(c->layers[i2])) || (rc = ensure_conv1_pack(c->layers[i1]))) return rc;
         a.g[0].w = L2.d_ww;
         a.g[1].w = L1.d_ww;

@@ -213,6 +213,7 @@ int launch_resize_cubic_u8(const uint8_t* src, int sw, uint8_t* dst, int dh, int
                            const int* yi, const int* ya, int B, long long sbytes, long long dbytes, hipStream_t s);
 int launch_fill_bgr(uint8_t* dst, long long npix, int b, int g, int r, hipStream_t s);
 int launch_scale_f32(float* p, long long n, float divisor, hipStream_t s);
+int launch_add_f32(float* acc, const float* v, long long n, hipStream_t s);      // acc[i] = acc[i] + v[i]
 int launch_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, int ldc, int coff, hipStream_t s);
 int launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, int lda, int coff, hipStream_t s);
 

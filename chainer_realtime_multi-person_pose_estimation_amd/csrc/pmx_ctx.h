@@ -34,6 +34,23 @@ struct ProfEntry {
 };
 struct ProfPending { int entry; hipEvent_t e0, e1; };
 
+// detect_precise runs its inference scales CONCURRENTLY: one image at 0.5x / 1x / 1.5x is 12 ... 108 one-per-CU blocks per layer for 256
+// CUs, so the four forward passes go to four streams ("lanes"), each with its own working set; a lane's fields are swapped into the
+// context while its scale is enqueued (the forward code keeps using c->stream / c->act0 / ...).  Scale k of a sequence runs on lane
+// k % PMX_PR_LANES and leaves its maps, resized to the original size, in pr_part[k]; pmx_precise_finish adds the parts IN SCALE ORDER
+// (the reference's left-to-right sum, pose_detector.py:463,467) and divides.
+constexpr int PMX_PR_LANES = 4;
+constexpr int PMX_SK_ZERO_BIAS = 1024;      // floats of the shared zero-bias vector of the split-K / unit-mode launches
+struct PrLane {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    float *in16 = nullptr, *act0 = nullptr, *act1 = nullptr, *cat = nullptr, *brA = nullptr, *brB = nullptr, *brT = nullptr;
+    uint8_t* u8_tmp = nullptr;
+    size_t cap_px = 0;                       // n * padded_h * padded_w the activation buffers hold
+    float* pr_tmp = nullptr; size_t pr_tmp_cap = 0;
+    float* sk_scratch = nullptr; size_t sk_floats = 0;
+};
+
 // ------------------------------------------------------------------------------------------- context
 struct pmx_ctx {
     int kind = NET_POSE;             // architecture: posenet | facenet | handnet
@@ -45,6 +62,10 @@ struct pmx_ctx {
     float* pr_tmp = nullptr; size_t pr_tmp_cap = 0;      // x8 up-sampled maps of one scale, planar [n][38][ph][pw] | [n][19][ph][pw]
     std::map<std::tuple<int, int, int>, int*> pr_tabs;   // cubic tables per axis, keyed (src, dst, fixed point?): built once, kept
     const uint8_t* pr_src = nullptr;                     // host images of the current begin / finish sequence already in u8_src
+    PrLane pr_lane[PMX_PR_LANES];                        // lanes 1 .. : own buffers; lane 0 = the context's own stream and buffers
+    std::vector<float*> pr_part; size_t pr_part_cap = 0; // per scale: [n][57][orig_h][orig_w] (PAF planes, then heat planes of every image)
+    hipEvent_t pr_src_ready = nullptr, pr_fin = nullptr; // originals uploaded / parts consumed by the last finish
+    int opt_precise_lanes = PMX_PR_LANES;                // 1: every scale on the context's own stream (A/B, tests)
     double* d_kp = nullptr;          // key-point records of pmx_keypoints
     size_t kp_cap = 0;
     int device = 0;

@@ -7,6 +7,7 @@
 #include <math.h>
 #include <string.h>
 #include <tuple>
+#include <utility>
 
 // ---------------------------------------------------------------------------------------- detect_precise on the device
 // OpenCV bicubic tables for one axis (A = -0.75): idx[k][d] (clamped, replicate border) and coef[k][d] float32, k = 0..3.
@@ -76,10 +77,50 @@ static int cubic_table(pmx_ctx* c, int src, int dst, bool fixed, const int** idx
     return PMX_OK;
 }
 
-// detect_precise (pose_detector.py:433-470) accumulated on the device, for a batch of n images of ONE original size (the reference
-// handles one image per call; n = 1 is that call).  Every scale runs the n images as one batch through the network -- a 184 x 248 input of
-// a single image is 23 x 31 maps, far too little for 256 CUs, eight of them are not -- and the (tiny, shared) resize tables are uploaded
-// once per step instead of once per image.  begin: zero the per-channel sums at the original size.
+// ---- lanes: one inference scale in flight per lane (pmx_ctx.h::PrLane) --------------------------------------------------------------
+template <typename T>
+static int lane_alloc(T** q, size_t count)
+{
+    if (*q) (void)hipFree(*q);
+    *q = nullptr;
+    PMX_HIP(hipMalloc((void**)q, count * sizeof(T)));
+    return PMX_OK;
+}
+// lane i >= 1 holds n x ph x pw pixels of working set (the sizes pmx_create gives the context's own buffers); lane 0 IS the context
+static int lane_ensure(pmx_ctx* c, int i, size_t n, size_t ph, size_t pw)
+{
+    PrLane& l = c->pr_lane[i];
+    if (!l.done) PMX_HIP(hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
+    if (i == 0) return PMX_OK;
+    if (!l.stream) PMX_HIP(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+    const size_t px = n * ph * pw;
+    if (px <= l.cap_px) return PMX_OK;
+    PMX_HIP(hipStreamSynchronize(l.stream));
+    l.cap_px = 0;
+    const size_t px8 = px / 64;
+    int rc;
+    if ((rc = lane_alloc(&l.in16, px * PMX_IN_C)) || (rc = lane_alloc(&l.act0, px * 64)) || (rc = lane_alloc(&l.act1, px * 16)) ||
+        (rc = lane_alloc(&l.cat, px8 * PMX_CAT_C)) || (rc = lane_alloc(&l.brA, px8 * 256)) || (rc = lane_alloc(&l.brB, px8 * 256)) ||
+        (rc = lane_alloc(&l.brT, px8 * 1024)) || (rc = lane_alloc(&l.u8_tmp, px * 3))) return rc;
+    PMX_HIP(hipMemsetAsync(l.cat, 0, px8 * PMX_CAT_C * sizeof(float), l.stream));      // pad channels stay zero (stream-ordered)
+    l.cap_px = px;
+    return PMX_OK;
+}
+// the lane's stream and working set <-> the context's (called in pairs around the enqueue of one scale; lane 0: nothing to do)
+static void lane_swap(pmx_ctx* c, int i)
+{
+    if (i == 0) return;
+    PrLane& l = c->pr_lane[i];
+    std::swap(c->stream, l.stream);
+    std::swap(c->in16, l.in16); std::swap(c->act0, l.act0); std::swap(c->act1, l.act1); std::swap(c->cat, l.cat);
+    std::swap(c->brA, l.brA); std::swap(c->brB, l.brB); std::swap(c->brT, l.brT); std::swap(c->u8_tmp, l.u8_tmp);
+    std::swap(c->pr_tmp, l.pr_tmp); std::swap(c->pr_tmp_cap, l.pr_tmp_cap);
+    std::swap(c->sk_scratch, l.sk_scratch); std::swap(c->sk_floats, l.sk_floats);
+}
+
+// detect_precise (pose_detector.py:433-470) on the device, for a batch of n images of ONE original size (the reference handles one image
+// per call; n = 1 is that call).  Every scale runs the n images as one batch through the network, the scales of a sequence run
+// concurrently on up to four lanes.  begin: reset the sequence.
 extern "C" int pmx_precise_begin_batch(pmx_ctx* c, int n_images, int orig_h, int orig_w)
 {
     PMX_CHECK(c && c->kind == NET_POSE, PMX_ERR_INVALID, "pmx_precise_begin: posenet context required");
@@ -97,8 +138,13 @@ extern "C" int pmx_precise_begin_batch(pmx_ctx* c, int n_images, int orig_h, int
         PMX_HIP(hipMalloc((void**)&c->ext_heat, need * PMX_N_HEAT * 4));
         c->ext_cap = need;
     }
-    PMX_HIP(hipMemsetAsync(c->ext_paf, 0, need * PMX_N_PAF * 4, c->stream));
-    PMX_HIP(hipMemsetAsync(c->ext_heat, 0, need * PMX_N_HEAT * 4, c->stream));
+    if (!c->pr_src_ready) PMX_HIP(hipEventCreateWithFlags(&c->pr_src_ready, hipEventDisableTiming));
+    if (!c->pr_fin) PMX_HIP(hipEventCreateWithFlags(&c->pr_fin, hipEventDisableTiming));
+    // the zero-bias vector of the unit-mode / split-K launches is shared by all lanes: it must exist (and be zero) before two streams can meet it
+    if (!c->sk_zero_bias) {
+        PMX_HIP(hipMalloc((void**)&c->sk_zero_bias, PMX_SK_ZERO_BIAS * sizeof(float)));
+        PMX_HIP(hipMemset(c->sk_zero_bias, 0, PMX_SK_ZERO_BIAS * sizeof(float)));
+    }
     c->pr_h = orig_h; c->pr_w = orig_w; c->pr_scales = 0; c->pr_n = n_images; c->pr_src = nullptr;
     c->maps_valid = false;
     return PMX_OK;
@@ -107,7 +153,8 @@ extern "C" int pmx_precise_begin(pmx_ctx* c, int orig_h, int orig_w) { return pm
 
 // one scale of the loop at :441-467 for every image of the batch: cubic resize of the uint8 image to (scaled_h, scaled_w) (:443), pad to a
 // multiple of 8 with (104, 117, 123) (:445), forward (:451), x8 cubic up-sampling of both outputs (:461,465), crop of the padding
-// (:462,466), cubic resize to the original size and accumulation (:463,467).  `imgs`: host uint8, n x orig_h x orig_w x 3, contiguous.
+// (:462,466), cubic resize to the original size (:463,467) into this scale's part.  `imgs`: host uint8, n x orig_h x orig_w x 3, contiguous.
+// Everything is enqueued on the scale's lane; nothing here waits for the device.
 extern "C" int pmx_precise_add_scale_batch(pmx_ctx* c, const uint8_t* imgs, int scaled_h, int scaled_w)
 {
     PMX_CHECK(c && imgs && c->pr_h > 0 && c->pr_n > 0, PMX_ERR_STATE, "pmx_precise_add_scale: call pmx_precise_begin first");
@@ -121,61 +168,98 @@ extern "C" int pmx_precise_add_scale_batch(pmx_ctx* c, const uint8_t* imgs, int 
     for (auto& l : c->layers) missing += l.set ? 0 : 1;
     PMX_CHECK(missing == 0, PMX_ERR_WEIGHTS, "pmx_precise_add_scale: %d layers have no weights", missing);
     int rc;
-    // original images -> device, ONCE per begin / finish sequence: every scale resizes the same originals (the caller passes the same
-    // images to every pmx_precise_add_scale* of a sequence -- include/pose_mi355x.h; round 4 uploaded them again from pageable memory per scale)
+    const int k = c->pr_scales, li = k % (c->opt_precise_lanes < 1 ? 1 : c->opt_precise_lanes);
+    hipStream_t main_stream = c->stream;
+    // original images -> device, ONCE per begin / finish sequence, on the context's stream: every scale resizes the same originals (the
+    // caller passes the same images to every pmx_precise_add_scale* of a sequence -- include/pose_mi355x.h)
     const size_t img_bytes = (size_t)oh * ow * 3, nsrc = img_bytes * n;
-    if (c->pr_scales == 0 || c->pr_src != imgs) {
+    if (k == 0 || c->pr_src != imgs) {
         if (nsrc > c->u8_src_cap) {
-            PMX_HIP(hipStreamSynchronize(c->stream));
+            PMX_HIP(hipDeviceSynchronize());          // (lanes of an earlier sequence may still read the old buffer)
             if (c->u8_src) (void)hipFree(c->u8_src);
             c->u8_src = nullptr; c->u8_src_cap = 0;
             PMX_HIP(hipMalloc((void**)&c->u8_src, nsrc));
             c->u8_src_cap = nsrc;
         }
-        PMX_HIP(hipMemcpyAsync(c->u8_src, imgs, nsrc, hipMemcpyHostToDevice, c->stream));
+        if (k > 0) {                                  // (a different buffer mid-sequence: the lanes still reading the old copy finish first)
+            for (int i = 1; i < PMX_PR_LANES; ++i)
+                if (c->pr_lane[i].done && c->pr_lane[i].stream) PMX_HIP(hipStreamWaitEvent(main_stream, c->pr_lane[i].done, 0));
+        }
+        PMX_HIP(hipMemcpyAsync(c->u8_src, imgs, nsrc, hipMemcpyHostToDevice, main_stream));
+        PMX_HIP(hipEventRecord(c->pr_src_ready, main_stream));
         c->pr_src = imgs;
     }
+    // this scale's part: [n][38][oh][ow] | [n][19][oh][ow]
+    const size_t opx = (size_t)oh * ow, part_floats = opx * 57 * n;
+    if (part_floats > c->pr_part_cap || (size_t)k >= c->pr_part.size()) {
+        if (part_floats > c->pr_part_cap) {           // a larger sequence than any before: all parts are re-made (nothing of the old ones is pending: k == 0 or synced)
+            PMX_HIP(hipDeviceSynchronize());
+            for (float*& q : c->pr_part) { if (q) (void)hipFree(q); q = nullptr; }
+            c->pr_part_cap = part_floats;
+        }
+        if ((size_t)k >= c->pr_part.size()) c->pr_part.resize(k + 1, nullptr);
+    }
+    for (size_t j = 0; j <= (size_t)k; ++j)
+        if (!c->pr_part[j]) PMX_HIP(hipMalloc((void**)&c->pr_part[j], c->pr_part_cap * sizeof(float)));
+    float* const part_paf = c->pr_part[k];
+    float* const part_heat = part_paf + opx * PMX_N_PAF * n;
+    if ((rc = lane_ensure(c, li, (size_t)n, (size_t)ph, (size_t)pw))) return rc;
     const int *xi, *yi; const void *xc, *yc;
-    // (1) uint8 cubic resize into the padded images (all images in one launch)
-    const size_t pad_bytes = (size_t)ph * pw * 3;
-    if ((rc = launch_fill_bgr(c->u8_tmp, (long long)n * ph * pw, 104, 117, 123, c->stream))) return rc;
-    if (scaled_h == oh && scaled_w == ow) {
-        for (int b = 0; b < n; ++b)
-            PMX_HIP(hipMemcpy2DAsync(c->u8_tmp + b * pad_bytes, (size_t)pw * 3, c->u8_src + b * img_bytes, (size_t)ow * 3, (size_t)ow * 3, oh,
-                                     hipMemcpyDeviceToDevice, c->stream));
-    } else {
-        if ((rc = cubic_table(c, ow, scaled_w, true, &xi, &xc)) || (rc = cubic_table(c, oh, scaled_h, true, &yi, &yc))) return rc;
-        if ((rc = launch_resize_cubic_u8(c->u8_src, ow, c->u8_tmp, scaled_h, scaled_w, pw, xi, (const int*)xc, yi, (const int*)yc, n, (long long)img_bytes,
-                                         (long long)pad_bytes, c->stream))) return rc;
-    }
-    // (2) network, the n images as one batch
-    if ((rc = launch_prep_u8(c->u8_tmp, c->in16, n, ph, pw, 255.0f, c->stream))) return rc;
-    if ((rc = pmx_forward_from_in16(c, n, ph, pw))) return rc;
+    // cubic tables first (a cache miss is a blocking copy into fresh memory: before the swap, so that an error leaves the context intact)
+    const int *t1xi = nullptr, *t1yi = nullptr; const void *t1xc = nullptr, *t1yc = nullptr;
+    const bool same = scaled_h == oh && scaled_w == ow;
+    if (!same && ((rc = cubic_table(c, ow, scaled_w, true, &t1xi, &t1xc)) || (rc = cubic_table(c, oh, scaled_h, true, &t1yi, &t1yc)))) return rc;
     const int fh = ph / 8, fw = pw / 8;
-    // (3) x8 cubic up-sampling of the PAF (38) and heat (19) channels of all images into PLANAR temporaries [n][38][ph][pw] | [n][19][ph][pw]
-    // (two cv2.resize calls per image in the reference; planar so that step (4) reads rows of one channel and both steps store full rows)
-    const size_t ppx = (size_t)ph * pw, ntmp = ppx * 57 * n;
-    if (ntmp > c->pr_tmp_cap) {
-        PMX_HIP(hipStreamSynchronize(c->stream));
-        if (c->pr_tmp) (void)hipFree(c->pr_tmp);
-        c->pr_tmp = nullptr; c->pr_tmp_cap = 0;
-        PMX_HIP(hipMalloc((void**)&c->pr_tmp, ntmp * sizeof(float)));
-        c->pr_tmp_cap = ntmp;
-    }
-    float* const t_paf = c->pr_tmp;
-    float* const t_heat = c->pr_tmp + ppx * PMX_N_PAF * n;
-    if ((rc = cubic_table(c, fw, pw, false, &xi, &xc)) || (rc = cubic_table(c, fh, ph, false, &yi, &yc))) return rc;
-    const long long sy = (long long)fw * PMX_CAT_C, sx = PMX_CAT_C, sb = (long long)fh * fw * PMX_CAT_C;
-    if ((rc = launch_resize_cubic_f32_planar(c->cat + PMX_CAT_PAF, sb, 1, sy, sx, n, PMX_N_PAF, t_paf, ph, pw, xi, (const float*)xc, yi, (const float*)yc, 0, c->stream))) return rc;
-    if ((rc = launch_resize_cubic_f32_planar(c->cat + PMX_CAT_HEAT, sb, 1, sy, sx, n, PMX_N_HEAT, t_heat, ph, pw, xi, (const float*)xc, yi, (const float*)yc, 0, c->stream))) return rc;
-    // (4) crop the padding (source extent scaled_h x scaled_w of the padded maps) and cubic resize to the original size, accumulating
-    if ((rc = cubic_table(c, scaled_w, ow, false, &xi, &xc)) || (rc = cubic_table(c, scaled_h, oh, false, &yi, &yc))) return rc;
-    if ((rc = launch_resize_cubic_f32_planar(t_paf, (long long)ppx * PMX_N_PAF, (long long)ppx, pw, 1, n, PMX_N_PAF, c->ext_paf, oh, ow, xi, (const float*)xc, yi,
-                                             (const float*)yc, 1, c->stream))) return rc;
-    if ((rc = launch_resize_cubic_f32_planar(t_heat, (long long)ppx * PMX_N_HEAT, (long long)ppx, pw, 1, n, PMX_N_HEAT, c->ext_heat, oh, ow, xi, (const float*)xc, yi,
-                                             (const float*)yc, 1, c->stream))) return rc;
+    const int *t3xi, *t3yi, *t4xi, *t4yi; const void *t3xc, *t3yc, *t4xc, *t4yc;
+    if ((rc = cubic_table(c, fw, pw, false, &t3xi, &t3xc)) || (rc = cubic_table(c, fh, ph, false, &t3yi, &t3yc)) ||
+        (rc = cubic_table(c, scaled_w, ow, false, &t4xi, &t4xc)) || (rc = cubic_table(c, scaled_h, oh, false, &t4yi, &t4yc))) return rc;
+    (void)xi; (void)yi; (void)xc; (void)yc;
+
+    lane_swap(c, li);                                 // from here on c->stream / c->in16 / ... are the lane's; every exit swaps back
+    auto body = [&]() -> int {
+        int rc2;
+        PMX_HIP(hipStreamWaitEvent(c->stream, c->pr_src_ready, 0));      // the originals are on the device
+        PMX_HIP(hipStreamWaitEvent(c->stream, c->pr_fin, 0));            // the last finish has read this scale's part
+        // (1) uint8 cubic resize into the padded images (all images in one launch)
+        const size_t pad_bytes = (size_t)ph * pw * 3;
+        if ((rc2 = launch_fill_bgr(c->u8_tmp, (long long)n * ph * pw, 104, 117, 123, c->stream))) return rc2;
+        if (same) {
+            for (int b = 0; b < n; ++b)
+                PMX_HIP(hipMemcpy2DAsync(c->u8_tmp + b * pad_bytes, (size_t)pw * 3, c->u8_src + b * img_bytes, (size_t)ow * 3, (size_t)ow * 3, oh,
+                                         hipMemcpyDeviceToDevice, c->stream));
+        } else if ((rc2 = launch_resize_cubic_u8(c->u8_src, ow, c->u8_tmp, scaled_h, scaled_w, pw, t1xi, (const int*)t1xc, t1yi, (const int*)t1yc, n,
+                                                 (long long)img_bytes, (long long)pad_bytes, c->stream))) return rc2;
+        // (2) network, the n images as one batch
+        if ((rc2 = launch_prep_u8(c->u8_tmp, c->in16, n, ph, pw, 255.0f, c->stream))) return rc2;
+        if ((rc2 = pmx_forward_from_in16(c, n, ph, pw))) return rc2;
+        // (3) x8 cubic up-sampling of the PAF (38) and heat (19) channels of all images into PLANAR temporaries [n][38][ph][pw] | [n][19][ph][pw]
+        // (two cv2.resize calls per image in the reference; planar so that step (4) reads rows of one channel and both steps store full rows)
+        const size_t ppx = (size_t)ph * pw, ntmp = ppx * 57 * n;
+        if (ntmp > c->pr_tmp_cap) {
+            PMX_HIP(hipStreamSynchronize(c->stream));
+            if (c->pr_tmp) (void)hipFree(c->pr_tmp);
+            c->pr_tmp = nullptr; c->pr_tmp_cap = 0;
+            PMX_HIP(hipMalloc((void**)&c->pr_tmp, ntmp * sizeof(float)));
+            c->pr_tmp_cap = ntmp;
+        }
+        float* const t_paf = c->pr_tmp;
+        float* const t_heat = c->pr_tmp + ppx * PMX_N_PAF * n;
+        const long long sy = (long long)fw * PMX_CAT_C, sx = PMX_CAT_C, sb = (long long)fh * fw * PMX_CAT_C;
+        if ((rc2 = launch_resize_cubic_f32_planar(c->cat + PMX_CAT_PAF, sb, 1, sy, sx, n, PMX_N_PAF, t_paf, ph, pw, t3xi, (const float*)t3xc, t3yi, (const float*)t3yc, 0, c->stream))) return rc2;
+        if ((rc2 = launch_resize_cubic_f32_planar(c->cat + PMX_CAT_HEAT, sb, 1, sy, sx, n, PMX_N_HEAT, t_heat, ph, pw, t3xi, (const float*)t3xc, t3yi, (const float*)t3yc, 0, c->stream))) return rc2;
+        // (4) crop the padding (source extent scaled_h x scaled_w of the padded maps) and cubic resize to the original size -> this scale's part
+        if ((rc2 = launch_resize_cubic_f32_planar(t_paf, (long long)ppx * PMX_N_PAF, (long long)ppx, pw, 1, n, PMX_N_PAF, part_paf, oh, ow, t4xi, (const float*)t4xc, t4yi,
+                                                  (const float*)t4yc, 0, c->stream))) return rc2;
+        if ((rc2 = launch_resize_cubic_f32_planar(t_heat, (long long)ppx * PMX_N_HEAT, (long long)ppx, pw, 1, n, PMX_N_HEAT, part_heat, oh, ow, t4xi, (const float*)t4xc, t4yi,
+                                                  (const float*)t4yc, 0, c->stream))) return rc2;
+        PMX_HIP(hipEventRecord(c->pr_lane[li].done, c->stream));
+        return PMX_OK;
+    };
+    rc = body();
+    lane_swap(c, li);
+    if (rc) return rc;
     c->pr_scales += 1;
-    c->maps_valid = false;       // the cat buffer holds one scale only; the averaged maps become valid in pmx_precise_finish
+    c->maps_valid = false;       // the cat buffers hold single scales only; the averaged maps become valid in pmx_precise_finish
     return PMX_OK;
 }
 extern "C" int pmx_precise_add_scale(pmx_ctx* c, const uint8_t* img, int scaled_h, int scaled_w)
@@ -184,13 +268,24 @@ extern "C" int pmx_precise_add_scale(pmx_ctx* c, const uint8_t* img, int scaled_
     return pmx_precise_add_scale_batch(c, img, scaled_h, scaled_w);
 }
 
-// :469-470: divide the sums by the number of scales and install them as the maps of a batch of n at the original size
+// :463,467,469-470: sum the scales' parts left to right starting from zero (the reference's `sum = sum + resized`), divide by the number
+// of scales and install the result as the maps of a batch of n at the original size
 extern "C" int pmx_precise_finish(pmx_ctx* c)
 {
     PMX_CHECK(c && c->pr_h > 0 && c->pr_scales > 0 && c->pr_n > 0, PMX_ERR_STATE, "pmx_precise_finish: nothing accumulated");
     PMX_DEV(c);
     int rc;
     const long long n = (long long)c->pr_n * c->pr_h * c->pr_w;
+    const int nl = c->opt_precise_lanes < 1 ? 1 : c->opt_precise_lanes;
+    for (int i = 0; i < PMX_PR_LANES && i < nl; ++i)
+        if (i < c->pr_scales && c->pr_lane[i].done) PMX_HIP(hipStreamWaitEvent(c->stream, c->pr_lane[i].done, 0));      // (a lane's last event covers all its scales)
+    PMX_HIP(hipMemsetAsync(c->ext_paf, 0, n * PMX_N_PAF * 4, c->stream));
+    PMX_HIP(hipMemsetAsync(c->ext_heat, 0, n * PMX_N_HEAT * 4, c->stream));
+    for (int k = 0; k < c->pr_scales; ++k) {
+        if ((rc = launch_add_f32(c->ext_paf, c->pr_part[k], n * PMX_N_PAF, c->stream))) return rc;
+        if ((rc = launch_add_f32(c->ext_heat, c->pr_part[k] + n * PMX_N_PAF, n * PMX_N_HEAT, c->stream))) return rc;
+    }
+    PMX_HIP(hipEventRecord(c->pr_fin, c->stream));
     if ((rc = launch_scale_f32(c->ext_paf, n * PMX_N_PAF, (float)c->pr_scales, c->stream))) return rc;
     if ((rc = launch_scale_f32(c->ext_heat, n * PMX_N_HEAT, (float)c->pr_scales, c->stream))) return rc;
     c->maps_valid = true; c->maps_external = true;

@@ -243,6 +243,12 @@ __global__ __launch_bounds__(256) void scale_f32_kernel(float* __restrict__ p, l
     if (i < n) p[i] = p[i] / divisor;
 }
 
+__global__ __launch_bounds__(256) void add_f32_kernel(float* __restrict__ acc, const float* __restrict__ v, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) acc[i] = acc[i] + v[i];
+}
+
 static inline unsigned nblocks(long long n) { return (unsigned)((n + 255) / 256); }
 
 int launch_prep_u8(const uint8_t* bgr, float* out16, int B, int H, int W, float divisor, hipStream_t s)
@@ -324,6 +330,13 @@ int launch_resize_cubic_u8(const uint8_t* src, int sw, uint8_t* dst, int dh, int
 int launch_fill_bgr(uint8_t* dst, long long npix, int b, int g, int r, hipStream_t s)
 {
     hipLaunchKernelGGL(fill_bgr_kernel, dim3(nblocks(npix)), dim3(256), 0, s, dst, npix, b, g, r);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+int launch_add_f32(float* acc, const float* v, long long n, hipStream_t s)
+{
+    hipLaunchKernelGGL(add_f32_kernel, dim3(nblocks(n)), dim3(256), 0, s, acc, v, n);
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }

@@ -241,3 +241,31 @@ def test_detect_precise_batch_equals_one_image_per_call(native):
         if rb is not None and single[i][0] is not None and sb == ss:
             assert len(rb[i][0]) == len(single[i][0][0])
     det.engine.close()
+
+
+@pytest.mark.gpu
+def test_precise_scales_in_flight_same_bits(native):
+    """detect_precise runs its four inference scales concurrently, one per lane (own stream and working set), and adds their parts in
+    scale order at the end (option precise_lanes, default 4): the averaged maps, peaks and poses are those of the scales run one after
+    the other on one stream (precise_lanes = 1) -- bit for bit, twice in a row (the second call reuses parts and lanes)."""
+    PD = pkg('pose_detector')
+    W_ = pkg('weights')
+    weights = W_.synthetic_weights(0)
+    rng = np.random.default_rng(77)
+    imgs = [rng.integers(0, 256, (120, 152, 3), dtype=np.uint8), rng.integers(0, 256, (120, 152, 3), dtype=np.uint8)]
+    det = PD.PoseDetector(weights=weights, device=0, precise=True, max_size=(368, 472))
+    got = {}
+    for lanes in (4, 1, 3):
+        det.engine.set_option('precise_lanes', lanes)
+        for rep, img in enumerate(imgs + imgs[:1]):
+            try:
+                det._detect_precise_device(img, fetch_maps=True)
+            except (IndexError, RuntimeError):
+                pass
+            got[(lanes, rep)] = (det.pafs.copy(), det.heatmaps.copy())
+    det.engine.set_option('precise_lanes', 4)
+    det.engine.close()
+    for rep in range(3):
+        for lanes in (1, 3):
+            assert np.array_equal(got[(4, rep)][0], got[(lanes, rep)][0]) and np.array_equal(got[(4, rep)][1], got[(lanes, rep)][1])
+    assert np.array_equal(got[(4, 0)][0], got[(4, 2)][0]) and not np.array_equal(got[(4, 0)][0], got[(4, 1)][0])
