@@ -270,12 +270,14 @@ static void pp_free(pmx_ctx* c)
 {
     PPBuffers& p = c->pp;
     void* ptrs[] = {p.pk_raw_key, p.pk_raw_score, p.pk_count, p.pk_x, p.pk_y, p.pk_score, p.pk_start, p.cn_a, p.cn_b, p.cn_score,
-                    p.cn_count, p.cn_need, p.cand_score, p.cand_idx, p.cand_used, p.sub_work, p.subsets, p.status, p.results};
+                    p.cn_count, p.cn_need, p.cand_score, p.cand_idx, p.cand_used, p.sub_work, p.subsets, p.status, p.results,
+                    p.scan_score, p.scan_idx, p.scan_cnt};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     p.pk_raw_key = nullptr; p.pk_raw_score = nullptr; p.pk_count = nullptr; p.pk_x = p.pk_y = nullptr; p.pk_score = nullptr;
     p.pk_start = nullptr; p.cn_a = p.cn_b = nullptr; p.cn_score = nullptr; p.cn_count = p.cn_need = nullptr;
     p.cand_score = nullptr; p.cand_idx = nullptr; p.cand_used = nullptr; p.sub_work = p.subsets = nullptr; p.status = nullptr;
     p.results = nullptr;
+    p.scan_score = nullptr; p.scan_idx = nullptr; p.scan_cnt = nullptr;
 }
 
 static int pp_alloc(pmx_ctx* c)
@@ -296,6 +298,10 @@ static int pp_alloc(pmx_ctx* c)
     if ((rc = dev_alloc(&p.cn_score, B * PMX_N_LIMBS * p.cap_pk))) return rc;
     if ((rc = dev_alloc(&p.cn_count, B * PMX_N_LIMBS))) return rc;
     if ((rc = dev_alloc(&p.cn_need, B * PMX_N_LIMBS))) return rc;
+    p.scan_cap = p.cap_cand > PMX_LDS_CANDIDATES ? p.cap_cand : PMX_LDS_CANDIDATES;
+    if ((rc = dev_alloc(&p.scan_score, B * PMX_N_LIMBS * p.scan_cap))) return rc;
+    if ((rc = dev_alloc(&p.scan_idx, B * PMX_N_LIMBS * p.scan_cap))) return rc;
+    if ((rc = dev_alloc(&p.scan_cnt, B * PMX_N_LIMBS))) return rc;
     if (p.cap_cand > 0) {
         if ((rc = dev_alloc(&p.cand_score, B * PMX_N_LIMBS * p.cap_cand))) return rc;
         if ((rc = dev_alloc(&p.cand_idx, B * PMX_N_LIMBS * p.cap_cand))) return rc;
@@ -477,6 +483,7 @@ extern "C" int pmx_set_option(pmx_ctx* c, const char* key, int value)
     else if (!strcmp(key, "conv_min_lds")) conv_set_min_lds(value);
     else if (!strcmp(key, "conv_v5_lds")) conv_set_v5_lds(value);
     else if (!strcmp(key, "pp_generic")) pp_set_generic(value);
+    else if (!strcmp(key, "pp_limbs_slices")) c->opt_limbs_slices = value;
     else if (!strcmp(key, "peaks_gpu_branch")) { c->opt_gpu_branch_peaks = value; c->tab_in_h = -1; }
     else if (!strcmp(key, "kp_flip_x")) c->opt_kp_flip_x = value != 0;
     else { pmx_set_error("pmx_set_option: unknown key '%s'", key); return PMX_ERR_INVALID; }
@@ -1320,8 +1327,11 @@ extern "C" int pmx_postprocess(pmx_ctx* c, int B, int map_h, int map_w, double i
         PMX_HIP(hipMemcpyAsync(c->d_scale, scale_xy, sizeof(double) * 2 * B, hipMemcpyHostToDevice, c->stream));
         dscale = c->d_scale;
     }
+    // the candidate scan of a limb over several blocks where the maps come at full resolution (detect_precise, pmx_set_maps: crowds of
+    // peaks, 19 blocks per image otherwise); the batch path's low-resolution maps keep the one-block form
+    c->pp_limbs_slices = c->opt_limbs_slices >= 0 ? c->opt_limbs_slices : (c->maps_external ? 8 : 0);
     rc = pp_launch(m, c->tab, c->pp, B, map_h, map_w, img_len, dscale, c->opt_keep_smoothed && c->pp.smoothed, c->stream,
-                   c->prof_on == 1 ? pp_prof_cb : nullptr, c);
+                   c->prof_on == 1 ? pp_prof_cb : nullptr, c, c->pp_limbs_slices);
     if (rc) return rc;
     c->pp_valid = true; c->pp_final = false; c->pp_B = B; c->pp_h = map_h; c->pp_w = map_w;
     c->pp_maps = m; c->pp_img_len = img_len; c->pp_has_scale = scale_xy != nullptr;
@@ -1408,7 +1418,7 @@ static int pp_finalize(pmx_ctx* c)
         if (rc) { c->pp_valid = false; return rc; }      // (old buffers and capacities stay in place; this batch has no results)
         c->pp_regrown += 1;
         rc = pp_launch(c->pp_maps, c->tab, c->pp, B, c->pp_h, c->pp_w, c->pp_img_len, c->pp_has_scale ? c->d_scale : nullptr,
-                       c->opt_keep_smoothed && c->pp.smoothed, c->stream, nullptr, nullptr);
+                       c->opt_keep_smoothed && c->pp.smoothed, c->stream, nullptr, nullptr, c->pp_limbs_slices);
         if (rc) { c->pp_valid = false; return rc; }
     }
     pmx_set_error("post-process capacities did not converge");

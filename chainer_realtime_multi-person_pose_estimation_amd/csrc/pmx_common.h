@@ -213,7 +213,8 @@ int launch_resize_cubic_u8(const uint8_t* src, int sw, uint8_t* dst, int dh, int
                            const int* yi, const int* ya, int B, long long sbytes, long long dbytes, hipStream_t s);
 int launch_fill_bgr(uint8_t* dst, long long npix, int b, int g, int r, hipStream_t s);
 int launch_scale_f32(float* p, long long n, float divisor, hipStream_t s);
-int launch_add_f32(float* acc, const float* v, long long n, hipStream_t s);      // acc[i] = acc[i] + v[i]
+// out[i] = (((0 + parts[0][off + i]) + parts[1][off + i]) + ...) / divisor, nparts <= 8
+int launch_sum_parts_f32(float* out, const float* const* parts, int nparts, long long off, long long n, float divisor, hipStream_t s);
 int launch_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, int ldc, int coff, hipStream_t s);
 int launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, int lda, int coff, hipStream_t s);
 
@@ -248,6 +249,9 @@ struct PPBuffers {
     int* cn_a; int* cn_b; double* cn_score;  // [B][19][cap_pk]
     int* cn_count;           // [B][19]
     int* cn_need;            // [B][19] accepted candidates before greedy matching (may exceed the candidate capacity)
+    double* scan_score; unsigned* scan_idx;  // [B][19][scan_cap] candidates of the sliced scan (pp_limbs_kernel<1> -> <2>), arbitrary order
+    int* scan_cnt;                           // [B][19] accepted candidates of the sliced scan (may exceed scan_cap)
+    int scan_cap;                            // max(PMX_LDS_CANDIDATES, cap_cand)
     double* cand_score; unsigned* cand_idx;  // [B][19][cap_cand] (large mode only)
     unsigned char* cand_used;                // [B][19][2][cap_pk] (large mode only)
     // grouping
@@ -266,4 +270,4 @@ int pp_keypoints_launch(const PPMaps& maps, const PPTables& tab, const PPBuffers
                         double thresh, double* d_out, hipStream_t stream);
 int pp_launch(const PPMaps& maps, const PPTables& tab, const PPBuffers& buf, int B, int map_h, int map_w,
               double img_len, const double* d_scale_xy, int keep_smoothed, hipStream_t stream,
-              void (*prof)(void*, const char*, int), void* prof_ctx);
+              void (*prof)(void*, const char*, int), void* prof_ctx, int limbs_slices = 0);      // limbs_slices > 1: the candidate scan of a limb over that many blocks

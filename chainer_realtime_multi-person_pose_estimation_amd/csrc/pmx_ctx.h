@@ -116,6 +116,8 @@ struct pmx_ctx {
     // options
     int opt_force[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // by ksize
     int opt_gpu_branch_peaks = 0;    // reference GPU-branch peak extraction (non-golden variant)
+    int opt_limbs_slices = -1;       // blocks per (limb, image) of the candidate scan: -1 = 8 for full-resolution (external) maps, else one; same results
+    int pp_limbs_slices = 0;         // ... of the last post-process (kept for the grow-and-re-run)
     int opt_kp_flip_x = 0;           // pmx_keypoints: mirror the resized heat maps left-right before the peaks (hand_detector.py:46-47)
     int tab_flip = 0;
     int opt_keep_smoothed = 0, opt_stop_stage = 6, opt_kernel_gen = 6;

@@ -169,6 +169,7 @@ extern "C" int pmx_precise_add_scale_batch(pmx_ctx* c, const uint8_t* imgs, int 
     for (auto& l : c->layers) missing += l.set ? 0 : 1;
     PMX_CHECK(missing == 0, PMX_ERR_WEIGHTS, "pmx_precise_add_scale: %d layers have no weights", missing);
     int rc;
+    PMX_CHECK(c->pr_scales < 8, PMX_ERR_CAPACITY, "pmx_precise_add_scale: at most 8 scales per sequence");
     const int k = c->pr_scales, li = k % (c->opt_precise_lanes < 1 ? 1 : c->opt_precise_lanes);
     hipStream_t main_stream = c->stream;
     // original images -> device, ONCE per begin / finish sequence, on the context's stream: every scale resizes the same originals (the
@@ -294,15 +295,10 @@ extern "C" int pmx_precise_finish(pmx_ctx* c)
     const int nl = c->opt_precise_lanes < 1 ? 1 : c->opt_precise_lanes;
     for (int i = 0; i < PMX_PR_LANES && i < nl; ++i)
         if (i < c->pr_scales && c->pr_lane[i].done) PMX_HIP(hipStreamWaitEvent(c->stream, c->pr_lane[i].done, 0));      // (a lane's last event covers all its scales)
-    PMX_HIP(hipMemsetAsync(c->ext_paf, 0, n * PMX_N_PAF * 4, c->stream));
-    PMX_HIP(hipMemsetAsync(c->ext_heat, 0, n * PMX_N_HEAT * 4, c->stream));
-    for (int k = 0; k < c->pr_scales; ++k) {
-        if ((rc = launch_add_f32(c->ext_paf, c->pr_part[k], n * PMX_N_PAF, c->stream))) return rc;
-        if ((rc = launch_add_f32(c->ext_heat, c->pr_part[k] + n * PMX_N_PAF, n * PMX_N_HEAT, c->stream))) return rc;
-    }
+    PMX_CHECK(c->pr_scales <= 8, PMX_ERR_CAPACITY, "pmx_precise_finish: %d scales (at most 8 per sequence)", c->pr_scales);
+    if ((rc = launch_sum_parts_f32(c->ext_paf, c->pr_part.data(), c->pr_scales, 0, n * PMX_N_PAF, (float)c->pr_scales, c->stream))) return rc;
+    if ((rc = launch_sum_parts_f32(c->ext_heat, c->pr_part.data(), c->pr_scales, n * PMX_N_PAF, n * PMX_N_HEAT, (float)c->pr_scales, c->stream))) return rc;
     PMX_HIP(hipEventRecord(c->pr_fin, c->stream));
-    if ((rc = launch_scale_f32(c->ext_paf, n * PMX_N_PAF, (float)c->pr_scales, c->stream))) return rc;
-    if ((rc = launch_scale_f32(c->ext_heat, n * PMX_N_HEAT, (float)c->pr_scales, c->stream))) return rc;
     c->maps_valid = true; c->maps_external = true;
     c->cur_B = c->pr_n; c->cur_fh = c->pr_h; c->cur_fw = c->pr_w;
     c->pp_valid = false;

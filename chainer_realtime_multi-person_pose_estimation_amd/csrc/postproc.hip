@@ -398,6 +398,12 @@ __device__ __forceinline__ bool cand_better(double s1, unsigned i1, double s2, u
     return s1 > s2 || (s1 == s2 && i1 < i2);
 }
 
+// MODE 0: one block per (limb, image) scans all nA x nB candidate pairs and matches (the batch path: a handful of peaks per joint type).
+// MODE 1 / 2 (crowds at full resolution -- detect_precise: ~45 peaks per type, 2000 pairs per limb, 19 blocks for 256 CUs): MODE 1 =
+// blockIdx.z slices the pair range, accepted candidates go to a per-(image, limb) list in device memory (slots by atomicAdd: the order
+// of the list is arbitrary, the matching below is a total order on (score, pair index) and does not depend on it); MODE 2 = the matching
+// of MODE 0 on that list.  Same arithmetic per pair, same result.
+template <int MODE>
 __global__ __launch_bounds__(256) void pp_limbs_kernel(PPMaps maps, PPTables tab, PPBuffers buf, double img_len)
 {
     // fast path: accepted candidates and the endpoint "used" flags of one limb live in LDS; large mode (buf.cap_cand > 0,
@@ -423,14 +429,19 @@ __global__ __launch_bounds__(256) void pp_limbs_kernel(PPMaps maps, PPTables tab
     }
     const bool large = buf.cap_cand > 0;
     const long long lb = (long long)b * PMX_N_LIMBS + l;
-    double* const cScore = large ? buf.cand_score + lb * buf.cap_cand : sScore;
-    unsigned* const cIdx = large ? buf.cand_idx + lb * buf.cap_cand : sIdx;
+    double* const scanScore = buf.scan_score + lb * buf.scan_cap;
+    unsigned* const scanIdx = buf.scan_idx + lb * buf.scan_cap;
+    // (MODE 1 writes the device list; MODE 2 in the large mode matches straight on it, else on a copy in LDS)
+    double* const cScore = MODE == 1 ? scanScore : large ? (MODE == 2 ? scanScore : buf.cand_score + lb * buf.cap_cand) : sScore;
+    unsigned* const cIdx = MODE == 1 ? scanIdx : large ? (MODE == 2 ? scanIdx : buf.cand_idx + lb * buf.cap_cand) : sIdx;
     unsigned char* const usedA = large ? buf.cand_used + lb * 2 * cap_pk : sUsed[0];
     unsigned char* const usedB = large ? usedA + cap_pk : sUsed[1];
-    const int ccap = large ? buf.cap_cand : PMX_LDS_CANDIDATES;
+    const int ccap = MODE == 1 ? buf.scan_cap : large ? buf.cap_cand : PMX_LDS_CANDIDATES;
     if (tid == 0) sNC = 0;
-    for (int i = tid; i < nA; i += 256) usedA[i] = 0;
-    for (int i = tid; i < nB; i += 256) usedB[i] = 0;
+    if (MODE != 1) {
+        for (int i = tid; i < nA; i += 256) usedA[i] = 0;
+        for (int i = tid; i < nB; i += 256) usedB[i] = 0;
+    }
     __syncthreads();
 
     const long long pbase = (long long)b * PMX_N_JOINTS * cap_pk;
@@ -441,9 +452,16 @@ __global__ __launch_bounds__(256) void pp_limbs_kernel(PPMaps maps, PPTables tab
     const long long P = (long long)nA * nB;
     const int g = tid >> 4, k = tid & 15;        // 16 pair slots per block iteration, 16 lanes per pair
     const int gl = lane & ~15;                   // first lane of my group inside the wave
-    for (long long base = 0; base < P; base += 16) {   // uniform trip count
+    // MODE 1: slice blockIdx.z of gridDim.z takes the pairs [p_lo, p_hi) (multiples of 16 pairs); MODE 2: no scan at all
+    long long p_lo = 0, p_hi = P;
+    if (MODE == 1) {
+        const long long per = ((P + 15) / 16 + gridDim.z - 1) / gridDim.z * 16;
+        p_lo = per * blockIdx.z; p_hi = min(P, p_lo + per);
+    }
+    if (MODE == 2) p_hi = 0;
+    for (long long base = p_lo; base < p_hi; base += 16) {   // uniform trip count
         const long long p = base + g;
-        const bool pv = p < P;
+        const bool pv = p < p_hi;
         const int ia = pv ? (int)(p / nB) : 0, ib = pv ? (int)(p - (long long)ia * nB) : 0;
         const double ax = (double)px[sA + ia], ay = (double)py[sA + ia];
         const double bx = (double)px[sB + ib], by = (double)py[sB + ib];
@@ -478,7 +496,7 @@ __global__ __launch_bounds__(256) void pp_limbs_kernel(PPMaps maps, PPTables tab
             if (!(prior < 0.0)) prior = 0.0;
             const double score = integ + prior;
             if (n_valid > PMX_N_INTEG_POINTS_THRESH && score > 0.0) {              // :156
-                const int slot = atomicAdd(&sNC, 1);
+                const int slot = MODE == 1 ? atomicAdd(buf.scan_cnt + lb, 1) : atomicAdd(&sNC, 1);
                 if (slot < ccap) {
                     cScore[slot] = score;
                     cIdx[slot] = (unsigned)p;
@@ -486,10 +504,15 @@ __global__ __launch_bounds__(256) void pp_limbs_kernel(PPMaps maps, PPTables tab
             }
         }
     }
+    if (MODE == 1) return;                       // (the list is complete at the kernel boundary)
     __syncthreads();
-    int nc = sNC;
+    int nc = MODE == 2 ? buf.scan_cnt[lb] : sNC;
+    if (MODE == 2 && !large && nc <= PMX_LDS_CANDIDATES) {      // the list -> LDS (the matching re-reads it once per accepted connection)
+        for (int e = tid; e < nc; e += 256) { sScore[e] = scanScore[e]; sIdx[e] = scanIdx[e]; }
+        __syncthreads();
+    }
     if (tid == 0) buf.cn_need[b * PMX_N_LIMBS + l] = nc;
-    if (nc > ccap || (!large && max(nA, nB) > PMX_LDS_USED)) {
+    if (nc > ccap || (MODE == 2 && nc > buf.scan_cap) || (!large && max(nA, nB) > PMX_LDS_USED)) {
         // does not fit: the host grows the candidate store (large mode) and re-runs the post-process of this batch
         if (tid == 0) { atomicOr(buf.status + b, PMX_IMG_CAND_OVERFLOW); *out_cnt = 0; }
         return;
@@ -697,7 +720,7 @@ void pp_set_generic(int on) { g_pp_generic = on; }
 
 int pp_launch(const PPMaps& maps, const PPTables& tab, const PPBuffers& buf, int B, int map_h, int map_w,
               double img_len, const double* d_scale_xy, int keep_smoothed, hipStream_t stream,
-              void (*prof)(void*, const char*, int), void* prof_ctx)
+              void (*prof)(void*, const char*, int), void* prof_ctx, int limbs_slices)
 {
     PMX_HIP(hipMemsetAsync(buf.pk_count, 0, sizeof(int) * B * PMX_N_JOINTS, stream));
     PMX_HIP(hipMemsetAsync(buf.status, 0, sizeof(int) * B, stream));
@@ -724,7 +747,13 @@ int pp_launch(const PPMaps& maps, const PPTables& tab, const PPBuffers& buf, int
     if (prof) prof(prof_ctx, "pp_sort", 0);
 
     if (prof) prof(prof_ctx, "pp_limbs", 1);
-    hipLaunchKernelGGL(pp_limbs_kernel, dim3(PMX_N_LIMBS, B), dim3(256), 0, stream, maps, tab, buf, img_len);
+    if (limbs_slices > 1) {
+        PMX_HIP(hipMemsetAsync(buf.scan_cnt, 0, sizeof(int) * B * PMX_N_LIMBS, stream));
+        hipLaunchKernelGGL(pp_limbs_kernel<1>, dim3(PMX_N_LIMBS, B, limbs_slices), dim3(256), 0, stream, maps, tab, buf, img_len);
+        hipLaunchKernelGGL(pp_limbs_kernel<2>, dim3(PMX_N_LIMBS, B), dim3(256), 0, stream, maps, tab, buf, img_len);
+    } else {
+        hipLaunchKernelGGL(pp_limbs_kernel<0>, dim3(PMX_N_LIMBS, B), dim3(256), 0, stream, maps, tab, buf, img_len);
+    }
     PMX_HIP(hipGetLastError());
     if (prof) prof(prof_ctx, "pp_limbs", 0);
 

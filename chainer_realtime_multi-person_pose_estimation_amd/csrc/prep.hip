@@ -243,10 +243,18 @@ __global__ __launch_bounds__(256) void scale_f32_kernel(float* __restrict__ p, l
     if (i < n) p[i] = p[i] / divisor;
 }
 
-__global__ __launch_bounds__(256) void add_f32_kernel(float* __restrict__ acc, const float* __restrict__ v, long long n)
+// out[i] = ((((0 + p0[i + off]) + p1[i + off]) + ...) / divisor: the per-scale parts of detect_precise added left to right from zero
+// (`sum = sum + resized`, pose_detector.py:463,467) and averaged (:469-470) in one pass over the data
+struct SumPartsArgs { const float* part[8]; int nparts; };
+__global__ __launch_bounds__(256) void sum_parts_f32_kernel(float* __restrict__ out, SumPartsArgs a, long long off, long long n, float divisor)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) acc[i] = acc[i] + v[i];
+    if (i >= n) return;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (k < a.nparts) v = v + a.part[k][off + i];
+    out[i] = v / divisor;
 }
 
 static inline unsigned nblocks(long long n) { return (unsigned)((n + 255) / 256); }
@@ -334,9 +342,13 @@ int launch_fill_bgr(uint8_t* dst, long long npix, int b, int g, int r, hipStream
     return PMX_OK;
 }
 
-int launch_add_f32(float* acc, const float* v, long long n, hipStream_t s)
+int launch_sum_parts_f32(float* out, const float* const* parts, int nparts, long long off, long long n, float divisor, hipStream_t s)
 {
-    hipLaunchKernelGGL(add_f32_kernel, dim3(nblocks(n)), dim3(256), 0, s, acc, v, n);
+    PMX_CHECK(nparts >= 1 && nparts <= 8, PMX_ERR_INVALID, "sum of parts: %d parts outside 1..8", nparts);
+    SumPartsArgs a;
+    for (int k = 0; k < 8; ++k) a.part[k] = k < nparts ? parts[k] : nullptr;
+    a.nparts = nparts;
+    hipLaunchKernelGGL(sum_parts_f32_kernel, dim3(nblocks(n)), dim3(256), 0, s, out, a, off, n, divisor);
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }

@@ -143,6 +143,8 @@ int pmx_synchronize(pmx_ctx* ctx);                    /* cuda.get_device_from_id
  *   "kp_flip_x" 0 | 1          pmx_keypoints: mirror the resized heat maps left-right before the peaks are taken (the reference's
  *                              `cv2.flip(heatmaps, 1)` for left hands, hand_detector.py:46-47)
  *   "peaks_gpu_branch"         the reference's GPU-branch peak extraction (17 x 17 un-normalised kernel, zero pad, >=)
+ *   "pp_limbs_slices" -1 | n   blocks per (limb, image) of the candidate-pair scan: -1 (default) = 8 where the maps come at full
+ *                              resolution (detect_precise, pmx_set_maps), one block otherwise; 0 / 1 = one block; same results
  *   "conv_min_lds", "conv_v5_lds", "pp_generic"   ablation switches, PROCESS-wide (not per context) */
 int pmx_set_option(pmx_ctx* ctx, const char* key, int value);
 
@@ -193,7 +195,7 @@ int pmx_precise_finish(pmx_ctx* ctx);
  * scale runs the n images as one batch through the network; finish() installs a batch of n -> pmx_postprocess(ctx, n, orig_h, orig_w,
  * orig_w, NULL).  bgr_nhwc: n x orig_h x orig_w x 3, contiguous.  Per image the results equal the single-image calls up to the
  * kernel-choice-by-launch-size rounding of the network. */
-int pmx_precise_begin_batch(pmx_ctx* ctx, int n_images, int orig_h, int orig_w);
+int pmx_precise_begin_batch(pmx_ctx* ctx, int n_images, int orig_h, int orig_w);      /* (at most 8 scales per sequence) */
 int pmx_precise_add_scale_batch(pmx_ctx* ctx, const uint8_t* bgr_nhwc, int scaled_h, int scaled_w);
 
 /* FaceDetector / HandDetector post-process (face_detector.py:37-38,58-68; hand_detector.py:41,68-78) for facenet / handnet

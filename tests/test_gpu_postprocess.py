@@ -36,15 +36,22 @@ def _compare(engine, image, ref_peaks, ref_conns, ref_subsets, ref_poses, ref_sc
         assert np.allclose(rec['scores'][:n], ref_scores, rtol=0, atol=SCORE_TOL)
 
 
+@pytest.mark.parametrize('slices', [0, 8, 3])
 @pytest.mark.parametrize('name', golden_cases())
-def test_reference_golden(engine, name):
+def test_reference_golden(engine, name, slices):
+    """slices: blocks per (limb, image) of the candidate-pair scan (option pp_limbs_slices; 0 = the one-block form of the batch path,
+    8 = what external full-resolution maps get by default): the list of accepted candidates comes in another order, the result is the same."""
     g = load_golden(name)
     map_h, map_w = [int(v) for v in g['map_hw']]
     orig_h, orig_w = [int(v) for v in g['orig_hw']]
-    engine.set_maps(g['paf_lo'][None], g['heat_lo'][None])
-    engine.postprocess(map_h, map_w, img_len=map_w, scale_xy=[[orig_w / map_w, orig_h / map_h]])
-    rec = engine.results()[0]
-    _compare(engine, 0, g['all_peaks'], conns_by_limb(g['connections']), g['subsets'], g['poses'], g['scores'], rec)
+    engine.set_option('pp_limbs_slices', slices)
+    try:
+        engine.set_maps(g['paf_lo'][None], g['heat_lo'][None])
+        engine.postprocess(map_h, map_w, img_len=map_w, scale_xy=[[orig_w / map_w, orig_h / map_h]])
+        rec = engine.results()[0]
+        _compare(engine, 0, g['all_peaks'], conns_by_limb(g['connections']), g['subsets'], g['poses'], g['scores'], rec)
+    finally:
+        engine.set_option('pp_limbs_slices', -1)
 
 
 def test_golden_through_pose_detector_api(native):
@@ -180,10 +187,12 @@ def test_candidate_store_overflow_equals_oracle(native):
     heat[8] = rng.random((46, 46)).astype('f') * 4           # right waist: limb 0 = neck -> right waist
     paf = np.zeros((38, 46, 46), 'f')
     paf[0] = 1.0                                             # x component of limb 0
-    e = _fresh(native)
-    ref, rec = _check_vs_oracle(e, paf, heat, 184, 184)
-    assert e.capacities()['candidates'] > 4096
-    e.close()
+    for slices in (-1, 0):                                   # (sliced scan -- the default for external maps -- and the one-block form)
+        e = _fresh(native)
+        e.set_option('pp_limbs_slices', slices)
+        ref, rec = _check_vs_oracle(e, paf, heat, 184, 184)
+        assert e.capacities()['candidates'] > 4096
+        e.close()
 
 
 @pytest.mark.parametrize('name', ['pp_crowd12_noise', 'pp_merge', 'pp_twosub', 'pp_netlike'])
