@@ -467,7 +467,6 @@ extern "C" int pmx_set_option(pmx_ctx* c, const char* key, int value)
     else if (!strcmp(key, "fuse_pairs")) c->opt_fuse_pairs = value;
     else if (!strcmp(key, "fuse_conv1")) c->opt_fuse_conv1 = value;
     else if (!strcmp(key, "conv1_wino")) c->opt_conv1_wino = value;
-    else if (!strcmp(key, "precise_excl")) c->opt_precise_excl = value;
     else if (!strcmp(key, "precise_lanes")) c->opt_precise_lanes = value < 1 ? 1 : (value > PMX_PR_LANES ? PMX_PR_LANES : value);
     else if (!strcmp(key, "cubic_rows")) prep_set_cubic_rows(value);      // (process-wide, like the other kernel-form switches of prep / post-process)
     else if (!strcmp(key, "precision")) c->opt_precision = value;

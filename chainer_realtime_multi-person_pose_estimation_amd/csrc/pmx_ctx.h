@@ -65,8 +65,6 @@ struct pmx_ctx {
     PrLane pr_lane[PMX_PR_LANES];                        // lanes 1 .. : own buffers; lane 0 = the context's own stream and buffers
     std::vector<float*> pr_part; size_t pr_part_cap = 0; // per scale: [n][57][orig_h][orig_w] (PAF planes, then heat planes of every image)
     hipEvent_t pr_src_ready = nullptr, pr_fin = nullptr; // originals uploaded / parts consumed by the last finish
-    unsigned pr_used = 0; int pr_excl = -1;              // lanes used in this sequence; lane of its last chip-filling ("exclusive") scale
-    int opt_precise_excl = 0;                            // 1: a scale whose launches fill the chip waits for the others and makes later ones wait (measured: no gain)
     int opt_precise_lanes = PMX_PR_LANES;                // 1: every scale on the context's own stream (A/B, tests)
     double* d_kp = nullptr;          // key-point records of pmx_keypoints
     size_t kp_cap = 0;

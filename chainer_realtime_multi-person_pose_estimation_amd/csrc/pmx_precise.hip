@@ -146,7 +146,6 @@ extern "C" int pmx_precise_begin_batch(pmx_ctx* c, int n_images, int orig_h, int
         PMX_HIP(hipMemset(c->sk_zero_bias, 0, PMX_SK_ZERO_BIAS * sizeof(float)));
     }
     c->pr_h = orig_h; c->pr_w = orig_w; c->pr_scales = 0; c->pr_n = n_images; c->pr_src = nullptr;
-    c->pr_used = 0; c->pr_excl = -1;
     c->maps_valid = false;
     return PMX_OK;
 }
@@ -217,23 +216,11 @@ extern "C" int pmx_precise_add_scale_batch(pmx_ctx* c, const uint8_t* imgs, int 
         (rc = cubic_table(c, scaled_w, ow, false, &t4xi, &t4xc)) || (rc = cubic_table(c, scaled_h, oh, false, &t4yi, &t4yc))) return rc;
     (void)xi; (void)yi; (void)xc; (void)yc;
 
-    // A scale whose launches fill the chip by themselves runs ALONE: its 7x7 layers are est_blocks one-per-CU blocks of ~200 us, and a
-    // second scale holding CUs when such a launch starts pushes part of it into a second round (measured: four scales of a 482 x 642 frame
-    // all in flight 17.7 ms against 19.3 one after the other -- the 192-block scale kept losing CUs to the others).  Scales below half
-    // the CUs share the chip (12 + 48 + 108 blocks of the three small scales: no launch ever waits for a CU).
-    const long long est_blocks = (long long)n * ((fh + 7) / 8) * ((fw + 15) / 16) * 2;
-    const bool exclusive = c->opt_precise_excl && est_blocks * 2 > conv_num_cus();
     lane_swap(c, li);                                 // from here on c->stream / c->in16 / ... are the lane's; every exit swaps back
     auto body = [&]() -> int {
         int rc2;
         PMX_HIP(hipStreamWaitEvent(c->stream, c->pr_src_ready, 0));      // the originals are on the device
         PMX_HIP(hipStreamWaitEvent(c->stream, c->pr_fin, 0));            // the last finish has read this scale's part
-        if (exclusive) {                                                 // after everything enqueued so far ...
-            for (int j = 0; j < PMX_PR_LANES; ++j)
-                if (j != li && (c->pr_used & (1u << j))) PMX_HIP(hipStreamWaitEvent(c->stream, c->pr_lane[j].done, 0));
-        } else if (c->pr_excl >= 0 && c->pr_excl != li) {                // ... and everything later after it
-            PMX_HIP(hipStreamWaitEvent(c->stream, c->pr_lane[c->pr_excl].done, 0));
-        }
         // (1) uint8 cubic resize into the padded images (all images in one launch)
         const size_t pad_bytes = (size_t)ph * pw * 3;
         if ((rc2 = launch_fill_bgr(c->u8_tmp, (long long)n * ph * pw, 104, 117, 123, c->stream))) return rc2;
@@ -272,8 +259,6 @@ extern "C" int pmx_precise_add_scale_batch(pmx_ctx* c, const uint8_t* imgs, int 
     rc = body();
     lane_swap(c, li);
     if (rc) return rc;
-    c->pr_used |= 1u << li;
-    if (exclusive) c->pr_excl = li;
     c->pr_scales += 1;
     c->maps_valid = false;       // the cat buffers hold single scales only; the averaged maps become valid in pmx_precise_finish
     return PMX_OK;

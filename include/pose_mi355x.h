@@ -128,7 +128,6 @@ int pmx_synchronize(pmx_ctx* ctx);                    /* cuda.get_device_from_id
  *   "fuse_conv1" 1 | 0         conv1_1 recomputed on conv1_2's halo tiles, one launch instead of two (default 1); identical bits
  *   "precise_lanes" 1..4       detect_precise: inference scales in flight at once, each on its own stream and working set (default 4;
  *                              1: one after the other on the context's stream); same bits
- *   "precise_excl" 0 | 1       detect_precise: a scale whose launches fill the chip runs alone (default 0: measured no gain)
  *   "cubic_rows" 1 | 0         detect_precise's float32 cubic resizes: separable through LDS (default) | one thread per element; same bits
  *   "conv1_wino" 1 | 0 | 2     that launch with conv1_2 as Winograd F(2x2, 3x3) on 16 x 16 squares (default 1: where "conv_algo" >= 1
  *                              and the launch has a block per CU; 2: whatever the launch size); 0: the direct 8 x 16 tiles everywhere
