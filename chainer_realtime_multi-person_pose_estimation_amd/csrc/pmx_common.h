@@ -263,7 +263,7 @@ struct PPBuffers {
     float* smoothed;         // optional [B][18][map_h][map_w]
 };
 #define PMX_LDS_CANDIDATES 4096     // candidate slots per limb in the LDS fast path
-#define PMX_LDS_SUBSETS 128         // subset rows in the LDS fast path
+#define PMX_LDS_SUBSETS 896         // subset rows in the LDS fast path (20 doubles each, dynamic LDS: 140 KB at most; the initial capacity is 128)
 #define PMX_LDS_USED 4096           // peaks per joint type whose "used" flags fit the LDS fast path
 void pp_set_generic(int on);
 int pp_keypoints_launch(const PPMaps& maps, const PPTables& tab, const PPBuffers& buf, int B, int n_ch, int map_h, int map_w,

@@ -568,12 +568,12 @@ __global__ __launch_bounds__(256) void pp_limbs_kernel(PPMaps maps, PPTables tab
 }
 
 // ============================================================================================= group
-// LDS_TABLE: the live subset rows sit in LDS (cap_sub <= PMX_LDS_SUBSETS, the normal case); otherwise in device memory
+// LDS_TABLE: the live subset rows sit in LDS (cap_sub <= PMX_LDS_SUBSETS = 896 rows: also the crowds of detect_precise); otherwise in device memory
 // (buf.sub_work) -- same code, entered by the host after a subset overflow.
 template <bool LDS_TABLE>
 __global__ __launch_bounds__(64) void pp_group_kernel(PPBuffers buf, const double* __restrict__ scale_xy)
 {
-    __shared__ double sS[LDS_TABLE ? PMX_LDS_SUBSETS * 20 : 20];
+    extern __shared__ double sS[];        // LDS_TABLE: cap_sub rows of 20 doubles (dynamic: up to PMX_LDS_SUBSETS rows = 140 KB for crowds)
     const int b = blockIdx.x, lane = threadIdx.x;
     const int cap_pk = buf.cap_pk, cap_sub = buf.cap_sub;
     double* const S = LDS_TABLE ? sS : buf.sub_work + (long long)b * cap_sub * 20;      // row r at S + 20 * r
@@ -758,10 +758,15 @@ int pp_launch(const PPMaps& maps, const PPTables& tab, const PPBuffers& buf, int
     if (prof) prof(prof_ctx, "pp_limbs", 0);
 
     if (prof) prof(prof_ctx, "pp_group", 1);
-    if (buf.cap_sub <= PMX_LDS_SUBSETS)
-        hipLaunchKernelGGL(pp_group_kernel<true>, dim3(B), dim3(64), 0, stream, buf, d_scale_xy);
-    else
-        hipLaunchKernelGGL(pp_group_kernel<false>, dim3(B), dim3(64), 0, stream, buf, d_scale_xy);
+    if (buf.cap_sub <= PMX_LDS_SUBSETS) {
+        const size_t lds = (size_t)buf.cap_sub * 20 * sizeof(double);
+        if (lds > 64 * 1024) {
+            static bool attr_set[PMX_MAX_DEVICES] = {};
+            if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(pp_group_kernel<true>), attr_set)) return rc;
+        }
+        hipLaunchKernelGGL(pp_group_kernel<true>, dim3(B), dim3(64), lds, stream, buf, d_scale_xy);
+    } else
+        hipLaunchKernelGGL(pp_group_kernel<false>, dim3(B), dim3(64), 20 * sizeof(double), stream, buf, d_scale_xy);
     PMX_HIP(hipGetLastError());
     if (prof) prof(prof_ctx, "pp_group", 0);
     return PMX_OK;

@@ -221,6 +221,21 @@ def test_growth_from_tiny_capacities_reproduces_goldens(native, name):
     e.close()
 
 
+@pytest.mark.parametrize('name', ['pp_crowd12_noise', 'pp_merge', 'pp_twosub'])
+def test_subset_table_in_device_memory_reproduces_goldens(native, name):
+    """The live subset rows of the grouping sit in LDS up to 896 rows (dynamic LDS; crowds included) and in device memory beyond: a context
+    pre-sized for 1024 subsets takes the device-memory form -- same goldens."""
+    g = load_golden(name)
+    map_h, map_w = [int(v) for v in g['map_hw']]
+    orig_h, orig_w = [int(v) for v in g['orig_hw']]
+    e = _fresh(native, subsets=1024, people=1024)
+    assert e.capacities()['subsets'] >= 1024
+    e.set_maps(g['paf_lo'][None], g['heat_lo'][None])
+    e.postprocess(map_h, map_w, img_len=map_w, scale_xy=[[orig_w / map_w, orig_h / map_h]])
+    _compare(e, 0, g['all_peaks'], conns_by_limb(g['connections']), g['subsets'], g['poses'], g['scores'], e.results()[0])
+    e.close()
+
+
 def test_fast_and_generic_peak_kernels_agree(engine):
     """The radius-10 fast path (LDS tables, sliding windows) and the generic-radius kernel: identical smoothed maps
     and peaks (both are also compared with the oracle elsewhere)."""
