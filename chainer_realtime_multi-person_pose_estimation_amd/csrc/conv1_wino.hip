@@ -65,8 +65,36 @@ __global__ __launch_bounds__(256, 1) void conv1_wino_kernel(const ConvArgs a)
     const int y0 = (trem / a.tiles_x) * (2 * TT), x0 = (trem % a.tiles_x) * (2 * TT);
     constexpr int OUTSIDE = (int)0x80000000;
 
-    // ---- input patch: 20 x 20 pixels x 3 channels through a buffer resource spanning the image (outside = 0 = conv1_1's padding)
-    {
+    // ---- input patch: 20 x 20 pixels x 3 channels through a buffer resource spanning the image (outside = 0 = conv1_1's padding).
+    // Either the preprocessed float input (NHWC, a.lda floats per pixel) or -- a.g[1].in set -- the uint8 BGR image itself, preprocessed
+    // here: x / divisor - 0.5 in float32, the reference's two operations (pose_detector.py:428-429; prep_u8_kernel's arithmetic), which
+    // saves the 64-bytes-per-pixel float copy of the network input (277 MB written and read back per batch of 32) and a launch.
+    if (a.g[1].in) {
+        const uint8_t* src8 = reinterpret_cast<const uint8_t*>(a.g[1].in) + (size_t)bimg * H * W * 3;
+        const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src8), 0, (unsigned)(H * W * 3), 0x00020000);
+        const float divisor = __builtin_bit_cast(float, (unsigned)a.kbounds);
+        unsigned char pb[2][3];
+        bool pin[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int f = tid + r * 256;
+            const int py = f / PW, px = f - py * PW;
+            const int gy = y0 - 2 + py, gx = x0 - 2 + px;
+            pin[r] = f < PPX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            const int o = pin[r] ? (gy * W + gx) * 3 : OUTSIDE;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) pb[r][ch] = __builtin_amdgcn_raw_buffer_load_b8(irsrc, o, ch, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int f = tid + r * 256;
+            if (f < PPX) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch)
+                    s_patch[f * 3 + ch] = pin[r] ? __fsub_rn(__fdiv_rn((float)pb[r][ch], divisor), 0.5f) : 0.f;
+            }
+        }
+    } else {
         const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g[0].in + (size_t)bimg * H * W * a.lda), 0,
                                                                                (unsigned)(H * W * a.lda) * 4u, 0x00020000);
         float4 pv[2];
@@ -321,7 +349,8 @@ __global__ __launch_bounds__(256, 1) void conv1_wino_kernel(const ConvArgs a)
 }
 
 // a.g[0] = conv1_2 (in = the 16-channel padded network input, w = its TRANSFORMED weights, pack_wino with cout_pad 64), a.g[1].w = conv1_1's
-// weights in lane order (pmx_api.hip::ensure_conv1_pack), a.g[1].bias = its bias
+// weights in lane order (pmx_api.hip::ensure_conv1_pack), a.g[1].bias = its bias; a.g[1].in != null: the uint8 BGR batch (B x H x W x 3) to
+// preprocess on the fly instead of reading a.g[0].in, a.kbounds = the bits of the float32 divisor (255 | 256)
 int conv1_wino_launch(const ConvArgs& a0, hipStream_t stream)
 {
     ConvArgs a = a0;
@@ -332,6 +361,7 @@ int conv1_wino_launch(const ConvArgs& a0, hipStream_t stream)
     a.tiles_x = (a.W + 2 * TT - 1) / (2 * TT);
     a.tiles_y = (a.H + 2 * TT - 1) / (2 * TT);
     a.ksplit = 1;
+    if (!a.g[1].in) a.kbounds = 0;
     static bool attr_set[PMX_MAX_DEVICES] = {};
     if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(conv1_wino_kernel), attr_set)) return rc;
     hipLaunchKernelGGL(conv1_wino_kernel, dim3((unsigned)(a.tiles_x * a.tiles_y * a.B)), dim3(256), LDS_BYTES, stream, a);

@@ -888,20 +888,32 @@ static int run_pair(pmx_ctx* c, const char* labelA, const char* labelB, int a0, 
     return prof_end(c);
 }
 
-// conv1_1 -> conv1_2 (+ pool): one launch when conv1_2 would take the 8 x 16 x 64 fp32 tiles (large maps), else two
+// which form conv1_1 -> conv1_2 (+ pool) takes: *fuse: one launch (direct conv1_2 on 8 x 16 x 64 tiles: large maps); returns true for
+// conv1_2 as Winograd F(2x2, 3x3) on 16 x 16 squares (conv1_wino.hip): wherever the Winograd kernels are allowed (conv_algo >= 1) and the
+// launch has at least one block per CU (smaller launches: the 8 x 16 direct tiles give twice the blocks); conv1_wino = 2: always
+static bool conv1_form(const pmx_ctx* c, int B, int H, int W, bool* fuse_out)
+{
+    const PackedLayer& L1 = c->layers[c->index.at("conv1_1")];
+    const PackedLayer& L2 = c->layers[c->index.at("conv1_2")];
+    const int v2 = conv_pick_variant(3, L2.cout_pad, H, W, B, c->opt_force[3], c->opt_kernel_gen, 1, L2.cin, 0);
+    const bool fuse = c->opt_fuse_conv1 && c->opt_kernel_gen >= 6 && c->opt_precision == 0 && c->opt_force[3] < 0 && L1.cin == 3 && L1.cout == 64 &&
+                      L2.cin == 64 && L2.cout == 64 && !strcmp(conv_variant(v2).name, "conv3x3_v5_t8x16_n64");
+    const bool pair_ok = c->opt_precision == 0 && c->opt_force[3] < 0 && L1.cin == 3 && L1.cout == 64 && L2.cin == 64 && L2.cout == 64 && H % 2 == 0 && W % 2 == 0;
+    if (fuse_out) *fuse_out = fuse;
+    return pair_ok && c->opt_conv1_wino && c->opt_conv_algo >= 1 &&
+           (c->opt_conv1_wino == 2 || (fuse && (long long)B * ((H + 15) / 16) * ((W + 15) / 16) >= conv_num_cus()));
+}
+
 static int run_conv1(pmx_ctx* c, int B, int H, int W)
 {
     const int i1 = c->index.at("conv1_1"), i2 = c->index.at("conv1_2");
     const PackedLayer& L1 = c->layers[i1];
     const PackedLayer& L2 = c->layers[i2];
-    const int v2 = conv_pick_variant(3, L2.cout_pad, H, W, B, c->opt_force[3], c->opt_kernel_gen, 1, L2.cin, 0);
-    const bool fuse = c->opt_fuse_conv1 && c->opt_kernel_gen >= 6 && c->opt_precision == 0 && c->opt_force[3] < 0 && L1.cin == 3 && L1.cout == 64 &&
-                      L2.cin == 64 && L2.cout == 64 && !strcmp(conv_variant(v2).name, "conv3x3_v5_t8x16_n64");
-    // conv1_2 as Winograd F(2x2, 3x3) on 16 x 16 squares (conv1_wino.hip) wherever the Winograd kernels are allowed (conv_algo >= 1) and
-    // the launch has at least one block per CU (smaller launches: the 8 x 16 direct tiles give twice the blocks); conv1_wino = 2: always
-    const bool pair_ok = c->opt_precision == 0 && c->opt_force[3] < 0 && L1.cin == 3 && L1.cout == 64 && L2.cin == 64 && L2.cout == 64 && H % 2 == 0 && W % 2 == 0;
-    const bool wino1 = pair_ok && c->opt_conv1_wino && c->opt_conv_algo >= 1 &&
-                       (c->opt_conv1_wino == 2 || (fuse && (long long)B * ((H + 15) / 16) * ((W + 15) / 16) >= conv_num_cus()));
+    bool fuse = false;
+    const bool wino1 = conv1_form(c, B, H, W, &fuse);
+    const uint8_t* in_u8 = c->in_u8;
+    c->in_u8 = nullptr;                                   // (valid for this forward only)
+    PMX_CHECK(!in_u8 || wino1, PMX_ERR_STATE, "conv1: a uint8 input without the kernel that preprocesses it");
     int rc;
     if (!fuse && !wino1) {
         if ((rc = run_conv(c, "conv1_1", i1, -1, c->in16, nullptr, PMX_IN_C, c->act0, nullptr, 64, B, H, W, 1, 0))) return rc;
@@ -916,9 +928,13 @@ static int run_conv1(pmx_ctx* c, int B, int H, int W)
         if ((rc = ensure_wino_pack(c->layers[i2])) || (rc = ensure_conv1_pack(c->layers[i1]))) return rc;
         a.g[0].w = L2.d_ww;
         a.g[1].w = L1.d_ww;
+        if (in_u8) {                                      // the kernel preprocesses the uint8 batch itself (pmx_forward_from_u8)
+            a.g[1].in = reinterpret_cast<const float*>(in_u8);
+            a.kbounds = (unsigned long long)__builtin_bit_cast(unsigned, c->in_div);
+        }
         if (c->prof_on == 1) {
             const double f1 = 2.0 * B * H * W * 9.0 * (double)L1.cout * L1.cin, f2 = 2.0 * B * H * W * 9.0 * (double)L2.cout * L2.cin;
-            if ((rc = prof_begin(c, "conv1_1+conv1_2|conv_wino1_f2x2_t16x16", f1 + f2, 4.0 * B * H * W * (3 + 64 / 4), f1 + f2 * 16.0 / 36.0))) return rc;
+            if ((rc = prof_begin(c, "conv1_1+conv1_2|conv_wino1_f2x2_t16x16", f1 + f2, (in_u8 ? 3.0 : 4.0 * 3) * B * H * W + 4.0 * B * H * W * (64 / 4), f1 + f2 * 16.0 / 36.0))) return rc;
         }
         if ((rc = conv1_wino_launch(a, c->stream))) return rc;
         return prof_end(c);
@@ -1062,8 +1078,20 @@ extern "C" int pmx_forward_u8(pmx_ctx* c, const uint8_t* img, int B, int H, int 
         PMX_HIP(hipMemcpyAsync(c->u8_tmp, img, (size_t)B * H * W * 3, hipMemcpyHostToDevice, c->stream));
         d = c->u8_tmp;
     }
+    return pmx_forward_from_u8(c, d, B, H, W, c->kind == NET_POSE ? 255.0f : 256.0f);
+}
+
+int pmx_forward_from_u8(pmx_ctx* c, const uint8_t* d, int B, int H, int W, float divisor)
+{
+    int rc;
+    if (conv1_form(c, B, H, W, nullptr)) {                // conv1_wino_kernel reads the uint8 pixels and preprocesses them in its patch load
+        c->in_u8 = d; c->in_div = divisor;
+        rc = pmx_forward_from_in16(c, B, H, W);
+        c->in_u8 = nullptr;
+        return rc;
+    }
     if (c->prof_on == 1 && (rc = prof_begin(c, "prep_u8|prep_u8", 0, (double)B * H * W * (3 + 64)))) return rc;
-    if ((rc = launch_prep_u8(d, c->in16, B, H, W, c->kind == NET_POSE ? 255.0f : 256.0f, c->stream))) return rc;
+    if ((rc = launch_prep_u8(d, c->in16, B, H, W, divisor, c->stream))) return rc;
     if ((rc = prof_end(c))) return rc;
     return pmx_forward_from_in16(c, B, H, W);
 }

@@ -79,6 +79,7 @@ struct pmx_ctx {
     float* nchw_tmp = nullptr;       // staging for NCHW host <-> NHWC device conversions
     size_t nchw_tmp_bytes = 0;
     uint8_t* u8_tmp = nullptr;
+    const uint8_t* in_u8 = nullptr; float in_div = 255.0f;      // set for ONE forward: conv1_wino_kernel preprocesses this uint8 batch itself
     uint8_t* u8_src = nullptr;       // original-size images awaiting the on-device resize
     size_t u8_src_cap = 0;
     int* rs_tab = nullptr;           // resize tables: x (4 * dw ints) then y (4 * dh ints)
@@ -153,5 +154,8 @@ struct pmx_ctx {
 #define PMX_DEV(c) PMX_HIP(hipSetDevice((c)->device))
 
 // pmx_api.hip
+// the network on a uint8 BGR batch on the device: preprocess (x / divisor - 0.5) + forward; where conv1 runs as conv1_wino_kernel the
+// preprocessing happens inside it (no float copy of the input), else prep_u8 fills c->in16 first
+int pmx_forward_from_u8(pmx_ctx* c, const uint8_t* d_u8, int B, int H, int W, float divisor);
 int pmx_forward_from_in16(pmx_ctx* c, int B, int H, int W);      // the network on the padded float input already in c->in16
 int pmx_ensure_tables(pmx_ctx* c, int in_h, int in_w, int out_h, int out_w, int flip_x = 0);   // up-sampling tables of the post-process

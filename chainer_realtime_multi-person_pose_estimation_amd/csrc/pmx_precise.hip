@@ -231,8 +231,7 @@ extern "C" int pmx_precise_add_scale_batch(pmx_ctx* c, const uint8_t* imgs, int 
         } else if ((rc2 = launch_resize_cubic_u8(c->u8_src, ow, c->u8_tmp, scaled_h, scaled_w, pw, t1xi, (const int*)t1xc, t1yi, (const int*)t1yc, n,
                                                  (long long)img_bytes, (long long)pad_bytes, c->stream))) return rc2;
         // (2) network, the n images as one batch
-        if ((rc2 = launch_prep_u8(c->u8_tmp, c->in16, n, ph, pw, 255.0f, c->stream))) return rc2;
-        if ((rc2 = pmx_forward_from_in16(c, n, ph, pw))) return rc2;
+        if ((rc2 = pmx_forward_from_u8(c, c->u8_tmp, n, ph, pw, 255.0f))) return rc2;
         // (3) x8 cubic up-sampling of the PAF (38) and heat (19) channels of all images into PLANAR temporaries [n][38][ph][pw] | [n][19][ph][pw]
         // (two cv2.resize calls per image in the reference; planar so that step (4) reads rows of one channel and both steps store full rows)
         const size_t ppx = (size_t)ph * pw, ntmp = ppx * 57 * n;
