@@ -50,12 +50,30 @@ def _hipcc():
     return 'hipcc'
 
 
+STAMP_PATH = os.path.join(CSRC, '.build_stamp')
+
+
+def source_digest():
+    """sha256 over every source / header the library is built from and the compile flags: what the .so on disk must have been built from."""
+    import hashlib
+    h = hashlib.sha256()
+    for src, extra in SOURCES:
+        h.update(('%s %s\n' % (src, ' '.join(extra))).encode())
+        h.update(open(os.path.join(CSRC, src), 'rb').read())
+    for hd in HEADERS:
+        h.update(open(hd if os.path.isabs(hd) else os.path.join(CSRC, hd), 'rb').read())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(LIB_PATH):
+    """True unless csrc/libpose_mi355x.so exists AND was built from exactly the sources on disk (content digest in csrc/.build_stamp,
+    written by build(): file times say nothing after a checkout or a copy to another box)."""
+    if not os.path.exists(LIB_PATH) or not os.path.exists(STAMP_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s, _ in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps)
+    try:
+        return open(STAMP_PATH).read().strip() != source_digest()
+    except OSError:
+        return True
 
 
 def build(force=False, verbose=False):
@@ -89,6 +107,8 @@ def _build_locked(verbose):
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
+    with open(STAMP_PATH, 'w') as f:
+        f.write(source_digest() + '\n')
     return LIB_PATH
 
 
