@@ -218,7 +218,14 @@ __global__ __launch_bounds__(256, 1) void conv1_wino_kernel(const ConvArgs a)
     // ---- conv1_2.  Transform items of this thread: tiles tt and tt + 32 (tile = 8 ty + tx of the block), channels 4 tc .. + 3 of the chunk.
     // Row i of V = B^T d B of a 4 x 4 window d:  w[jx] = d[ra][jx] (-|+) d[rb][jx] with (ra, rb, op) = (0, 2, -), (1, 2, +), (2, 1, -), (1, 3, -);
     // V[i][0..3] = (w0 - w2, w1 + w2, w2 - w1, w1 - w3) -- conv_wino_kernel's operations, row by row.
-    const int tt = tid >> 3, tc = tid & 7;
+    // (the two tiles whose items share a 16-lane LDS access are FOUR tile columns apart, not neighbours: 8 pixels x 68 floats = 32 banks,
+    //  so their 128-byte runs of the raw halo no longer overlap -- neighbours, 2 pixels apart, overlapped in 24 of 32 banks: PMC 37 % of the
+    //  LDS cycles were conflicts; a relabelling of which thread transforms which tile, nothing else)
+#ifndef PMX_WINO_TPERM
+#define PMX_WINO_TPERM 1
+#endif
+    const int tg = tid >> 3, tc = tid & 7;
+    const int tt = PMX_WINO_TPERM ? (tg & ~7) + ((tg & 7) >> 1) + 4 * (tg & 1) : tg;
     int t_raw[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
