@@ -223,3 +223,29 @@ def test_unpack_results_per_image_error_behaviour():
     det.model = None
     with pytest.raises(ValueError):
         PD.PoseDetector.detect_precise_batch(det, [])
+
+
+def test_needs_build_follows_the_source_digest(native, tmp_path, monkeypatch):
+    """The library on disk is 'up to date' iff csrc/.build_stamp holds the digest of the sources + flags it was built from (file times say
+    nothing after a checkout or a copy to the GPU box)."""
+    assert not native.needs_build()
+    assert open(native.STAMP_PATH).read().strip() == native.source_digest()
+    stamp = tmp_path / 'stamp'
+    stamp.write_text('0' * 64 + '\n')
+    monkeypatch.setattr(native, 'STAMP_PATH', str(stamp))
+    assert native.needs_build()
+    stamp.write_text(native.source_digest() + '\n')
+    assert not native.needs_build()
+
+
+def test_oracle_reads_the_conv1_winograd_launch_as_conv1_2():
+    """The fused conv1_1 + conv1_2 launch with conv1_2 in Winograd form is one profile entry; the twin runs conv1_1 on the direct chain and
+    conv1_2 on the Winograd chain (oracle/conv_fma_ref.py::wino_layers)."""
+    from oracle import conv_fma_ref as R
+    prof = [{'layer': 'conv1_1+conv1_2', 'kernel': 'conv_wino1_f2x2_t16x16'}, {'layer': 'conv2_1', 'kernel': 'conv_wino_f2x2_3x3'},
+            {'layer': 'conv5_4_CPM+conv5_5_CPM', 'kernel': 'conv1x1_pair_c512_n64'}, {'layer': 'Mconv1_stage2', 'kernel': 'conv_wino_f2x2_7x7r/t2m'}]
+    assert R.wino_layers(prof) == {'conv1_2', 'conv2_1', 'Mconv1_stage2'}
+    plan = R.splitk_plan(prof)
+    assert 'conv1_2' in plan.wino and plan.wino_tails == {'Mconv1_stage2': 2}
+    prof[0] = {'layer': 'conv1_1+conv1_2', 'kernel': 'conv1_fused_t8x16_n64'}
+    assert 'conv1_2' not in R.wino_layers(prof)
