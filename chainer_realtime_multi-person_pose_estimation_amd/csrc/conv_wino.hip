@@ -87,14 +87,17 @@ extern "C" int pmx_debug_block_times(unsigned long long* out, size_t n)
 #ifndef PMX_WINO_SOFF
 #define PMX_WINO_SOFF 1
 #endif
-// The transform's packed adds in ONE gap per group (1) instead of two per gap (0, the default).  tools/mfma_gap_probe.hip
+// The transform's packed adds in ONE gap per group (1, the default since round 5) instead of two per gap (0).  tools/mfma_gap_probe.hip
 // (profiles/r04_mfma_gap_probe.json): LDS reads, buffer loads and scalar instructions between two MFMAs of the single wave on a SIMD are
 // free, but a v_pk_add_f32 is not -- a gap that holds VALU work costs ~3.2 ns of matrix-pipe time once plus ~2.2 ns per instruction (2 in
 // every 2nd gap: 3.3 ns each, 8 in every 8th: 2.6 ns each).  In the kernel the clustered schedule (bit-identical, 60 Winograd tests) measured
-// +0.5 % on the 7x7 layers and -1.3 % on conv4_2 (profiles/r04_wino_ablation.json "vcluster"): the cluster waits for all twelve raw-halo
-// reads at once where the spread schedule waits for two -- not adopted
+// +0.5 % on the 7x7 layers and -1.3 % on conv4_2 in round 4 (profiles/r04_wino_ablation.json "vcluster": the cluster right behind the reads
+// waits for all twelve at once); round 5, four slots later: -1.6 % on the 7x7 layers (PMX_WINO_VCL_T1 below) -- adopted
+#ifndef PMX_WINO_VCL_T1
+#define PMX_WINO_VCL_T1 20
+#endif
 #ifndef PMX_WINO_VCLUSTER
-#define PMX_WINO_VCLUSTER 0
+#define PMX_WINO_VCLUSTER 1
 #endif
 static_assert(PMX_WINO_WLEAD1 >= 4 && PMX_WINO_WLEAD1 <= 15 && PMX_WINO_WLEAD2 >= 4 && PMX_WINO_WLEAD2 <= 7, "weight ring lead");
 template <int KS, int GEOM>
@@ -130,6 +133,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     // the transform's packed adds clustered into one gap per group (PMX_WINO_VCLUSTER): the run-geometry and merged-tail forms only -- on
     // the rectangle and multi-slab forms the register allocator answers the clusters with 3.4 KB of scratch per lane
     constexpr bool VCL = PMX_WINO_VCLUSTER && (GEOM == 1 || GEOM == 3);
+    // slot of the first cluster (the second follows eight slots later, the stores nine later still): 16 = right behind the reads
+    // (round 4: +0.5 % on the kernel of that round, not adopted); 20 / 22 = four / six slots later, all twelve raw-halo reads long landed.
+    // Round 5, on the kernel with the early phase barrier and the packed output transform: 7x7 layers -1.3 % (16), -1.6 % (20), -1.7 % (22)
+    // against the spread schedule, tails -1 % (profiles/r05_vcluster_ab.json): adopted with the cluster in slot 20
+    constexpr int VT = PMX_WINO_VCL_T1;
+    static_assert(VT >= 16 && VT <= 22, "clustered transform: first cluster in slots 16 .. 22 (its stores end before the halo slots at 40)");
     // UNIT (single images: 36 blocks of a 46x46 7x7 layer cannot fill 256 CUs): blockIdx.z = unit * groups + group, and a block runs
     // ONE unit of the work -- unit u < nu1: pass 1 over the chunks [u g, u g + g) (g = a.kbounds); 7x7: unit nu1: row 6 (pass 2a without
     // tap (6, 6)); unit nu1 + 1: column 6 (pass 2b); unit nu1 + 2: tap (6, 6) -- and writes its untransformed share of y (no bias / ReLU) to slab `unit`; conv_splitk_reduce_kernel adds the slabs in unit order
@@ -425,11 +434,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                         } else if (LAST && t == 14 && r == 0) {         // every wave has read what it needs of the old halo
                             if (repl) __syncthreads();
                             __builtin_amdgcn_sched_barrier(0);
-                        } else if (VCL && (t == 16 || t == 24)) {
+                        } else if (VCL && (t == VT || t == VT + 8)) {
                             // the 16 packed adds of B^T d (slot 16) / of (.) B (slot 24) in one gap each; the eight U stores follow one per slot
 #pragma unroll
                             for (int k8 = 0; k8 < 8; ++k8) {
-                                if (t == 16) {
+                                if (t == VT) {
                                     const int jx = k8 >> 1, wi = k8 & 1;
                                     if (PMX_ABLATE & 32) asm volatile("" : "=v"(wv[wi][jx]));
                                     else if (q == 0) wv[wi][jx] = wi == 0 ? pk_sub4(dd[0][jx], dd[2][jx]) : pk_add4(dd[1][jx], dd[2][jx]);
@@ -441,8 +450,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                                 }
                             }
                             __builtin_amdgcn_sched_barrier(0);
-                        } else if (VCL && t >= 25 && t < 33) {
-                            const int k8 = t - 25, il = k8 >> 2, jv = k8 & 3;
+                        } else if (VCL && t >= VT + 9 && t < VT + 17) {
+                            const int k8 = t - (VT + 9), il = k8 >> 2, jv = k8 & 3;
                             if (PMX_ABLATE & 64) asm volatile("" :: "v"(vvs[k8]));
                             else *reinterpret_cast<f32x4*>(&udst[(4 * il + jv) * 32 * C::LDU]) = vvs[k8];
                             __builtin_amdgcn_sched_barrier(0);
