@@ -93,6 +93,9 @@ extern "C" int pmx_debug_block_times(unsigned long long* out, size_t n)
 // every 2nd gap: 3.3 ns each, 8 in every 8th: 2.6 ns each).  In the kernel the clustered schedule (bit-identical, 60 Winograd tests) measured
 // +0.5 % on the 7x7 layers and -1.3 % on conv4_2 in round 4 (profiles/r04_wino_ablation.json "vcluster": the cluster right behind the reads
 // waits for all twelve at once); round 5, four slots later: -1.6 % on the 7x7 layers (PMX_WINO_VCL_T1 below) -- adopted
+#ifndef PMX_WINO_P2BAR
+#define PMX_WINO_P2BAR 0
+#endif
 #ifndef PMX_WINO_VCL_T1
 #define PMX_WINO_VCL_T1 20
 #endif
@@ -560,6 +563,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
         // H1 phases (16 steps x 8 MFMAs; during H0 sub-kernel 1 is transformed, during H1 the raw halo of the next chunk replaces this
         // one); then y += A^T-transform of the row planes.  Pass 2b per chunk: V0, V1 phases; then y += transform of the column planes.
         constexpr int PH = 64, PV = 72, PD = 80;
+        constexpr bool P2E = PMX_WINO_P2BAR != 0;
+        using early_t = std::true_type;
+        using late_t = std::false_type;
         constexpr int HBAR = C::NHF > 20 ? C::NHF : 20;      // H1 / V1: the slot of the barrier behind the halo stores (slots 0 .. NHF - 1)
         f32x16 e8[8];
         f32x4 bwr[8], bd[4], av[4];
@@ -599,9 +605,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
         };
         // one 8-plane phase: 16 steps s = f * 4 + st, per step the two lines l = 0, 1 x 4 MFMAs; A fragments one step ahead, weights
         // four steps ahead (ring of 8; `wnext(s)` loads step s of whatever phase follows), side slots m = 2, 3, 6, 7 of every step
-        auto phase8 = [&](const float* ub, int wplane, unsigned chb, auto&& wnext, auto&& side) {
-            av[0] = *reinterpret_cast<const f32x4*>(&ub[a_off]);
-            av[1] = *reinterpret_cast<const f32x4*>(&ub[4 * 32 * C::LDU + a_off]);
+        // PMX_WINO_P2BAR: like pass 1, the barrier that ends a phase sits eight MFMAs (= one step) before the phase's end -- every A
+        // fragment of the phase has been read by then (the barrier's lgkmcnt(0)), the side stores ended in slot 50 at the latest --
+        // and the first two A fragments of the phase that follows (`ubn`) are requested behind it, so the callers enter a phase
+        // with av[0], av[1] in flight instead of waiting for a barrier and an LDS read
+        auto phase8 = [&](const float* ub, int wplane, unsigned chb, auto&& wnext, auto&& side, auto early_c, const float* ubn) {
+            constexpr bool EARLY = P2E && decltype(early_c)::value;
+            if (!P2E) {
+                av[0] = *reinterpret_cast<const f32x4*>(&ub[a_off]);
+                av[1] = *reinterpret_cast<const f32x4*>(&ub[4 * 32 * C::LDU + a_off]);
+            }
 #pragma unroll
             for (int s2 = 0; s2 < 16; ++s2) {
                 const int f = s2 >> 2, st = s2 & 3;
@@ -609,6 +622,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                 for (int m = 0; m < 8; ++m) {
                     const int l = m >> 2, e = m & 3;
                     e8[l * 4 + f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(s2 & 1) * 2 + l][e], bwr[s2 & 7][e], e8[l * 4 + f], 0, 0, 0);
+                    if (EARLY && s2 == 15 && m == 0) { __syncthreads(); __builtin_amdgcn_sched_barrier(0); }
+                    if (EARLY && s2 == 15 && (m == 1 || m == 5)) {
+                        av[m == 1 ? 0 : 1] = *reinterpret_cast<const f32x4*>(&ubn[(m == 1 ? 0 : 4) * 32 * C::LDU + a_off]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     if (m == 0) {
                         constexpr int L2 = PMX_WINO_WLEAD2;
                         if (PMX_ABLATE & 2) {}
@@ -663,7 +681,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                         if (!UNIT) y[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[q & 3][e], bd[st][e], y[pp], 0, 0, 0);
                         if (e == 0) {
                             if (q < PMX_WINO_WLEAD2) { bwr[q] = wload(PH + (q >> 2), chb, q & 3); __builtin_amdgcn_sched_barrier(0); }
+                            if (P2E && q == 14) { __syncthreads(); __builtin_amdgcn_sched_barrier(0); }     // U half 0 = row-6 sub-kernel 0 (stores: slots 20..27)
                         } else if (e == 1) {
+                            if (P2E && q >= 14) {
+                                av[q - 14] = *reinterpret_cast<const f32x4*>(&s_u[(q - 14) * 4 * 32 * C::LDU + a_off]);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                             if (q + 2 < 16) {
                                 const int qn = q + 2, pn = qn & 3, sn = qn >> 2;
                                 ad[qn & 3] = *reinterpret_cast<const f32x4*>(&s_raw[a2_off + ((6 + (pn >> 1)) * C::HW + 6 + (pn & 1)) * C::LDR + sn * 8]);
@@ -675,7 +698,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                     }
                 }
             }
-            __syncthreads();                        // U half 0 = row-6 sub-kernel 0
+            if (!P2E) __syncthreads();              // U half 0 = row-6 sub-kernel 0
             // The raw halo is replaced without ever stopping the matrix pipe and without the staging registers meeting the transform's:
             // ---- H0: side = sub-kernel 1 (kx 3..5) -> U half 1 (the last reads of this chunk's raw halo, slots 2..27); then the halo of the
             // next chunk (chunk 0 again after the last one: pass 2b starts from it) global -> registers, one load per slot from slot 28
@@ -686,8 +709,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                    [&](int t) {
                        if (t >= 28 && t < 28 + C::NHF) { halo_load_slot(hreg, cnx, t - 28); __builtin_amdgcn_sched_barrier(0); }
                        else side1d(t, t_raw + (6 * C::HW + 3) * C::LDR, C::HW * C::LDR, C::LDR, u1);
-                   });
-            __syncthreads();                        // U half 1 = row-6 sub-kernel 1; nobody reads the old raw halo any more
+                   }, early_t{}, s_u + 8 * 32 * C::LDU);
+            if (!P2E) __syncthreads();              // U half 1 = row-6 sub-kernel 1; nobody reads the old raw halo any more
             // ---- H1: side = registers -> LDS, one ds_write_b128 per slot from slot 0 on, a barrier (slot 20), then column-6 sub-kernel 0
             // of the new chunk -> U half 0 (free: H1 reads half 1; needed after the last chunk, otherwise unused and overwritten by the
             // next D phase -- unconditional, because a branch per slot would cut the schedule into pieces); afterwards the next chunk's
@@ -701,7 +724,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                        if (t < C::NHF) { halo_store_slot(hreg, t); __builtin_amdgcn_sched_barrier(0); }
                        else if (t == HBAR) { __syncthreads(); __builtin_amdgcn_sched_barrier(0); }
                        else if (t >= HBAR + 2) side1d(t - HBAR, t_raw + (0 * C::HW + 6) * C::LDR, C::LDR, C::HW * C::LDR, u0);
-                   });
+                   }, late_t{}, nullptr);
         }
         __syncthreads();                            // U half 0 = column-6 sub-kernel 0 of chunk 0
         // y += A^T-transform of the row planes: e8[i * 4 + f]
@@ -750,8 +773,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                    [&](int t) {
                        if (MORE && t >= 28 && t < 28 + C::NHF) { halo_load_slot(hreg, ch + 1, t - 28); __builtin_amdgcn_sched_barrier(0); }
                        else side1d(t, t_raw + (3 * C::HW + 6) * C::LDR, C::LDR, C::HW * C::LDR, u1);
-                   });
-            __syncthreads();
+                   }, early_t{}, s_u + 8 * 32 * C::LDU);
+            if (!P2E) __syncthreads();
             // ---- V1: side = registers -> LDS (slots 0 ..), barrier (slot 20), the next chunk's sub-kernel 0 -> U half 0
             if constexpr (MORE)
                 phase8(s_u + 8 * 32 * C::LDU, PV + 4, chb,
@@ -760,14 +783,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                            if (t < C::NHF) { halo_store_slot(hreg, t); __builtin_amdgcn_sched_barrier(0); }
                            else if (t == HBAR) { __syncthreads(); __builtin_amdgcn_sched_barrier(0); }
                            else if (t >= HBAR + 2) side1d(t - HBAR, t_raw + (0 * C::HW + 6) * C::LDR, C::LDR, C::HW * C::LDR, u0);
-                       });
+                       }, early_t{}, s_u);
             else
                 phase8(s_u + 8 * 32 * C::LDU, PV + 4, chb,
                        [&](int s2n) { bwr[(s2n + 16) & 7] = wload(PV + 0 + (s2n >> 2), nxb, s2n & 3); },
-                       [&](int) {});
-            __syncthreads();
+                       [&](int) {}, late_t{}, nullptr);
+            if (!P2E || !MORE) __syncthreads();
         };
-        static_assert(HBAR + 28 <= 64 && 28 + C::NHF <= 64, "halo slots");
+        static_assert(HBAR + 28 <= 60 && 28 + C::NHF <= 60, "halo slots");
+        if (P2E) {                                  // the first V0's A fragments (later ones are requested inside the V1 before them)
+            av[0] = *reinterpret_cast<const f32x4*>(&s_u[a_off]);
+            av[1] = *reinterpret_cast<const f32x4*>(&s_u[4 * 32 * C::LDU + a_off]);
+        }
         for (int ch = 0; ch < nch - 1; ++ch) p2b_chunk(std::true_type{}, ch);
         p2b_chunk(std::false_type{}, nch - 1);
         // y += A^T-transform of the column planes: e8[j * 4 + f]
