@@ -276,9 +276,10 @@ extern "C" int pmx_precise_finish(pmx_ctx* c)
     PMX_DEV(c);
     int rc;
     const long long n = (long long)c->pr_n * c->pr_h * c->pr_w;
-    const int nl = c->opt_precise_lanes < 1 ? 1 : c->opt_precise_lanes;
-    for (int i = 0; i < PMX_PR_LANES && i < nl; ++i)
-        if (i < c->pr_scales && c->pr_lane[i].done) PMX_HIP(hipStreamWaitEvent(c->stream, c->pr_lane[i].done, 0));      // (a lane's last event covers all its scales)
+    // every lane that ever ran a scale (its last event covers all its scales; an event of an earlier sequence is complete and costs nothing):
+    // independent of the `precise_lanes` option, which may have changed since the scales were enqueued
+    for (int i = 0; i < PMX_PR_LANES; ++i)
+        if (c->pr_lane[i].done) PMX_HIP(hipStreamWaitEvent(c->stream, c->pr_lane[i].done, 0));
     PMX_CHECK(c->pr_scales <= 8, PMX_ERR_CAPACITY, "pmx_precise_finish: %d scales (at most 8 per sequence)", c->pr_scales);
     if ((rc = launch_sum_parts_f32(c->ext_paf, c->pr_part.data(), c->pr_scales, 0, n * PMX_N_PAF, (float)c->pr_scales, c->stream))) return rc;
     if ((rc = launch_sum_parts_f32(c->ext_heat, c->pr_part.data(), c->pr_scales, n * PMX_N_PAF, n * PMX_N_HEAT, (float)c->pr_scales, c->stream))) return rc;

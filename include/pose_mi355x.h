@@ -186,7 +186,8 @@ int pmx_postprocess(pmx_ctx* ctx, int batch, int map_h, int map_w, double img_le
  * finish() (average, :469-470; installs the full-resolution maps as a batch of one) -> pmx_postprocess(ctx, 1, orig_h,
  * orig_w, img_len = orig_w, NULL) (:475-481).  cv2.resize(INTER_CUBIC) is restated (uint8 fixed-point and float32 paths).
  * Every add_scale of one begin / finish sequence resizes the SAME original image(s): the host buffer is uploaded by the first call and
- * a later call that passes the same pointer reuses the device copy, so the pixels must not change between begin and finish. */
+ * a later call that passes the same pointer reuses the device copy, so the pixels must not change between begin and finish, and the
+ * buffer must stay allocated until a synchronising call (pmx_get_results, pmx_get_maps, pmx_synchronize) has returned: add_scale only enqueues. */
 int pmx_precise_begin(pmx_ctx* ctx, int orig_h, int orig_w);
 int pmx_precise_add_scale(pmx_ctx* ctx, const uint8_t* bgr_hwc, int scaled_h, int scaled_w);
 int pmx_precise_finish(pmx_ctx* ctx);
