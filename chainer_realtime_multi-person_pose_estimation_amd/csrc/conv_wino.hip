@@ -93,6 +93,9 @@ extern "C" int pmx_debug_block_times(unsigned long long* out, size_t n)
 // every 2nd gap: 3.3 ns each, 8 in every 8th: 2.6 ns each).  In the kernel the clustered schedule (bit-identical, 60 Winograd tests) measured
 // +0.5 % on the 7x7 layers and -1.3 % on conv4_2 in round 4 (profiles/r04_wino_ablation.json "vcluster": the cluster right behind the reads
 // waits for all twelve at once); round 5, four slots later: -1.6 % on the 7x7 layers (PMX_WINO_VCL_T1 below) -- adopted
+#ifndef PMX_WINO_UNIT_XCD
+#define PMX_WINO_UNIT_XCD 0
+#endif
 #ifndef PMX_WINO_P2BAR
 #define PMX_WINO_P2BAR 0
 #endif
@@ -150,8 +153,25 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     float* const s_raw = reinterpret_cast<float*>(smem4);
     float* const s_u = s_raw + C::RAW_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
-    const int unit = UNIT ? (int)blockIdx.z / a.ngroups : 0;
-    const bool g1 = (UNIT ? (int)blockIdx.z % a.ngroups : (int)blockIdx.z) != 0;
+    // Which piece of the launch this workgroup computes.  Workgroups go to the 8 XCDs round-robin in their linear order (x fastest), each
+    // XCD has its own L2, and in unit mode the gridDim.x blocks that read the same weights (same (unit, group, cout block) = same (y, z); 17
+    // for a 46 x 46 map) land on all 8 XCDs: every L2 fetches all the weights of the layer (125 - 138 MB per merged-tail launch against
+    // ~38 MB of unique traffic, profiles/r05_pmc_summary.json).  PMX_WINO_UNIT_XCD=1 hands XCD k a CONTIGUOUS range of the (z, y, x)-ordered
+    // pieces instead (two or three weight sets per L2 instead of fourteen; a pure relabelling, bit-identical).  Measured (round 5,
+    // profiles/r05_unit_xcd_ab.json): single image unchanged to 0.5 % either way -- the redundant fetch is not what the unit launches wait
+    // for; merged tails 1.61 -> 1.96 ms per batch of 32 (there the variant also duplicates the epilogue per unit type: 11.2k -> 14.9k
+    // instructions).  Off.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (UNIT && PMX_WINO_UNIT_XCD) {
+        const int nx = gridDim.x, ny = gridDim.y, lin = bx + nx * (by + ny * bz), nwg = nx * ny * (int)gridDim.z;
+        const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7, loc = lin >> 3;
+        const int j = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        const int yz = j / nx;
+        bx = j - yz * nx; bz = yz / ny; by = yz - bz * ny;
+        __builtin_assume(bx >= 0 && bx < 65536 && by >= 0 && by < 65536 && bz >= 0 && bz < 65536);      // (what the compiler knows of blockIdx)
+    }
+    const int unit = UNIT ? bz / a.ngroups : 0;
+    const bool g1 = (UNIT ? bz % a.ngroups : bz) != 0;
     ConvGroupArgs G;
     G.in = g1 ? a.g[1].in : a.g[0].in;
     G.w = g1 ? a.g[1].w : a.g[0].w;              // transformed weights [plane][chunk32][k8-step][cout_pad][8] (pmx_api.hip::pack_wino)
@@ -161,8 +181,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     if (UNIT) G.out += (size_t)unit * (size_t)a.slab_stride;
     const int H = a.H, W = a.W;
     int tile;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
+    if (UNIT && PMX_WINO_UNIT_XCD) {
+        tile = bx;
+    } else {                                      // (plain launches: gridDim.x is a multiple of 8 wherever it matters, XCD = blockIdx.x & 7)
+        const int nwg = gridDim.x, bid = bx;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
@@ -187,7 +209,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     const int mg_p0 = tile * PMX_WINO_RUN_TILES, mg_img0 = MERGE ? mg_p0 / mg_nt : 0, mg_tt0 = mg_p0 - mg_img0 * mg_nt;
     const int mg_n0 = min(mg_nt - mg_tt0, PMX_WINO_RUN_TILES), mg_n1 = min(mg_nt, PMX_WINO_RUN_TILES - mg_n0);
     const int mg_cb1 = 2 * mg_n0 + KS - 1, mg_cb2 = mg_cb1 + 2 * mg_n1 + KS - 1;
-    const int n0 = blockIdx.y * 128;
+    const int n0 = by * 128;
     const int n = n0 + wave * 32 + li;
     const float* in_b = G.in + (MERGE ? (size_t)0 : (size_t)bimg * H * W * a.lda);
     float bias = G.bias[n];                       // (pinned to a register further down, once the first halo loads are on their way:

@@ -3,7 +3,7 @@
 tools/_build/libpose_var_<tag>.so (the product library is untouched), and timed through the whole network with the layer profile on.
 
     python tools/kernel_variants.py build base: lead12:PMX_WINO_WLEAD1=12 lead12_6:PMX_WINO_WLEAD1=12,PMX_WINO_WLEAD2=6      (here: hipcc cross-compiles)
-    python tools/kernel_variants.py time [--steps 5] [--json out.json]                                                     (on the GPU box)
+    python tools/kernel_variants.py time [--steps 5] [--batch 32] [--json out.json]                                                (on the GPU box)
     python tools/kernel_variants.py time-conv [--iters 5] [--json out.json]            (GPU box: single layers through pmx_conv2d -- ablation builds)
 """
 import glob, importlib, json, os, subprocess, sys
@@ -50,12 +50,12 @@ def group(layer, kernel):
     return 'other'
 
 
-def time_all(steps, out_json):
+def time_all(steps, out_json, batch=32):
     res = {}
     for lib in sorted(glob.glob(os.path.join(OUT, 'libpose_var_*.so'))):
         tag = os.path.basename(lib)[len('libpose_var_'):-3]
         pj = os.path.join('/tmp', 'var_%s.json' % tag)
-        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'profile_driver.py'), '--lib', lib, '--batch', '32', '--steps', str(steps),
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'profile_driver.py'), '--lib', lib, '--batch', str(batch), '--steps', str(steps),
                             '--profile-json', pj], capture_output=True, text=True, timeout=300)
         if r.returncode:
             print(tag, 'FAILED', r.stderr[-400:]); continue
@@ -115,8 +115,8 @@ if __name__ == '__main__':
         time_conv(a.iters, a.json)
     elif len(sys.argv) > 1 and sys.argv[1] == 'time':
         import argparse
-        ap = argparse.ArgumentParser(); ap.add_argument('cmd'); ap.add_argument('--steps', type=int, default=5); ap.add_argument('--json', default=None)
+        ap = argparse.ArgumentParser(); ap.add_argument('cmd'); ap.add_argument('--steps', type=int, default=5); ap.add_argument('--json', default=None); ap.add_argument('--batch', type=int, default=32)
         a = ap.parse_args()
-        time_all(a.steps, a.json)
+        time_all(a.steps, a.json, a.batch)
     else:
         print(__doc__)
