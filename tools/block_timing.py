@@ -14,7 +14,8 @@ PKG = 'chainer_realtime_multi-person_pose_estimation_amd'
 ap = argparse.ArgumentParser()
 ap.add_argument('--ks', type=int, default=7); ap.add_argument('--cin', type=int, default=128); ap.add_argument('--cout', type=int, default=128)
 ap.add_argument('--hw', type=int, default=46); ap.add_argument('--batch', type=int, default=64); ap.add_argument('--pool', type=int, default=0)
-ap.add_argument('--json', default=None)
+ap.add_argument('--json', default=None); ap.add_argument('--raw', default=None, help='save the raw stamps (blocks x 8, 100 MHz ticks; column 7 = CU id) as .npy')
+ap.add_argument('--keep-tail', action='store_true', help='leave the wino_tail option alone (batch 1 then runs the unit-mode plan of the product)')
 a = ap.parse_args()
 native = importlib.import_module(PKG + '.native')
 out_dir = os.path.join(ROOT, 'tools', '_build')
@@ -35,7 +36,8 @@ L = native.load()
 L.pmx_debug_block_times.argtypes = [C.c_void_p, C.c_size_t]
 eng = native.Engine(0, max_batch=a.batch, max_h=max(368, a.hw), max_w=max(368, a.hw))
 eng.set_option('conv_algo', 1)
-eng.set_option('wino_tail', 0)          # one kernel for every block (the part-filled last block of an image runs in the same launch)
+if not a.keep_tail:
+    eng.set_option('wino_tail', 0)      # one kernel for every block (the part-filled last block of an image runs in the same launch)
 rng = np.random.default_rng(0)
 x = np.maximum(rng.standard_normal((a.batch, a.cin, a.hw, a.hw)), 0).astype('f')
 w = (rng.standard_normal((a.cout, a.cin, a.ks, a.ks)) / np.sqrt(a.cin * a.ks * a.ks)).astype('f')
@@ -44,6 +46,8 @@ y, ms = eng.conv2d(x, w, b, relu=True, pool=bool(a.pool), iters=3)
 t = np.zeros(8192 * 8, np.uint64)
 assert L.pmx_debug_block_times(t.ctypes.data, t.size) == 0
 t = t.reshape(8192, 8).astype(np.int64)
+if a.raw:
+    np.save(a.raw, t)
 # the stamps of the LAST launch that touched each slot: the main launch (lin < its grid) overwrites; keep blocks with a complete stamp set
 ok = (t[:, 0] > 0) & (t[:, 6] > t[:, 0]) & (t[:, 6] - t[:, 0] < 10_000_00)
 tt = t[ok]
