@@ -93,6 +93,9 @@ extern "C" int pmx_debug_block_times(unsigned long long* out, size_t n)
 // every 2nd gap: 3.3 ns each, 8 in every 8th: 2.6 ns each).  In the kernel the clustered schedule (bit-identical, 60 Winograd tests) measured
 // +0.5 % on the 7x7 layers and -1.3 % on conv4_2 in round 4 (profiles/r04_wino_ablation.json "vcluster": the cluster right behind the reads
 // waits for all twelve at once); round 5, four slots later: -1.6 % on the 7x7 layers (PMX_WINO_VCL_T1 below) -- adopted
+#ifndef PMX_WINO_VCL_GEOMS
+#define PMX_WINO_VCL_GEOMS 15       // bit g: geometry g runs the clustered transform (all four; 10 = single-slab runs + merged tails only)
+#endif
 #ifndef PMX_WINO_UNIT_XCD
 #define PMX_WINO_UNIT_XCD 0
 #endif
@@ -136,9 +139,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     static_assert(!(UNIT && POOL), "unit mode: the combine kernel pools");
     static_assert(GEOM != 3 || UNIT, "merged tails run in unit mode");
     constexpr bool MERGE = GEOM == 3;
-    // the transform's packed adds clustered into one gap per group (PMX_WINO_VCLUSTER): the run-geometry and merged-tail forms only -- on
-    // the rectangle and multi-slab forms the register allocator answers the clusters with 3.4 KB of scratch per lane
-    constexpr bool VCL = PMX_WINO_VCLUSTER && (GEOM == 1 || GEOM == 3);
+    // the transform's packed adds clustered into one gap per group (PMX_WINO_VCLUSTER), on every geometry (PMX_WINO_VCL_GEOMS).  The
+    // rectangle and multi-slab forms used to answer the clusters with 3.4 KB of scratch per lane: not register pressure but a DECLINED
+    // UNROLL -- with the clusters in it the body of the 32 x 4 slot loop crossed the unroller's size limit for `#pragma unroll`, the loop
+    // stayed a loop and every register array indexed by the slot number (accumulators, weight ring, staging) moved to scratch.  This file is
+    // therefore compiled with -mllvm -pragma-unroll-threshold=200000 (native.py::SOURCES): isa_stats.py shows 3 - 5 spilled registers on
+    // the 3x3 forms and 27 (before: 47) on the 7x7 rectangle form; measured profiles/r05_vcluster_all_geoms.json
+    constexpr bool VCL = PMX_WINO_VCLUSTER && ((PMX_WINO_VCL_GEOMS >> GEOM) & 1);
     // slot of the first cluster (the second follows eight slots later, the stores nine later still): 16 = right behind the reads
     // (round 4: +0.5 % on the kernel of that round, not adopted); 20 / 22 = four / six slots later, all twelve raw-halo reads long landed.
     // Round 5, on the kernel with the early phase barrier and the packed output transform: 7x7 layers -1.3 % (16), -1.6 % (20), -1.7 % (22)
@@ -415,10 +422,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
         const unsigned nplane_b = (LAST ? next_b : chunk_b) + (unsigned)(sub_n * 16) * freq_b;     // plane 0 of the next step
         const int src_cur = t_raw + ((3 * (sub >> 1)) * C::HW + 3 * (sub & 1)) * C::LDR;
         const int src_nxt = t_raw + ((3 * (sub_n >> 1)) * C::HW + 3 * (sub_n & 1)) * C::LDR;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        // (the two phases as two instances of a generic lambda rather than a loop: `#pragma unroll` on a body of this size is a request
+        //  the unroller may decline -- it did for the rectangle / multi-slab forms once the clustered transform was in the body, and the
+        //  register arrays indexed by r, s turned into 3 KB of scratch per lane)
+        auto phase_r = [&](auto r_c) {
+            constexpr int r = decltype(r_c)::value;
             // side work of this phase: rows (2, 3) of the current window (r = 0) / rows (0, 1) of the next one (r = 1)
-            const int q = r ^ 1;                                        // V row pair produced
+            constexpr int q = r ^ 1;                                    // V row pair produced
             const int src = (r == 0 ? src_cur : src_nxt) + q * C::HW * C::LDR;      // d rows q .. q + 2
             float* const udst = s_u + (q * 8) * 32 * C::LDU + t_u;
             f32x4 dd[3][4], wv[2][4], vv, vvs[8];
@@ -513,7 +523,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                     }
                 }
             }
-        }
+        };
+        phase_r(std::integral_constant<int, 0>{});
+        phase_r(std::integral_constant<int, 1>{});
     };
     static_assert(C::NHF <= 21, "halo slots");
     PMX_T(2);

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libpose_mi355x.so')
 HEADER = os.path.join(os.path.dirname(HERE), 'include', 'pose_mi355x.h')
-SOURCES = [('pmx_api.hip', []), ('pmx_precise.hip', []), ('conv_mfma.hip', []), ('conv_wino.hip', []), ('conv1_wino.hip', []), ('conv_select.hip', []), ('prep.hip', ['-ffp-contract=off']),
+SOURCES = [('pmx_api.hip', []), ('pmx_precise.hip', []), ('conv_mfma.hip', []), ('conv_wino.hip', ['-mllvm', '-pragma-unroll-threshold=200000']), ('conv1_wino.hip', []), ('conv_select.hip', []), ('prep.hip', ['-ffp-contract=off']),
            ('postproc.hip', ['-ffp-contract=off'])]
 HEADERS = ['pmx_common.h', 'pmx_ctx.h', 'wino_util.h', HEADER]
 

@@ -20,7 +20,7 @@ def build(specs):
     for spec in specs:
         spec, _, only = spec.partition('@')      # tag:DEF=1,DEF2=2[@file.hip+file2.hip]: the sources the flags apply to (default: the three below)
         tag, _, defs = spec.partition(':')
-        flags = ['-D' + d for d in defs.split(',') if d]
+        flags = [d if d.startswith('-') else '-D' + d for d in defs.split(',') if d]      # (an item that starts with '-' is passed as it is: -mllvm,-pragma-unroll-threshold=N)
         objs = []
         varied = tuple(only.split('+')) if only else ('conv_mfma.hip', 'conv_wino.hip', 'pmx_api.hip')
         for src, extra in native.SOURCES:
