@@ -249,3 +249,49 @@ def test_oracle_reads_the_conv1_winograd_launch_as_conv1_2():
     assert 'conv1_2' in plan.wino and plan.wino_tails == {'Mconv1_stage2': 2}
     prof[0] = {'layer': 'conv1_1+conv1_2', 'kernel': 'conv1_fused_t8x16_n64'}
     assert 'conv1_2' not in R.wino_layers(prof)
+
+
+def _kernel_metadata(lib_path, tmp_path):
+    """{demangled-ish kernel name: {'scratch': bytes per lane, 'vgpr_spill': n, 'agpr': n}} read from the AMDGPU metadata notes of every
+    gfx950 code object bundled into the library (llvm-objdump --offloading + llvm-readelf --notes: seconds, no compile)."""
+    import shutil
+    import subprocess
+    llvm = '/opt/rocm/lib/llvm/bin'
+    objdump, readelf = os.path.join(llvm, 'llvm-objdump'), os.path.join(llvm, 'llvm-readelf')
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip('llvm-objdump / llvm-readelf of the ROCm toolchain not found')
+    work = str(tmp_path / 'bundles')
+    os.makedirs(work)
+    shutil.copy(lib_path, os.path.join(work, 'lib.so'))      # (the tool writes the bundles next to its input)
+    subprocess.run([objdump, '--offloading', 'lib.so'], cwd=work, check=True, capture_output=True)
+    kernels, cur = {}, {}
+    for f in sorted(os.listdir(work)):
+        if 'gfx950' not in f:
+            continue
+        notes = subprocess.run([readelf, '--notes', f], cwd=work, check=True, capture_output=True, text=True).stdout
+        for line in notes.splitlines():
+            # kernel entries sit at the first list level ("  - .agpr_count: ..." then "    .key: value"); argument lists are nested deeper
+            if line.startswith('  - .'):
+                cur = {}
+                line = '    ' + line[4:]
+            if line.startswith('    .') and not line.startswith('     '):
+                key, _, val = line.strip().partition(':')
+                cur[key] = val.strip()
+                if key == '.wavefront_size' and cur.get('.name', '').startswith('_Z'):      # (the last key of an entry)
+                    kernels[cur['.name']] = {'scratch': int(cur['.private_segment_fixed_size']), 'vgpr_spill': int(cur.get('.vgpr_spill_count', 0)),
+                                             'agpr': int(cur.get('.agpr_count', 0))}
+    return kernels
+
+
+def test_no_kernel_of_the_library_lives_in_scratch(native, tmp_path):
+    """Guard against a DECLINED UNROLL (EXPERIMENTS E19): the Winograd kernels keep their accumulators, weight ring and staging in register
+    arrays indexed by unrolled loop counters; when the unroller declines a `#pragma unroll` (body over its size limit) those arrays move to
+    kilobytes of scratch per lane and the kernel runs at a fraction of its rate -- with bit-identical results, so no parity test notices.
+    Every kernel of the built library must stay under 256 bytes of scratch per lane (the largest today: 132, a few spilled registers)."""
+    kernels = _kernel_metadata(native.LIB_PATH, tmp_path)
+    wino = {k: v for k, v in kernels.items() if 'conv_wino_kernel' in k or 'conv1_wino_kernel' in k}
+    assert len(kernels) >= 40 and len(wino) >= 15, (len(kernels), len(wino))
+    heavy = {k: v for k, v in kernels.items() if v['scratch'] > 256}
+    assert not heavy, heavy
+    # one wave per SIMD with the whole accumulator file: every Winograd kernel holds its 16 frequency tiles in 256 AGPRs
+    assert all(v['agpr'] == 256 for v in wino.values()), {k: v['agpr'] for k, v in wino.items() if v['agpr'] != 256}
