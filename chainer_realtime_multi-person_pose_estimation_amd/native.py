@@ -94,15 +94,27 @@ def build(force=False, verbose=False):
 
 def _build_locked(verbose):
     hipcc = _hipcc()
-    objs = []
+    objs, cmds = [], []
     base = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
     for src, extra in SOURCES:
         obj = os.path.join(CSRC, src.replace('.hip', '.o'))
-        cmd = base + extra + ['-c', os.path.join(CSRC, src), '-o', obj]
+        cmds.append(base + extra + ['-c', os.path.join(CSRC, src), '-o', obj])
+        objs.append(obj)
+    # the translation units are independent: compile them side by side (conv_wino.hip alone is most of a serial build: 4.6 -> 3.7 min here)
+    from concurrent.futures import ThreadPoolExecutor
+
+    def compile_one(cmd):
         if verbose:
             print(' '.join(cmd))
-        subprocess.check_call(cmd, cwd=CSRC)
-        objs.append(obj)
+        r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError('%s failed (%d):\n%s' % (' '.join(cmd), r.returncode, (r.stdout + r.stderr)[-4000:]))
+    try:
+        jobs = max(1, min(len(cmds), len(os.sched_getaffinity(0))))
+    except (AttributeError, OSError):
+        jobs = 2
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        list(pool.map(compile_one, cmds))
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
     if verbose:
         print(' '.join(cmd))
