@@ -130,6 +130,19 @@ def self_launch(a):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def pick_device(local_rank, n_visible, world, backend, rank=0):
+    """Device index of this rank.  RCCL ("nccl"): one rank per GPU -- device LOCAL_RANK when the rank sees all GPUs of the node, device 0
+    when the launcher masks the GPUs per rank (one visible device each), otherwise there is no GPU for it.  Other backends (the gloo
+    smoke mode): ranks may share the visible GPU(s)."""
+    if backend != 'nccl':
+        return local_rank % max(1, n_visible)
+    if n_visible > local_rank:
+        return local_rank
+    if n_visible == 1 and world > 1:
+        return 0
+    raise SystemExit('bench.py: rank %d has no GPU (%d visible)' % (rank, n_visible))
+
+
 def core_limits():
     """What bounds the host cores of this process: os.cpu_count(), the affinity mask, the cgroup CPU quota (containers often
     expose all host CPUs through os.cpu_count() while the quota is far smaller)."""
@@ -260,13 +273,7 @@ def main():
     dist_mod = importlib.import_module(PKG + '.dist')
     if native.needs_build():
         native.build()          # serialised across ranks by a lock file
-    if a.backend != 'nccl':
-        local_rank = local_rank % max(1, torch.cuda.device_count())    # smoke mode: ranks may share a GPU
-    elif torch.cuda.device_count() <= local_rank:
-        if torch.cuda.device_count() == 1 and world > 1:
-            local_rank = 0           # a launcher that masks the GPUs per rank (HIP_VISIBLE_DEVICES = one device each): this rank's GPU is device 0
-        else:
-            raise SystemExit('bench.py: rank %d has no GPU (%d visible)' % (rank, torch.cuda.device_count()))
+    local_rank = pick_device(local_rank, torch.cuda.device_count(), world, a.backend, rank)
     torch.cuda.set_device(local_rank)
     use_group = world > 1 or a.force_gather
     if use_group:

@@ -35,3 +35,18 @@ def test_dominant_kernel_groups_labels_of_one_hip_kernel_and_keeps_issued_below_
     assert abs(issued / flop - 100 / 196) < 1e-12
     frac = issued / (ms * 1e-3) / 1e12 / bench.FP32_MFMA_PEAK_TFLOPS
     assert frac < 1.0 < flop / (ms * 1e-3) / 1e12 / bench.FP32_MFMA_PEAK_TFLOPS
+
+
+def test_pick_device_per_rank():
+    """RCCL: LOCAL_RANK when the rank sees the node's GPUs, device 0 under a launcher that masks one GPU per rank, a loud exit otherwise;
+    gloo smoke mode: ranks wrap around the visible GPUs."""
+    import pytest
+    assert [bench.pick_device(r, 8, 8, 'nccl') for r in range(8)] == list(range(8))
+    assert [bench.pick_device(r, 1, 8, 'nccl') for r in range(8)] == [0] * 8          # HIP_VISIBLE_DEVICES = one device per rank
+    assert bench.pick_device(0, 1, 1, 'nccl') == 0
+    with pytest.raises(SystemExit):
+        bench.pick_device(5, 4, 8, 'nccl')                                              # 4 GPUs for 8 ranks: no
+    with pytest.raises(SystemExit):
+        bench.pick_device(1, 1, 1, 'nccl')
+    assert [bench.pick_device(r, 1, 8, 'gloo') for r in range(8)] == [0] * 8
+    assert [bench.pick_device(r, 2, 4, 'gloo') for r in range(4)] == [0, 1, 0, 1]
