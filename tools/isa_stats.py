@@ -3,6 +3,8 @@
 
     python tools/isa_stats.py conv_wino.hip [-DFOO=1 ...] [--keep /tmp/x.s]
     ISA_REUSE=1 python tools/isa_stats.py conv_wino.hip --keep /tmp/x.s      (re-read an existing listing)
+The source is compiled with the per-file flags of the product build (native.py::SOURCES) + the flags given here; ISA_NO_PRODUCT_FLAGS=1 drops
+the former (e.g. to see conv_wino.hip without the raised unroll threshold).
 """
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,7 +44,11 @@ def main():
     flags = [a for a in args[1:] if a.startswith('-')]
     out = keep or '/tmp/isa_stats.s'
     if not os.environ.get('ISA_REUSE') or not os.path.exists(out):
-        extra = ['-ffp-contract=off'] if src in ('prep.hip', 'postproc.hip') else []
+        # the per-file flags of the product build (native.py::SOURCES), unless ISA_NO_PRODUCT_FLAGS=1 asks for the bare compile
+        sys.path.insert(0, ROOT)
+        import importlib
+        native = importlib.import_module('chainer_realtime_multi-person_pose_estimation_amd.native')
+        extra = [] if os.environ.get('ISA_NO_PRODUCT_FLAGS') else list(dict(native.SOURCES).get(src, []))
         subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only', '-S', '-o', out] + flags + extra +
                               [os.path.join(CSRC, src)], cwd=CSRC, stderr=subprocess.DEVNULL)
     for name, d in kernel_stats(out).items():
