@@ -715,12 +715,12 @@ def committed_census():
         return {'error': repr(e)}
 
 
-def rect_inputs(native, weights_mod, torch, dev, device_index, B, steps, square_fps, S):
+def rect_inputs(native, weights_mod, torch, dev, device_index, B, steps, square_fps, S, sizes=(('368x496', (368, 496)), ('496x368', (496, 368)))):
     """Landscape / portrait network inputs (compute_optimal_size, reference pose_detector.py:57-73, gives 368 x 496 for a 4:3 COCO
     frame): the same step at batch B on 46 x 62 / 62 x 46 feature maps -- frames/s, the rate per pixel relative to the square headline
     (1.0 = the same cost per pixel) and the dominant kernel's issued fraction of the fp32-MFMA peak."""
     out = {}
-    for name, (h, w) in (('368x496', (368, 496)), ('496x368', (496, 368))):
+    for name, (h, w) in sizes:
         eng = native.Engine(device_index, max_batch=B, max_h=h, max_w=w)
         try:
             wts = weights_mod.synthetic_weights(0)

@@ -221,11 +221,8 @@ __global__ __launch_bounds__(256, 1) void conv1_wino_kernel(const ConvArgs a)
     // (the two tiles whose items share a 16-lane LDS access are FOUR tile columns apart, not neighbours: 8 pixels x 68 floats = 32 banks,
     //  so their 128-byte runs of the raw halo no longer overlap -- neighbours, 2 pixels apart, overlapped in 24 of 32 banks: PMC 37 % of the
     //  LDS cycles were conflicts; a relabelling of which thread transforms which tile, nothing else)
-#ifndef PMX_WINO_TPERM
-#define PMX_WINO_TPERM 1
-#endif
     const int tg = tid >> 3, tc = tid & 7;
-    const int tt = PMX_WINO_TPERM ? (tg & ~7) + ((tg & 7) >> 1) + 4 * (tg & 1) : tg;
+    const int tt = (tg & ~7) + ((tg & 7) >> 1) + 4 * (tg & 1);
     int t_raw[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {

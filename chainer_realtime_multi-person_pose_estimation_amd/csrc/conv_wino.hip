@@ -57,18 +57,11 @@ extern "C" int pmx_debug_block_times(unsigned long long* out, size_t n)
 // [32 nfull, ntiles) (they lie in one tile row; nt of them, 16 <= nt <= 23) are the stream positions [b nt, (b + 1) nt), and block j owns the
 // positions [32 j, 32 j + 32): up to three images' segments, every MFMA row a real tile (46 x 46: 17 tiles per image -- one image per block
 // filled 17 of the 32 rows).  Raw halo = one tile row, the segments side by side, each with its own KS - 1 columns of overlap.
-#ifndef PMX_WINO_LDR3
-#define PMX_WINO_LDR3 48
-#endif
 // how far ahead of their MFMAs the transformed weights are requested: pass 1 in steps of 4 MFMAs (ring of 16), pass 2 in steps of 8 (ring
-// of 8).  8 / 4 = ~2000 cycles; 10 / 5, 12 / 6 and 15 / 7 measured 0.5 - 3 % slower on the 7x7 layers (tools/kernel_variants.py): the
-// weight stream is not what the matrix pipe waits for
-#ifndef PMX_WINO_WLEAD1
-#define PMX_WINO_WLEAD1 8
-#endif
-#ifndef PMX_WINO_WLEAD2
-#define PMX_WINO_WLEAD2 4
-#endif
+// of 8).  8 / 4 = ~2000 cycles; 10 / 5, 12 / 6 and 15 / 7 measured 0.5 - 3 % slower on the 7x7 layers: the weight stream is not what the
+// matrix pipe waits for
+constexpr int WLEAD1 = 8, WLEAD2 = 4;
+static_assert(WLEAD1 >= 4 && WLEAD1 <= 15 && WLEAD2 >= 4 && WLEAD2 <= 7, "weight ring lead");
 // Diagnostic builds only (tools/kernel_variants.py; the product library is built with 0): leave out parts of the phases' side work to see
 // what the matrix pipe waits for -- 1: the transform slots (LDS reads of the raw halo, B^T d B, U stores, halo staging), 2: the weight
 // loads, 4: the A-fragment LDS reads, 8: the barriers inside the phases; pass 1 only: 16: the raw-halo LDS reads of the transform, 32: its
@@ -76,39 +69,14 @@ extern "C" int pmx_debug_block_times(unsigned long long* out, size_t n)
 #ifndef PMX_ABLATE
 #define PMX_ABLATE 0
 #endif
-// the output transform two registers at a time through v_pk_add_f32 (1) or scalar (0): the same roundings; packed = 130 - 230 VALU
-// instructions less per block, 7x7 layers -0.5 %, 3x3 -0.3 % (profiles/r05_pkout_ab.json)
-#ifndef PMX_WINO_PKOUT
-#define PMX_WINO_PKOUT 1
-#endif
-#ifndef PMX_WINO_HOFF3
-#define PMX_WINO_HOFF3 0
-#endif
-#ifndef PMX_WINO_SOFF
-#define PMX_WINO_SOFF 1
-#endif
-// The transform's packed adds in ONE gap per group (1, the default since round 5) instead of two per gap (0).  tools/mfma_gap_probe.hip
-// (profiles/r04_mfma_gap_probe.json): LDS reads, buffer loads and scalar instructions between two MFMAs of the single wave on a SIMD are
-// free, but a v_pk_add_f32 is not -- a gap that holds VALU work costs ~3.2 ns of matrix-pipe time once plus ~2.2 ns per instruction (2 in
-// every 2nd gap: 3.3 ns each, 8 in every 8th: 2.6 ns each).  In the kernel the clustered schedule (bit-identical, 60 Winograd tests) measured
-// +0.5 % on the 7x7 layers and -1.3 % on conv4_2 in round 4 (profiles/r04_wino_ablation.json "vcluster": the cluster right behind the reads
-// waits for all twelve at once); round 5, four slots later: -1.6 % on the 7x7 layers (PMX_WINO_VCL_T1 below) -- adopted
-#ifndef PMX_WINO_VCL_GEOMS
-#define PMX_WINO_VCL_GEOMS 15       // bit g: geometry g runs the clustered transform (all four; 10 = single-slab runs + merged tails only)
-#endif
-#ifndef PMX_WINO_UNIT_XCD
-#define PMX_WINO_UNIT_XCD 0
-#endif
-#ifndef PMX_WINO_P2BAR
-#define PMX_WINO_P2BAR 0
-#endif
-#ifndef PMX_WINO_VCL_T1
-#define PMX_WINO_VCL_T1 20
-#endif
-#ifndef PMX_WINO_VCLUSTER
-#define PMX_WINO_VCLUSTER 1
-#endif
-static_assert(PMX_WINO_WLEAD1 >= 4 && PMX_WINO_WLEAD1 <= 15 && PMX_WINO_WLEAD2 >= 4 && PMX_WINO_WLEAD2 <= 7, "weight ring lead");
+// Schedule decisions that were A/B-measured and are now fixed (the rejected alternatives are gone from the source; EXPERIMENTS.md has the
+// numbers): the output transform two registers at a time through v_pk_add_f32 (-0.5 % on 7x7, profiles/r05_pkout_ab.json); the
+// transform's packed adds clustered in ONE gap per group of 16, first cluster in slot 20 (a gap that holds VALU work costs ~3.2 ns of
+// matrix-pipe time once plus ~2.2 ns per instruction, tools/mfma_gap_probe.hip: -1.6 % on 7x7, profiles/r05_vcluster_ab.json), on every
+// geometry (profiles/r05_vcluster_all_geoms.json); the chunk offset of a halo load in the scalar offset; halo offsets kept in registers
+// on the 7x7 forms only (3x3: +6 % on conv3_3); one barrier per pass-2 phase at its end (eight MFMAs earlier: +0.6 %,
+// profiles/r05_p2bar_ab.json); blocks of a unit-mode launch in their natural order on the XCDs (placed by weight set: no gain,
+// profiles/r05_unit_xcd_ab.json).
 template <int KS, int GEOM>
 struct WinoCfg {
     static constexpr int TH = 8, TW = 16, PADK = KS / 2, CKW = 32, LDU = CKW + 4;
@@ -117,7 +85,7 @@ struct WinoCfg {
     // enough for a pitch of 48 -> 2 pixels = 96 floats = 32 banks apart, no overlap
     // (GEOM 3, 7x7: 8 x 82 pixels only fit with a pitch of 32 -- two tiles of a transform read then share their banks: 2-way conflicts,
     //  on a launch that is 3 % of a layer)
-    static constexpr int LDR = (KS == 3 && PMX_WINO_LDR3 > 0) ? PMX_WINO_LDR3 : GEOM == 3 ? CKW : CKW + 4;
+    static constexpr int LDR = KS == 3 ? 48 : GEOM == 3 ? CKW : CKW + 4;
     static constexpr int RUN_TX = PMX_WINO_RUN_TX, RUN_W = 2 * RUN_TX;
     // GEOM 3 ("merged tails"): one tile row of up to three images side by side: 32 tiles + three times the KS - 1 columns of overlap
     static constexpr int HH = GEOM == 3 ? 2 + KS - 1 : GEOM ? 6 + KS - 1 : TH + KS - 1;
@@ -139,18 +107,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     static_assert(!(UNIT && POOL), "unit mode: the combine kernel pools");
     static_assert(GEOM != 3 || UNIT, "merged tails run in unit mode");
     constexpr bool MERGE = GEOM == 3;
-    // the transform's packed adds clustered into one gap per group (PMX_WINO_VCLUSTER), on every geometry (PMX_WINO_VCL_GEOMS).  The
-    // rectangle and multi-slab forms used to answer the clusters with 3.4 KB of scratch per lane: not register pressure but a DECLINED
-    // UNROLL -- with the clusters in it the body of the 32 x 4 slot loop crossed the unroller's size limit for `#pragma unroll`, the loop
-    // stayed a loop and every register array indexed by the slot number (accumulators, weight ring, staging) moved to scratch.  This file is
-    // therefore compiled with -mllvm -pragma-unroll-threshold=200000 (native.py::SOURCES): isa_stats.py shows 3 - 5 spilled registers on
-    // the 3x3 forms and 27 (before: 47) on the 7x7 rectangle form; measured profiles/r05_vcluster_all_geoms.json
-    constexpr bool VCL = PMX_WINO_VCLUSTER && ((PMX_WINO_VCL_GEOMS >> GEOM) & 1);
-    // slot of the first cluster (the second follows eight slots later, the stores nine later still): 16 = right behind the reads
-    // (round 4: +0.5 % on the kernel of that round, not adopted); 20 / 22 = four / six slots later, all twelve raw-halo reads long landed.
-    // Round 5, on the kernel with the early phase barrier and the packed output transform: 7x7 layers -1.3 % (16), -1.6 % (20), -1.7 % (22)
-    // against the spread schedule, tails -1 % (profiles/r05_vcluster_ab.json): adopted with the cluster in slot 20
-    constexpr int VT = PMX_WINO_VCL_T1;
+    // (the transform's packed adds sit clustered in one gap per group of 16.  The rectangle and multi-slab forms first answered the clusters
+    //  with 3.4 KB of scratch per lane: not register pressure but a DECLINED UNROLL -- with the clusters in it the body of the 32 x 4 slot
+    //  loop crossed the unroller's size limit for `#pragma unroll`, the loop stayed a loop and every register array indexed by the slot
+    //  number moved to scratch.  This file is therefore compiled with -mllvm -pragma-unroll-threshold=200000 (native.py::SOURCES);
+    //  tools/isa_stats.py shows what is left, tests/test_host.py holds the scratch ceiling)
+    // slot of the first cluster (the second follows eight slots later, the stores nine later still): all twelve raw-halo reads long landed
+    constexpr int VT = 20;
     static_assert(VT >= 16 && VT <= 22, "clustered transform: first cluster in slots 16 .. 22 (its stores end before the halo slots at 40)");
     // UNIT (single images: 36 blocks of a 46x46 7x7 layer cannot fill 256 CUs): blockIdx.z = unit * groups + group, and a block runs
     // ONE unit of the work -- unit u < nu1: pass 1 over the chunks [u g, u g + g) (g = a.kbounds); 7x7: unit nu1: row 6 (pass 2a without
@@ -161,22 +124,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     float* const s_u = s_raw + C::RAW_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
     // Which piece of the launch this workgroup computes.  Workgroups go to the 8 XCDs round-robin in their linear order (x fastest), each
-    // XCD has its own L2, and in unit mode the gridDim.x blocks that read the same weights (same (unit, group, cout block) = same (y, z); 17
-    // for a 46 x 46 map) land on all 8 XCDs: every L2 fetches all the weights of the layer (125 - 138 MB per merged-tail launch against
-    // ~38 MB of unique traffic, profiles/r05_pmc_summary.json).  PMX_WINO_UNIT_XCD=1 hands XCD k a CONTIGUOUS range of the (z, y, x)-ordered
-    // pieces instead (two or three weight sets per L2 instead of fourteen; a pure relabelling, bit-identical).  Measured (round 5,
-    // profiles/r05_unit_xcd_ab.json): single image unchanged to 0.5 % either way -- the redundant fetch is not what the unit launches wait
-    // for; merged tails 1.61 -> 1.96 ms per batch of 32 (there the variant also duplicates the epilogue per unit type: 11.2k -> 14.9k
-    // instructions).  Off.
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (UNIT && PMX_WINO_UNIT_XCD) {
-        const int nx = gridDim.x, ny = gridDim.y, lin = bx + nx * (by + ny * bz), nwg = nx * ny * (int)gridDim.z;
-        const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7, loc = lin >> 3;
-        const int j = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-        const int yz = j / nx;
-        bx = j - yz * nx; bz = yz / ny; by = yz - bz * ny;
-        __builtin_assume(bx >= 0 && bx < 65536 && by >= 0 && by < 65536 && bz >= 0 && bz < 65536);      // (what the compiler knows of blockIdx)
-    }
+    // XCD has its own L2.  (Unit mode: the gridDim.x blocks that read the same weights land on all 8 XCDs, so every L2 fetches all the
+    // weights of the layer -- 125 - 138 MB per merged-tail launch against ~38 MB unique; handing every XCD a contiguous range of pieces
+    // instead measured no gain: the redundant fetch is not what the unit launches wait for.)
+    const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     const int unit = UNIT ? bz / a.ngroups : 0;
     const bool g1 = (UNIT ? bz % a.ngroups : bz) != 0;
     ConvGroupArgs G;
@@ -188,9 +139,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     if (UNIT) G.out += (size_t)unit * (size_t)a.slab_stride;
     const int H = a.H, W = a.W;
     int tile;
-    if (UNIT && PMX_WINO_UNIT_XCD) {
-        tile = bx;
-    } else {                                      // (plain launches: gridDim.x is a multiple of 8 wherever it matters, XCD = blockIdx.x & 7)
+    {                                             // (plain launches: gridDim.x is a multiple of 8 wherever it matters, XCD = blockIdx.x & 7)
         const int nwg = gridDim.x, bid = bx;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
@@ -259,7 +208,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     // outside the map: stays out of the buffer's range whatever chunk offset is added) and kept in registers -- recomputed per use, the
     // compiler hoisted a second copy of this arithmetic (20 slots x (mul_hi, mul_lo, mad, cmp)) to right in front of the first MFMA
     // (7x7 only: on the 3x3 instantiations the kept offsets measured slower -- conv3_3 +6 % -- than the compiler's own placement)
-    constexpr bool HOFF = (GEOM != 0 && (KS == 7 || PMX_WINO_HOFF3)) || GEOM == 3;     // (merged tails: the per-slot segment arithmetic is never repeated)
+    constexpr bool HOFF = (GEOM != 0 && KS == 7) || GEOM == 3;     // (merged tails: the per-slot segment arithmetic is never repeated)
     int h_off[HOFF ? C::NHF : 1];
     auto halo_off_calc = [&](int r) -> int {
         const unsigned hp = (unsigned)(tid >> 3) + 32u * r;
@@ -285,8 +234,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
             const int off0 = HOFF ? h_off[HOFF ? r : 0] : halo_off_calc(r);
             // (the chunk's byte offset goes into the scalar offset, which the range check ignores: a pixel outside the image stays out of
             //  range, a pixel inside it stays inside its own channel row -- one VALU add less per load)
-            if (PMX_WINO_SOFF) hv[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off0, chunk * (C::CKW * 4), 0));
-            else hv[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off0 + chunk * (C::CKW * 4), 0, 0));
+            hv[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off0, chunk * (C::CKW * 4), 0));
         } else {
             hv[r] = *reinterpret_cast<const float4*>(in_b + h_goff[GEOM ? 0 : r] + chunk * C::CKW);
         }
@@ -331,11 +279,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     // weight panels are [plane][chunk32][k8-step 4][cout_pad][8]: the 64 lanes of one fragment load (32 channels x 2 halves x 16 B)
     // read 1 KB of contiguous, fully used cache lines (with the channel-major [cout_pad][32] layout each load touched 32 lines and used a
     // quarter of each, relying on the 32 KB L1 to keep them for the next three k8-steps -- it did not: weight loads cost 7.5 %)
-    // (PMX_WINO_WLAYOUT 1: [plane][chunk32][cout_pad / 32][k8-step 4][32][8] -- the k8-steps of this wave's 32 channels are 1 KB apart: a
-    //  constant on the vector offset = the load's immediate offset, no scalar add per load)
-    const unsigned b_off = PMX_WINO_WLAYOUT ? (unsigned)(((n >> 5) * 1024 + (n & 31) * 8 + kh * 4) * 4) : (unsigned)((n * 8 + kh * 4) * 4);
-    const unsigned st_b = PMX_WINO_WLAYOUT ? 0u : (unsigned)a.cout_pad * 8u * 4u;      // bytes between the k8-steps of a panel (in the scalar offset)
-    constexpr unsigned st_v = PMX_WINO_WLAYOUT ? 1024u : 0u;                               // ... (in the vector offset)
+    // ([plane][chunk32][cout_pad / 32][k8-step 4][32][8]: the k8-steps of this wave's 32 channels are 1 KB apart -- a constant on the
+    //  vector offset = the load's immediate offset, no scalar add per load)
+    const unsigned b_off = (unsigned)(((n >> 5) * 1024 + (n & 31) * 8 + kh * 4) * 4);
+    constexpr unsigned st_v = 1024u;                                       // bytes between the k8-steps of a panel (in the vector offset)
     const unsigned panel_b = (unsigned)a.cout_pad * C::CKW * 4u;          // bytes of one (plane, chunk) panel
     const unsigned freq_b = panel_b * (unsigned)nch;                       // bytes between planes (sub-kernel * 16 + frequency)
 
@@ -368,8 +315,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
         halo_load_slot(hreg, c0, r);
     }
 #pragma unroll
-    for (int st8 = 0; st8 < PMX_WINO_WLEAD1; ++st8)   // the first steps of the first phase: frequencies 0, 1, .. (x 4 k8-steps) of plane 0
-        bw[st8] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off + (unsigned)(st8 & 3) * st_v, (unsigned)c0 * panel_b + (unsigned)(st8 >> 2) * freq_b + (unsigned)(st8 & 3) * st_b, 0));
+    for (int st8 = 0; st8 < WLEAD1; ++st8)   // the first steps of the first phase: frequencies 0, 1, .. (x 4 k8-steps) of plane 0
+        bw[st8] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off + (unsigned)(st8 & 3) * st_v, (unsigned)c0 * panel_b + (unsigned)(st8 >> 2) * freq_b, 0));
     __builtin_amdgcn_sched_barrier(0);
     zero_acc();
     __builtin_amdgcn_sched_barrier(0);
@@ -431,7 +378,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
             constexpr int q = r ^ 1;                                    // V row pair produced
             const int src = (r == 0 ? src_cur : src_nxt) + q * C::HW * C::LDR;      // d rows q .. q + 2
             float* const udst = s_u + (q * 8) * 32 * C::LDU + t_u;
-            f32x4 dd[3][4], wv[2][4], vv, vvs[8];
+            f32x4 dd[3][4], wv[2][4], vvs[8];
 #pragma unroll
             for (int s = 0; s < 32; ++s) {                              // step = (frequency r * 8 + s / 4, k8-step s % 4)
                 const int f = r * 8 + (s >> 2);
@@ -439,13 +386,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                 for (int e = 0; e < 4; ++e) {
                     acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 3][e], bw[s & 15][e], acc[f], 0, 0, 0);
                     if (e == 0) {                                       // weights of step s + lead
-                        const int sn = s + PMX_WINO_WLEAD1;
+                        const int sn = s + WLEAD1;
                         unsigned so;
                         if (sn < 32) so = plane_b + (unsigned)(r * 8 + (sn >> 2)) * freq_b;
                         else if (r == 0) so = plane_b + (unsigned)(8 + ((sn - 32) >> 2)) * freq_b;
                         else so = nplane_b + (unsigned)((sn - 32) >> 2) * freq_b;
                         if (!(PMX_ABLATE & 2))
-                        bw[sn & 15] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off + (unsigned)(sn & 3) * st_v, so + (unsigned)(sn & 3) * st_b, 0));
+                        bw[sn & 15] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off + (unsigned)(sn & 3) * st_v, so, 0));
                         // THE barrier of the phase sits here, eight MFMAs before its end: U half q is complete (its last store is in slot
                         // 39; LAST, r = 0: and the new raw halo, slot 40 + NHF - 1 <= 60), every wave has read all it needs of U half r (the
                         // fragments of steps 30, 31 were requested at steps 28, 29).  The MFMAs that follow have their operands in
@@ -469,7 +416,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                         } else if (LAST && t == 14 && r == 0) {         // every wave has read what it needs of the old halo
                             if (repl) __syncthreads();
                             __builtin_amdgcn_sched_barrier(0);
-                        } else if (VCL && (t == VT || t == VT + 8)) {
+                        } else if (t == VT || t == VT + 8) {
                             // the 16 packed adds of B^T d (slot 16) / of (.) B (slot 24) in one gap each; the eight U stores follow one per slot
 #pragma unroll
                             for (int k8 = 0; k8 < 8; ++k8) {
@@ -485,30 +432,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                                 }
                             }
                             __builtin_amdgcn_sched_barrier(0);
-                        } else if (VCL && t >= VT + 9 && t < VT + 17) {
+                        } else if (t >= VT + 9 && t < VT + 17) {
                             const int k8 = t - (VT + 9), il = k8 >> 2, jv = k8 & 3;
                             if (PMX_ABLATE & 64) asm volatile("" :: "v"(vvs[k8]));
                             else *reinterpret_cast<f32x4*>(&udst[(4 * il + jv) * 32 * C::LDU]) = vvs[k8];
-                            __builtin_amdgcn_sched_barrier(0);
-                        } else if (VCL && t >= 16 && t < 40) {
-                            // (nothing: the spread schedule's slots)
-                        } else if (t >= 16 && t < 24) {                 // B^T d: q = 0: (d0 - d2, d1 + d2); q = 1: (d2 - d1, d1 - d3)
-                            const int jx = (t - 16) >> 1, wi = (t - 16) & 1;
-                            if (PMX_ABLATE & 32) asm volatile("" : "=v"(wv[wi][jx]));
-                            else if (q == 0) wv[wi][jx] = wi == 0 ? pk_sub4(dd[0][jx], dd[2][jx]) : pk_add4(dd[1][jx], dd[2][jx]);
-                            else wv[wi][jx] = wi == 0 ? pk_sub4(dd[1][jx], dd[0][jx]) : pk_sub4(dd[0][jx], dd[2][jx]);
-                            __builtin_amdgcn_sched_barrier(0);
-                        } else if (t >= 24 && t < 40) {                 // (.) B, one column per two slots: compute, store
-                            const int pidx = (t - 24) >> 1, il = pidx >> 2, jv = pidx & 3;
-                            if (((t - 24) & 1) == 0) {
-                                if (PMX_ABLATE & 32) asm volatile("" : "=v"(vv));
-                                else
-                                vv = jv == 0 ? pk_sub4(wv[il][0], wv[il][2]) : jv == 1 ? pk_add4(wv[il][1], wv[il][2]) : jv == 2 ? pk_sub4(wv[il][2], wv[il][1]) : pk_sub4(wv[il][1], wv[il][3]);
-                            } else if (PMX_ABLATE & 64) {
-                                asm volatile("" :: "v"(vv));
-                            } else {
-                                *reinterpret_cast<f32x4*>(&udst[(4 * il + jv) * 32 * C::LDU]) = vv;
-                            }
                             __builtin_amdgcn_sched_barrier(0);
                         } else if (LAST && ((t >= 40 && t < 40 + (C::NHF < 20 ? C::NHF : 20)) || (C::NHF > 20 && t == 15))) {
                             // the halo of the next chunk -> LDS (r = 0) / of the one after it -> registers: slots 40 .. 59 (before the
@@ -546,10 +473,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     }   // do_p1
 
     // ---- output transform Y = A^T M A per (tile, channel): y[2 * i + j] = pixel (i, j) of the tile
-    // (PMX_WINO_PKOUT: two registers at a time through the packed-fp32 adds -- the same roundings, half the VALU instructions)
+    // (two registers at a time through the packed-fp32 adds -- the same roundings as scalar adds, half the VALU instructions)
     f32x16 y[4];
     if (!UNIT || do_p1) {
-#if PMX_WINO_PKOUT
 #pragma unroll
         for (int rp = 0; rp < 8; ++rp) {
             f32x2 t0[4], t1[4];
@@ -565,19 +491,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
             y[0][2 * rp] = o0[0]; y[0][2 * rp + 1] = o0[1]; y[1][2 * rp] = o1[0]; y[1][2 * rp + 1] = o1[1];
             y[2][2 * rp] = o2[0]; y[2][2 * rp + 1] = o2[1]; y[3][2 * rp] = o3[0]; y[3][2 * rp + 1] = o3[1];
         }
-#else
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            float t0[4], t1[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                t0[j] = (acc[0 + j][reg] + acc[4 + j][reg]) + acc[8 + j][reg];
-                t1[j] = (acc[4 + j][reg] - acc[8 + j][reg]) - acc[12 + j][reg];
-            }
-            y[0][reg] = (t0[0] + t0[1]) + t0[2]; y[1][reg] = (t0[1] - t0[2]) - t0[3];
-            y[2][reg] = (t1[0] + t1[1]) + t1[2]; y[3][reg] = (t1[1] - t1[2]) - t1[3];
-        }
-#endif
     } else {
         // a unit block without pass 1 (row 6 / column 6 / tap (6, 6)): the transform of all-zero accumulators is +0 -- no accumulator
         // is zeroed or read for it
@@ -597,9 +510,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
         // H1 phases (16 steps x 8 MFMAs; during H0 sub-kernel 1 is transformed, during H1 the raw halo of the next chunk replaces this
         // one); then y += A^T-transform of the row planes.  Pass 2b per chunk: V0, V1 phases; then y += transform of the column planes.
         constexpr int PH = 64, PV = 72, PD = 80;
-        constexpr bool P2E = PMX_WINO_P2BAR != 0;
-        using early_t = std::true_type;
-        using late_t = std::false_type;
         constexpr int HBAR = C::NHF > 20 ? C::NHF : 20;      // H1 / V1: the slot of the barrier behind the halo stores (slots 0 .. NHF - 1)
         f32x16 e8[8];
         f32x4 bwr[8], bd[4], av[4];
@@ -610,7 +520,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                 for (int r16 = 0; r16 < 16; ++r16) e8[pl][r16] = 0.f;
         };
         auto wload = [&](int plane, unsigned chb, int st) -> f32x4 {
-            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off + (unsigned)st * st_v, chb + (unsigned)plane * freq_b + (unsigned)st * st_b, 0));
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off + (unsigned)st * st_v, chb + (unsigned)plane * freq_b, 0));
         };
         // 1-D transform of this thread's (tile, 4 channels): two lines (output rows i for the row class, output columns j for the
         // column class) of 4 samples each -> (d0 - d2, d1 + d2, d2 - d1, d1 - d3), slot by slot
@@ -620,16 +530,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                 const int l = (t - 2) >> 2, c = (t - 2) & 3;
                 dd[l][c] = *reinterpret_cast<const f32x4*>(&s_raw[base + l * line_stride + c * samp_stride]);
                 __builtin_amdgcn_sched_barrier(0);
-            } else if (VCL && t == 12) {                 // the 16 packed adds in one gap
+            } else if (t == 12) {                        // the 16 packed adds in one gap
 #pragma unroll
                 for (int k8 = 0; k8 < 8; ++k8) {
                     const int l = k8 >> 2, f = k8 & 3;
                     vv[l][f] = f == 0 ? pk_sub4(dd[l][0], dd[l][2]) : f == 1 ? pk_add4(dd[l][1], dd[l][2]) : f == 2 ? pk_sub4(dd[l][2], dd[l][1]) : pk_sub4(dd[l][1], dd[l][3]);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-            } else if (!VCL && t >= 12 && t < 20) {
-                const int l = (t - 12) >> 2, f = (t - 12) & 3;
-                vv[l][f] = f == 0 ? pk_sub4(dd[l][0], dd[l][2]) : f == 1 ? pk_add4(dd[l][1], dd[l][2]) : f == 2 ? pk_sub4(dd[l][2], dd[l][1]) : pk_sub4(dd[l][1], dd[l][3]);
                 __builtin_amdgcn_sched_barrier(0);
             } else if (t >= 20 && t < 28) {
                 const int l = (t - 20) >> 2, f = (t - 20) & 3;
@@ -639,16 +545,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
         };
         // one 8-plane phase: 16 steps s = f * 4 + st, per step the two lines l = 0, 1 x 4 MFMAs; A fragments one step ahead, weights
         // four steps ahead (ring of 8; `wnext(s)` loads step s of whatever phase follows), side slots m = 2, 3, 6, 7 of every step
-        // PMX_WINO_P2BAR: like pass 1, the barrier that ends a phase sits eight MFMAs (= one step) before the phase's end -- every A
-        // fragment of the phase has been read by then (the barrier's lgkmcnt(0)), the side stores ended in slot 50 at the latest --
-        // and the first two A fragments of the phase that follows (`ubn`) are requested behind it, so the callers enter a phase
-        // with av[0], av[1] in flight instead of waiting for a barrier and an LDS read
-        auto phase8 = [&](const float* ub, int wplane, unsigned chb, auto&& wnext, auto&& side, auto early_c, const float* ubn) {
-            constexpr bool EARLY = P2E && decltype(early_c)::value;
-            if (!P2E) {
-                av[0] = *reinterpret_cast<const f32x4*>(&ub[a_off]);
-                av[1] = *reinterpret_cast<const f32x4*>(&ub[4 * 32 * C::LDU + a_off]);
-            }
+        auto phase8 = [&](const float* ub, int wplane, unsigned chb, auto&& wnext, auto&& side) {
+            av[0] = *reinterpret_cast<const f32x4*>(&ub[a_off]);
+            av[1] = *reinterpret_cast<const f32x4*>(&ub[4 * 32 * C::LDU + a_off]);
 #pragma unroll
             for (int s2 = 0; s2 < 16; ++s2) {
                 const int f = s2 >> 2, st = s2 & 3;
@@ -656,13 +555,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                 for (int m = 0; m < 8; ++m) {
                     const int l = m >> 2, e = m & 3;
                     e8[l * 4 + f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(s2 & 1) * 2 + l][e], bwr[s2 & 7][e], e8[l * 4 + f], 0, 0, 0);
-                    if (EARLY && s2 == 15 && m == 0) { __syncthreads(); __builtin_amdgcn_sched_barrier(0); }
-                    if (EARLY && s2 == 15 && (m == 1 || m == 5)) {
-                        av[m == 1 ? 0 : 1] = *reinterpret_cast<const f32x4*>(&ubn[(m == 1 ? 0 : 4) * 32 * C::LDU + a_off]);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
                     if (m == 0) {
-                        constexpr int L2 = PMX_WINO_WLEAD2;
+                        constexpr int L2 = WLEAD2;
                         if (PMX_ABLATE & 2) {}
                         else if (s2 + L2 < 16) bwr[(s2 + L2) & 7] = wload(wplane + ((s2 + L2) >> 2), chb, (s2 + L2) & 3);
                         else wnext(s2 + L2 - 16);
@@ -714,13 +608,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                     for (int e = 0; e < 4; ++e) {
                         if (!UNIT) y[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[q & 3][e], bd[st][e], y[pp], 0, 0, 0);
                         if (e == 0) {
-                            if (q < PMX_WINO_WLEAD2) { bwr[q] = wload(PH + (q >> 2), chb, q & 3); __builtin_amdgcn_sched_barrier(0); }
-                            if (P2E && q == 14) { __syncthreads(); __builtin_amdgcn_sched_barrier(0); }     // U half 0 = row-6 sub-kernel 0 (stores: slots 20..27)
+                            if (q < WLEAD2) { bwr[q] = wload(PH + (q >> 2), chb, q & 3); __builtin_amdgcn_sched_barrier(0); }
                         } else if (e == 1) {
-                            if (P2E && q >= 14) {
-                                av[q - 14] = *reinterpret_cast<const f32x4*>(&s_u[(q - 14) * 4 * 32 * C::LDU + a_off]);
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
                             if (q + 2 < 16) {
                                 const int qn = q + 2, pn = qn & 3, sn = qn >> 2;
                                 ad[qn & 3] = *reinterpret_cast<const f32x4*>(&s_raw[a2_off + ((6 + (pn >> 1)) * C::HW + 6 + (pn & 1)) * C::LDR + sn * 8]);
@@ -732,7 +621,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                     }
                 }
             }
-            if (!P2E) __syncthreads();              // U half 0 = row-6 sub-kernel 0
+            __syncthreads();                        // U half 0 = row-6 sub-kernel 0
             // The raw halo is replaced without ever stopping the matrix pipe and without the staging registers meeting the transform's:
             // ---- H0: side = sub-kernel 1 (kx 3..5) -> U half 1 (the last reads of this chunk's raw halo, slots 2..27); then the halo of the
             // next chunk (chunk 0 again after the last one: pass 2b starts from it) global -> registers, one load per slot from slot 28
@@ -743,8 +632,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                    [&](int t) {
                        if (t >= 28 && t < 28 + C::NHF) { halo_load_slot(hreg, cnx, t - 28); __builtin_amdgcn_sched_barrier(0); }
                        else side1d(t, t_raw + (6 * C::HW + 3) * C::LDR, C::HW * C::LDR, C::LDR, u1);
-                   }, early_t{}, s_u + 8 * 32 * C::LDU);
-            if (!P2E) __syncthreads();              // U half 1 = row-6 sub-kernel 1; nobody reads the old raw halo any more
+                   });
+            __syncthreads();                        // U half 1 = row-6 sub-kernel 1; nobody reads the old raw halo any more
             // ---- H1: side = registers -> LDS, one ds_write_b128 per slot from slot 0 on, a barrier (slot 20), then column-6 sub-kernel 0
             // of the new chunk -> U half 0 (free: H1 reads half 1; needed after the last chunk, otherwise unused and overwritten by the
             // next D phase -- unconditional, because a branch per slot would cut the schedule into pieces); afterwards the next chunk's
@@ -758,7 +647,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                        if (t < C::NHF) { halo_store_slot(hreg, t); __builtin_amdgcn_sched_barrier(0); }
                        else if (t == HBAR) { __syncthreads(); __builtin_amdgcn_sched_barrier(0); }
                        else if (t >= HBAR + 2) side1d(t - HBAR, t_raw + (0 * C::HW + 6) * C::LDR, C::LDR, C::HW * C::LDR, u0);
-                   }, late_t{}, nullptr);
+                   });
         }
         __syncthreads();                            // U half 0 = column-6 sub-kernel 0 of chunk 0
         // y += A^T-transform of the row planes: e8[i * 4 + f]
@@ -782,7 +671,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
             }
             halo_load(hreg, 0);
 #pragma unroll
-            for (int s2n = 0; s2n < PMX_WINO_WLEAD2; ++s2n) bwr[s2n] = wload(PV + (s2n >> 2), 0u, s2n & 3);
+            for (int s2n = 0; s2n < WLEAD2; ++s2n) bwr[s2n] = wload(PV + (s2n >> 2), 0u, s2n & 3);
             halo_store(hreg);
             __syncthreads();
             if (nch > 1) {
@@ -807,8 +696,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                    [&](int t) {
                        if (MORE && t >= 28 && t < 28 + C::NHF) { halo_load_slot(hreg, ch + 1, t - 28); __builtin_amdgcn_sched_barrier(0); }
                        else side1d(t, t_raw + (3 * C::HW + 6) * C::LDR, C::LDR, C::HW * C::LDR, u1);
-                   }, early_t{}, s_u + 8 * 32 * C::LDU);
-            if (!P2E) __syncthreads();
+                   });
+            __syncthreads();
             // ---- V1: side = registers -> LDS (slots 0 ..), barrier (slot 20), the next chunk's sub-kernel 0 -> U half 0
             if constexpr (MORE)
                 phase8(s_u + 8 * 32 * C::LDU, PV + 4, chb,
@@ -817,18 +706,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
                            if (t < C::NHF) { halo_store_slot(hreg, t); __builtin_amdgcn_sched_barrier(0); }
                            else if (t == HBAR) { __syncthreads(); __builtin_amdgcn_sched_barrier(0); }
                            else if (t >= HBAR + 2) side1d(t - HBAR, t_raw + (0 * C::HW + 6) * C::LDR, C::LDR, C::HW * C::LDR, u0);
-                       }, early_t{}, s_u);
+                       });
             else
                 phase8(s_u + 8 * 32 * C::LDU, PV + 4, chb,
                        [&](int s2n) { bwr[(s2n + 16) & 7] = wload(PV + 0 + (s2n >> 2), nxb, s2n & 3); },
-                       [&](int) {}, late_t{}, nullptr);
-            if (!P2E || !MORE) __syncthreads();
+                       [&](int) {});
+            __syncthreads();
         };
         static_assert(HBAR + 28 <= 60 && 28 + C::NHF <= 60, "halo slots");
-        if (P2E) {                                  // the first V0's A fragments (later ones are requested inside the V1 before them)
-            av[0] = *reinterpret_cast<const f32x4*>(&s_u[a_off]);
-            av[1] = *reinterpret_cast<const f32x4*>(&s_u[4 * 32 * C::LDU + a_off]);
-        }
         for (int ch = 0; ch < nch - 1; ++ch) p2b_chunk(std::true_type{}, ch);
         p2b_chunk(std::false_type{}, nch - 1);
         // y += A^T-transform of the column planes: e8[j * 4 + f]

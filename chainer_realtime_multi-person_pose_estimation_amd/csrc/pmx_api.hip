@@ -135,10 +135,8 @@ static void pack_wino(const std::vector<float>& wp, int ks, int nch16, int cout_
         return wp[(((size_t)(ky * ks + kx) * nch16 + ci / CK) * cout_pad + n) * CK + ci % CK];
     };
     auto put = [&](int plane, int n, int ci, double v) {
-        if (PMX_WINO_WLAYOUT)      // [plane][chunk32][cout_pad / 32][k8-step][32][8]
-            out[(((((size_t)plane * nch32 + ci / 32) * (cout_pad / 32) + n / 32) * 4 + (ci % 32) / 8) * 32 + n % 32) * 8 + ci % 8] = (float)v;
-        else                       // [plane][chunk32][k8-step][cout_pad][8]
-            out[((((size_t)plane * nch32 + ci / 32) * 4 + (ci % 32) / 8) * cout_pad + n) * 8 + ci % 8] = (float)v;
+        // [plane][chunk32][cout_pad / 32][k8-step][32][8]: the four k8-steps of a wave's 32 channels are 1 KB apart (an immediate offset of the load)
+        out[(((((size_t)plane * nch32 + ci / 32) * (cout_pad / 32) + n / 32) * 4 + (ci % 32) / 8) * 32 + n % 32) * 8 + ci % 8] = (float)v;
     };
     for (int n = 0; n < cout_pad; ++n)
         for (int ci = 0; ci < cin_pad; ++ci) {
@@ -468,8 +466,13 @@ extern "C" int pmx_set_option(pmx_ctx* c, const char* key, int value)
     else if (!strcmp(key, "fuse_conv1")) c->opt_fuse_conv1 = value;
     else if (!strcmp(key, "conv1_wino")) c->opt_conv1_wino = value;
     else if (!strcmp(key, "precise_lanes")) c->opt_precise_lanes = value < 1 ? 1 : (value > PMX_PR_LANES ? PMX_PR_LANES : value);
+    else if (!strcmp(key, "precise_table_cap")) c->opt_precise_table_cap = value < 1 ? 1 : value;
     else if (!strcmp(key, "cubic_rows")) prep_set_cubic_rows(value);      // (process-wide, like the other kernel-form switches of prep / post-process)
-    else if (!strcmp(key, "precision")) c->opt_precision = value;
+    else if (!strcmp(key, "precision")) {
+        PMX_CHECK(value == 0 || conv_bf16x3_launch != nullptr, PMX_ERR_INVALID,
+                  "pmx_set_option: \"precision\" = %d needs the opt-in bf16x3 kernels, which this build does not carry (rebuild with PMX_BUILD_BF16X3=1)", value);
+        c->opt_precision = value;
+    }
     else if (!strcmp(key, "conv_algo")) c->opt_conv_algo = value;
     else if (!strcmp(key, "wino_min_fill")) c->opt_wino_min_fill = value;
     else if (!strcmp(key, "wino_unit_eff")) c->opt_wino_unit_eff = value;

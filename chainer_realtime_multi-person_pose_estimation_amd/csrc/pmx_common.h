@@ -82,12 +82,8 @@ struct ConvArgs {
     int run_j0, run_nb;
     int run_nslab;           // slabs of 46 columns per image (W / 46)
 };
-// Transformed Winograd weights (pmx_api.hip::pack_wino -> conv_wino_kernel): 1 = [plane][chunk32][cout_pad / 32][k8-step 4][32][8] -- the four
-// k8-steps of a wave's 32 channels are 1 KB apart, an immediate offset of the load; 0 = [plane][chunk32][k8-step 4][cout_pad][8] (a scalar
-// add per load)
-#ifndef PMX_WINO_WLAYOUT
-#define PMX_WINO_WLAYOUT 1
-#endif
+// Transformed Winograd weights (pmx_api.hip::pack_wino -> conv_wino_kernel): [plane][chunk32][cout_pad / 32][k8-step 4][32][8] -- the four
+// k8-steps of a wave's 32 channels are 1 KB apart, an immediate offset of the load
 // Winograd run geometry: tile columns of a 46-pixel-wide map / tiles per block
 #define PMX_WINO_RUN_TX 23
 #define PMX_WINO_RUN_TILES 32
@@ -193,6 +189,9 @@ int conv_num_variants();
 int conv_launch(int variant, const ConvArgs& a, int groups, hipStream_t stream);
 void conv_set_min_lds(int bytes);
 void conv_set_v5_lds(int bytes);        // LDS floor of the v5 / v8 kernels (caps the blocks per CU; tuning)
+int conv_v5_lds();
+// conv_bf16x3.hip (opt-in: built only with PMX_BUILD_BF16X3=1; a weak reference, null in the default library)
+int conv_bf16x3_launch(int ks, int mt, int pool, const ConvArgs& a, int groups, hipStream_t stream) __attribute__((weak));
 int conv_bf16x3_twin(int variant);      // the bf16x3 kernel with the geometry of a v6 variant, or -1
 void conv_set_num_cus(int n);     // compute units of the device the contexts run on (tile / kernel selection heuristics)
 int conv_num_cus();

@@ -38,19 +38,16 @@ static void make_cubic_table(int dst, int src, int* idx, float* coef)
 
 // Device copy of the cubic table of ONE axis for (src -> dst): [4 dst indices | 4 dst coefficients (float32, or 11-bit fixed point when
 // `fixed`)].  Tables are a pure function of (src, dst, fixed) and detect_precise asks for the same dozen on every call (4 scales x 3 resizes x
-// 2 axes), so they are built once and kept for the life of the context: no stream synchronisation and no blocking copy per scale (round 4
-// rebuilt and re-uploaded them three times per scale behind a hipStreamSynchronize each).  A fresh table is a fresh allocation, so nothing
-// in flight can be reading the memory it is copied to.
+// 2 axes), so they are built once and kept: no stream synchronisation and no blocking copy per scale (round 4 rebuilt and re-uploaded
+// them three times per scale behind a hipStreamSynchronize each).  A fresh table is a fresh allocation, so nothing in flight can be
+// reading the memory it is copied to.  NOTHING is ever freed here: a scale takes six tables and keeps their raw pointers for launches it
+// enqueues afterwards, on a lane whose stream this function does not see -- the cache is trimmed only between sequences
+// (cubic_tables_trim, called by pmx_precise_begin_batch behind a device synchronisation).
 static int cubic_table(pmx_ctx* c, int src, int dst, bool fixed, const int** idx, const void** coef)
 {
     const auto key = std::make_tuple(src, dst, fixed ? 1 : 0);
     auto it = c->pr_tabs.find(key);
     if (it == c->pr_tabs.end()) {
-        if (c->pr_tabs.size() >= 256) {                       // (a context fed ever new sizes: start over rather than grow without bound)
-            PMX_HIP(hipStreamSynchronize(c->stream));
-            for (auto& kv : c->pr_tabs) (void)hipFree(kv.second);
-            c->pr_tabs.clear();
-        }
         const size_t n = (size_t)4 * dst;
         std::vector<int> hi(2 * n);
         std::vector<float> hc(n);
@@ -74,6 +71,20 @@ static int cubic_table(pmx_ctx* c, int src, int dst, bool fixed, const int** idx
     }
     *idx = it->second;
     *coef = (const void*)(it->second + (size_t)4 * dst);
+    return PMX_OK;
+}
+
+// A context fed ever new image sizes (detect_precise over a data set: ~22 tables per distinct size) starts its cache over rather than grow
+// without bound -- at the START of a sequence only, and only after every lane has drained: no launch of an earlier sequence can still
+// be reading a table, and the new sequence has not taken a pointer yet.  `cap` = option "precise_table_cap" (entries; one sequence of 8
+// scales adds at most 48).
+static int cubic_tables_trim(pmx_ctx* c)
+{
+    if ((int)c->pr_tabs.size() < c->opt_precise_table_cap) return PMX_OK;
+    PMX_HIP(hipDeviceSynchronize());
+    for (auto& kv : c->pr_tabs) (void)hipFree(kv.second);
+    c->pr_tabs.clear();
+    c->pr_tabs_trims += 1;
     return PMX_OK;
 }
 
@@ -128,6 +139,7 @@ extern "C" int pmx_precise_begin_batch(pmx_ctx* c, int n_images, int orig_h, int
     PMX_CHECK(n_images >= 1 && n_images <= c->max_batch, PMX_ERR_CAPACITY, "pmx_precise_begin: %d images outside 1..%d (the context's batch capacity)",
               n_images, c->max_batch);
     PMX_DEV(c);
+    if (int rc = cubic_tables_trim(c)) return rc;
     const size_t need = (size_t)n_images * orig_h * orig_w;
     if (need > c->ext_cap) {
         PMX_HIP(hipStreamSynchronize(c->stream));
@@ -147,6 +159,13 @@ extern "C" int pmx_precise_begin_batch(pmx_ctx* c, int n_images, int orig_h, int
     }
     c->pr_h = orig_h; c->pr_w = orig_w; c->pr_scales = 0; c->pr_n = n_images; c->pr_src = nullptr;
     c->maps_valid = false;
+    return PMX_OK;
+}
+extern "C" int pmx_precise_table_stats(pmx_ctx* c, int* cached, int* trims)
+{
+    PMX_CHECK(c, PMX_ERR_INVALID, "null arg");
+    if (cached) *cached = (int)c->pr_tabs.size();
+    if (trims) *trims = c->pr_tabs_trims;
     return PMX_OK;
 }
 extern "C" int pmx_precise_begin(pmx_ctx* c, int orig_h, int orig_w) { return pmx_precise_begin_batch(c, 1, orig_h, orig_w); }

@@ -17,7 +17,12 @@ LIB_PATH = os.path.join(CSRC, 'libpose_mi355x.so')
 HEADER = os.path.join(os.path.dirname(HERE), 'include', 'pose_mi355x.h')
 SOURCES = [('pmx_api.hip', []), ('pmx_precise.hip', []), ('conv_mfma.hip', []), ('conv_wino.hip', ['-mllvm', '-pragma-unroll-threshold=200000']), ('conv1_wino.hip', []), ('conv_select.hip', []), ('prep.hip', ['-ffp-contract=off']),
            ('postproc.hip', ['-ffp-contract=off'])]
-HEADERS = ['pmx_common.h', 'pmx_ctx.h', 'wino_util.h', HEADER]
+# the opt-in bf16x3 kernels (option "precision" = 1; DESIGN.md 4.1.5: frozen, slower than the fp32 Winograd path) are NOT part of the
+# default library: PMX_BUILD_BF16X3=1 in the environment of the build adds their translation unit (the stamp then differs, so the
+# library is rebuilt when the variable changes)
+if os.environ.get('PMX_BUILD_BF16X3', '') not in ('', '0'):
+    SOURCES.append(('conv_bf16x3.hip', []))
+HEADERS = ['pmx_common.h', 'pmx_ctx.h', 'wino_util.h', 'conv_direct.h', HEADER]
 
 N_JOINTS, N_LIMBS, N_PAF, N_HEAT = 18, 19, 38, 19
 # initial capacities of a context (PMX_INIT_* in the header); they grow on demand, results are never truncated
@@ -53,13 +58,43 @@ def _hipcc():
 STAMP_PATH = os.path.join(CSRC, '.build_stamp')
 
 
+BASE_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+_hipcc_version_cache = {}
+
+
+def hipcc_version():
+    """First lines of `hipcc --version` (part of the build stamp: another compiler = another library)."""
+    hipcc = _hipcc()
+    if hipcc not in _hipcc_version_cache:
+        try:
+            out = subprocess.run([hipcc, '--version'], capture_output=True, text=True, timeout=120).stdout
+        except (OSError, subprocess.SubprocessError):
+            out = ''
+        _hipcc_version_cache[hipcc] = '\n'.join(l for l in out.splitlines() if 'version' in l.lower())
+    return _hipcc_version_cache[hipcc]
+
+
 def source_digest():
-    """sha256 over every source / header the library is built from and the compile flags: what the .so on disk must have been built from."""
+    """sha256 over every source / header the library is built from, the compile flags (base + per file) and the compiler version:
+    what the .so on disk must have been built from."""
     import hashlib
     h = hashlib.sha256()
+    h.update((' '.join(BASE_FLAGS) + '\n' + hipcc_version() + '\n').encode())
     for src, extra in SOURCES:
         h.update(('%s %s\n' % (src, ' '.join(extra))).encode())
         h.update(open(os.path.join(CSRC, src), 'rb').read())
+    for hd in HEADERS:
+        h.update(open(hd if os.path.isabs(hd) else os.path.join(CSRC, hd), 'rb').read())
+    return h.hexdigest()
+
+
+def object_digest(src, extra):
+    """sha256 over what ONE object file is compiled from: its source, every header, its flags, the compiler.  build() keeps it next to the
+    object (csrc/.<name>.o.stamp) and compiles only the translation units whose digest changed (conv_wino.hip alone is three minutes)."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update((' '.join(BASE_FLAGS + list(extra)) + '\n' + hipcc_version() + '\n').encode())
+    h.update(open(os.path.join(CSRC, src), 'rb').read())
     for hd in HEADERS:
         h.update(open(hd if os.path.isabs(hd) else os.path.join(CSRC, hd), 'rb').read())
     return h.hexdigest()
@@ -95,11 +130,25 @@ def build(force=False, verbose=False):
 def _build_locked(verbose):
     hipcc = _hipcc()
     objs, cmds = [], []
-    base = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+    # the stamp records what the compiler was GIVEN: digest taken before the (minutes-long) compile, written after a successful link -- a
+    # source edited meanwhile leaves a stamp that does not match the tree, i.e. needs_build() stays true
+    digest = source_digest()
+    base = [hipcc] + BASE_FLAGS
+    stamps = []
     for src, extra in SOURCES:
         obj = os.path.join(CSRC, src.replace('.hip', '.o'))
-        cmds.append(base + extra + ['-c', os.path.join(CSRC, src), '-o', obj])
         objs.append(obj)
+        stamp, dg = os.path.join(CSRC, '.' + os.path.basename(obj) + '.stamp'), object_digest(src, extra)
+        try:
+            fresh = os.path.exists(obj) and open(stamp).read().strip() == dg
+        except OSError:
+            fresh = False
+        if fresh and not os.environ.get('PMX_BUILD_ALL'):
+            continue
+        if os.path.exists(stamp):
+            os.remove(stamp)
+        cmds.append(base + extra + ['-c', os.path.join(CSRC, src), '-o', obj])
+        stamps.append((stamp, dg))
     # the translation units are independent: compile them side by side (conv_wino.hip alone is most of a serial build: 4.6 -> 3.7 min here)
     from concurrent.futures import ThreadPoolExecutor
 
@@ -110,17 +159,20 @@ def _build_locked(verbose):
         if r.returncode:
             raise RuntimeError('%s failed (%d):\n%s' % (' '.join(cmd), r.returncode, (r.stdout + r.stderr)[-4000:]))
     try:
-        jobs = max(1, min(len(cmds), len(os.sched_getaffinity(0))))
+        jobs = max(1, min(max(1, len(cmds)), len(os.sched_getaffinity(0))))
     except (AttributeError, OSError):
         jobs = 2
     with ThreadPoolExecutor(max_workers=jobs) as pool:
         list(pool.map(compile_one, cmds))
+    for stamp, dg in stamps:
+        with open(stamp, 'w') as f:
+            f.write(dg + '\n')
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
     with open(STAMP_PATH, 'w') as f:
-        f.write(source_digest() + '\n')
+        f.write(digest + '\n')
     return LIB_PATH
 
 
@@ -132,6 +184,15 @@ def header_symbols():
 
 
 _lib = None
+
+
+def has_bf16x3():
+    """Does the loaded library carry the opt-in bf16x3 kernels (conv_bf16x3.hip, built only with PMX_BUILD_BF16X3=1)?"""
+    try:
+        C.c_void_p.in_dll(load(), 'conv_bf16x3_probe')
+        return True
+    except ValueError:
+        return False
 
 
 def load():
@@ -159,6 +220,7 @@ def load():
         'pmx_precise_finish': (ci, [vp]),
         'pmx_precise_begin_batch': (ci, [vp, ci, ci, ci]),
         'pmx_precise_add_scale_batch': (ci, [vp, vp, ci, ci]),
+        'pmx_precise_table_stats': (ci, [vp, ip, ip]),
         'pmx_destroy': (None, [vp]),
         'pmx_set_stream': (ci, [vp, vp]),
         'pmx_synchronize': (ci, [vp]),
@@ -376,12 +438,27 @@ class Engine(object):
         self._check(self.lib.pmx_precise_begin_batch(self._ctx, int(n_images), int(orig_h), int(orig_w)))
         self._precise_hw = (int(orig_h), int(orig_w))
         self._precise_n = int(n_images)
+        # host buffers handed to add_scale: the C ABI wants them alive and unchanged until a synchronising call and recognises "the same
+        # images" by their address -- so the engine keeps the contiguous copy it made of the caller's array for the whole sequence
+        # (released by the next precise_begin) and hands the SAME copy to every add_scale that gets the same caller object
+        self._precise_src_obj = None
+        self._precise_src_arr = None
 
     def precise_add_scale(self, img_u8, scaled_h, scaled_w):
         """img_u8: (H, W, 3) for a batch of one, (n, H, W, 3) for the n images precise_begin announced."""
-        img = np.ascontiguousarray(img_u8, dtype=np.uint8)
+        if self._precise_src_obj is img_u8 and self._precise_src_arr is not None:
+            img = self._precise_src_arr
+        else:
+            img = np.ascontiguousarray(img_u8, dtype=np.uint8)
+            self._precise_src_obj, self._precise_src_arr = img_u8, img
         assert img.shape[-3:-1] == self._precise_hw and img.size == self._precise_n * self._precise_hw[0] * self._precise_hw[1] * 3, img.shape
         self._check(self.lib.pmx_precise_add_scale_batch(self._ctx, _ptr(img), int(scaled_h), int(scaled_w)))
+
+    def precise_table_stats(self):
+        """(cached cubic tables, times the cache was started over) -- include/pose_mi355x.h::pmx_precise_table_stats."""
+        n, t = C.c_int(0), C.c_int(0)
+        self._check(self.lib.pmx_precise_table_stats(self._ctx, C.byref(n), C.byref(t)))
+        return n.value, t.value
 
     def precise_finish(self):
         self._check(self.lib.pmx_precise_finish(self._ctx))

@@ -58,8 +58,9 @@ class PoseDetector(object):
         self._weights = w
         self._gpu_branch_peaks = bool(gpu_branch_peaks)
         if precision not in ('f32', 'bf16x3'):
-            raise ValueError("precision must be 'f32' (default: the fp32 FMA chain the parity tests specify) or 'bf16x3' (large batches: "
-                             "3x3 / 7x7 layers on the bf16 matrix cores with three-term splits, fp32-grade accuracy, ~1.7x the throughput)")
+            raise ValueError("precision must be 'f32' (default: the fp32 arithmetic the parity tests specify) or 'bf16x3' (opt-in, frozen: "
+                             "3x3 / 7x7 layers on the bf16 matrix cores with three-term splits, fp32-grade accuracy, SLOWER than the fp32 "
+                             "Winograd path since round 5; needs a library built with PMX_BUILD_BF16X3=1)")
         self._precision = precision
         self.engine = None
         self._make_engine(max_batch, mh, mw)

@@ -128,6 +128,7 @@ int pmx_synchronize(pmx_ctx* ctx);                    /* cuda.get_device_from_id
  *   "fuse_conv1" 1 | 0         conv1_1 recomputed on conv1_2's halo tiles, one launch instead of two (default 1); identical bits
  *   "precise_lanes" 1..4       detect_precise: inference scales in flight at once, each on its own stream and working set (default 4;
  *                              1: one after the other on the context's stream); same bits
+ *   "precise_table_cap" n      detect_precise: cached cubic tables at which the next pmx_precise_begin* starts the cache over (default 208)
  *   "cubic_rows" 1 | 0         detect_precise's float32 cubic resizes: separable through LDS (default) | one thread per element; same bits
  *   "conv1_wino" 1 | 0 | 2     that launch with conv1_2 as Winograd F(2x2, 3x3) on 16 x 16 squares (default 1: where "conv_algo" >= 1
  *                              and the launch has a block per CU; 2: whatever the launch size); 0: the direct 8 x 16 tiles everywhere
@@ -197,6 +198,10 @@ int pmx_precise_finish(pmx_ctx* ctx);
  * kernel-choice-by-launch-size rounding of the network. */
 int pmx_precise_begin_batch(pmx_ctx* ctx, int n_images, int orig_h, int orig_w);      /* (at most 8 scales per sequence) */
 int pmx_precise_add_scale_batch(pmx_ctx* ctx, const uint8_t* bgr_nhwc, int scaled_h, int scaled_w);
+/* the per-axis cubic tables a context caches (~22 per distinct original size) and how often the cache was started over.  That happens
+ * only inside pmx_precise_begin*, behind a device synchronisation, once `cached` has reached option "precise_table_cap" (default 208):
+ * never while a sequence holds table pointers. */
+int pmx_precise_table_stats(pmx_ctx* ctx, int* cached, int* trims);
 
 /* FaceDetector / HandDetector post-process (face_detector.py:37-38,58-68; hand_detector.py:41,68-78) for facenet / handnet
  * contexts: F.resize_images(hs[-1], (out_h, out_w)) + gaussian_filter + per-channel arg-max.  out: batch x (maps - 1) x 4

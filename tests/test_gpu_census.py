@@ -15,9 +15,10 @@ sys.path.insert(0, os.path.join(ROOT, 'tools'))
 pytestmark = pytest.mark.gpu
 
 
-def test_census_64_frames_default_path_and_bf16x3(native):
+def test_census_64_frames_default_path(native):
+    """(+ the opt-in bf16x3 mode where the library was built with it: PMX_BUILD_BF16X3=1)"""
     import parity_census
-    out = parity_census.run_census(frames=64, batch=32, seed0=9100, bf16x3=True)
+    out = parity_census.run_census(frames=64, batch=32, seed0=9100, bf16x3=native.has_bf16x3())
     parity_census.check(out)                     # every disagreement a near-tie; scores of matched peaks / people within 1e-4
     for name, s in out['paths'].items():
         print('\n[census %s] %d / %d frames identical; %d of %d peaks disagree (max margin %.3g); smallest margin of an accepted peak %.3g, '

@@ -269,3 +269,40 @@ def test_precise_scales_in_flight_same_bits(native):
         for lanes in (1, 3):
             assert np.array_equal(got[(4, rep)][0], got[(lanes, rep)][0]) and np.array_equal(got[(4, rep)][1], got[(lanes, rep)][1])
     assert np.array_equal(got[(4, 0)][0], got[(4, 2)][0]) and not np.array_equal(got[(4, 0)][0], got[(4, 1)][0])
+
+
+@pytest.mark.gpu
+def test_precise_table_cache_trims_only_between_sequences(native):
+    """A context fed ever new image sizes (detect_precise over a data set) starts its cubic-table cache over -- but only inside
+    pmx_precise_begin*, behind a device synchronisation, never while a sequence holds table pointers (the round-5 code evicted inside
+    cubic_table(), i.e. between the six lookups of ONE scale, with lanes still in flight: freed / recycled tables under running
+    kernels).  14 distinct sizes through one context whose cap is lowered so that the cache is trimmed several times; every result is
+    bit-identical to that of a fresh context that never trims."""
+    PD = pkg('pose_detector')
+    W_ = pkg('weights')
+    weights = W_.synthetic_weights(0)
+    rng = np.random.default_rng(91)
+    sizes = [(48 + 4 * i, 64 + 4 * i + 4 * ((3 * i) % 7)) for i in range(14)]          # the 2x scale is at most 736 x 1264
+    assert len(set(sizes)) == 14
+    imgs = [rng.integers(0, 256, s + (3,), dtype=np.uint8) for s in sizes]
+    det = PD.PoseDetector(weights=weights, device=0, precise=True, max_size=(744, 1280))      # (no re-created context on the way: it would forget the option)
+    det.engine.set_option('precise_table_cap', 30)          # one sequence adds up to 24 tables: trimmed at (almost) every second begin
+    got = []
+    for img in imgs:
+        try:
+            det._detect_precise_device(img, fetch_maps=True)
+        except (IndexError, RuntimeError):                  # random-weight maps may overflow a capacity; the maps are what is compared
+            pass
+        got.append((det.pafs.copy(), det.heatmaps.copy()))
+    cached, trims = det.engine.precise_table_stats()
+    assert trims >= 4 and cached <= 30 + 24, (cached, trims)
+    det.engine.close()
+    for i in (0, 5, 9, 13):
+        fresh = PD.PoseDetector(weights=weights, device=0, precise=True, max_size=(744, 1280))
+        try:
+            fresh._detect_precise_device(imgs[i], fetch_maps=True)
+        except (IndexError, RuntimeError):
+            pass
+        assert fresh.engine.precise_table_stats()[1] == 0
+        assert np.array_equal(fresh.pafs, got[i][0]) and np.array_equal(fresh.heatmaps, got[i][1]), i
+        fresh.engine.close()

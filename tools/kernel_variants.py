@@ -2,7 +2,7 @@
 """A/B builds of the convolution kernels: conv_mfma.hip / conv_wino.hip (and pmx_api.hip, which packs their weights) compiled with extra -D flags, linked with the product's other objects into
 tools/_build/libpose_var_<tag>.so (the product library is untouched), and timed through the whole network with the layer profile on.
 
-    python tools/kernel_variants.py build base: lead12:PMX_WINO_WLEAD1=12 lead12_6:PMX_WINO_WLEAD1=12,PMX_WINO_WLEAD2=6      (here: hipcc cross-compiles)
+    python tools/kernel_variants.py build base: noxf:PMX_ABLATE=1 nowl:PMX_ABLATE=2      (here: hipcc cross-compiles)
     python tools/kernel_variants.py time [--steps 5] [--batch 32] [--json out.json]                                                (on the GPU box)
     python tools/kernel_variants.py time-conv [--iters 5] [--json out.json]            (GPU box: single layers through pmx_conv2d -- ablation builds)
 """

@@ -28,7 +28,9 @@ sys.path.insert(0, ROOT)
 PKG = 'chainer_realtime_multi-person_pose_estimation_amd'
 
 
-def run_census(frames=512, batch=32, size=368, seed0=7000, bf16x3=False, threads=None, log=None):
+def run_census(frames=512, batch=32, size=368, seed0=7000, bf16x3=False, threads=None, log=None, extra_modes=()):
+    """extra_modes: ((name, {engine option: value, ...}), ...) -- further engine configurations compared with the SAME oracle frames (e.g.
+    ('conv1_direct', {'conv1_wino': 0}), ('direct_kernels', {'conv_algo': 0})): which kernel family a drift of the census comes from."""
     import torch
     from oracle import census, network_ref, postprocess_ref
     native = importlib.import_module(PKG + '.native')
@@ -51,7 +53,8 @@ def run_census(frames=512, batch=32, size=368, seed0=7000, bf16x3=False, threads
     w = weights_mod.calibrate_head(w, paf[0], heat[0])
     eng.set_weights({k: w[k] for k in ('Mconv7_stage6_L1', 'Mconv7_stage6_L2')})
     eng.set_option('keep_smoothed', 1)
-    modes = [('f32_default_batch_path', 0)] + ([('bf16x3_opt_in', 1)] if bf16x3 else [])
+    modes = [('f32_default_batch_path', {})] + ([('bf16x3_opt_in', {'precision': 1})] if bf16x3 else []) + [(n, dict(o)) for n, o in extra_modes]
+    defaults = {'precision': 0, 'conv1_wino': 1, 'conv_algo': 1, 'ksplit': 0, 'wino_tail': -1, 'wino_geom': -1}      # what a mode's options are reset to
     per_mode = {name: [] for name, _ in modes}
     t_gpu = t_cpu = 0.0
     nb = (frames + B - 1) // B
@@ -64,8 +67,10 @@ def run_census(frames=512, batch=32, size=368, seed0=7000, bf16x3=False, threads
             o = postprocess_ref.postprocess_from_net_output(opaf[0], oheat[0], map_h, map_w)
             oracle.append(dict({k: o[k] for k in ('all_peaks', 'poses', 'scores', 'smoothed', 'connections')}, paf_lo=opaf[0]))
         t_cpu += time.perf_counter() - t0
-        for name, prec in modes:
-            eng.set_option('precision', prec)
+        for name, opts in modes:
+            for k, v in opts.items():
+                assert k in defaults, 'census mode option %r has no reset value' % k
+                eng.set_option(k, v)
             t0 = time.perf_counter()
             eng.detect_batch(imgs, map_h, map_w)
             rec = eng.results()
@@ -89,7 +94,8 @@ def run_census(frames=512, batch=32, size=368, seed0=7000, bf16x3=False, threads
                 f['frame'] = it * B + i
                 f['seed'] = seed0 + it
                 per_mode[name].append(f)
-        eng.set_option('precision', 0)
+            for k in opts:
+                eng.set_option(k, defaults[k])
         if log:
             done = len(per_mode[modes[0][0]])
             log('batch %d/%d: %d frames, %s' % (it + 1, nb, done, ', '.join(
@@ -128,8 +134,15 @@ def main():
     ap.add_argument('--h', type=int, default=368, help='network input height (multiple of 8)')
     ap.add_argument('--w', type=int, default=368, help='network input width: --h 368 --w 496 = the 46 x 62 maps of a 4:3 frame')
     ap.add_argument('--out', default=None)
+    ap.add_argument('--mode', action='append', default=[], metavar='NAME:opt=val[,opt=val]',
+                    help='a further engine configuration on the same frames, e.g. conv1_direct:conv1_wino=0  direct_kernels:conv_algo=0')
     a = ap.parse_args()
-    out = run_census(a.frames, a.batch, (a.h, a.w), a.seed0, a.bf16x3, a.threads or None, log=lambda s: print(s, file=sys.stderr, flush=True))
+    extra = []
+    for m in a.mode:
+        name, _, kv = m.partition(':')
+        extra.append((name, {k: int(v) for k, v in (x.split('=') for x in kv.split(',') if x)}))
+    out = run_census(a.frames, a.batch, (a.h, a.w), a.seed0, a.bf16x3, a.threads or None, log=lambda s: print(s, file=sys.stderr, flush=True),
+                     extra_modes=extra)
     check(out)
     txt = json.dumps(out, indent=1)
     if a.out:
