@@ -104,6 +104,8 @@ def parse():
                     'part of the default run -- DESIGN.md section 7)')
     ap.add_argument('--engine-opt', action='append', default=[], metavar='KEY=VALUE', help='pmx_set_option on the engine before the run (A/B '
                     'switches such as wino_xcd_groups=0); repeatable; recorded in config.engine_options')
+    ap.add_argument('--validate-images', type=int, default=0, help='N > 1 / --force-gather: records per rank that rank 0 re-computes and compares '
+                    'after the timed region (0 = the whole shard)')
     ap.add_argument('--force-gather', action='store_true', help='N = 1: still create a one-rank process group and route the records '
                     'through the RCCL gather (dist.RecordPipe), the code path of N > 1')
     return ap.parse_args()
@@ -130,17 +132,23 @@ def self_launch(a):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def pick_device(local_rank, n_visible, world, backend, rank=0):
-    """Device index of this rank.  RCCL ("nccl"): one rank per GPU -- device LOCAL_RANK when the rank sees all GPUs of the node, device 0
-    when the launcher masks the GPUs per rank (one visible device each), otherwise there is no GPU for it.  Other backends (the gloo
-    smoke mode): ranks may share the visible GPU(s)."""
+MASK_VARS = ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES', 'GPU_DEVICE_ORDINAL')
+
+
+def pick_device(local_rank, n_visible, world, backend, rank=0, env=None):
+    """Device index of this rank.  RCCL ("nccl"): one rank per GPU -- device LOCAL_RANK when the rank sees all GPUs of the node; device 0
+    when the launcher masks the GPUs per rank (one visible device each AND a visibility variable set in this rank's environment: on an
+    unmasked single-GPU box every rank would land on the same GPU); otherwise there is no GPU for it.  Other backends (the gloo smoke
+    mode): ranks may share the visible GPU(s)."""
+    env = os.environ if env is None else env
     if backend != 'nccl':
         return local_rank % max(1, n_visible)
     if n_visible > local_rank:
         return local_rank
-    if n_visible == 1 and world > 1:
+    if n_visible == 1 and world > 1 and any(env.get(v, '') != '' for v in MASK_VARS):
         return 0
-    raise SystemExit('bench.py: rank %d has no GPU (%d visible)' % (rank, n_visible))
+    raise SystemExit('bench.py: rank %d has no GPU of its own (%d visible, %d ranks, none of %s set): RCCL needs one GPU per rank'
+                     % (rank, n_visible, world, ' / '.join(MASK_VARS)))
 
 
 def core_limits():
@@ -469,9 +477,26 @@ def main():
         out['records_path'] = ('dist.RecordPipe (pmx_results_snapshot into the send slot on the device -> one RCCL gather per step -> one D2H copy on rank 0)'
                                if use_group and a.backend == 'nccl' else 'dist.RecordPipe over %s (host slots)' % a.backend if use_group
                                else 'pmx_get_results (one D2H copy)')
+        if use_group:
+            # the SCALE record validates itself: the records that came through the gather against rank 0's own re-run of every shard
+            chk = validate_shards(eng, torch, dev, dist_mod, rec, B, S, map_s, world, a.validate_images)
+            out['shard_records_match'] = chk['shard_records_match']
+            out['records_compared'] = chk['records_compared']
+            out['max_abs_score_diff'] = chk['max_abs_score_diff']
+            out['shard_validation'] = chk
+            if not chk['shard_records_match']:
+                sys.stderr.write('bench.py: ERROR: gathered records differ from rank 0\'s re-run of the shards: %s\n' % json.dumps(chk))
         out['ranks_seen'] = [r_['rank'] for r_ in rank_info]
         out['devices'] = rank_info
         out['distinct_gpus'] = len(set((r_['pci_bus_id'] or r_['uuid'] or r_['rank']) for r_ in rank_info))
+        if use_group and a.backend == 'nccl' and out['distinct_gpus'] != world:
+            # not asserted (a box may report one address for distinct GPUs) but the record says so itself: not a scaling figure
+            out['scaling_record_valid'] = False
+            out['scaling_record_invalid_reason'] = '%d ranks on %d distinct GPU addresses' % (world, out['distinct_gpus'])
+        elif use_group:
+            out['scaling_record_valid'] = bool(a.backend == 'nccl' and out.get('shard_records_match', False))
+            if a.backend != 'nccl':
+                out['scaling_record_invalid_reason'] = 'backend %s: ranks share GPUs (code-path check, not a scaling figure)' % a.backend
         roof = None
         if prof:
             # dominant kernel = the HIP kernel (as rocprofv3 groups them) with the largest total time in the timed region: the 7x7
@@ -558,6 +583,65 @@ def main():
     if use_group:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def compare_records(gathered, recomputed, score_tol=1e-5):
+    """Two result-record arrays of the same images (native.result_dtype; the person capacities may differ): people / peak counts and poses
+    must be identical, scores within `score_tol`.  Returns what the SCALE line reports."""
+    n = min(len(gathered), len(recomputed))
+    out = {'records_compared': int(n), 'records_with_identical_counts_and_poses': 0, 'max_abs_score_diff': 0.0, 'bitwise_equal_records': 0,
+           'first_mismatch': None}
+    for i in range(n):
+        a, b = gathered[i], recomputed[i]
+        na, nb = int(a['n_people']), int(b['n_people'])
+        same = na == nb and int(a['n_peaks']) == int(b['n_peaks']) and int(a['status']) == int(b['status']) and \
+            np.array_equal(a['poses'][:na], b['poses'][:nb])
+        if same:
+            out['records_with_identical_counts_and_poses'] += 1
+            d = float(np.max(np.abs(a['scores'][:na] - b['scores'][:nb]))) if na else 0.0
+            out['max_abs_score_diff'] = max(out['max_abs_score_diff'], d)
+            if d == 0.0:
+                out['bitwise_equal_records'] += 1
+        elif out['first_mismatch'] is None:
+            out['first_mismatch'] = {'record': i, 'n_people': [na, nb], 'n_peaks': [int(a['n_peaks']), int(b['n_peaks'])],
+                                     'status': [int(a['status']), int(b['status'])]}
+    out['shard_records_match'] = bool(n > 0 and out['records_with_identical_counts_and_poses'] == n and out['max_abs_score_diff'] <= score_tol)
+    return out
+
+
+def validate_shards(eng, torch, dev, dist_mod, rec, B, S, map_s, world, limit=0):
+    """Rank 0, after the timed region of an N > 1 run (or --force-gather): are the GATHERED records right?  The global batch is one seeded
+    stream, so rank 0 regenerates the images of every rank's shard (all B of them, or the first `limit`), runs them itself -- same
+    batch size, hence the same kernel forms as the owning rank used -- fetches the records the plain way (pmx_get_results) and compares
+    them with what came through the record pipe: counts and poses exact, scores <= 1e-5 (a shard re-run at ANOTHER batch size may differ
+    in the last bits: the path is not batch-invariant; at the same size the kernels are deterministic, so
+    `bitwise_equal_records` is expected to equal `records_compared`).  A wrong rank order, a stale slot, a truncated frame or a rank that
+    computed on the wrong images all show up here; the rate alone would not notice."""
+    total = {'records_compared': 0, 'records_with_identical_counts_and_poses': 0, 'max_abs_score_diff': 0.0, 'bitwise_equal_records': 0,
+             'first_mismatch': None, 'ranks_checked': [], 'images_per_rank': None}
+    rng = np.random.default_rng(1)
+    for r in range(world):
+        lo, hi = dist_mod.shard_range(B * world, r, world)
+        imgs = rng.integers(0, 256, (hi - lo, S, S, 3), dtype=np.uint8)          # (the stream position of rank r's shard)
+        k = hi - lo if not limit else min(limit, hi - lo)
+        total['images_per_rank'] = k
+        d = torch.from_numpy(imgs).to(dev)
+        # the whole shard runs (the kernel forms depend on the batch size); the first k records are compared
+        eng.detect_batch(device_ptr=d.data_ptr(), shape=(hi - lo, S, S), map_h=map_s, map_w=map_s)
+        mine = eng.results()
+        c = compare_records(rec[lo:lo + k], mine[:k])
+        total['ranks_checked'].append(r)
+        for key in ('records_compared', 'records_with_identical_counts_and_poses', 'bitwise_equal_records'):
+            total[key] += c[key]
+        total['max_abs_score_diff'] = max(total['max_abs_score_diff'], c['max_abs_score_diff'])
+        if c['first_mismatch'] is not None and total['first_mismatch'] is None:
+            total['first_mismatch'] = dict(c['first_mismatch'], rank=r)
+        del d
+    total['shard_records_match'] = bool(total['records_compared'] > 0 and total['max_abs_score_diff'] <= 1e-5 and
+                                        total['records_with_identical_counts_and_poses'] == total['records_compared'])
+    total['how'] = ('rank 0 regenerated every rank\'s shard of the seeded global batch, ran it at the same batch size and compared pmx_get_results '
+                    'with the records gathered through dist.RecordPipe in the last timed step: counts / poses exact, scores <= 1e-5')
+    return total
 
 
 def device_identity(torch, rank, local_rank):

@@ -52,17 +52,27 @@ __global__ __launch_bounds__(256, 1) void conv1_wino_kernel(const ConvArgs a)
     float* const s_patch = s_u;            // (dead before U half 0 is first written)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
     const int th = wave >> 1, chh = wave & 1;
-    const int H = a.H, W = a.W;
     int tile;
     {   // consecutive blocks of an XCD = neighbouring squares (their halos overlap in that XCD's L2)
         const int nwg = gridDim.x, bid = blockIdx.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    // heterogeneous launch (a.nseg > 0; pmx_common.h::ConvSeg): the segment this block's square belongs to -- scalar work on block-uniform
+    // values; from here on the block is a block of a launch of that segment alone
+    int H = a.H, W = a.W, s_tiles_x = a.tiles_x, tiles_per_img = a.tiles_x * a.tiles_y;
+    size_t s_pix_in = 0, s_pix_out = 0;
+    if (a.nseg > 0) {
+        int sg = 0;
+        for (int k = 1; k < a.nseg; ++k) sg = tile >= a.segs[k].tile0 ? k : sg;
+        const ConvSeg S = a.segs[sg];
+        H = S.H; W = S.W; s_tiles_x = S.tiles_x; tiles_per_img = S.tiles_img;
+        s_pix_in = (size_t)(unsigned)S.pix0; s_pix_out = (size_t)(unsigned)S.pixo;
+        tile -= S.tile0;
+    }
     const int bimg = tile / tiles_per_img;
     const int trem = tile - bimg * tiles_per_img;
-    const int y0 = (trem / a.tiles_x) * (2 * TT), x0 = (trem % a.tiles_x) * (2 * TT);
+    const int y0 = (trem / s_tiles_x) * (2 * TT), x0 = (trem % s_tiles_x) * (2 * TT);
     constexpr int OUTSIDE = (int)0x80000000;
 
     // ---- input patch: 20 x 20 pixels x 3 channels through a buffer resource spanning the image (outside = 0 = conv1_1's padding).
@@ -70,7 +80,7 @@ __global__ __launch_bounds__(256, 1) void conv1_wino_kernel(const ConvArgs a)
     // here: x / divisor - 0.5 in float32, the reference's two operations (pose_detector.py:428-429; prep_u8_kernel's arithmetic), which
     // saves the 64-bytes-per-pixel float copy of the network input (277 MB written and read back per batch of 32) and a launch.
     if (a.g[1].in) {
-        const uint8_t* src8 = reinterpret_cast<const uint8_t*>(a.g[1].in) + (size_t)bimg * H * W * 3;
+        const uint8_t* src8 = reinterpret_cast<const uint8_t*>(a.g[1].in) + (s_pix_in + (size_t)bimg * H * W) * 3;
         const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src8), 0, (unsigned)(H * W * 3), 0x00020000);
         const float divisor = __builtin_bit_cast(float, (unsigned)a.kbounds);
         unsigned char pb[2][3];
@@ -95,7 +105,7 @@ __global__ __launch_bounds__(256, 1) void conv1_wino_kernel(const ConvArgs a)
             }
         }
     } else {
-        const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g[0].in + (size_t)bimg * H * W * a.lda), 0,
+        const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g[0].in + (s_pix_in + (size_t)bimg * H * W) * a.lda), 0,
                                                                                (unsigned)(H * W * a.lda) * 4u, 0x00020000);
         float4 pv[2];
 #pragma unroll
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(256, 1) void conv1_wino_kernel(const ConvArgs a)
         for (int h2 = 0; h2 < 2; ++h2) pooled[2 * rp + h2] = fmaxf(fmaxf(o0[h2], o1[h2]), fmaxf(o2[h2], o3[h2]));
     }
     const int Hp = H >> 1, Wp = W >> 1, ldc_b = a.ldc * 4;
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.g[0].out + (size_t)bimg * Hp * Wp * a.ldc, 0, (unsigned)(Hp * Wp * ldc_b), 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.g[0].out + (s_pix_out + (size_t)bimg * Hp * Wp) * a.ldc, 0, (unsigned)(Hp * Wp * ldc_b), 0x00020000);
     const int tb = 32 * th + li;
     const int py = (y0 >> 1) + (tb >> 3), px = (x0 >> 1) + (tb & 7);
     const int o = (py < Hp && px < Wp) ? (int)__umul24(__umul24(py, Wp) + px, ldc_b) + (chh * 32 + 4 * kh) * 4 : OUTSIDE;
@@ -368,7 +378,8 @@ int conv1_wino_launch(const ConvArgs& a0, hipStream_t stream)
     if (!a.g[1].in) a.kbounds = 0;
     static bool attr_set[PMX_MAX_DEVICES] = {};
     if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(conv1_wino_kernel), attr_set)) return rc;
-    hipLaunchKernelGGL(conv1_wino_kernel, dim3((unsigned)(a.tiles_x * a.tiles_y * a.B)), dim3(256), LDS_BYTES, stream, a);
+    PMX_CHECK(a.nseg == 0 || (a.segs && a.seg_tiles > 0), PMX_ERR_INVALID, "conv1 winograd: segments without a table");
+    hipLaunchKernelGGL(conv1_wino_kernel, dim3(a.nseg ? (unsigned)a.seg_tiles : (unsigned)(a.tiles_x * a.tiles_y * a.B)), dim3(256), LDS_BYTES, stream, a);
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }

@@ -137,17 +137,32 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     G.out = g1 ? a.g[1].out : a.g[0].out;
     G.cout = g1 ? a.g[1].cout : a.g[0].cout;
     if (UNIT) G.out += (size_t)unit * (size_t)a.slab_stride;
-    const int H = a.H, W = a.W;
     int tile;
     {                                             // (plain launches: gridDim.x is a multiple of 8 wherever it matters, XCD = blockIdx.x & 7)
         const int nwg = gridDim.x, bid = bx;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
+    // Heterogeneous launches (rectangles, plain mode; a.nseg > 0): the launch is a stream of SEGMENTS -- n images of one map size each
+    // (the scales of detect_precise, the size classes of a mixed batch) -- laid end to end in the activation buffers; segment s owns the
+    // tiles [segs[s].tile0, segs[s + 1].tile0) of the launch.  All of this is scalar work on block-uniform values (one s_load per field):
+    // the block then behaves exactly like a block of a launch of that segment alone -- same tiles, same halo, same arithmetic, same bits
+    // (a plain block's result does not depend on which launch it is part of).
+    constexpr bool SEGS = GEOM == 0 && !UNIT;
+    int H = a.H, W = a.W, s_tiles_x = a.tiles_x, s_tiles_img = a.tiles_x * a.tiles_y;
+    size_t s_pix_in = 0, s_pix_out = 0;
+    if (SEGS && a.nseg > 0) {
+        int sg = 0;
+        for (int k = 1; k < a.nseg; ++k) sg = tile >= a.segs[k].tile0 ? k : sg;
+        const ConvSeg S = a.segs[sg];
+        H = S.H; W = S.W; s_tiles_x = S.tiles_x; s_tiles_img = S.tiles_img;
+        s_pix_in = (size_t)(unsigned)S.pix0; s_pix_out = (size_t)(unsigned)S.pixo;
+        tile -= S.tile0;
+    }
     // GEOM 1: the map is cut into vertical slabs of 46 columns (23 tile columns; 46 / 92 / 184-wide maps = 1 / 2 / 4 slabs); block trem of
     // this launch in (image, slab) bslab = the 32 consecutive Winograd tiles [t0, t0 + 32) of that slab (row-major), tile rows r0 .. r0 + 2;
     // raw halo row 0 / column 0 = image row 2 r0 - PADK / column 46 slab - PADK (halo columns inside the map come from the neighbour slab)
-    const int tiles_per_img = MERGE ? 1 : GEOM ? a.run_nb : a.tiles_x * a.tiles_y;
+    const int tiles_per_img = MERGE ? 1 : GEOM ? a.run_nb : s_tiles_img;
     const int bslab = tile / tiles_per_img;
     const int trem = tile - bslab * tiles_per_img;
     // (GEOM 1 = a single slab, the 46-wide maps of the 7x7 layers: the slab arithmetic is compiled out -- its extra scalar registers
@@ -157,8 +172,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     const int sx0 = SLABS ? (bslab - bimg * a.run_nslab) * C::RUN_W : 0;
     const int t0 = MERGE ? a.run_j0 * PMX_WINO_RUN_TILES : GEOM ? (a.run_j0 + trem) * PMX_WINO_RUN_TILES : 0;      // (MERGE: first tail tile of an image)
     const int r0 = GEOM ? t0 / C::RUN_TX : 0;
-    const int ntiles = C::RUN_TX * ((a.H + 1) >> 1);
-    const int y0 = GEOM ? 2 * r0 : (trem / a.tiles_x) * C::TH, x0 = GEOM ? sx0 : (trem % a.tiles_x) * C::TW;
+    const int ntiles = C::RUN_TX * ((H + 1) >> 1);
+    const int y0 = GEOM ? 2 * r0 : (trem / s_tiles_x) * C::TH, x0 = GEOM ? sx0 : (trem % s_tiles_x) * C::TW;
     // MERGE: block `tile` = stream positions [32 tile, 32 tile + 32) = segment s (s = 0, 1, 2) of image mg_img0 + s: mg_n0 / mg_n1 / the
     // rest tiles from tail tile mg_tt0 (s = 0) / 0 on, halo columns from 0 / mg_cb1 / mg_cb2 on (2 n + KS - 1 of them)
     const int mg_nt = ntiles - t0, mg_tx0 = t0 - r0 * C::RUN_TX;
@@ -167,7 +182,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     const int mg_cb1 = 2 * mg_n0 + KS - 1, mg_cb2 = mg_cb1 + 2 * mg_n1 + KS - 1;
     const int n0 = by * 128;
     const int n = n0 + wave * 32 + li;
-    const float* in_b = G.in + (MERGE ? (size_t)0 : (size_t)bimg * H * W * a.lda);
+    const float* in_b = G.in + (MERGE ? (size_t)0 : (s_pix_in + (size_t)bimg * H * W) * a.lda);
     float bias = G.bias[n];                       // (pinned to a register further down, once the first halo loads are on their way:
                                                   //  pinned here the block waited a full memory round trip before issuing anything else)
     const int nch = a.nch;                        // chunks of 32 input channels
@@ -178,37 +193,22 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     const bool do_p1 = !UNIT || unit < nu1, do_p2a = !UNIT || unit == nu1, do_p2b = !UNIT || unit == nu1 + 1;
     const bool do_pd = UNIT && unit == nu1 + 2;   // unit mode: tap (6, 6) is a unit of its own (in pass 2a otherwise)
 
-    // raw halo staging: slot r of a thread = pixel (tid >> 3) + 32 r of the halo, channels 4 (tid & 7) .. + 3 of the chunk.
-    // GEOM 0: global offsets and an in-image mask per slot in registers (the LDS offset is recomputed at the write).
-    // GEOM 1 (20 slots for 7x7): nothing per slot is kept -- the loads go through a buffer resource that spans exactly this image, so
-    // rows above / below the map fall out of its range and return 0; columns left / right of it get an out-of-range offset
-    int h_goff[GEOM ? 1 : C::NHF];
-    unsigned h_ok = 0;
-    if (!GEOM) {
-#pragma unroll
-        for (int r = 0; r < (GEOM ? 0 : C::NHF); ++r) {
-            const int f = tid + r * 256;
-            const bool slot = f < C::NPX * (C::CKW / 4);
-            const int hp = slot ? f / (C::CKW / 4) : 0, c4 = f % (C::CKW / 4);
-            const int hy = hp / C::HW, hx = hp - hy * C::HW;
-            const int gy = y0 + hy - C::PADK, gx = x0 + hx - C::PADK;
-            const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-            const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-            h_goff[r] = (cy * W + cx) * a.lda + c4 * 4;
-            h_ok |= (slot && inb) ? (1u << r) : 0u;
-        }
-    }
+    // raw halo staging: slot r of a thread = pixel (tid >> 3) + 32 r of the halo, channels 4 (tid & 7) .. + 3 of the chunk.  Nothing per slot
+    // but one byte offset: the loads go through a buffer resource that spans exactly this image, so rows above / below the map fall out
+    // of its range and return 0 = the zero padding; columns left / right of it get an out-of-range offset.  (Round 6: also the rectangles
+    // -- until then GEOM 0 kept a clamped global offset and an in-image mask per slot, added the chunk offset with 64-bit vector
+    // arithmetic in front of every load and selected zeros at the LDS store.)
     // (MERGE: the resource spans the whole batch -- rows outside an image would land in its neighbour, so they are masked like the columns)
     const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0,
-                                                                           MERGE ? (unsigned)(a.B * H * W * a.lda) * 4u : GEOM ? (unsigned)(H * W * a.lda) * 4u : 0u, 0x00020000);
+                                                                           MERGE ? (unsigned)(a.B * H * W * a.lda) * 4u : (unsigned)(H * W * a.lda) * 4u, 0x00020000);
     const int hbase_b = (((y0 - C::PADK) * W + x0 - C::PADK) * a.lda + (tid & 7) * 4) * 4;     // byte offset of halo pixel (0, 0), may be negative
-    const int hrow_skip = SLABS ? W - C::HW : -(KS - 1);                                     // image pixels between the end of a halo row and the next
+    const int hrow_skip = (SLABS || GEOM == 0) ? W - C::HW : -(KS - 1);                      // image pixels between the end of a halo row and the next
     const int lda_b = a.lda * 4;
     // GEOM 1 / 2: byte offset of slot r's pixel in the image for chunk 0, computed ONCE with the first halo load (0x80000000 = the column is
     // outside the map: stays out of the buffer's range whatever chunk offset is added) and kept in registers -- recomputed per use, the
     // compiler hoisted a second copy of this arithmetic (20 slots x (mul_hi, mul_lo, mad, cmp)) to right in front of the first MFMA
     // (7x7 only: on the 3x3 instantiations the kept offsets measured slower -- conv3_3 +6 % -- than the compiler's own placement)
-    constexpr bool HOFF = (GEOM != 0 && KS == 7) || GEOM == 3;     // (merged tails: the per-slot segment arithmetic is never repeated)
+    constexpr bool HOFF = GEOM == 0 || KS == 7 || GEOM == 3;     // (merged tails: the per-slot segment arithmetic is never repeated)
     int h_off[HOFF ? C::NHF : 1];
     auto halo_off_calc = [&](int r) -> int {
         const unsigned hp = (unsigned)(tid >> 3) + 32u * r;
@@ -224,26 +224,21 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
         }
         // halo pixel (hy, hx) = image pixel (y0 - PADK + hy, x0 - PADK + hx): hp + (W - HW) hy pixels after halo pixel (0, 0) in the image
         int off = hbase_b + ((int)hp + (int)hy * hrow_skip) * lda_b;
-        if (SLABS ? (unsigned)(x0 - C::PADK) + hx >= (unsigned)W          // (left of the map the sum wraps around: also out)
-                  : hx - (unsigned)C::PADK >= (unsigned)C::RUN_W) off = (int)0x80000000;
+        if ((SLABS || GEOM == 0) ? (unsigned)(x0 - C::PADK) + hx >= (unsigned)W          // (left of the map the sum wraps around: also out)
+                                 : hx - (unsigned)C::PADK >= (unsigned)C::RUN_W) off = (int)0x80000000;
         return off;
     };
     auto halo_off_init = [&](int r) { if constexpr (HOFF) h_off[r] = halo_off_calc(r); };
     auto halo_load_slot = [&](float4 (&hv)[C::NHF], int chunk, int r) {       // r is a compile-time constant at every call
-        if constexpr (GEOM != 0) {
-            const int off0 = HOFF ? h_off[HOFF ? r : 0] : halo_off_calc(r);
-            // (the chunk's byte offset goes into the scalar offset, which the range check ignores: a pixel outside the image stays out of
-            //  range, a pixel inside it stays inside its own channel row -- one VALU add less per load)
-            hv[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off0, chunk * (C::CKW * 4), 0));
-        } else {
-            hv[r] = *reinterpret_cast<const float4*>(in_b + h_goff[GEOM ? 0 : r] + chunk * C::CKW);
-        }
+        const int off0 = HOFF ? h_off[HOFF ? r : 0] : halo_off_calc(r);
+        // (the chunk's byte offset goes into the scalar offset, which the range check ignores: a pixel outside the image stays out of
+        //  range, a pixel inside it stays inside its own channel row -- one VALU add less per load)
+        hv[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off0, chunk * (C::CKW * 4), 0));
     };
     float* const s_raw_t = s_raw + (tid >> 3) * C::LDR + (tid & 7) * 4;       // slot r of this thread: + r * 32 * LDR floats (an immediate offset)
     auto halo_store_slot = [&](const float4 (&hv)[C::NHF], int r) {
         const int f = tid + r * 256;
-        float4 v = hv[r];
-        if (!GEOM && !((h_ok >> r) & 1)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v = hv[r];
         // (only the last slot can fall behind the halo; spelled out because the compiler does not bound tid by the block size)
         if (r * 256 + 255 < C::NPX * (C::CKW / 4) || f < C::NPX * (C::CKW / 4)) *reinterpret_cast<float4*>(s_raw_t + r * (32 * C::LDR)) = v;
     };
@@ -311,7 +306,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
     if (do_p1) {
 #pragma unroll
     for (int r = 0; r < C::NHF; ++r) {               // first halo: offsets computed and loads issued slot by slot
-        if (GEOM) halo_off_init(r);
+        halo_off_init(r);
         halo_load_slot(hreg, c0, r);
     }
 #pragma unroll
@@ -582,7 +577,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
 #pragma unroll
         for (int st = 0; st < 4; ++st) bd[st] = wload(PD, 0u, st);
         if (UNIT) {                                 // standalone: stage chunk 0, keep chunk 1 in the registers
-            if (GEOM) {
+            {
 #pragma unroll
                 for (int r = 0; r < C::NHF; ++r) halo_off_init(r);
             }
@@ -665,7 +660,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
         if (do_p2b) {
         zero8();
         if (UNIT) {                                 // standalone: stage chunk 0, first weights, sub-kernel 0 of chunk 0 (not overlapped)
-            if (GEOM) {
+            {
 #pragma unroll
                 for (int r = 0; r < C::NHF; ++r) halo_off_init(r);
             }
@@ -729,7 +724,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
         if (do_pd) {
             // ================= unit mode: tap (6, 6) over all chunks, straight from the raw halo =================
             f32x4 bdn[4];
-            if (GEOM) {
+            {
 #pragma unroll
                 for (int r = 0; r < C::NHF; ++r) halo_off_init(r);
             }
@@ -784,7 +779,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a)
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y11), srsrc, o + 3 * ldc_b, 0, 0);
         }
     } else {
-        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(G.out + (size_t)bimg * opix * a.ldc, 0, (unsigned)(opix * ldc_b), 0x00020000);
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(G.out + (s_pix_out + (size_t)bimg * opix) * a.ldc, 0, (unsigned)(opix * ldc_b), 0x00020000);
         const int n_b = nok ? n * 4 : -1;                            // (a lane without a real output channel: every offset out of range)
         // run geometry: (tile row, tile column) of the lane's first tile by one division, then stepped from register row to register row
         // (the rows of a lane are the tiles tb + 0, 1, 2, 3, 8, 9, ...: steps of 1 or 5 < 23, at most one wrap)
@@ -836,7 +831,7 @@ static int launch_wino(const ConvArgs& a0, int groups, hipStream_t stream)
     PMX_CHECK(!!a.pool == !!POOL, PMX_ERR_INVALID, "conv wino: pool mismatch");
     PMX_CHECK(!POOL || (a.H % 2 == 0 && a.W % 2 == 0), PMX_ERR_INVALID, "conv: pooled layer needs even H, W");
     PMX_CHECK(a.cout_pad % 128 == 0, PMX_ERR_INVALID, "conv wino: cout_pad %d not a multiple of 128", a.cout_pad);
-    PMX_CHECK((long long)a.H * a.W * a.lda < (1ll << 31), PMX_ERR_INVALID, "conv: image too large for 32-bit offsets");
+    PMX_CHECK((long long)(a.H + C::TH + KS) * (a.W + C::TW + KS) * a.lda * 4 < (1ll << 31), PMX_ERR_INVALID, "conv: image too large for 32-bit byte offsets");
     PMX_CHECK((long long)(a.H + 2) * (a.W + 2) * a.ldc * 4 < (1ll << 31), PMX_ERR_INVALID, "conv: output image too large for 32-bit byte offsets");
     a.tiles_x = (a.W + C::TW - 1) / C::TW;
     a.tiles_y = (a.H + C::TH - 1) / C::TH;
@@ -845,7 +840,10 @@ static int launch_wino(const ConvArgs& a0, int groups, hipStream_t stream)
     static bool attr_set[PMX_MAX_DEVICES] = {};
     if (int rc = conv_allow_big_lds(reinterpret_cast<const void*>(kern), attr_set)) return rc;
     if (UNIT) { a.ngroups = groups; PMX_CHECK(a.ksplit >= 2 && a.ksplit <= 8 && a.kbounds >= 1, PMX_ERR_INVALID, "conv wino: bad unit plan"); }
-    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.cout_pad / 128), (unsigned)(groups * (UNIT ? a.ksplit : 1)));
+    // heterogeneous launch: the caller built the segment table (conv_build_segs: sizes checked there) and says how many tiles it holds
+    PMX_CHECK(a.nseg == 0 || (!UNIT && a.segs && a.seg_tiles > 0), PMX_ERR_INVALID, "conv wino: segments only in plain mode, with a table");
+    const unsigned gx = a.nseg ? (unsigned)a.seg_tiles : (unsigned)(a.tiles_x * a.tiles_y * a.B);
+    dim3 grid(gx, (unsigned)(a.cout_pad / 128), (unsigned)(groups * (UNIT ? a.ksplit : 1)));
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, a);
     PMX_HIP(hipGetLastError());
     return PMX_OK;

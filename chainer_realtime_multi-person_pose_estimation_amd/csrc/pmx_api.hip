@@ -413,6 +413,9 @@ extern "C" void pmx_destroy(pmx_ctx* c)
                     c->tab.ylo, c->tab.yhi, c->tab.gauss};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : c->pr_tabs) (void)hipFree(kv.second);
+    for (auto& kv : c->tab_cache) (void)hipFree(kv.second.xi0);        // (one allocation per cached table set: pmx_multi.hip)
+    void* mptrs[] = {c->d_segs, c->mi_src, c->mi_tab};
+    for (void* p : mptrs) if (p) (void)hipFree(p);
     for (float* q : c->pr_part) if (q) (void)hipFree(q);
     for (int i = 1; i < PMX_PR_LANES; ++i) {
         PrLane& l = c->pr_lane[i];
@@ -776,23 +779,48 @@ static int wino_mode(const pmx_ctx* c, int ks, int cin_pad, int cout_pad, int co
 }
 
 // one launch of 1 or 2 groups (same geometry); in/out pointers are already offset to the group's channels
+// `level` (heterogeneous forward only, c->segs non-empty): the resolution level of the layer's input, 0 = network input .. 3 = 1/8; B, H, W
+// then carry the image count and the LARGEST map of the level (launch checks), the geometry comes from the segment table of the level
 static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float* in0, const float* in1, int lda,
-                    float* out0, float* out1, int ldc, int B, int H, int W, int relu, int pool)
+                    float* out0, float* out1, int ldc, int B, int H, int W, int relu, int pool, int level = -1)
 {
     const PackedLayer& L0 = c->layers[li0];
     const int groups = li1 >= 0 ? 2 : 1;
+    const bool seg = !c->segs.empty() && level >= 0;
+    const double npix = seg ? (double)c->seg_pix[level] : (double)B * H * W;
     ConvArgs a;
     memset(&a, 0, sizeof a);
     a.g[0].in = in0; a.g[0].w = L0.d_w; a.g[0].bias = L0.d_b; a.g[0].out = out0; a.g[0].cout = L0.cout;
-    double flops = 2.0 * B * H * W * (double)L0.cout * L0.cin * L0.ks * L0.ks;
+    double flops = 2.0 * npix * (double)L0.cout * L0.cin * L0.ks * L0.ks;
     if (groups == 2) {
         const PackedLayer& L1 = c->layers[li1];
         a.g[1].in = in1; a.g[1].w = L1.d_w; a.g[1].bias = L1.d_b; a.g[1].out = out1; a.g[1].cout = L1.cout;
-        flops += 2.0 * B * H * W * (double)L1.cout * L1.cin * L1.ks * L1.ks;
+        flops += 2.0 * npix * (double)L1.cout * L1.cin * L1.ks * L1.ks;
     }
     a.B = B; a.H = H; a.W = W; a.lda = lda; a.ldc = ldc; a.nch = L0.nch; a.cout_pad = L0.cout_pad;
     a.relu = relu; a.pool = pool;
     int rc;
+    if (seg) {
+        // heterogeneous launch: the plain Winograd kernel on 8 x 16 rectangles over all segments (every 3x3 / 7x7 layer of the pose network
+        // qualifies; its per-pixel arithmetic is that of a plain launch of each image alone -- oracle/conv_fma_ref::conv_wino)
+        PMX_CHECK(wino_eligible(L0.ks, L0.cin_pad, L0.cout_pad) && c->opt_precision == 0 &&
+                  (groups == 1 || (wino_eligible(c->layers[li1].ks, c->layers[li1].cin_pad, c->layers[li1].cout_pad) && c->layers[li1].cout == L0.cout)),
+                  PMX_ERR_INVALID, "heterogeneous forward: layer %s has no Winograd form", label);
+        if ((rc = ensure_wino_pack(c->layers[li0])) || (groups == 2 && (rc = ensure_wino_pack(c->layers[li1])))) return rc;
+        a.nch = L0.cin_pad / 32;
+        a.g[0].w = L0.d_ww;
+        if (groups == 2) a.g[1].w = c->layers[li1].d_ww;
+        const int t = PMX_SEG_RECT(level, pool);
+        a.nseg = (int)c->segs.size(); a.segs = c->d_segs + (size_t)t * c->segs.size(); a.seg_tiles = c->seg_tiles[t];
+        const bool prof_seg = c->prof_on == 1 || (c->prof_on == 2 && L0.ks == 7);
+        if (prof_seg) {
+            const double bytes = 4.0 * npix * ((double)L0.cin * groups + (double)L0.cout * groups / (pool ? 4 : 1));
+            if ((rc = prof_begin(c, std::string(label) + (L0.ks == 7 ? "|conv_wino_f2x2_7x7/seg" : "|conv_wino_f2x2_3x3/seg"), flops, bytes,
+                                 flops * (L0.ks == 7 ? 100.0 / 196.0 : 16.0 / 36.0)))) return rc;
+        }
+        if ((rc = conv_wino_launch(a, L0.ks, groups, c->stream))) return rc;
+        return prof_seg ? prof_end(c) : PMX_OK;
+    }
     int v = conv_pick_variant(L0.ks, L0.cout_pad, H, W, B * groups, c->opt_force[L0.ks], c->opt_kernel_gen, pool, groups == 1 ? L0.cin : 9999,
                               c->opt_precision == 1 && L0.ks > 1);
     if (c->opt_precision == 1 && L0.ks > 1 && conv_bf16x3_twin(v) >= 0) {
@@ -860,14 +888,18 @@ static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float
 // (else, or with option fuse_pairs = 0, as two run_conv launches through `mid`): bit-identical either way
 static int run_pair(pmx_ctx* c, const char* labelA, const char* labelB, int a0, int a1, int b0, int b1, const float* in0,
                     const float* in1, int lda, float* mid0, float* mid1, int ldm, float* out0, float* out1, int ldc, int B, int H,
-                    int W, int reluB)
+                    int W, int reluB, int level = -1)
 {
     const PackedLayer& LA = c->layers[a0];
     const PackedLayer& LB = c->layers[b0];
     const int groups = a1 >= 0 ? 2 : 1;
+    // (heterogeneous forward: a 1x1 layer only sees pixels -- the segments' maps are one run of seg_pix[level] pixels)
+    const bool seg = !c->segs.empty() && level >= 0;
+    const long long npix = seg ? c->seg_pix[level] : (long long)B * H * W;
     const bool ok = c->opt_fuse_pairs && c->opt_kernel_gen >= 6 && LA.ks == 1 && LB.ks == 1 && LA.cin_pad == 128 && LB.cin == LA.cout &&
                     conv_pair_supported(LA.cin, LA.cout, LB.cout_pad) && (groups == 1 || c->layers[b1].cout_pad == LB.cout_pad);
     int rc;
+    PMX_CHECK(ok || !seg, PMX_ERR_INVALID, "heterogeneous forward: the 1x1 pair %s + %s has no fused form", labelA, labelB);
     if (!ok) {
         if ((rc = run_conv(c, labelA, a0, a1, in0, in1, lda, mid0, mid1, ldm, B, H, W, 1, 0))) return rc;
         return run_conv(c, labelB, b0, b1, mid0, mid1, ldm, out0, out1, ldc, B, H, W, reluB, 0);
@@ -880,12 +912,12 @@ static int run_pair(pmx_ctx* c, const char* labelA, const char* labelB, int a0, 
         const PackedLayer& Bl = c->layers[g ? b1 : b0];
         p.g[g].in = g ? in1 : in0; p.g[g].w1 = A.d_w; p.g[g].b1 = A.d_b; p.g[g].w2 = Bl.d_w; p.g[g].b2 = Bl.d_b;
         p.g[g].out = g ? out1 : out0; p.g[g].cout = Bl.cout;
-        flops += 2.0 * B * H * W * ((double)A.cout * A.cin + (double)Bl.cout * Bl.cin);
+        flops += 2.0 * (double)npix * ((double)A.cout * A.cin + (double)Bl.cout * Bl.cin);
     }
-    p.npix = (long long)B * H * W; p.lda = lda; p.ldc = ldc; p.cmid = LA.cout; p.cout_pad = LB.cout_pad; p.relu2 = reluB;
+    p.npix = npix; p.lda = lda; p.ldc = ldc; p.cmid = LA.cout; p.cout_pad = LB.cout_pad; p.relu2 = reluB;
     if (c->prof_on == 1) {
         const std::string kn = "conv1x1_pair_c" + std::to_string(LA.cout) + "_n" + std::to_string(LB.cout_pad);
-        if ((rc = prof_begin(c, std::string(labelA) + "+" + labelB + "|" + kn, flops, 4.0 * B * H * W * groups * (LA.cin + LB.cout)))) return rc;
+        if ((rc = prof_begin(c, std::string(labelA) + "+" + labelB + "|" + kn, flops, 4.0 * (double)npix * groups * (LA.cin + LB.cout)))) return rc;
     }
     if ((rc = conv_pair_launch(p, groups, c->stream))) return rc;
     return prof_end(c);
@@ -894,6 +926,13 @@ static int run_pair(pmx_ctx* c, const char* labelA, const char* labelB, int a0, 
 // which form conv1_1 -> conv1_2 (+ pool) takes: *fuse: one launch (direct conv1_2 on 8 x 16 x 64 tiles: large maps); returns true for
 // conv1_2 as Winograd F(2x2, 3x3) on 16 x 16 squares (conv1_wino.hip): wherever the Winograd kernels are allowed (conv_algo >= 1) and the
 // launch has at least one block per CU (smaller launches: the 8 x 16 direct tiles give twice the blocks); conv1_wino = 2: always
+// conv1_1 + conv1_2 have the shapes conv1_wino_kernel is written for (3 -> 64 -> 64, fp32)?
+static bool conv1_pairable(const pmx_ctx* c)
+{
+    const PackedLayer& L1 = c->layers[c->index.at("conv1_1")];
+    const PackedLayer& L2 = c->layers[c->index.at("conv1_2")];
+    return c->opt_precision == 0 && c->opt_force[3] < 0 && L1.cin == 3 && L1.cout == 64 && L2.cin == 64 && L2.cout == 64;
+}
 static bool conv1_form(const pmx_ctx* c, int B, int H, int W, bool* fuse_out)
 {
     const PackedLayer& L1 = c->layers[c->index.at("conv1_1")];
@@ -913,10 +952,12 @@ static int run_conv1(pmx_ctx* c, int B, int H, int W)
     const PackedLayer& L1 = c->layers[i1];
     const PackedLayer& L2 = c->layers[i2];
     bool fuse = false;
-    const bool wino1 = conv1_form(c, B, H, W, &fuse);
+    const bool seg = !c->segs.empty();
+    const bool wino1 = seg ? conv1_pairable(c) : conv1_form(c, B, H, W, &fuse);
     const uint8_t* in_u8 = c->in_u8;
     c->in_u8 = nullptr;                                   // (valid for this forward only)
     PMX_CHECK(!in_u8 || wino1, PMX_ERR_STATE, "conv1: a uint8 input without the kernel that preprocesses it");
+    PMX_CHECK(!seg || (wino1 && in_u8), PMX_ERR_INVALID, "heterogeneous forward: needs conv1 as conv1_wino_kernel on a uint8 input");
     int rc;
     if (!fuse && !wino1) {
         if ((rc = run_conv(c, "conv1_1", i1, -1, c->in16, nullptr, PMX_IN_C, c->act0, nullptr, 64, B, H, W, 1, 0))) return rc;
@@ -935,9 +976,11 @@ static int run_conv1(pmx_ctx* c, int B, int H, int W)
             a.g[1].in = reinterpret_cast<const float*>(in_u8);
             a.kbounds = (unsigned long long)__builtin_bit_cast(unsigned, c->in_div);
         }
+        if (seg) { a.nseg = (int)c->segs.size(); a.segs = c->d_segs + (size_t)PMX_SEG_CONV1 * c->segs.size(); a.seg_tiles = c->seg_tiles[PMX_SEG_CONV1]; }
         if (c->prof_on == 1) {
-            const double f1 = 2.0 * B * H * W * 9.0 * (double)L1.cout * L1.cin, f2 = 2.0 * B * H * W * 9.0 * (double)L2.cout * L2.cin;
-            if ((rc = prof_begin(c, "conv1_1+conv1_2|conv_wino1_f2x2_t16x16", f1 + f2, (in_u8 ? 3.0 : 4.0 * 3) * B * H * W + 4.0 * B * H * W * (64 / 4), f1 + f2 * 16.0 / 36.0))) return rc;
+            const double np0 = seg ? (double)c->seg_pix[0] : (double)B * H * W;
+            const double f1 = 2.0 * np0 * 9.0 * (double)L1.cout * L1.cin, f2 = 2.0 * np0 * 9.0 * (double)L2.cout * L2.cin;
+            if ((rc = prof_begin(c, "conv1_1+conv1_2|conv_wino1_f2x2_t16x16", f1 + f2, (in_u8 ? 3.0 : 4.0 * 3) * np0 + 4.0 * np0 * (64 / 4), f1 + f2 * 16.0 / 36.0))) return rc;
         }
         if ((rc = conv1_wino_launch(a, c->stream))) return rc;
         return prof_end(c);
@@ -997,37 +1040,40 @@ static int forward_cpm(pmx_ctx* c, int B, int H, int W)
 #undef RUN1
     c->maps_valid = true; c->maps_external = false;
     c->cur_B = B; c->cur_fh = H8; c->cur_fw = W8;
+    c->cur_segs.clear();
     c->pp_valid = false;
     return PMX_OK;
 }
 
 int pmx_forward_from_in16(pmx_ctx* c, int B, int H, int W)
 {
+    PMX_CHECK(c->segs.empty() || c->kind == NET_POSE, PMX_ERR_INVALID, "heterogeneous forward: posenet only");
     if (c->kind != NET_POSE) return forward_cpm(c, B, H, W);
     auto id = [&](const char* n) { return c->index.at(n); };
     int rc;
     const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
 #define RUN(...) do { if ((rc = run_conv(c, __VA_ARGS__))) return rc; } while (0)
     // stem (CocoPoseNet.py:136-151)
+    // (the last argument = the resolution level, read only by a heterogeneous forward: pmx_multi.hip)
     if ((rc = run_conv1(c, B, H, W))) return rc;
-    RUN("conv2_1", id("conv2_1"), -1, c->act1, nullptr, 64, c->act0, nullptr, 128, B, H2, W2, 1, 0);
-    RUN("conv2_2", id("conv2_2"), -1, c->act0, nullptr, 128, c->act1, nullptr, 128, B, H2, W2, 1, 1);
-    RUN("conv3_1", id("conv3_1"), -1, c->act1, nullptr, 128, c->act0, nullptr, 256, B, H4, W4, 1, 0);
-    RUN("conv3_2", id("conv3_2"), -1, c->act0, nullptr, 256, c->act1, nullptr, 256, B, H4, W4, 1, 0);
-    RUN("conv3_3", id("conv3_3"), -1, c->act1, nullptr, 256, c->act0, nullptr, 256, B, H4, W4, 1, 0);
-    RUN("conv3_4", id("conv3_4"), -1, c->act0, nullptr, 256, c->act1, nullptr, 256, B, H4, W4, 1, 1);
-    RUN("conv4_1", id("conv4_1"), -1, c->act1, nullptr, 256, c->act0, nullptr, 512, B, H8, W8, 1, 0);
-    RUN("conv4_2", id("conv4_2"), -1, c->act0, nullptr, 512, c->act1, nullptr, 512, B, H8, W8, 1, 0);
-    RUN("conv4_3_CPM", id("conv4_3_CPM"), -1, c->act1, nullptr, 512, c->act0, nullptr, 256, B, H8, W8, 1, 0);
-    RUN("conv4_4_CPM", id("conv4_4_CPM"), -1, c->act0, nullptr, 256, c->cat + PMX_CAT_FEAT, nullptr, PMX_CAT_C, B, H8, W8, 1, 0);
+    RUN("conv2_1", id("conv2_1"), -1, c->act1, nullptr, 64, c->act0, nullptr, 128, B, H2, W2, 1, 0, 1);
+    RUN("conv2_2", id("conv2_2"), -1, c->act0, nullptr, 128, c->act1, nullptr, 128, B, H2, W2, 1, 1, 1);
+    RUN("conv3_1", id("conv3_1"), -1, c->act1, nullptr, 128, c->act0, nullptr, 256, B, H4, W4, 1, 0, 2);
+    RUN("conv3_2", id("conv3_2"), -1, c->act0, nullptr, 256, c->act1, nullptr, 256, B, H4, W4, 1, 0, 2);
+    RUN("conv3_3", id("conv3_3"), -1, c->act1, nullptr, 256, c->act0, nullptr, 256, B, H4, W4, 1, 0, 2);
+    RUN("conv3_4", id("conv3_4"), -1, c->act0, nullptr, 256, c->act1, nullptr, 256, B, H4, W4, 1, 1, 2);
+    RUN("conv4_1", id("conv4_1"), -1, c->act1, nullptr, 256, c->act0, nullptr, 512, B, H8, W8, 1, 0, 3);
+    RUN("conv4_2", id("conv4_2"), -1, c->act0, nullptr, 512, c->act1, nullptr, 512, B, H8, W8, 1, 0, 3);
+    RUN("conv4_3_CPM", id("conv4_3_CPM"), -1, c->act1, nullptr, 512, c->act0, nullptr, 256, B, H8, W8, 1, 0, 3);
+    RUN("conv4_4_CPM", id("conv4_4_CPM"), -1, c->act0, nullptr, 256, c->cat + PMX_CAT_FEAT, nullptr, PMX_CAT_C, B, H8, W8, 1, 0, 3);
     // stage 1 (CocoPoseNet.py:154-165); L1 = PAF branch, L2 = heat-map branch
     float* cat = c->cat;
-    RUN("conv5_1_CPM", id("conv5_1_CPM_L1"), id("conv5_1_CPM_L2"), cat, cat, PMX_CAT_C, c->brA, c->brA + 128, 256, B, H8, W8, 1, 0);
-    RUN("conv5_2_CPM", id("conv5_2_CPM_L1"), id("conv5_2_CPM_L2"), c->brA, c->brA + 128, 256, c->brB, c->brB + 128, 256, B, H8, W8, 1, 0);
-    RUN("conv5_3_CPM", id("conv5_3_CPM_L1"), id("conv5_3_CPM_L2"), c->brB, c->brB + 128, 256, c->brA, c->brA + 128, 256, B, H8, W8, 1, 0);
+    RUN("conv5_1_CPM", id("conv5_1_CPM_L1"), id("conv5_1_CPM_L2"), cat, cat, PMX_CAT_C, c->brA, c->brA + 128, 256, B, H8, W8, 1, 0, 3);
+    RUN("conv5_2_CPM", id("conv5_2_CPM_L1"), id("conv5_2_CPM_L2"), c->brA, c->brA + 128, 256, c->brB, c->brB + 128, 256, B, H8, W8, 1, 0, 3);
+    RUN("conv5_3_CPM", id("conv5_3_CPM_L1"), id("conv5_3_CPM_L2"), c->brB, c->brB + 128, 256, c->brA, c->brA + 128, 256, B, H8, W8, 1, 0, 3);
     // conv5_4 (128 -> 512, ReLU) -> conv5_5 (512 -> 38 | 19): one launch
     if ((rc = run_pair(c, "conv5_4_CPM", "conv5_5_CPM", id("conv5_4_CPM_L1"), id("conv5_4_CPM_L2"), id("conv5_5_CPM_L1"), id("conv5_5_CPM_L2"),
-                       c->brA, c->brA + 128, 256, c->brT, c->brT + 512, 1024, cat + PMX_CAT_PAF, cat + PMX_CAT_HEAT, PMX_CAT_C, B, H8, W8, 0)))
+                       c->brA, c->brA + 128, 256, c->brT, c->brT + 512, 1024, cat + PMX_CAT_PAF, cat + PMX_CAT_HEAT, PMX_CAT_C, B, H8, W8, 0, 3)))
         return rc;
     // stages 2-6 (CocoPoseNet.py:168-260)
     char n1[48], n2[48], m1[48], m2[48], lab[48], lab2[48];
@@ -1042,22 +1088,30 @@ int pmx_forward_from_in16(pmx_ctx* c, int B, int H, int W)
             else { in0 = c->brB; in1 = c->brB + 128; lda = 256; }
             if (i % 2 == 1) { o0 = c->brA; o1 = c->brA + 128; }
             else { o0 = c->brB; o1 = c->brB + 128; }
-            RUN(lab, id(n1), id(n2), in0, in1, lda, o0, o1, 256, B, H8, W8, 1, 0);
+            RUN(lab, id(n1), id(n2), in0, in1, lda, o0, o1, 256, B, H8, W8, 1, 0, 3);
         }
         // Mconv6 (1x1 128 -> 128, ReLU; reads Mconv5's output in brA) -> Mconv7 (1x1 128 -> 38 | 19, into the cat slices): one launch
         snprintf(n1, sizeof n1, "Mconv6_stage%d_L1", s); snprintf(n2, sizeof n2, "Mconv6_stage%d_L2", s);
         snprintf(m1, sizeof m1, "Mconv7_stage%d_L1", s); snprintf(m2, sizeof m2, "Mconv7_stage%d_L2", s);
         snprintf(lab, sizeof lab, "Mconv6_stage%d", s); snprintf(lab2, sizeof lab2, "Mconv7_stage%d", s);
         if ((rc = run_pair(c, lab, lab2, id(n1), id(n2), id(m1), id(m2), c->brA, c->brA + 128, 256, c->brB, c->brB + 128, 256,
-                           cat + PMX_CAT_PAF, cat + PMX_CAT_HEAT, PMX_CAT_C, B, H8, W8, 0))) return rc;
+                           cat + PMX_CAT_PAF, cat + PMX_CAT_HEAT, PMX_CAT_C, B, H8, W8, 0, 3))) return rc;
     }
 #undef RUN
     c->maps_valid = true; c->maps_external = false;
     c->cur_B = B; c->cur_fh = H8; c->cur_fw = W8;
+    c->cur_segs = c->segs;           // (empty for a uniform batch)
     c->pp_valid = false;
     return PMX_OK;
 }
 
+int pmx_check_weights(pmx_ctx* c)
+{
+    int missing = 0;
+    for (auto& l : c->layers) missing += l.set ? 0 : 1;
+    PMX_CHECK(missing == 0, PMX_ERR_WEIGHTS, "forward: %d of %d layers have no weights", missing, (int)c->layers.size());
+    return PMX_OK;
+}
 static int check_forward_args(pmx_ctx* c, const void* p, int B, int H, int W)
 {
     PMX_CHECK(c && p, PMX_ERR_INVALID, "forward: null arg");
@@ -1087,7 +1141,7 @@ extern "C" int pmx_forward_u8(pmx_ctx* c, const uint8_t* img, int B, int H, int 
 int pmx_forward_from_u8(pmx_ctx* c, const uint8_t* d, int B, int H, int W, float divisor)
 {
     int rc;
-    if (conv1_form(c, B, H, W, nullptr)) {                // conv1_wino_kernel reads the uint8 pixels and preprocesses them in its patch load
+    if (!c->segs.empty() || conv1_form(c, B, H, W, nullptr)) {                // conv1_wino_kernel reads the uint8 pixels and preprocesses them in its patch load
         c->in_u8 = d; c->in_div = divisor;
         rc = pmx_forward_from_in16(c, B, H, W);
         c->in_u8 = nullptr;
@@ -1116,7 +1170,9 @@ extern "C" int pmx_forward_f32(pmx_ctx* c, const float* x, int B, int H, int W, 
 // OpenCV INTER_LINEAR uint8 tables for one axis: [idx0 | idx1 | coef0 | coef1], each `dst` ints.
 // fx = float((d + 0.5) * scale - 0.5) with scale = 1 / (dst / src) in double; s = floor(fx); fx -= s;
 // s < 0 -> (0, fx = 0); s >= src - 1 -> (src - 1, fx = 0); coefficients cvRound((1 - fx) * 2048), cvRound(fx * 2048).
-static void make_resize_table(int dst, int src, int* tab)
+void pmx_make_resize_table(int dst, int src, int* tab);
+static void make_resize_table(int dst, int src, int* tab) { pmx_make_resize_table(dst, src, tab); }
+void pmx_make_resize_table(int dst, int src, int* tab)
 {
     const double scale = 1.0 / ((double)dst / (double)src);
     for (int d = 0; d < dst; ++d) {
@@ -1188,6 +1244,7 @@ extern "C" int pmx_get_maps(pmx_ctx* c, float* paf, float* heat)
 {
     PMX_CHECK(c, PMX_ERR_INVALID, "null ctx");
     PMX_CHECK(c->maps_valid, PMX_ERR_STATE, "pmx_get_maps: no forward / set_maps yet");
+    PMX_CHECK(c->cur_segs.empty(), PMX_ERR_STATE, "pmx_get_maps: the current maps are those of a mixed-size batch (use pmx_get_image_maps)");
     PMX_DEV(c);
     const int B = c->cur_B, fh = c->cur_fh, fw = c->cur_fw;
     PMX_CHECK(c->kind == NET_POSE || !paf, PMX_ERR_INVALID, "pmx_get_maps: facenet / handnet have no PAF output (pass NULL)");
@@ -1232,6 +1289,7 @@ extern "C" int pmx_set_maps(pmx_ctx* c, const float* paf, const float* heat, int
     PMX_HIP(hipStreamSynchronize(c->stream));    // host buffers may be released by the caller
     c->maps_valid = true; c->maps_external = true;
     c->cur_B = B; c->cur_fh = fh; c->cur_fw = fw;
+    c->cur_segs.clear();
     c->pp_valid = false;
     return PMX_OK;
 }
@@ -1326,6 +1384,7 @@ extern "C" int pmx_postprocess(pmx_ctx* c, int B, int map_h, int map_w, double i
     PMX_CHECK(c->kind == NET_POSE, PMX_ERR_STATE, "pmx_postprocess: posenet only (use pmx_keypoints for facenet / handnet)");
     PMX_CHECK(c->maps_valid, PMX_ERR_STATE, "pmx_postprocess: no network output (call forward or set_maps first)");
     PMX_CHECK(B == c->cur_B, PMX_ERR_INVALID, "pmx_postprocess: batch %d != batch of the current maps %d", B, c->cur_B);
+    PMX_CHECK(c->cur_segs.empty(), PMX_ERR_STATE, "pmx_postprocess: the current maps are those of a mixed-size batch (use pmx_postprocess_images)");
     PMX_CHECK(map_h >= 1 && map_w >= 1 && (long long)map_h * map_w < (1ll << 31), PMX_ERR_INVALID, "pmx_postprocess: bad map size");
     PMX_DEV(c);
     int rc;
@@ -1365,7 +1424,25 @@ extern "C" int pmx_postprocess(pmx_ctx* c, int B, int map_h, int map_w, double i
     if (rc) return rc;
     c->pp_valid = true; c->pp_final = false; c->pp_B = B; c->pp_h = map_h; c->pp_w = map_w;
     c->pp_maps = m; c->pp_img_len = img_len; c->pp_has_scale = scale_xy != nullptr;
+    c->pp_calls.clear();
     return PMX_OK;
+}
+
+// the post-process buffers as the images [base, ...) see them: every per-image array moved on by `base` images (strides: pp_alloc)
+PPBuffers pmx_pp_view(const PPBuffers& p, int base)
+{
+    PPBuffers v = p;
+    const size_t b = (size_t)base, npk = (size_t)PMX_N_JOINTS * p.cap_pk, nl = (size_t)PMX_N_LIMBS;
+    v.pk_raw_key += b * npk; v.pk_raw_score += b * npk; v.pk_count += b * PMX_N_JOINTS;
+    v.pk_x += b * npk; v.pk_y += b * npk; v.pk_score += b * npk; v.pk_start += b * (PMX_N_JOINTS + 1);
+    v.cn_a += b * nl * p.cap_pk; v.cn_b += b * nl * p.cap_pk; v.cn_score += b * nl * p.cap_pk;
+    v.cn_count += b * nl; v.cn_need += b * nl;
+    v.scan_score += b * nl * p.scan_cap; v.scan_idx += b * nl * p.scan_cap; v.scan_cnt += b * nl;
+    if (p.cand_score) { v.cand_score += b * nl * p.cap_cand; v.cand_idx += b * nl * p.cap_cand; v.cand_used += b * nl * 2 * p.cap_pk; }
+    if (p.sub_work) v.sub_work += b * p.cap_sub * 20;
+    v.subsets += b * p.cap_sub * 20; v.status += b; v.results += b * p.rec_bytes;
+    v.smoothed = nullptr;            // (sized for ONE map size: not available per segment)
+    return v;
 }
 
 // ---- capacities: the reference has none (np.vstack / lists); ours grow on demand ------------------------------------------
@@ -1447,8 +1524,14 @@ static int pp_finalize(pmx_ctx* c)
         int rc = pp_realloc(c, cap_pk, cap_sub, cap_cand, cap_ppl);
         if (rc) { c->pp_valid = false; return rc; }      // (old buffers and capacities stay in place; this batch has no results)
         c->pp_regrown += 1;
-        rc = pp_launch(c->pp_maps, c->tab, c->pp, B, c->pp_h, c->pp_w, c->pp_img_len, c->pp_has_scale ? c->d_scale : nullptr,
-                       c->opt_keep_smoothed && c->pp.smoothed, c->stream, nullptr, nullptr, c->pp_limbs_slices);
+        if (c->pp_calls.empty()) {
+            rc = pp_launch(c->pp_maps, c->tab, c->pp, B, c->pp_h, c->pp_w, c->pp_img_len, c->pp_has_scale ? c->d_scale : nullptr,
+                           c->opt_keep_smoothed && c->pp.smoothed, c->stream, nullptr, nullptr, c->pp_limbs_slices);
+        } else {                     // a mixed batch: every segment again, on its own slice of the (new) buffers
+            for (const PPCall& q : c->pp_calls)
+                if ((rc = pp_launch(q.maps, q.tab, pmx_pp_view(c->pp, q.base), q.B, q.map_h, q.map_w, q.img_len, q.has_scale ? c->d_scale + 2 * q.base : nullptr,
+                                    0, c->stream, nullptr, nullptr, q.limbs_slices))) break;
+        }
         if (rc) { c->pp_valid = false; return rc; }
     }
     pmx_set_error("post-process capacities did not converge");

@@ -61,6 +61,17 @@ struct ConvGroupArgs {
     int cout;           // real output channels (<= cout_pad)
     int pad_;
 };
+// Heterogeneous launches: a SEGMENT = n images of one map size.  The segments of a launch lie end to end in the activation buffers
+// (segment s, image i at pixel pix0 + i * H * W of the input, pixo + i * (output pixels per image) of the output) and own consecutive
+// tiles of the launch.  The table lives in device memory (one per resolution level and tile shape of a forward: conv_build_segs).
+struct ConvSeg {
+    int H, W;            // map size of the segment's images at this layer (before the optional pool)
+    int tiles_x;         // tile columns per image
+    int tiles_img;       // tiles per image
+    int tile0;           // first tile of the segment in the launch
+    int n;               // images
+    int pix0, pixo;      // first input / output pixel of the segment in the launch's buffers
+};
 struct ConvArgs {
     ConvGroupArgs g[2];
     int B, H, W;        // conv input == output spatial size (before the optional 2x2 pool)
@@ -81,6 +92,9 @@ struct ConvArgs {
     // tile grid of one image); this launch covers the blocks [run_j0, run_j0 + run_nb) of every image
     int run_j0, run_nb;
     int run_nslab;           // slabs of 46 columns per image (W / 46)
+    // heterogeneous launch (rectangles of conv_wino_kernel, squares of conv1_wino_kernel; plain mode): nseg segments, seg_tiles tiles in all
+    int nseg, seg_tiles;
+    const ConvSeg* segs;     // device memory
 };
 // Transformed Winograd weights (pmx_api.hip::pack_wino -> conv_wino_kernel): [plane][chunk32][cout_pad / 32][k8-step 4][32][8] -- the four
 // k8-steps of a wave's 32 channels are 1 KB apart, an immediate offset of the load

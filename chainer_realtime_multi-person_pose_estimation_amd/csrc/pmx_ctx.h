@@ -51,8 +51,28 @@ struct PrLane {
     float* sk_scratch = nullptr; size_t sk_floats = 0;
 };
 
+// Heterogeneous batches (pmx_multi.hip): a SEGMENT = n images of one network-input size.  The segments of a forward lie end to end in
+// every activation buffer; per resolution level (0 = input .. 3 = 1/8) and tile shape a device table tells the kernels which tiles
+// belong to which segment (pmx_common.h::ConvSeg).  Tables of one forward: conv1's 16 x 16 squares at level 0 (output = level 1), the
+// 8 x 16 rectangles of levels 1, 2 (un-pooled / pooled output) and 3.
+struct SegDesc { int n, H, W; };
+enum { PMX_SEG_CONV1 = 0, PMX_SEG_L1 = 1, PMX_SEG_L1P = 2, PMX_SEG_L2 = 3, PMX_SEG_L2P = 4, PMX_SEG_L3 = 5, PMX_SEG_TABLES = 6 };
+#define PMX_SEG_RECT(level, pool) ((level) == 1 ? ((pool) ? PMX_SEG_L1P : PMX_SEG_L1) : (level) == 2 ? ((pool) ? PMX_SEG_L2P : PMX_SEG_L2) : PMX_SEG_L3)
+// one post-process launch set of the current results: a uniform batch is one call (base 0), a mixed batch one per segment
+struct PPCall { PPMaps maps; PPTables tab; int base, B, map_h, map_w; double img_len; bool has_scale; int limbs_slices; };
+
 // ------------------------------------------------------------------------------------------- context
 struct pmx_ctx {
+    // heterogeneous forward / post-process state
+    std::vector<SegDesc> segs;       // non-empty only WHILE a heterogeneous forward is being enqueued (run_conv / run_pair / run_conv1 look at it)
+    std::vector<SegDesc> cur_segs;   // layout of the current network output when it came from a heterogeneous forward (else empty)
+    ConvSeg* d_segs = nullptr; size_t d_segs_cap = 0;     // device: PMX_SEG_TABLES tables of segs.size() entries
+    int seg_tiles[PMX_SEG_TABLES] = {};                   // tiles per launch, per table
+    long long seg_pix[4] = {};                            // pixels of all segments, per level
+    std::vector<PPCall> pp_calls;                         // non-empty: the post-process of the current results ran per segment
+    std::map<std::tuple<int, int, int, int>, PPTables> tab_cache;   // up-sampling tables per (in_h, in_w, out_h, out_w) of the per-segment calls
+    uint8_t* mi_src = nullptr; size_t mi_src_cap = 0;     // pmx_detect_images: original-size images awaiting the device resize
+    int* mi_tab = nullptr; size_t mi_tab_cap = 0;         // ... and their resize tables
     int kind = NET_POSE;             // architecture: posenet | facenet | handnet
     int n_heat = PMX_N_HEAT;         // heat-map channels of the last layer (19 | 71 | 22)
     int cat_c = PMX_CAT_C;           // channels of the cat buffer (192 | 208 | 160)
@@ -161,3 +181,6 @@ struct pmx_ctx {
 int pmx_forward_from_u8(pmx_ctx* c, const uint8_t* d_u8, int B, int H, int W, float divisor);
 int pmx_forward_from_in16(pmx_ctx* c, int B, int H, int W);      // the network on the padded float input already in c->in16
 int pmx_ensure_tables(pmx_ctx* c, int in_h, int in_w, int out_h, int out_w, int flip_x = 0);   // up-sampling tables of the post-process
+PPBuffers pmx_pp_view(const PPBuffers& p, int base);         // the post-process buffers of the images [base, ...) (every per-image array offset)
+void pmx_make_resize_table(int dst, int src, int* tab);      // OpenCV INTER_LINEAR uint8 table of one axis: [idx0 | idx1 | coef0 | coef1] x dst
+int pmx_check_weights(pmx_ctx* c);                            // PMX_ERR_WEIGHTS unless every layer has weights

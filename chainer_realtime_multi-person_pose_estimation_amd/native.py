@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libpose_mi355x.so')
 HEADER = os.path.join(os.path.dirname(HERE), 'include', 'pose_mi355x.h')
-SOURCES = [('pmx_api.hip', []), ('pmx_precise.hip', []), ('conv_mfma.hip', []), ('conv_wino.hip', ['-mllvm', '-pragma-unroll-threshold=200000']), ('conv1_wino.hip', []), ('conv_select.hip', []), ('prep.hip', ['-ffp-contract=off']),
+SOURCES = [('pmx_api.hip', []), ('pmx_precise.hip', []), ('pmx_multi.hip', []), ('conv_mfma.hip', []), ('conv_wino.hip', ['-mllvm', '-pragma-unroll-threshold=200000']), ('conv1_wino.hip', []), ('conv_select.hip', []), ('prep.hip', ['-ffp-contract=off']),
            ('postproc.hip', ['-ffp-contract=off'])]
 # the opt-in bf16x3 kernels (option "precision" = 1; DESIGN.md 4.1.5: frozen, slower than the fp32 Winograd path) are NOT part of the
 # default library: PMX_BUILD_BF16X3=1 in the environment of the build adds their translation unit (the stamp then differs, so the
@@ -40,6 +40,12 @@ def result_dtype(people_cap):
 
 
 RESULT_DTYPE = result_dtype(INIT_PEOPLE)       # layout at the initial person capacity
+
+
+class PmxImage(C.Structure):
+    """include/pose_mi355x.h::pmx_image -- one image of a mixed-size batch (pmx_detect_images)."""
+    _fields_ = [('bgr', C.c_void_p), ('src_h', C.c_int), ('src_w', C.c_int), ('net_h', C.c_int), ('net_w', C.c_int),
+                ('map_h', C.c_int), ('map_w', C.c_int)]
 
 
 class PmxError(RuntimeError):
@@ -236,6 +242,10 @@ def load():
         'pmx_set_gaussian': (ci, [vp, vp, ci]),
         'pmx_postprocess': (ci, [vp, ci, ci, ci, cd, vp]),
         'pmx_detect_batch': (ci, [vp, vp, ci, ci, ci, ci, ci, ci, cd, vp]),
+        'pmx_detect_images': (ci, [vp, vp, ci]),
+        'pmx_forward_u8_images': (ci, [vp, vp, vp, ci, ci]),
+        'pmx_postprocess_images': (ci, [vp, vp, ci, vp]),
+        'pmx_get_image_maps': (ci, [vp, ci, vp, vp, ci, ci]),
         'pmx_results_layout': (ci, [vp, ip, C.POINTER(C.c_size_t)]),
         'pmx_get_results': (ci, [vp, ci, vp, C.c_size_t]),
         'pmx_results_device_ptr': (ci, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
@@ -416,7 +426,7 @@ class Engine(object):
 
     def get_maps(self):
         """posenet: (paf, heat); facenet / handnet: heat only (B, 71 | 22, h, w)."""
-        fh, fw = self._fhw
+        fh, fw = self._fhw if self._fhw is not None else (1, 1)      # (a mixed batch has no common size: the library refuses, see image_maps)
         heat = np.empty((self._B, self.n_heat, fh, fw), np.float32)
         if self.arch != 'posenet':
             self._check(self.lib.pmx_get_maps(self._ctx, None, _ptr(heat)))
@@ -480,6 +490,56 @@ class Engine(object):
         self._check(self.lib.pmx_set_maps(self._ctx, _ptr(paf), _ptr(heat), B, fh, fw))
         self._B = B
         self._fhw = (fh, fw)
+
+    # ---- mixed-size batches (pmx_detect_images and its two halves) ------------------------------------
+    def detect_images(self, imgs, net_hw, map_hw):
+        """imgs: list of H x W x 3 uint8 BGR arrays of ANY sizes; net_hw / map_hw: per image (h, w) of the network input / the up-sampled
+        maps.  cv2.resize (:493), network and post-process on the device, one launch per layer over all images; records (results()) in
+        image order."""
+        keep = [np.ascontiguousarray(im, dtype=np.uint8) for im in imgs]
+        B = len(keep)
+        arr = (PmxImage * B)()
+        for i, im in enumerate(keep):
+            assert im.ndim == 3 and im.shape[2] == 3
+            arr[i].bgr = im.ctypes.data
+            arr[i].src_h, arr[i].src_w = im.shape[0], im.shape[1]
+            arr[i].net_h, arr[i].net_w = int(net_hw[i][0]), int(net_hw[i][1])
+            arr[i].map_h, arr[i].map_w = int(map_hw[i][0]), int(map_hw[i][1])
+        self._check(self.lib.pmx_detect_images(self._ctx, arr, B))
+        self._B = B
+        self._fhw = None
+        self._map = None
+        self._img_fhw = [(int(h) // 8, int(w) // 8) for h, w in net_hw]
+        self._img_map = [(int(h), int(w)) for h, w in map_hw]
+
+    def forward_u8_images(self, imgs):
+        """the network alone on uint8 images already at their network sizes (multiples of 8)"""
+        keep = [np.ascontiguousarray(im, dtype=np.uint8) for im in imgs]
+        flat = np.concatenate([k.reshape(-1) for k in keep])
+        hw = np.ascontiguousarray([[k.shape[0], k.shape[1]] for k in keep], dtype=np.int32)
+        self._check(self.lib.pmx_forward_u8_images(self._ctx, _ptr(flat), _ptr(hw), len(keep), 0))
+        self._B = len(keep)
+        self._fhw = None
+        self._img_fhw = [(k.shape[0] // 8, k.shape[1] // 8) for k in keep]
+
+    def postprocess_images(self, map_hw, scale_xy=None):
+        hw = np.ascontiguousarray(map_hw, dtype=np.int32).reshape(-1, 2)
+        sp = None
+        if scale_xy is not None:
+            scale_xy = np.ascontiguousarray(scale_xy, dtype=np.float64).reshape(len(hw), 2)
+            sp = _ptr(scale_xy)
+        self._check(self.lib.pmx_postprocess_images(self._ctx, _ptr(hw), len(hw), sp))
+        self._map = None
+        self._img_map = [(int(h), int(w)) for h, w in hw]
+
+    def image_maps(self, image, fh=None, fw=None):
+        """(paf 38 x fh x fw, heat 19 x fh x fw) of ONE image of the current batch (uniform or mixed)."""
+        if fh is None:
+            fh, fw = self._img_fhw[image] if self._fhw is None else self._fhw
+        paf = np.empty((N_PAF, fh, fw), np.float32)
+        heat = np.empty((N_HEAT, fh, fw), np.float32)
+        self._check(self.lib.pmx_get_image_maps(self._ctx, int(image), _ptr(paf), _ptr(heat), int(fh), int(fw)))
+        return paf, heat
 
     # ---- post-process ------------------------------------------------------------------------------
     def postprocess(self, map_h, map_w, img_len, scale_xy=None):

@@ -345,13 +345,20 @@ class PoseDetector(object):
         return hands
 
     def detect_batch(self, imgs):
-        """Batched `__call__`: list of H x W x 3 uint8 BGR images of ONE common size -> list of (poses, scores),
-        each identical to what `__call__` returns for that image (the reference handles one image per call)."""
+        """Batched `__call__`: list of H x W x 3 uint8 BGR images -> list of (poses, scores), one per image in the order given (the
+        reference handles one image per call).  Images of ONE common size run as a uniform batch; images of DIFFERENT sizes (the
+        reference picks the network size per image, :490-493) run as a mixed batch -- one launch per layer over all size classes
+        (include/pose_mi355x.h::pmx_detect_images) -- instead of one call per image.  Per image the result is what `__call__` returns
+        for it, up to the kernel-choice-by-launch-size rounding of the network."""
         imgs = [np.asarray(im) for im in imgs]
-        shape = imgs[0].shape
+        if len(imgs) == 0:
+            raise ValueError('detect_batch needs at least one image')
         for im in imgs:
-            if im.shape != shape or im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
-                raise ValueError('detect_batch needs uint8 H x W x 3 images of one common size')
+            if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
+                raise ValueError('detect_batch needs uint8 H x W x 3 images')
+        shape = imgs[0].shape
+        if any(im.shape != shape for im in imgs):
+            return self._detect_mixed(imgs)
         orig_h, orig_w, _ = shape
         input_w, input_h = self.compute_optimal_size(imgs[0], params['inference_img_size'])   # :490
         map_w, map_h = self.compute_optimal_size(imgs[0], params['heatmap_size'])            # :491
@@ -376,6 +383,37 @@ class PoseDetector(object):
             self.engine.set_maps(np.stack(pafs), np.stack(heats))
             self.engine.postprocess(map_h, map_w, img_len=map_w, scale_xy=scale)                # :501-516
         return unpack_results(self.engine.results())
+
+    def _detect_mixed(self, imgs):
+        """detect_batch for images of different sizes.  Images are sorted by network size (few segments), results return in the caller's
+        order.  `model=` callables: one call per image, as the reference does."""
+        if self.model is not None:
+            return [self.detect_batch([im])[0] for im in imgs]
+        if self._weights is None or self.engine.weights_missing():
+            raise RuntimeError('PoseDetector has no weights: pass weights_file=, weights= or model=')
+        net, mp = [], []
+        for im in imgs:
+            w_, h_ = self.compute_optimal_size(im, params['inference_img_size'])                 # :490
+            mw_, mh_ = self.compute_optimal_size(im, params['heatmap_size'])                     # :491
+            net.append((h_, w_))
+            mp.append((mh_, mw_))
+        order = sorted(range(len(imgs)), key=lambda i: (net[i], mp[i], i))
+        px = sum(h * w for h, w in net)
+        mb, mh, mw = self._cap
+        if len(imgs) > mb or px > mb * mh * mw:
+            # capacity is a pixel budget (max_batch x max_h x max_w) and an image count: grow both as needed
+            nb = max(mb, len(imgs))
+            side = max(mh * mw, -(-px // nb))
+            self._make_engine(nb, mh, -(-side // (mh * 8)) * 8)          # (max_w: a multiple of 8)
+        self.engine.detect_images([imgs[i] for i in order], [net[i] for i in order], [mp[i] for i in order])
+        res = unpack_results(self.engine.results(), return_exceptions=True)
+        out = [None] * len(imgs)
+        for k, i in enumerate(order):
+            out[i] = res[k]
+        for r in out:                                  # (the reference would have raised on that image's call)
+            if isinstance(r, Exception):
+                raise r
+        return out
 
     def detect_maps(self, paf, heat, map_h, map_w, img_len=None, scale_xy=None):
         """Post-process only (pose_detector.py:501-517) on network outputs paf (B,38,h,w), heat (B,19,h,w)."""

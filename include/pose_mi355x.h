@@ -213,6 +213,33 @@ int pmx_keypoints(pmx_ctx* ctx, int batch, int out_h, int out_w, double thresh, 
 int pmx_detect_batch(pmx_ctx* ctx, const uint8_t* bgr_nhwc, int batch, int h, int w, int on_device,
                      int map_h, int map_w, double img_len, const double* scale_xy);
 
+/* ---- batches of images of DIFFERENT sizes ------------------------------------------------------------------------
+ * The reference takes any image in any call and picks the network size per image (pose_detector.py:490-493, compute_optimal_size
+ * :57-73), so a stream of frames has a new size every few images.  pmx_detect_images is `PoseDetector.__call__` (:484-517) for B
+ * such images in ONE call: per image the cv2.resize of :493 on the device, the network over all images as one launch per layer
+ * (consecutive images of one network size form a segment; the segments lie end to end in the activation buffers and a per-level
+ * table tells a block which segment its tile belongs to), the post-process per run of images with equal sizes -- with the image's
+ * own map size (:491, :501-502), img_len = map_w (:511) and coordinate rescale orig / map (:513-514).  Records in image order
+ * (pmx_get_results as usual).  Capacity: B <= max_batch and the sum of net_h * net_w <= max_batch * max_h * max_w of pmx_create.
+ * Per image the maps equal those of a single-image call that runs the plain Winograd kernels (options "conv_algo" 2, "conv1_wino" 2)
+ * bit for bit; against the default single-image call (unit-mode / split-K kernels) they differ by fp32 rounding like any two batch
+ * sizes do.  Callers sort their images by size to get few segments; any order is valid. */
+typedef struct pmx_image {
+    const uint8_t* bgr;      /* src_h x src_w x 3 uint8 BGR, host memory; read before the call returns */
+    int src_h, src_w;        /* original size */
+    int net_h, net_w;        /* network input size: compute_optimal_size(orig, inference_img_size), multiples of 8 */
+    int map_h, map_w;        /* size the network maps are up-sampled to: compute_optimal_size(orig, heatmap_size) */
+} pmx_image;
+int pmx_detect_images(pmx_ctx* ctx, const pmx_image* images, int batch);
+/* the two halves apart: the network on uint8 images already at their network sizes, pixels end to end (image i: net_hw[2 i] x
+ * net_hw[2 i + 1] x 3; host or device memory), and the post-process of those maps (image i up-sampled to map_hw[2 i] x map_hw[2 i + 1],
+ * img_len = that width; scale_xy: batch x 2 doubles or NULL as in pmx_postprocess) */
+int pmx_forward_u8_images(pmx_ctx* ctx, const uint8_t* bgr, const int* net_hw, int batch, int on_device);
+int pmx_postprocess_images(pmx_ctx* ctx, const int* map_hw, int batch, const double* scale_xy);
+/* parity accessor: the network output of ONE image of the current batch (uniform or mixed) as NCHW float32, paf 38 x fh x fw and heat
+ * 19 x fh x fw (either may be NULL); fh x fw must be the image's map size (network size / 8).  Synchronises. */
+int pmx_get_image_maps(pmx_ctx* ctx, int image, float* paf, float* heat, int fh, int fw);
+
 /* results.  pmx_results_layout synchronises, grows the capacities and re-runs the post-process if an image overflowed them,
  * and returns the layout of the (now final) records; pmx_get_results does the same and copies `batch` records to `out`
  * (out_bytes >= batch * bytes_per_record, else PMX_ERR_CAPACITY). */

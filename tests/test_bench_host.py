@@ -42,7 +42,10 @@ def test_pick_device_per_rank():
     gloo smoke mode: ranks wrap around the visible GPUs."""
     import pytest
     assert [bench.pick_device(r, 8, 8, 'nccl') for r in range(8)] == list(range(8))
-    assert [bench.pick_device(r, 1, 8, 'nccl') for r in range(8)] == [0] * 8          # HIP_VISIBLE_DEVICES = one device per rank
+    masked = {'HIP_VISIBLE_DEVICES': '3'}
+    assert [bench.pick_device(r, 1, 8, 'nccl', env=masked) for r in range(8)] == [0] * 8          # HIP_VISIBLE_DEVICES = one device per rank
+    with pytest.raises(SystemExit):
+        bench.pick_device(3, 1, 8, 'nccl', env={})                                      # one unmasked GPU for 8 RCCL ranks: all on one device
     assert bench.pick_device(0, 1, 1, 'nccl') == 0
     with pytest.raises(SystemExit):
         bench.pick_device(5, 4, 8, 'nccl')                                              # 4 GPUs for 8 ranks: no
@@ -50,3 +53,45 @@ def test_pick_device_per_rank():
         bench.pick_device(1, 1, 1, 'nccl')
     assert [bench.pick_device(r, 1, 8, 'gloo') for r in range(8)] == [0] * 8
     assert [bench.pick_device(r, 2, 4, 'gloo') for r in range(4)] == [0, 1, 0, 1]
+
+
+def test_compare_records_counts_poses_exact_scores_to_tolerance():
+    """bench.compare_records (the self-validation of an N > 1 line): identical counts / poses + scores within 1e-5 -> match; a pose that
+    moved, a lost person, or a score off by more than the tolerance -> no match, with the first offending record named; person
+    capacities of the two arrays may differ (a rank whose capacity grew)."""
+    import importlib
+    import numpy as np
+    native = importlib.import_module(bench.PKG + '.native')
+    rng = np.random.default_rng(0)
+
+    def make(cap, n_people):
+        r = np.zeros(len(n_people), native.result_dtype(cap))
+        for i, n in enumerate(n_people):
+            r[i]['n_people'] = n
+            r[i]['n_peaks'] = 10 * n + i
+            r[i]['poses'][:n] = rng.integers(0, 300, (n, 18, 3))
+            r[i]['scores'][:n] = rng.random(n) * 30
+        return r
+    a = make(64, [3, 0, 5, 1])
+    b = np.zeros(4, native.result_dtype(128))
+    for f in ('n_people', 'n_peaks', 'status', 'n_subsets_raw'):
+        b[f] = a[f]
+    b['poses'][:, :64] = a['poses']
+    b['scores'][:, :64] = a['scores']
+    ok = bench.compare_records(a, b)
+    assert ok['shard_records_match'] and ok['records_compared'] == 4 and ok['bitwise_equal_records'] == 4 and ok['max_abs_score_diff'] == 0.0
+    b['scores'][2, 1] += 3e-6
+    near = bench.compare_records(a, b)
+    assert near['shard_records_match'] and near['bitwise_equal_records'] == 3 and 2e-6 < near['max_abs_score_diff'] < 4e-6
+    b['scores'][2, 1] += 1e-3
+    assert not bench.compare_records(a, b)['shard_records_match']
+    b['scores'][2, 1] = a['scores'][2, 1]
+    b['poses'][0, 2, 5, 0] += 1.0
+    bad = bench.compare_records(a, b)
+    assert not bad['shard_records_match'] and bad['first_mismatch']['record'] == 0 and bad['records_with_identical_counts_and_poses'] == 3
+    b['poses'][0] = 0
+    b['poses'][0, :64] = a['poses'][0]
+    b['n_people'][3] = 0
+    lost = bench.compare_records(a, b)
+    assert not lost['shard_records_match'] and lost['first_mismatch'] == {'record': 3, 'n_people': [1, 0], 'n_peaks': [13, 13], 'status': [0, 0]}
+    assert not bench.compare_records(a[:0], b[:0])['shard_records_match']            # nothing compared is not a match

@@ -42,6 +42,10 @@ def test_two_ranks_equal_one_rank(tmp_path):
     assert line2['n_gpus'] == 2 and line2['config']['global_batch'] == 8 and line2['config']['records_gathered'] == 8
     assert len(line2['per_rank_frames_per_s']) == 2 and line2['gather_ms_per_step_rank0'] >= 0
     assert line2['collectives_per_step'] == 1.0 and 'RecordPipe' in line2['records_path']      # one gather per step, nothing else
+    # the line validates itself: rank 0 re-ran both shards and compared them with what came through the gather
+    assert line2['shard_records_match'] is True and line2['records_compared'] == 8 and line2['max_abs_score_diff'] <= 1e-5
+    assert line2['shard_validation']['ranks_checked'] == [0, 1] and line2['shard_validation']['bitwise_equal_records'] == 8
+    assert line2['scaling_record_valid'] is False and 'gloo' in line2['scaling_record_invalid_reason']      # shared GPU: never a scaling figure
     r1 = _run(['--gpus', '1', '--batch', '8', '--dump-records', f1] + common)
     assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-4000:]
     line1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith('{')][-1])
@@ -72,6 +76,7 @@ def test_eight_ranks_through_the_launcher(tmp_path):
     assert line['collectives_per_step'] == 1.0 and 'RecordPipe' in line['records_path']
     assert len(line['per_rank_frames_per_s']) == 8 and len(line['per_rank_frames_per_s_min_max']) == 2
     assert line['gather_ms_per_step_rank0'] >= 0 and line['scaling'] == 'weak'
+    assert line['shard_records_match'] is True and line['records_compared'] == 16 and line['shard_validation']['ranks_checked'] == list(range(8))
     rec = np.load(f8)
     assert len(rec) == 16 and int(rec['n_peaks'].sum()) > 0
 
@@ -89,10 +94,12 @@ def test_one_rank_through_the_rccl_gather_equals_plain_run(tmp_path):
     assert 'rccl' in lg['backend'] and 'RecordPipe' in lg['records_path'] and 'RCCL gather' in lg['records_path'] and lg['ranks_seen'] == [0]
     assert lg['collectives_per_step'] == 1.0 and 'RCCL' in lg['config']['parallelism']
     assert len(lg['devices']) == 1 and (lg['devices'][0]['uuid'] or lg['devices'][0]['pci_bus_id'])
+    assert lg['shard_records_match'] is True and lg['records_compared'] == 4 and lg['scaling_record_valid'] is True
     rp = _run(common + ['--dump-records', fp])
     assert rp.returncode == 0, rp.stdout[-2000:] + rp.stderr[-4000:]
     lp = json.loads([l for l in rp.stdout.splitlines() if l.startswith('{')][-1])
     assert lp['backend'] is None and 'pmx_get_results' in lp['records_path'] and 'RCCL' not in lp['config']['parallelism']
+    assert 'shard_records_match' not in lp                                             # (no gather, nothing to validate)
     a, b = np.load(fg), np.load(fp)
     assert a.dtype == b.dtype and a.tobytes() == b.tobytes() and int(a['n_peaks'].sum()) > 0
 
