@@ -559,6 +559,7 @@ def main():
             if a.bf16x3:
                 out['bf16x3'] = bf16x3_mode(eng, torch, dev, d_imgs, B, S, map_s, a.steps)
             out['rect_368x496'] = rect_inputs(native, weights_mod, torch, dev, local_rank, B, a.steps, frames / dt, S)
+            out['mixed_sizes'] = mixed_sizes_mode(weights_mod, local_rank, B, max(2, a.steps // 4))
             out['precise'] = precise_mode(weights_mod, local_rank, with_oracle=not a.no_cpu_baseline)
             eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(B, S, S), map_h=map_s, map_w=map_s)     # restore the batch state
             rec = eng.results()                                                                             # for keypoint_match
@@ -844,6 +845,56 @@ def rect_inputs(native, weights_mod, torch, dev, device_index, B, steps, square_
         finally:
             eng.close()
     return out
+
+
+def mixed_sizes_mode(weights_mod, device_index, batch=32, steps=5):
+    """A stream of frames of DIFFERENT sizes (COCO-val style: 640 x 480, 480 x 640, 640 x 427, 500 x 375, 640 x 640 ...) through
+    PoseDetector.detect_batch: the mixed batch (one launch per layer over all size classes: pmx_detect_images) against the reference's way
+    (one image per call, pose_detector.py:484-517) and against a uniform 368 x 496 batch.  Host images in every call: uploads, device
+    cv2.resize, network, post-process, records."""
+    PD = importlib.import_module(PKG + '.pose_detector')
+    native = importlib.import_module(PKG + '.native')
+    weights = weights_mod.synthetic_weights(0)
+    eng = native.Engine(device_index, max_batch=1, max_h=368, max_w=368)
+    try:
+        eng.set_weights(weights)
+        eng.forward_u8(np.random.default_rng(1234).integers(0, 256, (1, 368, 368, 3), dtype=np.uint8))
+        paf, heat = eng.get_maps()
+    finally:
+        eng.close()
+    weights = weights_mod.calibrate_head(weights, paf[0], heat[0])
+    rng = np.random.default_rng(7)
+    classes = [(480, 640), (640, 480), (427, 640), (375, 500), (640, 640), (426, 640), (480, 640), (333, 500), (500, 375), (640, 427)]
+    sizes = [classes[int(rng.integers(0, len(classes)))] for _ in range(batch)]
+    imgs = [rng.integers(0, 256, s_ + (3,), dtype=np.uint8) for s_ in sizes]
+    det = PD.PoseDetector(weights=weights, device=device_index, max_batch=batch, max_size=(368, 496))
+    try:
+        net = [det.compute_optimal_size(im, 368)[::-1] for im in imgs]
+        npx = sum(h * w for h, w in net)
+
+        def timed(fn, n):
+            fn(); det.engine.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                r = fn()
+            det.engine.synchronize()
+            return (time.perf_counter() - t0) / n, r
+        t_mixed, res = timed(lambda: det.detect_batch(imgs), steps)
+        t_loop, res1 = timed(lambda: [det(im) for im in imgs], max(1, steps // 2))
+        same = sum(1 for x, y in zip(res, res1) if np.asarray(x[0]).shape == np.asarray(y[0]).shape and np.array_equal(np.asarray(x[0]), np.asarray(y[0])))
+        uni = [rng.integers(0, 256, (368, 496, 3), dtype=np.uint8) for _ in range(batch)]
+        t_uni, _ = timed(lambda: det.detect_batch(uni), steps)
+    finally:
+        det.engine.close()
+    return {'batch': batch, 'original_sizes': sorted(set('%dx%d' % s_ for s_ in sizes)), 'distinct_network_sizes': len(set(net)),
+            'network_pixels_in_368x368_frames': npx / (368.0 * 368.0),
+            'mixed_batch_ms': t_mixed * 1e3, 'one_image_per_call_ms': t_loop * 1e3, 'speedup_vs_one_image_per_call': t_loop / t_mixed,
+            'frames_per_s': batch / t_mixed, 'frames_per_s_one_image_per_call': batch / t_loop,
+            'uniform_368x496_batch_ms': t_uni * 1e3,
+            'rate_per_pixel_vs_uniform_368x496_batch': (t_uni / (batch * 368 * 496)) / (t_mixed / npx),
+            'frames_with_poses_identical_to_the_single_image_call': same, 'people_found': int(sum(len(r[1]) for r in res)),
+            'note': 'PoseDetector.detect_batch on host images of %d different sizes (pmx_detect_images: one launch per layer over the size classes) vs '
+                    'one __call__ per image (the default single-image kernels: unit mode / split-K)' % len(set(sizes))}
 
 
 def precise_mode(weights_mod, device_index, with_oracle=True, shape=(482, 642)):

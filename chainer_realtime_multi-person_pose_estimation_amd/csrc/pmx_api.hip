@@ -469,6 +469,8 @@ extern "C" int pmx_set_option(pmx_ctx* c, const char* key, int value)
     else if (!strcmp(key, "fuse_conv1")) c->opt_fuse_conv1 = value;
     else if (!strcmp(key, "conv1_wino")) c->opt_conv1_wino = value;
     else if (!strcmp(key, "precise_lanes")) c->opt_precise_lanes = value < 1 ? 1 : (value > PMX_PR_LANES ? PMX_PR_LANES : value);
+    else if (!strcmp(key, "precise_plain")) c->opt_precise_plain = value;
+    else if (!strcmp(key, "precise_lane_priority")) c->opt_precise_lane_priority = value != 0;
     else if (!strcmp(key, "precise_table_cap")) c->opt_precise_table_cap = value < 1 ? 1 : value;
     else if (!strcmp(key, "cubic_rows")) prep_set_cubic_rows(value);      // (process-wide, like the other kernel-form switches of prep / post-process)
     else if (!strcmp(key, "precision")) {

@@ -103,7 +103,19 @@ static int lane_ensure(pmx_ctx* c, int i, size_t n, size_t ph, size_t pw)
     PrLane& l = c->pr_lane[i];
     if (!l.done) PMX_HIP(hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
     if (i == 0) return PMX_OK;
-    if (!l.stream) PMX_HIP(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+    if (!l.stream) {
+        // Stream priorities (option "precise_lane_priority", default on): the reference's scale order is 0.5, 1, 1.5, 2, so the last lane carries
+        // the largest scale -- the longest chain of the sequence (8.4 of ~19 ms of single-lane time for a 482 x 642 frame), whose 7x7 layers
+        // are 192 one-per-CU blocks: it finishes a layer in ONE round only if it gets its CUs the moment it asks for them.  With equal
+        // priorities the lanes take CUs from each other in arrival order, the large lane's launches split over two rounds and its chain --
+        // the critical path -- doubles.  The highest priority for lane 3, the lowest for lane 1: the small scales fill what the large one
+        // leaves free.
+        int lo = 0, hi = 0;
+        PMX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));          // (lo = numerically greatest = least urgent)
+        int prio = 0;
+        if (c->opt_precise_lane_priority) prio = i == PMX_PR_LANES - 1 ? hi : i == 1 ? lo : (lo + hi) / 2;
+        PMX_HIP(hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, prio));
+    }
     const size_t px = n * ph * pw;
     if (px <= l.cap_px) return PMX_OK;
     PMX_HIP(hipStreamSynchronize(l.stream));
@@ -249,8 +261,17 @@ extern "C" int pmx_precise_add_scale_batch(pmx_ctx* c, const uint8_t* imgs, int 
                                          hipMemcpyDeviceToDevice, c->stream));
         } else if ((rc2 = launch_resize_cubic_u8(c->u8_src, ow, c->u8_tmp, scaled_h, scaled_w, pw, t1xi, (const int*)t1xc, t1yi, (const int*)t1yc, n,
                                                  (long long)img_bytes, (long long)pad_bytes, c->stream))) return rc2;
-        // (2) network, the n images as one batch
-        if ((rc2 = pmx_forward_from_u8(c, c->u8_tmp, n, ph, pw, 255.0f))) return rc2;
+        // (2) network, the n images as one batch.  With several scales in flight the chip is shared: what counts is the CU time a scale
+        // consumes, not how fast it would finish alone -- so the lanes run the PLAIN Winograd kernel on every eligible layer ("conv_algo" 2:
+        // 0.83 of the matrix peak per block) instead of the unit-mode / split-K forms the selection gives a launch that has the chip to
+        // itself (0.45: they trade CU time for latency).  Round 6, 482 x 642 frame, lanes with priorities: 14.2 -> 13.5 ms per image
+        // (profiles/r06_precise_priority_ab.json).  Option "precise_plain": -1 (default) = when more than one lane is in use, 0 / 1 = never / always.
+        const int algo_saved = c->opt_conv_algo;
+        const bool plain = c->opt_precise_plain < 0 ? c->opt_precise_lanes > 1 : c->opt_precise_plain != 0;
+        if (plain && c->opt_conv_algo == 1) c->opt_conv_algo = 2;
+        rc2 = pmx_forward_from_u8(c, c->u8_tmp, n, ph, pw, 255.0f);
+        c->opt_conv_algo = algo_saved;
+        if (rc2) return rc2;
         // (3) x8 cubic up-sampling of the PAF (38) and heat (19) channels of all images into PLANAR temporaries [n][38][ph][pw] | [n][19][ph][pw]
         // (two cv2.resize calls per image in the reference; planar so that step (4) reads rows of one channel and both steps store full rows)
         const size_t ppx = (size_t)ph * pw, ntmp = ppx * 57 * n;

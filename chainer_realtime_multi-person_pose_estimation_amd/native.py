@@ -100,10 +100,22 @@ def object_digest(src, extra):
     import hashlib
     h = hashlib.sha256()
     h.update((' '.join(BASE_FLAGS + list(extra)) + '\n' + hipcc_version() + '\n').encode())
-    h.update(open(os.path.join(CSRC, src), 'rb').read())
-    for hd in HEADERS:
-        h.update(open(hd if os.path.isabs(hd) else os.path.join(CSRC, hd), 'rb').read())
+    for path in _local_includes(os.path.join(CSRC, src)):
+        h.update(open(path, 'rb').read())
     return h.hexdigest()
+
+
+def _local_includes(path, seen=None):
+    """`path` and every file it reaches through #include "..." (the project's own headers: quoted includes, resolved against the
+    including file's directory), in a fixed order."""
+    seen = [] if seen is None else seen
+    path = os.path.normpath(path)
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.append(path)
+    for m in re.finditer(r'^\s*#\s*include\s+"([^"]+)"', open(path, errors='replace').read(), flags=re.M):
+        _local_includes(os.path.join(os.path.dirname(path), m.group(1)), seen)
+    return seen
 
 
 def needs_build():

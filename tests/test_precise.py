@@ -123,6 +123,7 @@ def test_device_cubic_path_equals_host_restatement(native, shape, rows):
     img = rng.integers(0, 256, shape + (3,), dtype=np.uint8)
     dev = PD.PoseDetector(weights=weights, device=0, precise=True, max_size=(368, 472))
     dev.engine.set_option('cubic_rows', rows)
+    dev.engine.set_option('precise_plain', 0)      # the seam below runs single forwards with the default kernel selection: same kernels on both sides
     res_dev = None
     try:
         res_dev = dev(img)
@@ -257,6 +258,7 @@ def test_precise_scales_in_flight_same_bits(native):
     got = {}
     for lanes in (4, 1, 3):
         det.engine.set_option('precise_lanes', lanes)
+        det.engine.set_option('precise_plain', 1)            # (-1, the default, means "plain kernels when lanes > 1": the one-lane run would pick other kernels)
         for rep, img in enumerate(imgs + imgs[:1]):
             try:
                 det._detect_precise_device(img, fetch_maps=True)
@@ -264,6 +266,7 @@ def test_precise_scales_in_flight_same_bits(native):
                 pass
             got[(lanes, rep)] = (det.pafs.copy(), det.heatmaps.copy())
     det.engine.set_option('precise_lanes', 4)
+    det.engine.set_option('precise_plain', -1)
     det.engine.close()
     for rep in range(3):
         for lanes in (1, 3):
