@@ -34,6 +34,10 @@ import time
 
 import numpy as np
 
+# (the same default the package sets at import, here before anything can initialise the HIP runtime: detect_precise keeps four scales in
+#  flight on four streams; with ROCm's default of 4 hardware queues per process they would share queues with this harness's other streams
+#  -- profiles/r06_hw_queues.json.  A runtime setting of the process, stated in the line as `hw_queues`.)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = 'chainer_realtime_multi-person_pose_estimation_amd'
@@ -561,6 +565,7 @@ def main():
             out['rect_368x496'] = rect_inputs(native, weights_mod, torch, dev, local_rank, B, a.steps, frames / dt, S)
             out['mixed_sizes'] = mixed_sizes_mode(weights_mod, local_rank, B, max(2, a.steps // 4))
             out['precise'] = precise_mode(weights_mod, local_rank, with_oracle=not a.no_cpu_baseline)
+            out['precise']['hw_queues'] = 'GPU_MAX_HW_QUEUES=%s' % os.environ.get('GPU_MAX_HW_QUEUES')
             eng.detect_batch(device_ptr=d_imgs.data_ptr(), shape=(B, S, S), map_h=map_s, map_w=map_s)     # restore the batch state
             rec = eng.results()                                                                             # for keypoint_match
         if world == 1 and not a.no_cpu_baseline:

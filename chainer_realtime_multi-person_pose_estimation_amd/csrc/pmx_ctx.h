@@ -79,6 +79,7 @@ struct pmx_ctx {
     int cat_heat = PMX_CAT_HEAT;     // first heat-map channel in the cat buffer (168 | 128 | 128)
     // detect_precise accumulation state (pmx_precise_*)
     int pr_h = 0, pr_w = 0, pr_scales = 0, pr_n = 0;      // original size, scales accumulated so far, images of the batch
+    unsigned pr_mask = 0;                                 // slots (positions in the reference's scale loop) filled so far
     float* pr_tmp = nullptr; size_t pr_tmp_cap = 0;      // x8 up-sampled maps of one scale, planar [n][38][ph][pw] | [n][19][ph][pw]
     std::map<std::tuple<int, int, int>, int*> pr_tabs;   // cubic tables per axis, keyed (src, dst, fixed point?): built once, kept
     const uint8_t* pr_src = nullptr;                     // host images of the current begin / finish sequence already in u8_src

@@ -169,7 +169,7 @@ extern "C" int pmx_precise_begin_batch(pmx_ctx* c, int n_images, int orig_h, int
         PMX_HIP(hipMalloc((void**)&c->sk_zero_bias, PMX_SK_ZERO_BIAS * sizeof(float)));
         PMX_HIP(hipMemset(c->sk_zero_bias, 0, PMX_SK_ZERO_BIAS * sizeof(float)));
     }
-    c->pr_h = orig_h; c->pr_w = orig_w; c->pr_scales = 0; c->pr_n = n_images; c->pr_src = nullptr;
+    c->pr_h = orig_h; c->pr_w = orig_w; c->pr_scales = 0; c->pr_mask = 0; c->pr_n = n_images; c->pr_src = nullptr;
     c->maps_valid = false;
     return PMX_OK;
 }
@@ -186,7 +186,21 @@ extern "C" int pmx_precise_begin(pmx_ctx* c, int orig_h, int orig_w) { return pm
 // multiple of 8 with (104, 117, 123) (:445), forward (:451), x8 cubic up-sampling of both outputs (:461,465), crop of the padding
 // (:462,466), cubic resize to the original size (:463,467) into this scale's part.  `imgs`: host uint8, n x orig_h x orig_w x 3, contiguous.
 // Everything is enqueued on the scale's lane; nothing here waits for the device.
+static int precise_add_scale(pmx_ctx* c, const uint8_t* imgs, int scaled_h, int scaled_w, int slot);
 extern "C" int pmx_precise_add_scale_batch(pmx_ctx* c, const uint8_t* imgs, int scaled_h, int scaled_w)
+{
+    return precise_add_scale(c, imgs, scaled_h, scaled_w, -1);
+}
+// The same with the POSITION of the scale in the reference's loop given explicitly (slot 0 .. 7; each once per sequence): the parts are
+// summed in slot order (:463,467) whatever order the scales were enqueued in -- so a caller can enqueue the LARGEST scale first.  Its
+// chain of ~100 launches is the critical path of the sequence; enqueued last (the reference's order 0.5, 1, 1.5, 2) it starts only after
+// the host has spent ~1 ms enqueueing the three smaller ones.  Slot s runs on lane s % lanes (the priorities follow the slot).
+extern "C" int pmx_precise_add_scale_at(pmx_ctx* c, const uint8_t* imgs, int scaled_h, int scaled_w, int slot)
+{
+    PMX_CHECK(slot >= 0 && slot < 8, PMX_ERR_INVALID, "pmx_precise_add_scale_at: slot %d outside 0..7", slot);
+    return precise_add_scale(c, imgs, scaled_h, scaled_w, slot);
+}
+static int precise_add_scale(pmx_ctx* c, const uint8_t* imgs, int scaled_h, int scaled_w, int slot)
 {
     PMX_CHECK(c && imgs && c->pr_h > 0 && c->pr_n > 0, PMX_ERR_STATE, "pmx_precise_add_scale: call pmx_precise_begin first");
     PMX_CHECK(scaled_h >= 1 && scaled_w >= 1, PMX_ERR_INVALID, "bad size");
@@ -200,12 +214,18 @@ extern "C" int pmx_precise_add_scale_batch(pmx_ctx* c, const uint8_t* imgs, int 
     PMX_CHECK(missing == 0, PMX_ERR_WEIGHTS, "pmx_precise_add_scale: %d layers have no weights", missing);
     int rc;
     PMX_CHECK(c->pr_scales < 8, PMX_ERR_CAPACITY, "pmx_precise_add_scale: at most 8 scales per sequence");
-    const int k = c->pr_scales, li = k % (c->opt_precise_lanes < 1 ? 1 : c->opt_precise_lanes);
+    if (slot < 0) {                                   // the next free position
+        slot = 0;
+        while (slot < 8 && ((c->pr_mask >> slot) & 1u)) ++slot;
+    }
+    PMX_CHECK(slot < 8 && !((c->pr_mask >> slot) & 1u), PMX_ERR_STATE, "pmx_precise_add_scale: slot %d already holds a scale of this sequence", slot);
+    const bool first = c->pr_mask == 0;
+    const int k = slot, li = k % (c->opt_precise_lanes < 1 ? 1 : c->opt_precise_lanes);
     hipStream_t main_stream = c->stream;
     // original images -> device, ONCE per begin / finish sequence, on the context's stream: every scale resizes the same originals (the
     // caller passes the same images to every pmx_precise_add_scale* of a sequence -- include/pose_mi355x.h)
     const size_t img_bytes = (size_t)oh * ow * 3, nsrc = img_bytes * n;
-    if (k == 0 || c->pr_src != imgs) {
+    if (first || c->pr_src != imgs) {
         if (nsrc > c->u8_src_cap) {
             PMX_HIP(hipDeviceSynchronize());          // (lanes of an earlier sequence may still read the old buffer)
             if (c->u8_src) (void)hipFree(c->u8_src);
@@ -213,7 +233,7 @@ extern "C" int pmx_precise_add_scale_batch(pmx_ctx* c, const uint8_t* imgs, int 
             PMX_HIP(hipMalloc((void**)&c->u8_src, nsrc));
             c->u8_src_cap = nsrc;
         }
-        if (k > 0) {                                  // (a different buffer mid-sequence: the lanes still reading the old copy finish first)
+        if (!first) {                                 // (a different buffer mid-sequence: the lanes still reading the old copy finish first)
             for (int i = 1; i < PMX_PR_LANES; ++i)
                 if (c->pr_lane[i].done && c->pr_lane[i].stream) PMX_HIP(hipStreamWaitEvent(main_stream, c->pr_lane[i].done, 0));
         }
@@ -299,6 +319,7 @@ extern "C" int pmx_precise_add_scale_batch(pmx_ctx* c, const uint8_t* imgs, int 
     lane_swap(c, li);
     if (rc) return rc;
     c->pr_scales += 1;
+    c->pr_mask |= 1u << slot;
     c->maps_valid = false;       // the cat buffers hold single scales only; the averaged maps become valid in pmx_precise_finish
     return PMX_OK;
 }
@@ -321,13 +342,14 @@ extern "C" int pmx_precise_finish(pmx_ctx* c)
     for (int i = 0; i < PMX_PR_LANES; ++i)
         if (c->pr_lane[i].done) PMX_HIP(hipStreamWaitEvent(c->stream, c->pr_lane[i].done, 0));
     PMX_CHECK(c->pr_scales <= 8, PMX_ERR_CAPACITY, "pmx_precise_finish: %d scales (at most 8 per sequence)", c->pr_scales);
+    PMX_CHECK(c->pr_mask == (1u << c->pr_scales) - 1u, PMX_ERR_STATE, "pmx_precise_finish: the slots of the sequence have gaps (mask 0x%x, %d scales)", c->pr_mask, c->pr_scales);
     if ((rc = launch_sum_parts_f32(c->ext_paf, c->pr_part.data(), c->pr_scales, 0, n * PMX_N_PAF, (float)c->pr_scales, c->stream))) return rc;
     if ((rc = launch_sum_parts_f32(c->ext_heat, c->pr_part.data(), c->pr_scales, n * PMX_N_PAF, n * PMX_N_HEAT, (float)c->pr_scales, c->stream))) return rc;
     PMX_HIP(hipEventRecord(c->pr_fin, c->stream));
     c->maps_valid = true; c->maps_external = true;
     c->cur_B = c->pr_n; c->cur_fh = c->pr_h; c->cur_fw = c->pr_w;
     c->pp_valid = false;
-    c->pr_scales = 0;
+    c->pr_scales = 0; c->pr_mask = 0;
     return PMX_OK;
 }
 

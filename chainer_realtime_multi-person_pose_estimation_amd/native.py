@@ -11,6 +11,13 @@ import sys
 
 import numpy as np
 
+# ROCm maps a process's HIP streams onto at most GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue run one after
+# the other.  detect_precise keeps four scales in flight on four streams next to the context's own, a copy stream and whatever the
+# application (torch ...) has created: with the default, two lanes regularly land on one queue and the four "concurrent" scales run as
+# three or two -- 20.2 instead of 14.0 ms per 482 x 642 image inside bench.py's process (profiles/r06_hw_queues.json).  The variable is
+# read when the HIP runtime initialises, i.e. at the first HIP call of the process: set here, at import, unless the user has set it.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libpose_mi355x.so')
@@ -238,6 +245,7 @@ def load():
         'pmx_precise_finish': (ci, [vp]),
         'pmx_precise_begin_batch': (ci, [vp, ci, ci, ci]),
         'pmx_precise_add_scale_batch': (ci, [vp, vp, ci, ci]),
+        'pmx_precise_add_scale_at': (ci, [vp, vp, ci, ci, ci]),
         'pmx_precise_table_stats': (ci, [vp, ip, ip]),
         'pmx_destroy': (None, [vp]),
         'pmx_set_stream': (ci, [vp, vp]),
@@ -466,15 +474,19 @@ class Engine(object):
         self._precise_src_obj = None
         self._precise_src_arr = None
 
-    def precise_add_scale(self, img_u8, scaled_h, scaled_w):
-        """img_u8: (H, W, 3) for a batch of one, (n, H, W, 3) for the n images precise_begin announced."""
+    def precise_add_scale(self, img_u8, scaled_h, scaled_w, slot=None):
+        """img_u8: (H, W, 3) for a batch of one, (n, H, W, 3) for the n images precise_begin announced.  slot: the scale's position in the
+        reference's loop (the parts are summed in slot order); None = the next free one."""
         if self._precise_src_obj is img_u8 and self._precise_src_arr is not None:
             img = self._precise_src_arr
         else:
             img = np.ascontiguousarray(img_u8, dtype=np.uint8)
             self._precise_src_obj, self._precise_src_arr = img_u8, img
         assert img.shape[-3:-1] == self._precise_hw and img.size == self._precise_n * self._precise_hw[0] * self._precise_hw[1] * 3, img.shape
-        self._check(self.lib.pmx_precise_add_scale_batch(self._ctx, _ptr(img), int(scaled_h), int(scaled_w)))
+        if slot is None:
+            self._check(self.lib.pmx_precise_add_scale_batch(self._ctx, _ptr(img), int(scaled_h), int(scaled_w)))
+        else:
+            self._check(self.lib.pmx_precise_add_scale_at(self._ctx, _ptr(img), int(scaled_h), int(scaled_w), int(slot)))
 
     def precise_table_stats(self):
         """(cached cubic tables, times the cache was started over) -- include/pose_mi355x.h::pmx_precise_table_stats."""

@@ -32,6 +32,8 @@ from .entity import JointType, params
 
 
 class PoseDetector(object):
+    precise_largest_first = True      # detect_precise enqueues its largest scale first (same results: the parts are summed in the reference's order)
+
     def __init__(self, arch=None, weights_file=None, model=None, device=-1, precise=False, weights=None,
                  max_batch=1, max_size=None, gpu_branch_peaks=False, precision='f32'):
         self.arch = arch
@@ -229,8 +231,11 @@ class PoseDetector(object):
         self._grow(n, -(-big[0] // ds) * ds, -(-big[1] // ds) * ds)
         batch = np.stack(imgs)
         self.engine.precise_begin(orig_img_h, orig_img_w, n)
-        for sh, sw in sizes:
-            self.engine.precise_add_scale(batch, sh, sw)                                             # :443-467
+        # the largest scale is enqueued FIRST (its chain of launches is the critical path of the sequence) but keeps its position in the
+        # reference's loop: the parts are summed in slot order (:463,467)
+        order = sorted(range(len(sizes)), key=lambda i: -sizes[i][0] * sizes[i][1]) if self.precise_largest_first else range(len(sizes))
+        for slot in order:
+            self.engine.precise_add_scale(batch, sizes[slot][0], sizes[slot][1], slot=slot)          # :443-467
         self.engine.precise_finish()                                                                 # :469-470
         if fetch_maps:
             self.pafs, self.heatmaps = self.engine.get_maps()                                       # (n, 38 | 19, H, W)

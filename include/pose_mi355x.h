@@ -203,6 +203,10 @@ int pmx_precise_finish(pmx_ctx* ctx);
  * kernel-choice-by-launch-size rounding of the network. */
 int pmx_precise_begin_batch(pmx_ctx* ctx, int n_images, int orig_h, int orig_w);      /* (at most 8 scales per sequence) */
 int pmx_precise_add_scale_batch(pmx_ctx* ctx, const uint8_t* bgr_nhwc, int scaled_h, int scaled_w);
+/* the same with the scale's POSITION in the reference's loop given (slot 0 .. 7, each once per sequence, no gaps at finish): the parts are
+ * summed in slot order (:463,467) whatever order the scales are enqueued in, so the caller can enqueue the largest scale -- the longest
+ * chain of the sequence -- first.  pmx_precise_add_scale* without a slot take the next free one. */
+int pmx_precise_add_scale_at(pmx_ctx* ctx, const uint8_t* bgr_nhwc, int scaled_h, int scaled_w, int slot);
 /* the per-axis cubic tables a context caches (~22 per distinct original size) and how often the cache was started over.  That happens
  * only inside pmx_precise_begin*, behind a device synchronisation, once `cached` has reached option "precise_table_cap" (default 208):
  * never while a sequence holds table pointers. */

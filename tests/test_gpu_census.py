@@ -32,6 +32,15 @@ def test_census_64_frames_default_path(native):
     f32 = out['paths']['f32_default_batch_path']
     # healthy fixture => identical: a frame without any near-tie pixel (all margins above the two networks' difference) must match exactly
     assert f32['mismatching_peaks'] == 0 or f32['max_margin_of_a_mismatch'] < 1e-5
+    # CEILINGS of the default path, so that a kernel change cannot widen the disagreement silently.  Measured on these
+    # 64 frames with the round-6 kernels: 62 identical, 2 disagreeing peaks of 9 796, largest margin of a flip 8.2e-8; on 512 frames
+    # (profiles/r06_parity_census.json): 501 identical, 14 peaks, 3.8e-7 -- and the same census with conv1 on the direct kernel (503, 12,
+    # 1.3e-7) or every layer on the direct kernels (496, 24, 3.8e-7) shows the spread between summation orders, i.e. the 3.8e-7 is a
+    # property of those frames' near-ties, not of one kernel.  A flip needs |margin| <= twice the maps' difference (~1e-6 here).
+    assert f32['max_margin_of_a_mismatch'] <= 1e-6, json.dumps(f32)
+    assert f32['frames_identical'] >= 60, json.dumps(f32)                       # <= 6 % of the frames (measured 3 %)
+    assert f32['mismatching_peaks'] <= 6, json.dumps(f32)
+    assert f32['max_abs_peak_score_diff'] <= 1e-5 and f32['max_abs_score_diff_matched_people'] <= 2e-5, json.dumps(f32)
 
 
 def test_config5_precise_482x642_native_network_vs_precise_ref(native):

@@ -309,3 +309,42 @@ def test_precise_table_cache_trims_only_between_sequences(native):
         assert fresh.engine.precise_table_stats()[1] == 0
         assert np.array_equal(fresh.pafs, got[i][0]) and np.array_equal(fresh.heatmaps, got[i][1]), i
         fresh.engine.close()
+
+
+@pytest.mark.gpu
+def test_precise_enqueue_order_does_not_change_bits(native):
+    """pmx_precise_add_scale_at: the scale's position in the reference's loop (slot) is given explicitly, the parts are summed in slot order
+    (:463,467) -- so the averaged maps do not depend on the order the scales are ENQUEUED in (PoseDetector enqueues the largest first: its
+    chain is the critical path).  In order without slots == in order with slots == reversed == what PoseDetector does; a slot used twice
+    and a gap at finish are refused."""
+    import math
+    PD = pkg('pose_detector')
+    E = pkg('entity')
+    weights = pkg('weights').synthetic_weights(0)
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, (120, 152, 3), dtype=np.uint8)
+    det = PD.PoseDetector(weights=weights, device=0, precise=True, max_size=(368, 472))
+    try:
+        det._detect_precise_device(img, fetch_maps=True)
+    except (IndexError, RuntimeError):
+        pass
+    ref = (det.pafs.copy(), det.heatmaps.copy())
+    eng = det.engine
+    sizes = []
+    for scale in E.params['inference_scales']:
+        m = scale * E.params['inference_img_size'] / min(img.shape[:2])
+        sizes.append((math.ceil(img.shape[0] * m), math.ceil(img.shape[1] * m)))
+    for order, with_slot in (([0, 1, 2, 3], False), ([0, 1, 2, 3], True), ([3, 2, 1, 0], True), ([2, 0, 3, 1], True)):
+        eng.precise_begin(img.shape[0], img.shape[1], 1)
+        for k in order:
+            eng.precise_add_scale(img, sizes[k][0], sizes[k][1], slot=k if with_slot else None)
+        eng.precise_finish()
+        paf, heat = eng.get_maps()
+        assert np.array_equal(paf[0], ref[0]) and np.array_equal(heat[0], ref[1]), (order, with_slot)
+    eng.precise_begin(img.shape[0], img.shape[1], 1)
+    eng.precise_add_scale(img, sizes[1][0], sizes[1][1], slot=1)
+    with pytest.raises(native.PmxError):
+        eng.precise_add_scale(img, sizes[1][0], sizes[1][1], slot=1)          # the slot is taken
+    with pytest.raises(native.PmxError):
+        eng.precise_finish()                                                   # slot 0 is missing
+    eng.close()
