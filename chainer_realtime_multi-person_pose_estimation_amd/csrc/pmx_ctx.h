@@ -87,7 +87,7 @@ struct pmx_ctx {
     std::vector<float*> pr_part; size_t pr_part_cap = 0; // per scale: [n][57][orig_h][orig_w] (PAF planes, then heat planes of every image)
     hipEvent_t pr_src_ready = nullptr, pr_fin = nullptr; // originals uploaded / parts consumed by the last finish
     int opt_precise_lanes = PMX_PR_LANES;                // 1: every scale on the context's own stream (A/B, tests)
-    int opt_precise_plain = -1;                          // detect_precise's forwards on the plain Winograd kernels: -1 = when lanes > 1, 0 never, 1 always
+    int opt_precise_plain = -1;                          // detect_precise's forwards on the plain Winograd kernels: -1 = when all four lanes are in use, 0 never, 1 always
     int opt_precise_lane_priority = 1;                   // lane streams with priorities (largest scale first); read when a lane's stream is created
     int opt_precise_table_cap = 208;                     // cached cubic tables at which the next pmx_precise_begin* starts the cache over (256 - 48)
     int pr_tabs_trims = 0;                               // how often that happened (diagnostics: option query "precise_table_trims")

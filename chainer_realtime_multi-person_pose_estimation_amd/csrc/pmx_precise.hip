@@ -220,7 +220,13 @@ static int precise_add_scale(pmx_ctx* c, const uint8_t* imgs, int scaled_h, int 
     }
     PMX_CHECK(slot < 8 && !((c->pr_mask >> slot) & 1u), PMX_ERR_STATE, "pmx_precise_add_scale: slot %d already holds a scale of this sequence", slot);
     const bool first = c->pr_mask == 0;
-    const int k = slot, li = k % (c->opt_precise_lanes < 1 ? 1 : c->opt_precise_lanes);
+    // Lane of this scale, by ENQUEUE order: the first scale of a sequence -- the largest one when the caller follows the advice above --
+    // gets lane 3, whose stream carries the highest priority, to itself; the others go round-robin over the remaining lanes in use
+    // (0 = the context's own stream, then 2, then 1 = the lowest priority).  One lane: everything on the context's stream.
+    const int L = c->opt_precise_lanes < 1 ? 1 : (c->opt_precise_lanes > PMX_PR_LANES ? PMX_PR_LANES : c->opt_precise_lanes);
+    static const int others[PMX_PR_LANES - 1] = {0, 2, 1};
+    const int k = slot, e = c->pr_scales;
+    const int li = L == 1 ? 0 : (e == 0 ? PMX_PR_LANES - 1 : others[(e - 1) % (L - 1)]);
     hipStream_t main_stream = c->stream;
     // original images -> device, ONCE per begin / finish sequence, on the context's stream: every scale resizes the same originals (the
     // caller passes the same images to every pmx_precise_add_scale* of a sequence -- include/pose_mi355x.h)
@@ -285,9 +291,11 @@ static int precise_add_scale(pmx_ctx* c, const uint8_t* imgs, int scaled_h, int 
         // consumes, not how fast it would finish alone -- so the lanes run the PLAIN Winograd kernel on every eligible layer ("conv_algo" 2:
         // 0.83 of the matrix peak per block) instead of the unit-mode / split-K forms the selection gives a launch that has the chip to
         // itself (0.45: they trade CU time for latency).  Round 6, 482 x 642 frame, lanes with priorities: 14.2 -> 13.5 ms per image
-        // (profiles/r06_precise_priority_ab.json).  Option "precise_plain": -1 (default) = when more than one lane is in use, 0 / 1 = never / always.
+        // (profiles/r06_precise_priority_ab.json).  Option "precise_plain": -1 (default) = when all four lanes are in use, 0 / 1 = never / always.
         const int algo_saved = c->opt_conv_algo;
-        const bool plain = c->opt_precise_plain < 0 ? c->opt_precise_lanes > 1 : c->opt_precise_plain != 0;
+        // (-1 = only with all four lanes in use: a lane that carries two scales one after the other wants the latency-oriented forms --
+        //  three lanes 15.0 -> 20.4 ms, two 16.0 -> 25.0 with the plain kernels, profiles/r06_precise_probe_lanes.json)
+        const bool plain = c->opt_precise_plain < 0 ? c->opt_precise_lanes >= PMX_PR_LANES : c->opt_precise_plain != 0;
         if (plain && c->opt_conv_algo == 1) c->opt_conv_algo = 2;
         rc2 = pmx_forward_from_u8(c, c->u8_tmp, n, ph, pw, 255.0f);
         c->opt_conv_algo = algo_saved;

@@ -129,7 +129,7 @@ int pmx_synchronize(pmx_ctx* ctx);                    /* cuda.get_device_from_id
  *   "precise_lanes" 1..4       detect_precise: inference scales in flight at once, each on its own stream and working set (default 4;
  *                              1: one after the other on the context's stream); same bits
  *   "precise_plain" -1 | 0 | 1  detect_precise's forward passes on the plain Winograd kernels ("conv_algo" 2 for their duration): -1 (default) =
- *                              when more than one lane is in use (scales that share the chip should spend as little CU time as possible),
+ *                              when all four lanes are in use (scales that share the chip should spend as little CU time as possible),
  *                              0 = the default selection, 1 = always.  Changes the fp32 rounding of the maps like any kernel choice
  *   "precise_lane_priority" 1 | 0   detect_precise: the lanes' streams get priorities, the last lane (the reference's largest scale) the highest
  *                              (default 1; takes effect for lanes created afterwards, i.e. set it before the first detect_precise); same bits

@@ -258,7 +258,7 @@ def test_precise_scales_in_flight_same_bits(native):
     got = {}
     for lanes in (4, 1, 3):
         det.engine.set_option('precise_lanes', lanes)
-        det.engine.set_option('precise_plain', 1)            # (-1, the default, means "plain kernels when lanes > 1": the one-lane run would pick other kernels)
+        det.engine.set_option('precise_plain', 1)            # (-1, the default, means "plain kernels with all four lanes in use": the other runs would pick other kernels)
         for rep, img in enumerate(imgs + imgs[:1]):
             try:
                 det._detect_precise_device(img, fetch_maps=True)

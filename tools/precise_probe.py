@@ -14,11 +14,12 @@ img = np.random.default_rng(55).integers(0, 256, (H, W, 3), dtype=np.uint8)
 wts = [None]
 
 
-def probe(prio, plain, largest_first):
+def probe(prio, plain, largest_first, lanes=4):
     det = PD.PoseDetector(weights=wts[0] or W_.synthetic_weights(0), device=0, precise=True, max_size=(736, 984))
     det.precise_largest_first = bool(largest_first)
     det.engine.set_option('precise_lane_priority', prio)
     det.engine.set_option('precise_plain', plain)
+    det.engine.set_option('precise_lanes', lanes)
     if wts[0] is None:
         cal = PD.resize_cubic_u8(img, int(np.ceil(W * 368 / min(H, W))), int(np.ceil(H * 368 / min(H, W))))
         cal, _ = det.pad_image(cal, 8, (104, 117, 123))
@@ -40,7 +41,14 @@ def probe(prio, plain, largest_first):
 
 
 out = {}
-for rep in range(2):
+if 'lanes' in sys.argv:              # second experiment: lanes in use x kernel selection, priorities on, largest scale first
+    for rep in range(2):
+        for lanes in (4, 3, 2, 1):
+            for plain in (0, 1):
+                key = 'lanes_%d_plain_%d' % (lanes, plain)
+                out.setdefault(key, []).append(probe(1, plain, 1, lanes))
+                print(key, out[key]); sys.stdout.flush()
+for rep in range(0 if 'lanes' in sys.argv else 2):
     for prio in (0, 1):
         for plain in (0, 1):
             for lf in (0, 1):
