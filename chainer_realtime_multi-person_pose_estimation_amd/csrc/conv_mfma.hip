@@ -1305,9 +1305,6 @@ int conv_splitk_reduce(const SplitKReduceArgs& r, int groups, hipStream_t stream
 // [w * CMID / 4, (w + 1) * CMID / 4) (weights L2 -> registers), bias + ReLU, hidden tile -> LDS, then waves 0 .. N2T - 1 each
 // compute one 32-channel tile of the second layer over all CMID hidden channels.  Every output walks K in the same order
 // as the single-layer kernels (chunk -> half -> k, one sequential FMA chain) -> bit-identical to running the two layers apart.
-#ifndef PMX_PAIR_ROT
-#define PMX_PAIR_ROT 1
-#endif
 template <int CMID, int N2T>
 __global__ __launch_bounds__(256) void conv1x1_pair_kernel(const PairArgs a)
 {
@@ -1381,11 +1378,12 @@ __global__ __launch_bounds__(256) void conv1x1_pair_kernel(const PairArgs a)
             sH[row * LDH + (wave * NT1 + u) * 32 + li] = fmaxf(acc[u][reg] + bias1[u], 0.f);
         }
     __syncthreads();
-    // second layer: N2T of the four waves take one 32-channel tile each over all CMID hidden channels.  WHICH waves rotates with the block
-    // (PMX_PAIR_ROT): with waves 0 .. N2T - 1 of every block the SIMDs those waves sit on carried 2x the matrix work of the others (two
-    // blocks per CU); a tile that holds padding channels only (the 19 heat-map channels of a 64-channel pad) is not computed at all
-    const int w2t = PMX_PAIR_ROT ? ((wave + 2 * (int)(blockIdx.x & 1) + (int)((blockIdx.x >> 1) & 1)) & 3) : wave;
-    if (w2t >= N2T || (PMX_PAIR_ROT && w2t * 32 >= cout)) return;
+    // second layer: N2T of the four waves take one 32-channel tile each over all CMID hidden channels.  WHICH waves rotates with the block:
+    // with waves 0 .. N2T - 1 of every block the SIMDs those waves sit on carried 2x the matrix work of the others (two blocks per CU:
+    // -3 %, profiles/r05_pair_rotation_ab.json); a tile that holds padding channels only (the 19 heat-map channels of a 64-channel pad)
+    // is not computed at all
+    const int w2t = (wave + 2 * (int)(blockIdx.x & 1) + (int)((blockIdx.x >> 1) & 1)) & 3;
+    if (w2t >= N2T || w2t * 32 >= cout) return;
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w2), 0, 0x7fffffff, 0x00020000);
     const int n = w2t * 32 + li;
     const float bias2 = b2[n];

@@ -111,8 +111,9 @@ if os.path.exists(bl):
     lines = [l for l in open(bl) if l.startswith('{')]
     if lines:
         json.dump(json.loads(lines[-1]), open(os.path.join(P, rnd + '_bench.json'), 'w'), indent=1)
-for k, e in summary['kernels'].items():
-    print(k[:60], json.dumps(e['derived']))
+if os.path.exists(os.path.join(P, rnd + '_pmc_summary.json')):
+    for k, e in json.load(open(os.path.join(P, rnd + '_pmc_summary.json')))['kernels'].items():
+        print(k[:60], json.dumps(e['derived']))
 
 # the bench line's roofline, recomputed from the rocprofv3 kernel stats of the same command: issued / algorithmic FLOP per launch (from the
 # bench line = the engine's launch plan) over rocprofv3's average duration of that kernel
