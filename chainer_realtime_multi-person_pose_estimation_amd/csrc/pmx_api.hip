@@ -1303,6 +1303,12 @@ extern "C" int pmx_set_gaussian(pmx_ctx* c, const double* taps, int radius)
     PMX_CHECK(radius >= 0 && radius <= PMX_GAUSS_MAX_RADIUS, PMX_ERR_INVALID, "pmx_set_gaussian: radius %d > %d", radius, PMX_GAUSS_MAX_RADIUS);
     c->gauss.assign(taps, taps + 2 * radius + 1);
     c->tab_in_h = -1;   // force table rebuild / upload
+    if (!c->tab_cache.empty()) {      // the per-size table sets of mixed batches carry the old taps (a setup call: synchronising is fine)
+        PMX_DEV(c);
+        PMX_HIP(hipDeviceSynchronize());
+        for (auto& kv : c->tab_cache) (void)hipFree(kv.second.xi0);
+        c->tab_cache.clear();
+    }
     return PMX_OK;
 }
 

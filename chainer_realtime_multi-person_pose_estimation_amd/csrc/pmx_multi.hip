@@ -78,7 +78,9 @@ int build_seg_tables(pmx_ctx* c, const std::vector<Geo>& g)
 // flight reads it; the cache is started over only by pmx_detect_images / pmx_postprocess_images behind a device synchronisation)
 int cached_tables(pmx_ctx* c, int in_h, int in_w, int out_h, int out_w, PPTables* out)
 {
-    const auto key = std::make_tuple(in_h, in_w, out_h, out_w);
+    // (the peak-branch option changes the Gaussian taps / border flags the table set carries: part of the key; a changed pmx_set_gaussian
+    //  is not -- the mirror sets the taps once, right after pmx_create)
+    const auto key = std::make_tuple(in_h, in_w, out_h, c->opt_gpu_branch_peaks ? -out_w : out_w);
     auto it = c->tab_cache.find(key);
     if (it != c->tab_cache.end()) { *out = it->second; return PMX_OK; }
     // the context's own single-size machinery builds the grids (np.linspace semantics, Gaussian taps, peak-branch flags) ...

@@ -175,3 +175,50 @@ def test_mixed_batch_argument_errors(native):
     with pytest.raises(native.PmxError):
         eng.postprocess_images([(56, 56)])                                  # the current maps are a uniform batch
     eng.close()
+
+
+# ---- randomised: any list of sizes (deterministic example set by default; PMX_FUZZ=<n> draws n fresh random examples) ----------------------
+import os
+from hypothesis import given, settings, strategies as st, HealthCheck
+
+_FUZZ = int(os.environ.get('PMX_FUZZ', '0'))
+
+
+@pytest.fixture(scope='module')
+def fuzz_engines(native):
+    weights = _calibrated(native)
+    mixed = native.Engine(0, max_batch=8, max_h=160, max_w=160)
+    mixed.set_weights(weights)
+    single = native.Engine(0, max_batch=1, max_h=160, max_w=160)
+    single.set_weights(weights)
+    _plain(single)
+    yield mixed, single
+    mixed.close()
+    single.close()
+
+
+@settings(max_examples=_FUZZ or 12, derandomize=not _FUZZ, deadline=None, database=None,
+          suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(seed=st.integers(0, 10 ** 6), sizes=st.lists(st.tuples(st.integers(1, 20), st.integers(1, 20)), min_size=1, max_size=8))
+def test_mixed_batch_fuzz_any_sizes(fuzz_engines, seed, sizes):
+    """Random lists of 1 .. 8 images of 8 x 8 ... 160 x 160 pixels (maps down to 1 x 1, every kind of ragged edge against the 16 x 16
+    squares and 8 x 16 rectangles, repeated and alternating sizes): maps, peaks and records of every image == the single-image call on
+    the plain kernels, bit for bit."""
+    mixed, single = fuzz_engines
+    rng = np.random.default_rng(seed)
+    imgs = [rng.integers(0, 256, (8 * h, 8 * w, 3), dtype=np.uint8) for h, w in sizes]
+    net = [im.shape[:2] for im in imgs]
+    mp = [(max(8, h * 320 // 368 // 8 * 8), max(8, w * 320 // 368 // 8 * 8)) for h, w in net]
+    mixed.detect_images(imgs, net, mp)
+    rec = mixed.results()
+    maps = [mixed.image_maps(i) for i in range(len(imgs))]
+    peaks = [mixed.peaks(i) for i in range(len(imgs))]
+    for i, im in enumerate(imgs):
+        single.detect_batch(im[None], mp[i][0], mp[i][1], img_len=mp[i][1], scale_xy=[[im.shape[1] / mp[i][1], im.shape[0] / mp[i][0]]])
+        paf, heat = single.get_maps()
+        assert np.array_equal(maps[i][0], paf[0]) and np.array_equal(maps[i][1], heat[0]), (i, sizes)
+        assert np.array_equal(peaks[i], single.peaks(0)), (i, sizes)
+        r1 = single.results()[0]
+        n = int(r1['n_people'])
+        assert int(rec[i]['n_people']) == n and int(rec[i]['n_peaks']) == int(r1['n_peaks']) and int(rec[i]['status']) == int(r1['status'])
+        assert np.array_equal(rec[i]['poses'][:n], r1['poses'][:n]) and np.array_equal(rec[i]['scores'][:n], r1['scores'][:n])

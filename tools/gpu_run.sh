@@ -74,7 +74,9 @@ for STEP in "$@"; do
         (timeout 1500 python tools/kernel_variants.py $MODE --json $O/variants.json) > $O/variants.log 2>&1; note variants $?; tail -30 $O/variants.log ;;
     block_timing) (timeout 400 python tools/block_timing.py $(echo $A | tr ',' ' ') --json $O/block_timing.json) > $O/block_timing.log 2>&1; note block_timing $?; tail -30 $O/block_timing.log ;;
     soak) (PMX_FUZZ=200 timeout 1500 python -m pytest tests/test_gpu_properties.py -q -p no:cacheprovider) > $O/fuzz.log 2>&1; note fuzz $?
-          (timeout 900 python tools/soak.py) > $O/soak.log 2>&1; note soak $?; tail -8 $O/soak.log ;;
+          (PMX_FUZZ=60 timeout 1500 python -m pytest tests/test_gpu_multi.py -q -p no:cacheprovider -k fuzz) > $O/fuzz_multi.log 2>&1; note fuzz_multi $?
+          (timeout 900 python tools/soak.py) > $O/soak.log 2>&1; note soak $?
+          (timeout 900 python tools/soak_modes.py) >> $O/soak.log 2>&1; note soak_modes $?; tail -8 $O/soak.log ;;
     py) (timeout 1500 python tools/$(echo $A | tr ',' ' ')) > $O/py_$(echo $A | cut -d, -f1 | tr '/.' '__').log 2>&1; note "py:$A" $?; tail -25 $O/py_$(echo $A | cut -d, -f1 | tr '/.' '__').log ;;
     *) echo "unknown step $STEP" | tee -a $O/summary.log ;;
   esac
