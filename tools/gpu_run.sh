@@ -12,8 +12,8 @@
 #   bench_fast                 bench.py --no-cpu-baseline --no-extras bench_ranks:<n>  bench.py --gpus n over gloo on this one GPU
 #   census  census1  census_rect  census_modes    the margin census: 512 frames batch 32 | 128 frames batch 1 | 368x496 + 496x368 |
 #                              512 frames with the conv1-direct and direct-kernel engine modes next to the default (drift attribution)
-#   rp_bench rp_drv rp_b1 rp_rect rp_precise      rocprofv3 --kernel-trace --stats of bench.py / the batch-32 driver / batch 1 / 368x496 /
-#                              detect_precise
+#   rp_bench rp_drv rp_b1 rp_rect rp_precise rp_mixed   rocprofv3 --kernel-trace --stats of bench.py / the batch-32 driver / batch 1 /
+#                              368x496 / detect_precise / the mixed-size batch
 #   pmc                        the five PMC passes of the batch-32 driver (one counter group per pass, MI355X_MICROARCH.md)
 #   pmc_b1                     the same of the batch-1 driver
 #   rect_batches               landscape / portrait rate per pixel vs the square case at batch 8, 16, 24, 32
@@ -59,6 +59,7 @@ for STEP in "$@"; do
     rp_b1) rp b1 300 python $R/tools/profile_driver.py --batch 1 --steps 20 ;;
     rp_rect) rp rect 300 python $R/tools/rect_time.py --h 368 --w 496 --batch 32 --steps 3 ;;
     rp_precise) rp precise 400 python $R/tools/precise_bench_driver.py ;;
+    rp_mixed) rp mixed 400 python $R/tools/mixed_batch_time.py --steps 3 ;;
     pmc) pmc "" --batch 32 --steps 1 ;;
     pmc_b1) pmc _b1 --batch 1 --steps 4 ;;
     rect_batches) (timeout 900 python tools/rect_batches.py --json $O/rect_batches.json) > $O/rect_batches.log 2>&1; note rect_batches $?; tail -12 $O/rect_batches.log ;;

@@ -42,7 +42,8 @@ if os.path.exists(os.path.join(G, 'parity_census_368x496.json')) and os.path.exi
 if os.path.exists(os.path.join(G, 'rp_bench', 'bench_kernel_stats.csv')):      # rocprofv3 --kernel-trace --stats -- python bench.py
     shutil.copy(os.path.join(G, 'rp_bench', 'bench_kernel_stats.csv'), os.path.join(P, rnd + '_bench_kernel_stats.csv'))
 
-for sub, stem, dst in (('rp_b1', 'b1', '_b1_kernel_stats.csv'), ('rp_rect', 'rect', '_rect_368x496_kernel_stats.csv'), ('rp_precise', 'precise', '_precise_kernel_stats.csv')):
+for sub, stem, dst in (('rp_b1', 'b1', '_b1_kernel_stats.csv'), ('rp_rect', 'rect', '_rect_368x496_kernel_stats.csv'), ('rp_precise', 'precise', '_precise_kernel_stats.csv'),
+                       ('rp_mixed', 'mixed', '_mixed_batch_kernel_stats.csv')):
     f = os.path.join(G, sub, stem + '_kernel_stats.csv')
     if os.path.exists(f):
         shutil.copy(f, os.path.join(P, rnd + dst))
