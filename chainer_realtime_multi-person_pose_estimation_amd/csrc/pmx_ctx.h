@@ -36,8 +36,9 @@ struct ProfPending { int entry; hipEvent_t e0, e1; };
 
 // detect_precise runs its inference scales CONCURRENTLY: one image at 0.5x / 1x / 1.5x is 12 ... 108 one-per-CU blocks per layer for 256
 // CUs, so the four forward passes go to four streams ("lanes"), each with its own working set; a lane's fields are swapped into the
-// context while its scale is enqueued (the forward code keeps using c->stream / c->act0 / ...).  Scale k of a sequence runs on lane
-// k % PMX_PR_LANES and leaves its maps, resized to the original size, in pr_part[k]; pmx_precise_finish adds the parts IN SCALE ORDER
+// context while its scale is enqueued (the forward code keeps using c->stream / c->act0 / ...).  The first scale enqueued in a
+// sequence runs on lane 3 (highest stream priority), the others round-robin on the remaining lanes in use (pmx_precise.hip); the scale in
+// slot k leaves its maps, resized to the original size, in pr_part[k]; pmx_precise_finish adds the parts IN SLOT ORDER
 // (the reference's left-to-right sum, pose_detector.py:463,467) and divides.
 constexpr int PMX_PR_LANES = 4;
 constexpr int PMX_SK_ZERO_BIAS = 1024;      // floats of the shared zero-bias vector of the split-K / unit-mode launches
