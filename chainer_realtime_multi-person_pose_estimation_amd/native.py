@@ -611,10 +611,19 @@ class Engine(object):
         return cap.value, nbytes.value
 
     def results(self):
-        """Structured array (B,) of result_dtype(people_cap) (synchronises)."""
-        cap, _ = self.results_layout()
-        out = np.empty(self._B, dtype=result_dtype(cap))
-        self._check(self.lib.pmx_get_results(self._ctx, self._B, _ptr(out), out.nbytes))
+        """Structured array (B,) of result_dtype(people_cap) (synchronises).  ONE device round trip in the common case: the buffer is sized
+        for the context's current person capacity (a host-side query) and pmx_get_results checks the status words it has just copied; only
+        if an image overflowed a capacity -- the library then grows it and re-runs the post-process, so the record size changes -- the
+        call comes back with PMX_ERR_CAPACITY and is repeated with the new layout (pmx_results_layout)."""
+        v = [C.c_int(0) for _ in range(4)]
+        self._check(self.lib.pmx_get_capacities(self._ctx, *[C.byref(x) for x in v]))
+        out = np.empty(self._B, dtype=result_dtype(v[2].value))
+        rc = self.lib.pmx_get_results(self._ctx, self._B, _ptr(out), out.nbytes)
+        if rc == 5:                                   # PMX_ERR_CAPACITY: the person capacity grew under the call
+            cap, _ = self.results_layout()
+            out = np.empty(self._B, dtype=result_dtype(cap))
+            rc = self.lib.pmx_get_results(self._ctx, self._B, _ptr(out), out.nbytes)
+        self._check(rc)
         return out
 
     def results_device_ptr(self):
