@@ -295,3 +295,20 @@ def test_no_kernel_of_the_library_lives_in_scratch(native, tmp_path):
     assert not heavy, heavy
     # one wave per SIMD with the whole accumulator file: every Winograd kernel holds its 16 frequency tiles in 256 AGPRs
     assert all(v['agpr'] == 256 for v in wino.values()), {k: v['agpr'] for k, v in wino.items() if v['agpr'] != 256}
+
+
+def test_public_header_is_plain_c():
+    """include/pose_mi355x.h is the C ABI: it must compile as C99 (and as C++) on its own -- plain pointers, sizes and one POD struct
+    (pmx_image), no C++ or HIP types in any signature."""
+    import shutil
+    import subprocess
+    native = pkg('native')
+    for cc, lang, std in (('gcc', 'c', '-std=c99'), ('g++', 'c++', '-std=c++11')):
+        if shutil.which(cc) is None:
+            continue
+        r = subprocess.run([cc, '-x', lang, std, '-fsyntax-only', '-Wall', '-Werror', native.HEADER], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    import re
+    code = re.sub(r'/\*.*?\*/', '', open(native.HEADER).read(), flags=re.S)          # declarations without the comments
+    assert 'hipStream_t' not in code and 'hip/' not in code and 'torch' not in code.lower() and '#include <' in code
+    assert set(re.findall(r'#include <([^>]+)>', code)) <= {'stddef.h', 'stdint.h'}
