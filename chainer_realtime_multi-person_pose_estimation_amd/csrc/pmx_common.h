@@ -224,7 +224,8 @@ int launch_resize_cubic_f32_planar(const float* src, long long sb, long long sc,
 void prep_set_cubic_rows(int on);     // 1 (default): separable form through LDS; 0: one thread per element (same bits)
 int launch_resize_cubic_u8(const uint8_t* src, int sw, uint8_t* dst, int dh, int dw, int dpitch, const int* xi, const int* xa,
                            const int* yi, const int* ya, int B, long long sbytes, long long dbytes, hipStream_t s);
-int launch_fill_bgr(uint8_t* dst, long long npix, int b, int g, int r, hipStream_t s);
+// n padded images of ph x pw (dense, one after the other): the pixels outside the top-left sh x sw of each <- (b, g, r)
+int launch_fill_pad_bgr(uint8_t* dst, int n, int ph, int pw, int sh, int sw, int b, int g, int r, hipStream_t s);
 int launch_scale_f32(float* p, long long n, float divisor, hipStream_t s);
 // out[i] = (((0 + parts[0][off + i]) + parts[1][off + i]) + ...) / divisor, nparts <= 8
 int launch_sum_parts_f32(float* out, const float* const* parts, int nparts, long long off, long long n, float divisor, hipStream_t s);

@@ -280,7 +280,7 @@ static int precise_add_scale(pmx_ctx* c, const uint8_t* imgs, int scaled_h, int 
         PMX_HIP(hipStreamWaitEvent(c->stream, c->pr_fin, 0));            // the last finish has read this scale's part
         // (1) uint8 cubic resize into the padded images (all images in one launch)
         const size_t pad_bytes = (size_t)ph * pw * 3;
-        if ((rc2 = launch_fill_bgr(c->u8_tmp, (long long)n * ph * pw, 104, 117, 123, c->stream))) return rc2;
+        if ((rc2 = launch_fill_pad_bgr(c->u8_tmp, n, ph, pw, scaled_h, scaled_w, 104, 117, 123, c->stream))) return rc2;
         if (same) {
             for (int b = 0; b < n; ++b)
                 PMX_HIP(hipMemcpy2DAsync(c->u8_tmp + b * pad_bytes, (size_t)pw * 3, c->u8_src + b * img_bytes, (size_t)ow * 3, (size_t)ow * 3, oh,

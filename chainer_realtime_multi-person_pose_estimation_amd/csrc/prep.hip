@@ -230,11 +230,17 @@ __global__ __launch_bounds__(256) void resize_cubic_u8_kernel(const uint8_t* __r
     }
 }
 
-__global__ __launch_bounds__(256) void fill_bgr_kernel(uint8_t* __restrict__ dst, long long npix, int b, int g, int r)
+// The padding of detect_precise's network inputs (pose_detector.py:445: pad bottom / right to a multiple of 8 with (104, 117, 123)): only
+// the strips outside the resized image are written -- the columns [sw, pw) of the rows above sh, the whole rows [sh, ph) -- instead of
+// filling the padded image before the resize overwrites most of it (until round 6: 2.2 MB of byte stores at the head of the largest
+// scale's chain, 6 % of detect_precise's kernel time in profiles/r06_precise_kernel_stats.csv).  grid (ph, n); one block per row.
+__global__ __launch_bounds__(256) void fill_pad_bgr_kernel(uint8_t* __restrict__ dst, int ph, int pw, int sh, int sw, long long img_bytes, int b, int g, int r)
 {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= npix) return;
-    dst[i * 3] = (uint8_t)b; dst[i * 3 + 1] = (uint8_t)g; dst[i * 3 + 2] = (uint8_t)r;
+    const int row = blockIdx.x;
+    uint8_t* const p = dst + (long long)blockIdx.y * img_bytes + (long long)row * pw * 3;
+    for (int x = (row < sh ? sw : 0) + threadIdx.x; x < pw; x += 256) {
+        p[x * 3] = (uint8_t)b; p[x * 3 + 1] = (uint8_t)g; p[x * 3 + 2] = (uint8_t)r;
+    }
 }
 
 __global__ __launch_bounds__(256) void scale_f32_kernel(float* __restrict__ p, long long n, float divisor)
@@ -335,9 +341,11 @@ int launch_resize_cubic_u8(const uint8_t* src, int sw, uint8_t* dst, int dh, int
     return PMX_OK;
 }
 
-int launch_fill_bgr(uint8_t* dst, long long npix, int b, int g, int r, hipStream_t s)
+int launch_fill_pad_bgr(uint8_t* dst, int n, int ph, int pw, int sh, int sw, int b, int g, int r, hipStream_t s)
 {
-    hipLaunchKernelGGL(fill_bgr_kernel, dim3(nblocks(npix)), dim3(256), 0, s, dst, npix, b, g, r);
+    if (ph == sh && pw == sw) return PMX_OK;          // nothing to pad
+    PMX_CHECK(n >= 1 && n <= 65535 && ph >= sh && pw >= sw && sh >= 0 && sw >= 0, PMX_ERR_INVALID, "pad fill: bad geometry");
+    hipLaunchKernelGGL(fill_pad_bgr_kernel, dim3((unsigned)ph, (unsigned)n), dim3(256), 0, s, dst, ph, pw, sh, sw, (long long)ph * pw * 3, b, g, r);
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
