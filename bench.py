@@ -34,10 +34,21 @@ import time
 
 import numpy as np
 
-# (the same default the package sets at import, here before anything can initialise the HIP runtime: detect_precise keeps four scales in
-#  flight on four streams; with ROCm's default of 4 hardware queues per process they would share queues with this harness's other streams
-#  -- profiles/r06_hw_queues.json.  A runtime setting of the process, stated in the line as `hw_queues`.)
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+# Hardware queues of the process (read when the HIP runtime initialises, so set before anything can touch it; stated in the line as
+# `hw_queues`).  One rank: the package's own default, 2 -- the setting under which detect_precise's four prioritised lanes interleave best
+# both alone and inside this harness (profiles/r06_hw_queues.json).  Several ranks: 8, so that RCCL's streams never share a hardware
+# queue with the compute stream (the record gather of step k runs under the convolutions of step k + 1).
+def _multi_rank_argv(argv):
+    if int(os.environ.get('WORLD_SIZE', '1') or 1) > 1 or '--force-gather' in argv:      # (--force-gather: the one-rank RCCL group, same setting as N > 1)
+        return True
+    for i, a in enumerate(argv):
+        v = a.split('=', 1)[1] if a.startswith('--gpus=') else (argv[i + 1] if a == '--gpus' and i + 1 < len(argv) else None)
+        if v is not None and v.isdigit() and int(v) > 1:
+            return True
+    return False
+
+
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8' if _multi_rank_argv(sys.argv[1:]) else '2')
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = 'chainer_realtime_multi-person_pose_estimation_amd'

@@ -11,12 +11,15 @@ import sys
 
 import numpy as np
 
-# ROCm maps a process's HIP streams onto at most GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue run one after
-# the other.  detect_precise keeps four scales in flight on four streams next to the context's own, a copy stream and whatever the
-# application (torch ...) has created: with the default, two lanes regularly land on one queue and the four "concurrent" scales run as
-# three or two -- 20.2 instead of 14.0 ms per 482 x 642 image inside bench.py's process (profiles/r06_hw_queues.json).  The variable is
-# read when the HIP runtime initialises, i.e. at the first HIP call of the process: set here, at import, unless the user has set it.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+# ROCm maps a process's HIP streams onto at most GPU_MAX_HW_QUEUES hardware queues per priority level (default 4); streams that share a
+# queue run one after the other.  detect_precise keeps four scales in flight on four prioritised streams next to the context's own, a copy
+# stream and whatever the application (torch ...) has created, and how its chains interleave depends on this number: measured on five boxes
+# of the pool, the precise leg alone in a process / inside bench.py's process (profiles/r06_hw_queues.json): 1 queue 19.4 / 19.4 ms per
+# 482 x 642 image, 2 queues 14.1 / 14.0, 3 queues 16.2 / 14.2, 4 (the default) 16.2 / 19.5, 8 queues 16.0 / 14.0 -- two is the only
+# setting that gives the fast interleaving in both kinds of process; the batch, single-image and mixed-batch paths do not depend on it.
+# The variable is read when the HIP runtime initialises, i.e. at the first HIP call of the process: set here, at import, unless the user
+# has set it.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '2')
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')

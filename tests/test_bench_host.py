@@ -95,3 +95,13 @@ def test_compare_records_counts_poses_exact_scores_to_tolerance():
     lost = bench.compare_records(a, b)
     assert not lost['shard_records_match'] and lost['first_mismatch'] == {'record': 3, 'n_people': [1, 0], 'n_peaks': [13, 13], 'status': [0, 0]}
     assert not bench.compare_records(a[:0], b[:0])['shard_records_match']            # nothing compared is not a match
+
+
+def test_hardware_queue_default_follows_the_rank_count(monkeypatch):
+    # one rank: the package's default (2 queues: detect_precise's lanes); several ranks / the one-rank RCCL group: 8 (RCCL's streams apart)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    f = bench._multi_rank_argv
+    assert not f([]) and not f(['--gpus', '1']) and not f(['--steps', '5', '--gpus=1'])
+    assert f(['--gpus', '2']) and f(['--gpus=8', '--steps', '3']) and f(['--force-gather'])
+    monkeypatch.setenv('WORLD_SIZE', '4')
+    assert f([]) and f(['--gpus', '4'])
