@@ -47,6 +47,40 @@ static double wino_tail_makespan(int ks, int nch, int g, long long nblk, int ncu
     return end;
 }
 
+// The unit plan of `nblk` blocks (images x 128-channel blocks x groups) that finishes first: chunks per pass-1 unit g -> S = ceil(nch / g)
+// (+ 3 for 7x7) units, 2 <= S <= 8, by the dispatch simulation above + the combine's slab reads; forced_g > 0 pins g (if it is a valid plan).
+// A pure function of its arguments: memoised -- run_conv asks for every layer of every forward, and the simulation is a heap walk over
+// units x blocks per candidate.  Returns the makespan in microseconds, *g_out = 0 when no plan exists (nch too small).
+static double wino_best_unit_g(int ks, int nch, long long nblk, int ncu, int forced_g, int* g_out)
+{
+    const int extra = ks == 7 ? 3 : 0;
+    struct Key { int ks, nch, forced; long long nblk, ncu; bool operator<(const Key& k) const { return std::tie(ks, nch, forced, nblk, ncu) < std::tie(k.ks, k.nch, k.forced, k.nblk, k.ncu); } };
+    static std::mutex mu;
+    static std::map<Key, std::pair<double, int>> memo;
+    const Key key{ks, nch, forced_g, nblk, ncu};
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = memo.find(key);
+        if (it != memo.end()) { *g_out = it->second.second; return it->second.first; }
+    }
+    double best = 1e30;
+    int best_g = 0;
+    for (int gg = 1; gg <= nch; ++gg) {
+        const int SS = (nch + gg - 1) / gg + extra;
+        if (SS < 2 || SS > 8 || (gg > 1 && (nch + gg - 2) / (gg - 1) + extra == SS)) continue;      // (same unit count as a smaller g: skip)
+        const double t = wino_tail_makespan(ks, nch, gg, nblk, ncu) + 2.0 * SS;   // + the combine's slab reads
+        if (t < best) { best = t; best_g = gg; }
+    }
+    if (forced_g > 0 && forced_g <= nch) {
+        const int SS = (nch + forced_g - 1) / forced_g + extra;
+        if (SS >= 2 && SS <= 8) { best_g = forced_g; best = wino_tail_makespan(ks, nch, best_g, nblk, ncu) + 2.0 * SS; }
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    memo[key] = std::make_pair(best, best_g);
+    *g_out = best_g;
+    return best;
+}
+
 // *run = 1: mode 1 in the run geometry (46-pixel-wide maps, no pool); *tail_g > 0: its part-filled last blocks in unit mode, g chunks per
 // pass-1 unit (launch_wino_run)
 int wino_select(const WinoSelectOpts& o, int ks, int cin_pad, int cout_pad, int cout, int ldc, int images, int H, int W, int pool, int* unit_g,
@@ -55,14 +89,26 @@ int wino_select(const WinoSelectOpts& o, int ks, int cin_pad, int cout_pad, int 
     *unit_g = 0; *run = 0; *tail_g = 0;
     if (o.conv_algo < 1 || o.precision != 0 || o.forced_variant >= 0 || !wino_eligible(ks, cin_pad, cout_pad)) return 0;
     const int nch = cin_pad / 32, extra = ks == 7 ? 3 : 0;     // 7x7: + row 6, column 6, tap (6, 6)
-    int g = 0, S = 0;
-    if (o.ksplit == 0 && cout % 4 == 0 && ldc % 4 == 0 && nch >= 2) {       // unit plan: as many units as 8 slabs allow
+    const long long ncu = conv_num_cus(), nb = cout_pad / 128;
+    int g = 0, S = 0;        // the plan with as many units as 8 slabs allow (tails under conv_algo 2; whole launches with wino_unit_g = -1)
+    int gu = 0;              // the plan of a whole launch in unit mode (single images, small batches)
+    if (o.ksplit == 0 && cout % 4 == 0 && ldc % 4 == 0 && nch >= 2) {
         const int nu1_max = 8 - extra;
         g = (nch + nu1_max - 1) / nu1_max;
         const int nu1 = (nch + g - 1) / g;
         if (nu1 >= 2) S = nu1 + extra; else g = 0;
+        // Until round 6 whole launches used that plan too -- which for the wide 3x3 layers of one 368 x 368 image is 576 unit blocks = 2.25
+        // rounds of the 256 CUs paid as 3 (conv4_2: 72 tile blocks x 8 units of 2 chunks).  Now the plan the dispatch simulation finishes
+        // first (the one the tails use): conv4_2 as 3 units of 6 / 6 / 4 chunks = 216 blocks in ONE round, conv4_1 / conv4_3 as 3 / 6 units;
+        // the 46 x 46 7x7 layers keep their 7 units (252 blocks), the 46 x 62 ones take 5 (240 blocks instead of 336).
+        gu = g;
+        if (g && o.wino_unit_g >= 0) {
+            const long long ub = (long long)((H + 7) / 8) * ((W + 15) / 16) * images * nb;         // unit mode keeps the rectangles
+            int bg = 0;
+            (void)wino_best_unit_g(ks, nch, ub, (int)ncu, o.wino_unit_g, &bg);
+            if (bg) gu = bg;
+        }
     }
-    const long long ncu = conv_num_cus(), nb = cout_pad / 128;
     // run geometry: blocks of 32 consecutive tiles; the part-filled last block of an image (if any) can run as S unit blocks
     // (3x3 layers with fewer than four chunks keep the rectangles: their blocks are so short -- conv2_1: 24 us -- that the larger first
     //  halo of a run costs more than the padding it saves: measured +3 %)
@@ -76,7 +122,7 @@ int wino_select(const WinoSelectOpts& o, int ks, int cin_pad, int cout_pad, int 
         if (tail_ok && o.wino_tail == 1) *tail_g = g;
         return 1;
     }
-    if (o.conv_algo == 3) { *unit_g = g; return g ? 2 : 0; }               // tests: unit mode wherever it applies
+    if (o.conv_algo == 3) { *unit_g = gu; return gu ? 2 : 0; }             // tests: unit mode wherever it applies
     // cost of the plain kernel in rounds of one block per CU (equal blocks: a round costs the same however full it is)
     const long long blocks = geom_run ? (long long)nblk * nslab * images * nb : (long long)((H + 7) / 8) * ((W + 15) / 16) * images * nb;
     const long long rounds = (blocks + ncu - 1) / ncu;
@@ -86,37 +132,12 @@ int wino_select(const WinoSelectOpts& o, int ks, int cin_pad, int cout_pad, int 
         // the full blocks as whole rounds + the tail as unit blocks (best g by a dispatch simulation) + two more launches and the combine
         const double t_block = nch * (ks == 7 ? WINO_T7_CHUNK_US : WINO_T3_CHUNK_US);
         const long long main_rounds = ((long long)nfull * nslab * images * nb + ncu - 1) / ncu;
-        // the best g is a pure function of (ks, nch, tail blocks, CUs, forced g): memoised -- run_conv asks for every layer of every
-        // forward, and the dispatch simulation is a heap walk over units x blocks per candidate
-        struct Key { int ks, nch, forced; long long nblk, ncu; bool operator<(const Key& k) const { return std::tie(ks, nch, forced, nblk, ncu) < std::tie(k.ks, k.nch, k.forced, k.nblk, k.ncu); } };
-        static std::mutex mu;
-        static std::map<Key, std::pair<double, int>> memo;
         // (merged tails: the tail tiles of a group's images as one stream, 32 per block)
         const int grp = std::max(1, o.groups);
         const bool merge = o.wino_tail_merge != 0 && wino_tail_mergeable(images / grp, H, W, o.lda);
-        const Key key{ks, nch, o.wino_tail_g, merge ? (long long)grp * wino_tail_merged_blocks(images / grp, H) * nb : (long long)images * nslab * nb, ncu};
-        double best = 1e30;
+        const long long tail_blocks = merge ? (long long)grp * wino_tail_merged_blocks(images / grp, H) * nb : (long long)images * nslab * nb;
         int best_g = 0;
-        bool hit = false;
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            auto it = memo.find(key);
-            if (it != memo.end()) { best = it->second.first; best_g = it->second.second; hit = true; }
-        }
-        if (!hit) {
-            for (int gg = 1; gg <= nch; ++gg) {
-                const int SS = (nch + gg - 1) / gg + extra;
-                if (SS < 2 || SS > 8 || (gg > 1 && (nch + gg - 2) / (gg - 1) + extra == SS)) continue;      // (same unit count as a smaller g: skip)
-                const double t = wino_tail_makespan(ks, nch, gg, key.nblk, (int)ncu) + 2.0 * SS;   // + the combine's slab reads
-                if (t < best) { best = t; best_g = gg; }
-            }
-            if (o.wino_tail_g > 0 && o.wino_tail_g <= nch) {
-                const int SS = (nch + o.wino_tail_g - 1) / o.wino_tail_g + extra;
-                if (SS >= 2 && SS <= 8) { best_g = o.wino_tail_g; best = wino_tail_makespan(ks, nch, best_g, key.nblk, (int)ncu) + 2.0 * SS; }
-            }
-            std::lock_guard<std::mutex> lk(mu);
-            memo[key] = std::make_pair(best, best_g);
-        }
+        const double best = wino_best_unit_g(ks, nch, tail_blocks, (int)ncu, o.wino_tail_g, &best_g);
         const double cost = (double)main_rounds + (best + 10.0) / t_block;
         if (best_g && (o.wino_tail == 1 || cost < plain_cost)) { plain_cost = cost; tg = best_g; }
     }
@@ -129,7 +150,8 @@ int wino_select(const WinoSelectOpts& o, int ks, int cin_pad, int cout_pad, int 
                                 (double)ublocks * (S + 1) * 65536.0 / 3.0e12 / t_block + 0.03;      // in rounds of the plain kernel
         // (a handful of unit blocks cannot beat the direct kernels' split-K, which cuts the same work into more and smaller blocks:
         //  184 x 248 input, one image: 12 tiles x 7 units = 84 blocks took 1.9 ms per forward against 1.4 ms)
-        if (est_unit < plain_cost && ublocks * S * 2 >= ncu) { *unit_g = g; return 2; }
+        // (the choice of the MODE is made with the many-unit plan, as before round 6; the plan itself is gu)
+        if (est_unit < plain_cost && ublocks * S * 2 >= ncu) { *unit_g = gu; return 2; }
     }
     if (blocks * 100 >= (long long)o.wino_min_fill * rounds * ncu) { *run = geom_run; *tail_g = tg; return 1; }
     return 0;

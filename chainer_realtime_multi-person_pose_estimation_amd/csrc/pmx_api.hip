@@ -484,6 +484,7 @@ extern "C" int pmx_set_option(pmx_ctx* c, const char* key, int value)
     else if (!strcmp(key, "wino_geom")) c->opt_wino_geom = value;
     else if (!strcmp(key, "wino_tail")) c->opt_wino_tail = value;
     else if (!strcmp(key, "wino_tail_g")) c->opt_wino_tail_g = value;
+    else if (!strcmp(key, "wino_unit_g")) c->opt_wino_unit_g = value;
     else if (!strcmp(key, "wino_tail_merge")) c->opt_wino_tail_merge = value;
     else if (!strcmp(key, "ksplit")) c->opt_ksplit = value;
     else if (!strcmp(key, "ksplit_plan")) c->opt_ksplit = value > 0 ? -value : 0;     // decimal digits = chunks per slice, e.g. 3221
@@ -776,7 +777,7 @@ static int wino_mode(const pmx_ctx* c, int ks, int cin_pad, int cout_pad, int co
     WinoSelectOpts o;
     o.conv_algo = c->opt_conv_algo; o.precision = c->opt_precision; o.forced_variant = c->opt_force[ks]; o.ksplit = c->opt_ksplit;
     o.wino_unit_eff = c->opt_wino_unit_eff; o.wino_min_fill = c->opt_wino_min_fill; o.wino_geom = c->opt_wino_geom; o.wino_tail = c->opt_wino_tail;
-    o.wino_tail_g = c->opt_wino_tail_g; o.wino_tail_merge = c->opt_wino_tail_merge; o.groups = groups; o.lda = lda;
+    o.wino_tail_g = c->opt_wino_tail_g; o.wino_tail_merge = c->opt_wino_tail_merge; o.groups = groups; o.lda = lda; o.wino_unit_g = c->opt_wino_unit_g;
     return wino_select(o, ks, cin_pad, cout_pad, cout, ldc, images, H, W, pool, unit_g, run, tail_g);
 }
 

@@ -142,6 +142,7 @@ void conv_set_launch_events(hipEvent_t e0, hipEvent_t e1);
 struct WinoSelectOpts {      // the context options the choice depends on (pmx_set_option keys of the same names)
     int conv_algo, precision, forced_variant, ksplit, wino_unit_eff, wino_min_fill, wino_geom, wino_tail, wino_tail_g;
     int wino_tail_merge = 1;     // the tails of all images as one stream of tiles (0: one part-filled block per image)
+    int wino_unit_g = 0;         // chunks per pass-1 unit of a launch in unit mode: 0 = the plan that finishes first (dispatch simulation), > 0 = forced, -1 = as many units as 8 slabs allow (the rule until round 6)
     int groups = 1;              // branch groups in the launch (`images` counts images x groups)
     int lda = 0;                 // input channel stride (floats) of the launch: bounds the merged-tail form (wino_tail_mergeable)
 };

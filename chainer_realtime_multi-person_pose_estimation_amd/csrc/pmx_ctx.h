@@ -158,6 +158,7 @@ struct pmx_ctx {
                                      // model (conv_algo 1), 0 never, 1 wherever a unit plan exists.  Changes the summation of those tiles (C twin: unit_from)
     int opt_wino_tail_merge = 1;     // the tails of all images of a launch as one stream of tiles, 32 per block (0: one part-filled block per image)
     int opt_wino_tail_g = 0;         // tuning: chunks per pass-1 unit of the tail (0 = automatic)
+    int opt_wino_unit_g = 0;         // tuning: chunks per pass-1 unit of a launch in unit mode (0 = automatic, -1 = as many units as 8 slabs allow)
     int opt_precision = 0;           // 0: fp32 MFMA everywhere (the path whose results are specified); 1: bf16x3 kernels where a
                                      // v6 kernel would run (fp32-grade accuracy at 2.67x the matrix rate, NOT the fp32 FMA chain)
     int opt_conv1_wino = 1;          // fused conv1_1 + conv1_2 with conv1_2 as Winograd F(2x2, 3x3) (conv1_wino_kernel) where conv_algo allows Winograd

@@ -118,6 +118,10 @@ int pmx_synchronize(pmx_ctx* ctx);                    /* cuda.get_device_from_id
  *                              0 never, 1 wherever a unit plan exists.  The tiles of that block (row-major index >= 32 * full blocks)
  *                              are then summed unit by unit (C twin: `unit_from`); profile label "...r/t<chunks per unit>"
  *   "wino_tail_g" n            tuning: chunks per pass-1 unit of those tails (0 = automatic)
+ *   "wino_unit_g" n            chunks per pass-1 unit of a launch that runs in unit mode as a whole (single images, small batches):
+ *                              0 (default) = the plan a dispatch simulation over the device's CUs finishes first (one 368 x 368 image:
+ *                              conv4_2 as 3 units of 6 / 6 / 4 chunks = 216 blocks in one round), n > 0 = n chunks, -1 = as many
+ *                              units as 8 slabs allow (the rule until round 6).  Part of the arithmetic: profile label ".../u<n>"
  *   "wino_tail_merge" 1 | 0    batches of 46-wide maps whose tail lies in one tile row (46 x 46: 17 tiles per image): 1 (default) = the
  *                              tails of all images of the launch as one stream of tiles, 32 per block (every MFMA row a real tile);
  *                              0 = one part-filled block per image.  Same units, same bits; profile label "...r/t<g>m"

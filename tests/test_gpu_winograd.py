@@ -354,14 +354,36 @@ def test_winograd_unit_mode_bit_exact_vs_c_twin(engine, B, cin, H, W, cout, k, r
     separate blocks writing slabs that the combine kernel adds in unit order == the twin's unit_g form, bit for bit."""
     x, w, b = _data(cin + H, B, cin, H, W, cout, k)
     nch = (cin + 31) // 32
-    nu1_max = 8 - (3 if k == 7 else 0)                  # conv_algo 3: up to 8 slabs (pmx_api.hip::wino_units_g)
+    nu1_max = 8 - (3 if k == 7 else 0)                  # wino_unit_g -1: as many units as 8 slabs allow (conv_select.hip)
     g = -(-nch // nu1_max)
-    y = _run(engine, x, w, b, relu, pool, 3)
+    engine.set_option('wino_unit_g', -1)
+    try:
+        y = _run(engine, x, w, b, relu, pool, 3)
+    finally:
+        engine.set_option('wino_unit_g', 0)
     ref = R.conv_wino(x, w, b, relu, pool, unit_g=g)
     assert np.array_equal(y, ref), (np.abs(y - ref).max(), int((y != ref).sum()))
     assert not np.array_equal(y, R.conv_wino(x, w, b, relu, pool)), 'unit mode did not run'
     t = N.conv2d_ref(x, w, b, relu=relu, pool=pool)
     assert np.abs(y - t).max() <= TOL * max(1.0, np.abs(t).max())
+
+
+@pytest.mark.parametrize('B,cin,H,W,cout,k,g', [(1, 512, 46, 46, 512, 3, 6), (1, 512, 46, 46, 512, 3, 3), (1, 256, 46, 46, 512, 3, 3),
+                                                 (1, 512, 46, 46, 256, 3, 5), (1, 128, 46, 46, 128, 7, 2), (2, 192, 20, 30, 128, 7, 3),
+                                                 (1, 256, 46, 46, 128, 3, 4), (1, 128, 46, 46, 128, 7, 4)])      # (7x7 with ONE pass-1 unit + row 6, column 6, tap (6, 6))
+def test_winograd_unit_plans_bit_exact_vs_c_twin(engine, B, cin, H, W, cout, k, g):
+    """Any unit plan -- g chunks per pass-1 unit, the last unit shorter (512 channels as 6 / 6 / 4 chunks, 5 / 5 / 5 / 1) -- equals the
+    twin's unit_g form bit for bit: since round 6 the selection takes the plan a dispatch simulation finishes first (one 368 x 368 image:
+    conv4_2 as 3 units = 216 blocks in one round of the CUs instead of 8 units = 576 blocks), here forced through `wino_unit_g`."""
+    x, w, b = _data(cin + H + g, B, cin, H, W, cout, k)
+    engine.set_option('wino_unit_g', g)
+    try:
+        y = _run(engine, x, w, b, True, False, 3)
+    finally:
+        engine.set_option('wino_unit_g', 0)
+    ref = R.conv_wino(x, w, b, True, False, unit_g=g)
+    assert np.array_equal(y, ref), (np.abs(y - ref).max(), int((y != ref).sum()))
+    assert not np.array_equal(y, R.conv_wino(x, w, b, True, False, unit_g=1)), 'the forced plan did not run'
 
 
 def test_single_image_368_default_plan_bit_exact(native):
