@@ -434,3 +434,28 @@ def test_random_run_geometry_shapes_bit_exact(engine, seed, k, B, H, slabs, nch,
     ref = R.conv_wino(x, w, b, relu, pool, unit_g=g, unit_from=uf) if tailed else R.conv_wino(x, w, b, relu, pool)
     assert y.shape == ref.shape
     assert np.array_equal(y, ref), (k, B, cin, H, W, cout, relu, pool, tailed, float(np.abs(y - ref).max()), int((y != ref).sum()))
+
+
+@settings(max_examples=_FUZZ or 16, derandomize=not _FUZZ, deadline=None, database=None,
+          suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(seed=st.integers(0, 10 ** 6), k=st.sampled_from([3, 7]), B=st.integers(1, 3), H=st.integers(1, 50), W=st.integers(1, 70),
+       nch=st.integers(2, 16), cout=st.sampled_from([100, 128, 132, 256]), gsel=st.integers(0, 15), pool=st.booleans())
+def test_random_unit_plans_bit_exact(engine, seed, k, B, H, W, nch, cout, gsel, pool):
+    """Whole launches in unit mode (rectangles) under a random unit plan -- g chunks per pass-1 unit among the plans with 2 .. 8 slabs,
+    any map size, 2-16 chunks, padded output channels, pooled 3x3 layers (the combine pools) -- equal the twin's unit_g form bit for bit."""
+    extra = 3 if k == 7 else 0
+    plans = [g for g in range(1, nch + 1) if 2 <= -(-nch // g) + extra <= 8]
+    if k == 7:
+        nch = min(nch, 8)                      # (a 7x7 layer of 16 chunks at 50 x 70 is seconds of twin time; the network's widest is 6)
+        plans = [g for g in range(1, nch + 1) if 2 <= -(-nch // g) + extra <= 8]
+    g = plans[gsel % len(plans)]
+    pool = pool and k == 3 and H % 2 == 0 and W % 2 == 0
+    x, w, b = _data(seed, B, 32 * nch, H, W, cout, k)
+    engine.set_option('wino_unit_g', g)
+    try:
+        y = _run(engine, x, w, b, True, pool, 3)
+    finally:
+        engine.set_option('wino_unit_g', 0)
+    ref = R.conv_wino(x, w, b, True, pool, unit_g=g)
+    assert y.shape == ref.shape
+    assert np.array_equal(y, ref), (k, B, nch, H, W, cout, g, pool, float(np.abs(y - ref).max()), int((y != ref).sum()))
