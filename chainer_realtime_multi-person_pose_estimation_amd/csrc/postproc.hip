@@ -714,6 +714,16 @@ __global__ __launch_bounds__(64) void pp_group_kernel(PPBuffers buf, const doubl
     }
 }
 
+// counters / status words / records of the batch <- 0 (the records are a multiple of 8 bytes: pmx_image_info is 16, the rest doubles)
+__global__ __launch_bounds__(256) void pp_clear_kernel(PPBuffers buf, int B, int scan)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < buf.rec_bytes * (size_t)B / 8) reinterpret_cast<unsigned long long*>(buf.results)[i] = 0ull;
+    if (i < (size_t)B * PMX_N_JOINTS) buf.pk_count[i] = 0;
+    if (i < (size_t)B) buf.status[i] = 0;
+    if (scan && i < (size_t)B * PMX_N_LIMBS) buf.scan_cnt[i] = 0;       // (the sliced candidate scan of pp_limbs_kernel<1>)
+}
+
 // ============================================================================================== host
 static int g_pp_generic = 0;      // 1: always use the generic-radius peaks kernel (tests compare both paths)
 void pp_set_generic(int on) { g_pp_generic = on; }
@@ -722,9 +732,13 @@ int pp_launch(const PPMaps& maps, const PPTables& tab, const PPBuffers& buf, int
               double img_len, const double* d_scale_xy, int keep_smoothed, hipStream_t stream,
               void (*prof)(void*, const char*, int), void* prof_ctx, int limbs_slices)
 {
-    PMX_HIP(hipMemsetAsync(buf.pk_count, 0, sizeof(int) * B * PMX_N_JOINTS, stream));
-    PMX_HIP(hipMemsetAsync(buf.status, 0, sizeof(int) * B, stream));
-    PMX_HIP(hipMemsetAsync(buf.results, 0, buf.rec_bytes * B, stream));   // unused rows of a record are zero
+    // peak counters, status words and records start from zero (unused rows of a record stay zero): one launch instead of three memsets
+    // (a single image per call is ~100 launches of 2 ms in all: every launch counts)
+    {
+        const size_t n8 = buf.rec_bytes * (size_t)B / 8;
+        hipLaunchKernelGGL(pp_clear_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, stream, buf, B, limbs_slices > 1 ? 1 : 0);
+        PMX_HIP(hipGetLastError());
+    }
     const int tiles_x = (map_w + PK_TS - 1) / PK_TS, tiles_y = (map_h + PK_TS - 1) / PK_TS;
 
     if (prof) prof(prof_ctx, "pp_peaks", 1);
@@ -748,7 +762,6 @@ int pp_launch(const PPMaps& maps, const PPTables& tab, const PPBuffers& buf, int
 
     if (prof) prof(prof_ctx, "pp_limbs", 1);
     if (limbs_slices > 1) {
-        PMX_HIP(hipMemsetAsync(buf.scan_cnt, 0, sizeof(int) * B * PMX_N_LIMBS, stream));
         hipLaunchKernelGGL(pp_limbs_kernel<1>, dim3(PMX_N_LIMBS, B, limbs_slices), dim3(256), 0, stream, maps, tab, buf, img_len);
         hipLaunchKernelGGL(pp_limbs_kernel<2>, dim3(PMX_N_LIMBS, B), dim3(256), 0, stream, maps, tab, buf, img_len);
     } else {
