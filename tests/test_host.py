@@ -312,3 +312,18 @@ def test_public_header_is_plain_c():
     code = re.sub(r'/\*.*?\*/', '', open(native.HEADER).read(), flags=re.S)          # declarations without the comments
     assert 'hipStream_t' not in code and 'hip/' not in code and 'torch' not in code.lower() and '#include <' in code
     assert set(re.findall(r'#include <([^>]+)>', code)) <= {'stddef.h', 'stdint.h'}
+
+
+def test_package_sets_two_hardware_queues_unless_the_user_chose():
+    """native.py sets GPU_MAX_HW_QUEUES=2 at import (detect_precise's lanes: profiles/r06_hw_queues.json) and leaves a user's value alone --
+    checked in fresh interpreters, because the variable only counts before the HIP runtime initialises."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ("import os, importlib; importlib.import_module('chainer_realtime_multi-person_pose_estimation_amd.native'); "
+            "print(os.environ.get('GPU_MAX_HW_QUEUES'))")
+    env = {k: v for k, v in os.environ.items() if k != 'GPU_MAX_HW_QUEUES'}
+    out = subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == '2', (out.stdout, out.stderr[-400:])
+    out = subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=dict(env, GPU_MAX_HW_QUEUES='5'), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == '5', (out.stdout, out.stderr[-400:])
