@@ -64,6 +64,7 @@ def rocprof_kernel(label):
     """HIP kernel (as rocprofv3 --kernel-trace names it) behind an engine profile label -- the key the live HIP-event figures and
     the committed rocprofv3 / PMC summaries share.  Labels: csrc/pmx_api.hip::run_conv."""
     import re
+    label = re.sub(r'@\d+\+\d+$', '', label)        # ("@<first image>+<count>": one half of a batch cut in two by images -- same kernels)
     m = re.match(r'conv_wino_f2x2_(\d)x\d(r?)(/[ut]\d+m?)?(:units|:combine)?$', label)      # ".../t<g>m": merged tails
     if m:
         ks, run, plan, part = m.group(1), m.group(2), m.group(3) or '', m.group(4) or ''

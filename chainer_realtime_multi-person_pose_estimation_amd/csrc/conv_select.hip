@@ -157,3 +157,45 @@ int wino_select(const WinoSelectOpts& o, int ks, int cin_pad, int cout_pad, int 
     return 0;
 }
 
+// A launch of the plain kernel whose last round of the CUs is part-filled pays a whole round for it (equal one-per-CU blocks).  Where that
+// costs more than running the images of that round in the finer-grained forms, run_conv cuts the batch in two: the first *n0 images --
+// whole rounds -- through the plain kernel, the rest through whatever the selection gives THEIR count (unit mode with the plan of
+// wino_best_unit_g; a landscape batch of 8: 5 images = 240 blocks in one round + 3 images as 720 unit blocks instead of 384 blocks = 2
+// rounds).  Returns n0 (0: no split).  Part of the arithmetic like every launch form: the results of image i then depend on which side of
+// n0 it lies (profile label "...@<first image>+<count>").  Option "wino_split" = 0 turns it off.
+int wino_split_images(const WinoSelectOpts& o, int ks, int cin_pad, int cout_pad, int cout, int ldc, int B, int groups, int H, int W, int pool)
+{
+    if (!o.wino_split || B < 2 || o.conv_algo != 1) return 0;
+    int ug = 0, run = 0, tg = 0;
+    if (wino_select(o, ks, cin_pad, cout_pad, cout, ldc, B * groups, H, W, pool, &ug, &run, &tg) != 1) return 0;
+    const int nch = cin_pad / 32;
+    const long long ncu = conv_num_cus(), nb = cout_pad / 128;
+    const long long rects = (long long)((H + 7) / 8) * ((W + 15) / 16);
+    long long bpi;                   // blocks of the main launch per image (all groups)
+    if (run) {
+        const int ntiles = PMX_WINO_RUN_TX * ((H + 1) / 2), nblk = (ntiles + PMX_WINO_RUN_TILES - 1) / PMX_WINO_RUN_TILES, nfull = ntiles / PMX_WINO_RUN_TILES;
+        bpi = (long long)(tg ? nfull : nblk) * (W / (PMX_WINO_RUN_TX * 2)) * nb * groups;
+    } else
+        bpi = rects * nb * groups;
+    const long long total = bpi * B, full = total / ncu;
+    if (full < 1 || total % ncu == 0) return 0;
+    const int n0 = (int)(full * ncu / bpi);
+    if (n0 < 1 || n0 >= B) return 0;
+    const int rem = B - n0;
+    int ug2 = 0, run2 = 0, tg2 = 0;
+    const int m2 = wino_select(o, ks, cin_pad, cout_pad, cout, ldc, rem * groups, H, W, pool, &ug2, &run2, &tg2);
+    const double t_block = nch * (ks == 7 ? WINO_T7_CHUNK_US : WINO_T3_CHUNK_US);
+    double rem_us;
+    if (m2 == 2) {
+        int g = 0;
+        rem_us = wino_best_unit_g(ks, nch, rects * rem * groups * nb, (int)ncu, o.wino_unit_g, &g) + 10.0;      // + the combine launch
+        if (!g) return 0;
+    } else if (m2 == 1)
+        rem_us = (double)((bpi * rem + ncu - 1) / ncu) * t_block;
+    else
+        return 0;
+    const double whole_us = (double)(full + 1) * t_block;
+    const double split_us = (double)((bpi * n0 + ncu - 1) / ncu) * t_block + rem_us + 10.0;                       // + one more launch
+    const double thr = o.wino_split >= 50 ? o.wino_split / 100.0 : 0.97;          // (option value >= 50: the threshold in percent, for measurements)
+    return split_us < thr * whole_us ? n0 : 0;
+}

@@ -205,9 +205,11 @@ static std::vector<int> concat_map_cpm(int C)
 }
 
 
-static int prof_begin(pmx_ctx* c, const std::string& name, double flops, double bytes, double issued = -1.0, bool record = true)
+static int prof_begin(pmx_ctx* c, const std::string& name0, double flops, double bytes, double issued = -1.0, bool record = true)
 {
     if (!c->prof_on) return PMX_OK;
+    // (one half of a batch cut in two by images, run_conv: the label carries "@<first image>+<count>")
+    const std::string name = c->split_suffix.empty() ? name0 : name0 + c->split_suffix;
     int idx;
     auto it = c->prof_index.find(name);
     if (it == c->prof_index.end()) {
@@ -485,6 +487,7 @@ extern "C" int pmx_set_option(pmx_ctx* c, const char* key, int value)
     else if (!strcmp(key, "wino_tail")) c->opt_wino_tail = value;
     else if (!strcmp(key, "wino_tail_g")) c->opt_wino_tail_g = value;
     else if (!strcmp(key, "wino_unit_g")) c->opt_wino_unit_g = value;
+    else if (!strcmp(key, "wino_split")) c->opt_wino_split = value;
     else if (!strcmp(key, "wino_tail_merge")) c->opt_wino_tail_merge = value;
     else if (!strcmp(key, "ksplit")) c->opt_ksplit = value;
     else if (!strcmp(key, "ksplit_plan")) c->opt_ksplit = value > 0 ? -value : 0;     // decimal digits = chunks per slice, e.g. 3221
@@ -771,14 +774,19 @@ static int launch_wino_run(pmx_ctx* c, const ConvArgs& a0, int ks, int groups, i
 
 // Which form a 3x3 / 7x7 layer takes (conv_select.hip): 0 = direct kernels (+ split-K), 1 = the Winograd kernel (*run: in the run geometry,
 // *tail_g > 0: its part-filled last blocks in unit mode), 2 = the Winograd kernel in unit mode (*unit_g = chunks per pass-1 unit)
-static int wino_mode(const pmx_ctx* c, int ks, int cin_pad, int cout_pad, int cout, int ldc, int images, int H, int W, int pool, int* unit_g,
-                     int* run, int* tail_g, int groups = 1, int lda = 0)
+static WinoSelectOpts wino_opts(const pmx_ctx* c, int ks, int groups, int lda)
 {
     WinoSelectOpts o;
     o.conv_algo = c->opt_conv_algo; o.precision = c->opt_precision; o.forced_variant = c->opt_force[ks]; o.ksplit = c->opt_ksplit;
     o.wino_unit_eff = c->opt_wino_unit_eff; o.wino_min_fill = c->opt_wino_min_fill; o.wino_geom = c->opt_wino_geom; o.wino_tail = c->opt_wino_tail;
     o.wino_tail_g = c->opt_wino_tail_g; o.wino_tail_merge = c->opt_wino_tail_merge; o.groups = groups; o.lda = lda; o.wino_unit_g = c->opt_wino_unit_g;
-    return wino_select(o, ks, cin_pad, cout_pad, cout, ldc, images, H, W, pool, unit_g, run, tail_g);
+    o.wino_split = c->opt_wino_split;
+    return o;
+}
+static int wino_mode(const pmx_ctx* c, int ks, int cin_pad, int cout_pad, int cout, int ldc, int images, int H, int W, int pool, int* unit_g,
+                     int* run, int* tail_g, int groups = 1, int lda = 0)
+{
+    return wino_select(wino_opts(c, ks, groups, lda), ks, cin_pad, cout_pad, cout, ldc, images, H, W, pool, unit_g, run, tail_g);
 }
 
 // one launch of 1 or 2 groups (same geometry); in/out pointers are already offset to the group's channels
@@ -790,6 +798,23 @@ static int run_conv(pmx_ctx* c, const char* label, int li0, int li1, const float
     const PackedLayer& L0 = c->layers[li0];
     const int groups = li1 >= 0 ? 2 : 1;
     const bool seg = !c->segs.empty() && level >= 0;
+    // a batch whose plain launch would end in a part-filled round of the CUs: the images of the whole rounds first, then the rest through
+    // the selection of THEIR count (conv_select.hip::wino_split_images); each half is an ordinary run_conv on its images
+    if (!seg && c->split_suffix.empty() && c->opt_wino_split && B >= 2 && L0.ks > 1 && wino_eligible(L0.ks, L0.cin_pad, L0.cout_pad) &&
+        (groups == 1 || (wino_eligible(c->layers[li1].ks, c->layers[li1].cin_pad, c->layers[li1].cout_pad) && c->layers[li1].cout == L0.cout))) {
+        const int n0 = wino_split_images(wino_opts(c, L0.ks, groups, lda), L0.ks, L0.cin_pad, L0.cout_pad, L0.cout, ldc, B, groups, H, W, pool);
+        if (n0 > 0 && n0 < B) {
+            const size_t pin = (size_t)n0 * H * W * lda, pout = (size_t)n0 * (pool ? H / 2 : H) * (pool ? W / 2 : W) * ldc;
+            c->split_suffix = "@0+" + std::to_string(n0);
+            int rc = run_conv(c, label, li0, li1, in0, in1, lda, out0, out1, ldc, n0, H, W, relu, pool, level);
+            if (!rc) {
+                c->split_suffix = "@" + std::to_string(n0) + "+" + std::to_string(B - n0);
+                rc = run_conv(c, label, li0, li1, in0 + pin, in1 ? in1 + pin : nullptr, lda, out0 + pout, out1 ? out1 + pout : nullptr, ldc, B - n0, H, W, relu, pool, level);
+            }
+            c->split_suffix.clear();
+            return rc;
+        }
+    }
     const double npix = seg ? (double)c->seg_pix[level] : (double)B * H * W;
     ConvArgs a;
     memset(&a, 0, sizeof a);

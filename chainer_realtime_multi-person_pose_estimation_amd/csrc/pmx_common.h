@@ -142,6 +142,7 @@ void conv_set_launch_events(hipEvent_t e0, hipEvent_t e1);
 struct WinoSelectOpts {      // the context options the choice depends on (pmx_set_option keys of the same names)
     int conv_algo, precision, forced_variant, ksplit, wino_unit_eff, wino_min_fill, wino_geom, wino_tail, wino_tail_g;
     int wino_tail_merge = 1;     // the tails of all images as one stream of tiles (0: one part-filled block per image)
+    int wino_split = 1;          // 1: a batch whose plain launch ends in a part-filled round may be cut in two by images (wino_split_images)
     int wino_unit_g = 0;         // chunks per pass-1 unit of a launch in unit mode: 0 = the plan that finishes first (dispatch simulation), > 0 = forced, -1 = as many units as 8 slabs allow (the rule until round 6)
     int groups = 1;              // branch groups in the launch (`images` counts images x groups)
     int lda = 0;                 // input channel stride (floats) of the launch: bounds the merged-tail form (wino_tail_mergeable)
@@ -151,6 +152,8 @@ bool wino_eligible(int ks, int cin_pad, int cout_pad);
 // part-filled last blocks, which then run in unit mode), 2 = the Winograd kernel in unit mode (*unit_g = chunks per pass-1 unit)
 int wino_select(const WinoSelectOpts& o, int ks, int cin_pad, int cout_pad, int cout, int ldc, int images, int H, int W, int pool, int* unit_g,
                 int* run, int* tail_g);
+// images [0, n0) of a batch of B through the plain kernel, the rest through the selection of their own count; 0 = the whole batch at once
+int wino_split_images(const WinoSelectOpts& o, int ks, int cin_pad, int cout_pad, int cout, int ldc, int B, int groups, int H, int W, int pool);
 struct SplitPlan { int S; unsigned long long bounds; int sizes[8]; };
 struct SplitKReduceArgs {
     const float* slabs[2];   // per group: ksplit slabs of B x H x W x ld_slab floats

@@ -158,6 +158,8 @@ struct pmx_ctx {
                                      // model (conv_algo 1), 0 never, 1 wherever a unit plan exists.  Changes the summation of those tiles (C twin: unit_from)
     int opt_wino_tail_merge = 1;     // the tails of all images of a launch as one stream of tiles, 32 per block (0: one part-filled block per image)
     int opt_wino_tail_g = 0;         // tuning: chunks per pass-1 unit of the tail (0 = automatic)
+    int opt_wino_split = 1;          // a batch whose plain launch ends in a part-filled round of the CUs is cut in two by images (0: never)
+    std::string split_suffix;        // run_conv inside a split: "@<first image>+<count>", appended to the profile labels
     int opt_wino_unit_g = 0;         // tuning: chunks per pass-1 unit of a launch in unit mode (0 = automatic, -1 = as many units as 8 slabs allow)
     int opt_precision = 0;           // 0: fp32 MFMA everywhere (the path whose results are specified); 1: bf16x3 kernels where a
                                      // v6 kernel would run (fp32-grade accuracy at 2.67x the matrix rate, NOT the fp32 FMA chain)

@@ -118,6 +118,12 @@ int pmx_synchronize(pmx_ctx* ctx);                    /* cuda.get_device_from_id
  *                              0 never, 1 wherever a unit plan exists.  The tiles of that block (row-major index >= 32 * full blocks)
  *                              are then summed unit by unit (C twin: `unit_from`); profile label "...r/t<chunks per unit>"
  *   "wino_tail_g" n            tuning: chunks per pass-1 unit of those tails (0 = automatic)
+ *   "wino_split" 1 | 0 | pct   a batch whose plain launch of a 3x3 / 7x7 layer would end in a part-filled round of the CUs (equal
+ *                              one-per-CU blocks: the round costs as much as a full one) is cut in two by images: the images of the
+ *                              whole rounds through the plain kernel, the rest through the launch form of THEIR count (unit mode) --
+ *                              1 (default) where the cost model gains >= 3 %, 0 never, 50 .. 100 = that threshold in percent.
+ *                              Eight 368 x 496 frames: 5 + 3, 14.4 -> 13.4 ms.  Part of the arithmetic (an image's rounding then depends
+ *                              on which side of the cut it lies): profile label "...@<first image>+<count>"
  *   "wino_unit_g" n            chunks per pass-1 unit of a launch that runs in unit mode as a whole (single images, small batches):
  *                              0 (default) = the plan a dispatch simulation over the device's CUs finishes first (one 368 x 368 image:
  *                              conv4_2 as 3 units of 6 / 6 / 4 chunks = 216 blocks in one round), n > 0 = n chunks, -1 = as many

@@ -138,11 +138,34 @@ class LaunchPlan(dict):
     wino_tails = {}
 
 
-def splitk_plan(profile):
+def _for_image(profile, image):
+    """Profile entries that describe how `image` ran.  A batch whose plain launch would end in a part-filled round of the CUs is cut in two
+    by images (csrc/conv_select.hip::wino_split_images); the two halves of such a layer carry "@<first image>+<count>" at the end of their
+    kernel label and may run different launch forms -- the plan of a forward is then a plan PER IMAGE.  Returns copies with the suffix
+    removed; entries of the other half are dropped."""
+    import re
+    out, split = [], False
+    for e in profile:
+        m = re.search(r'@(\d+)\+(\d+)$', e['kernel'])
+        if not m:
+            out.append(e)
+            continue
+        split = True
+        a, n = int(m.group(1)), int(m.group(2))
+        if image is not None and a <= image < a + n:
+            out.append(dict(e, kernel=e['kernel'][:m.start()]))
+    if split and image is None:
+        raise ValueError('this forward cut a batch in two by images: ask for the plan of one image (splitk_plan(profile, image=i))')
+    return out
+
+
+def splitk_plan(profile, image=None):
     """Launch plan of one forward from an engine profile of the SAME forward (native.Engine.profile()): {layer label: chunks of
     every K slice} (the kernel label carries "/k3-2-2-1" where the launch was split) and, as attribute `.wino`, the layers that
     ran on the Winograd kernel (the kernel choice depends on the launch size).  Labels are the layer names without the _L1 / _L2
-    branch suffix.  forward_fma(weights, x, splitk=plan) restates exactly that forward."""
+    branch suffix.  forward_fma(weights, x, splitk=plan) restates exactly that forward.  `image`: which image of the batch the plan is
+    for -- needed (only) when the forward cut a batch in two by images (_for_image)."""
+    profile = _for_image(profile, image)
     plan = LaunchPlan()
     plan.wino_units, plan.wino_tails = {}, {}
     for e in profile:

@@ -56,18 +56,22 @@ def engine(native):
     e.close()
 
 
-def forward_plan(engine, run, with_wino=False):
+def forward_plan(engine, run, with_wino=False, image=None, with_profile=False):
     """Run `run()` (one forward through `engine`) with the per-launch profiler on and return the split-K plan the kernels used
     ({layer label: K slices}, oracle/conv_fma_ref.py::splitk_plan) -- what the order-defined oracle needs to reproduce a
-    small-launch forward bit for bit.  with_wino: return (plan, labels of the layers that ran as Winograd, out)."""
+    small-launch forward bit for bit.  with_wino: return (plan, labels of the layers that ran as Winograd, out).  with_profile: return
+    (profile, out) instead -- a forward that cut its batch in two by images has one plan PER IMAGE (splitk_plan(profile, image=i));
+    `image`: the plan of that image."""
     from oracle import conv_fma_ref
     engine.profile_reset()
     engine.profile_enable(True)
     try:
         out = run()
         prof = engine.profile()
-        plan = conv_fma_ref.splitk_plan(prof)
-        wino = conv_fma_ref.wino_layers(prof)
+        if with_profile:
+            return prof, out
+        plan = conv_fma_ref.splitk_plan(prof, image=image)
+        wino = conv_fma_ref.wino_layers(conv_fma_ref._for_image(prof, image))
     finally:
         engine.profile_enable(False)
         engine.profile_reset()

@@ -23,6 +23,9 @@ def test_profile_labels_map_to_hip_kernels():
     assert m('conv7x7_v6_t17x32_n128') == 'conv_mfma_v6_kernel<7, 17, 0>'
     assert m('conv3x3_v5_t8x16_n64').startswith('conv_mfma_v5_kernel<3, 8, 16, 64,')
     assert m('pp_peaks') == 'pp_peaks'
+    # one half of a batch cut in two by images: the same kernels
+    assert m('conv_wino_f2x2_7x7@0+5') == 'conv_wino_kernel<7, 0, 0, 0>' and m('conv_wino_f2x2_7x7/u2@5+3') == 'conv_wino_kernel<7, 0, 1, 0>'
+    assert m('conv_wino_f2x2_3x3r/t3m:units@0+22') == 'conv_wino_kernel<3, 0, 1, 3>'
 
 
 def test_dominant_kernel_groups_labels_of_one_hip_kernel_and_keeps_issued_below_algorithmic():

@@ -168,3 +168,21 @@ def test_merged_tail_geometry_covers_every_tail_tile_once():
                 assert all(sum(n for _, _, n, _ in segs) == 32 for segs in blocks[:-1])                      # only the last block is part-filled
     assert {45, 46, 37, 38, 23, 24, 51, 52} <= merge_h and 44 not in merge_h and 40 not in merge_h
     assert [len(s) for s in R.wino_merged_tail_blocks(5, 46, 46, 7)] == [2, 3, 2]                            # 17 + 15 | 2 + 17 + 13 | 4 + 17
+
+
+def test_launch_plan_of_a_batch_cut_in_two_by_images():
+    """A batch whose plain launch would end in a part-filled round of the CUs is cut in two by images (csrc/conv_select.hip::
+    wino_split_images); the halves carry "@<first image>+<count>" in their labels and may run different forms: the plan is per image."""
+    from oracle import conv_fma_ref as R
+    prof = [{'layer': 'conv2_2', 'kernel': 'conv_wino_f2x2_3x3'}, {'layer': 'Mconv2_stage3', 'kernel': 'conv_wino_f2x2_7x7@0+5'},
+            {'layer': 'Mconv2_stage3', 'kernel': 'conv_wino_f2x2_7x7/u2@5+3'}, {'layer': 'conv4_2', 'kernel': 'conv_wino_f2x2_3x3r/t6m@0+6'},
+            {'layer': 'conv4_2', 'kernel': 'conv_wino_f2x2_3x3r/t6m:units@0+6'}, {'layer': 'conv4_2', 'kernel': 'conv_wino_f2x2_3x3/u3@6+2'}]
+    with pytest.raises(ValueError):
+        R.splitk_plan(prof)
+    p0, p6, p23 = R.splitk_plan(prof, image=0), R.splitk_plan(prof, image=5), R.splitk_plan(prof, image=7)
+    assert p0.wino == p6.wino == p23.wino == {'conv2_2', 'Mconv2_stage3', 'conv4_2'}
+    assert p0.wino_units == {} and p0.wino_tails == {'conv4_2': 6}
+    assert p6.wino_units == {'Mconv2_stage3': 2} and p6.wino_tails == {'conv4_2': 6}
+    assert p23.wino_units == {'Mconv2_stage3': 2, 'conv4_2': 3} and p23.wino_tails == {}
+    assert R.splitk_plan(prof[:1]).wino == {'conv2_2'}          # (no split: no image needed)
+
