@@ -442,6 +442,39 @@ def test_batch_cut_in_two_by_images_bit_exact_per_image(native):
     assert np.abs(paf0 - paf).max() <= 2e-5 * scale and np.abs(heat0 - heat).max() <= 2e-5 * scale
 
 
+def test_cut_batches_equal_uncut_batches_to_rounding(native):
+    """Random uniform batches (2-32 frames, 64-400 pixels a side) with the cut on and off: the maps agree to fp32 rounding (2e-5 of the map
+    scale -- the bar between any two launch forms), the images in front of a cut bit for bit, a second run of the same batch reproduces
+    the first bit for bit; and the case list does contain cuts."""
+    weights = pkg('weights').synthetic_weights(0)
+    rng = np.random.default_rng(2026)
+    eng = native.Engine(0, max_batch=32, max_h=496, max_w=496)
+    eng.set_weights(weights)
+    cuts = 0
+    cases = [(8, 368, 496), (12, 368, 496), (24, 496, 368)] + [(int(rng.integers(2, 33)), int(rng.integers(8, 51)) * 8, int(rng.integers(8, 51)) * 8) for _ in range(9)]
+    for B, h, w in cases:
+        imgs = rng.integers(0, 256, (B, h, w, 3), dtype=np.uint8)
+        eng.set_option('wino_split', 1)
+        prof, _ = forward_plan(eng, lambda: eng.forward_u8(imgs), with_profile=True)
+        paf1, heat1 = eng.get_maps()
+        eng.forward_u8(imgs)
+        paf1b, heat1b = eng.get_maps()
+        assert np.array_equal(paf1, paf1b) and np.array_equal(heat1, heat1b), (B, h, w)
+        eng.set_option('wino_split', 0)
+        eng.forward_u8(imgs)
+        paf0, heat0 = eng.get_maps()
+        import re
+        firsts = [int(re.search(r'@(\d+)\+\d+$', p['kernel']).group(1)) for p in prof if '@' in p['kernel']]
+        n_front = min([f for f in firsts if f > 0], default=B)       # images in front of every cut of this forward
+        cuts += bool(firsts)
+        assert np.array_equal(paf0[:n_front], paf1[:n_front]) and np.array_equal(heat0[:n_front], heat1[:n_front]), (B, h, w, n_front)
+        scale = max(1.0, float(np.abs(paf0).max()), float(np.abs(heat0).max()))
+        assert np.abs(paf0 - paf1).max() <= 2e-5 * scale and np.abs(heat0 - heat1).max() <= 2e-5 * scale, (B, h, w)
+    eng.set_option('wino_split', 1)
+    eng.close()
+    assert cuts >= 3, cuts
+
+
 # ---- randomised shapes for the run geometry (deterministic example set by default; PMX_FUZZ=<n> draws n fresh random examples) ----------
 import os as _os
 from hypothesis import given, settings, strategies as st, HealthCheck
