@@ -403,14 +403,14 @@ def test_single_image_368_default_plan_bit_exact(native):
     assert np.array_equal(paf, rpaf) and np.array_equal(heat, rheat), (np.abs(paf - rpaf).max(), np.abs(heat - rheat).max())
 
 
-def test_batch_cut_in_two_by_images_bit_exact_per_image(native):
+@pytest.mark.parametrize('B,h,w,must_cut,min_cut', [(32, 184, 248, 'Mconv2_stage3', 25), (24, 64, 144, 'conv3_4', 1)])      # (conv3_4: a POOLED layer cut)
+def test_batch_cut_in_two_by_images_bit_exact_per_image(native, B, h, w, must_cut, min_cut):
     """A batch whose plain 7x7 launches would end in a part-filled round of the CUs (32 frames of 184 x 248: 12 blocks per image = 384 =
     1.5 rounds) is cut in two by images (conv_select.hip::wino_split_images): whole rounds through the plain kernel, the rest through
     the selection of their own count (unit mode).  The profile labels say which image took which form ("@<first>+<count>"), and
     forward_fma with the plan OF AN IMAGE reproduces that image's maps bit for bit -- on both sides of the cut; with the option off the
     batch runs as one launch per layer and every image has the same plan."""
     weights = pkg('weights').synthetic_weights(0)
-    B, h, w = 32, 184, 248
     eng = native.Engine(0, max_batch=B, max_h=h, max_w=w)
     eng.set_weights(weights)
     imgs = np.random.default_rng(77).integers(0, 256, (B, h, w, 3), dtype=np.uint8)
@@ -420,15 +420,15 @@ def test_batch_cut_in_two_by_images_bit_exact_per_image(native):
     if not cut:
         eng.close()
         pytest.skip('no layer was cut: the cut is a function of the CU count, the shapes of this test are chosen for 256 CUs')
-    assert len(cut) >= 25 and 'Mconv2_stage3' in cut, cut
+    assert len(cut) >= min_cut and must_cut in cut, cut
     import re
-    n0 = {int(re.search(r'@0\+(\d+)$', p['kernel']).group(1)) for p in prof if p['layer'] == 'Mconv2_stage3' and '@0+' in p['kernel']}
+    n0 = {int(re.search(r'@0\+(\d+)$', p['kernel']).group(1)) for p in prof if p['layer'] == must_cut and '@0+' in p['kernel']}
     assert len(n0) == 1
     n0 = n0.pop()
     assert 0 < n0 < B
     for i in (0, n0 - 1, n0, B - 1):
         plan = R.splitk_plan(prof, image=i)
-        assert ('Mconv2_stage3' in plan.wino_units) == (i >= n0), (i, n0, plan.wino_units)
+        assert (must_cut in plan.wino_units) == (i >= n0), (i, n0, plan.wino_units)
         rpaf, rheat = R.forward_fma(weights, P.preprocess(imgs[i]), splitk=plan)
         assert np.array_equal(paf[i], rpaf[0]) and np.array_equal(heat[i], rheat[0]), (i, np.abs(paf[i] - rpaf[0]).max(), np.abs(heat[i] - rheat[0]).max())
     eng.set_option('wino_split', 0)
@@ -436,7 +436,8 @@ def test_batch_cut_in_two_by_images_bit_exact_per_image(native):
     paf0, heat0 = eng.get_maps()
     eng.close()
     assert not any('@' in p['kernel'] for p in prof0)
-    assert np.array_equal(paf0[:n0], paf[:n0]) and np.array_equal(heat0[:n0], heat[:n0])          # plain blocks do not depend on the batch they are part of
+    nf = min(int(re.search(r'@(\d+)\+\d+$', p['kernel']).group(1)) for p in prof if '@' in p['kernel'] and '@0+' not in p['kernel'])      # images in front of EVERY cut
+    assert np.array_equal(paf0[:nf], paf[:nf]) and np.array_equal(heat0[:nf], heat[:nf])          # plain blocks do not depend on the batch they are part of
     assert not np.array_equal(paf0[n0:], paf[n0:])
     scale = max(1.0, float(np.abs(paf0).max()), float(np.abs(heat0).max()))
     assert np.abs(paf0 - paf).max() <= 2e-5 * scale and np.abs(heat0 - heat).max() <= 2e-5 * scale
